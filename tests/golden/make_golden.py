@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the REAL reference built by oracle/Makefile.ref (run in the build container only:
+needs /root/reference).  Everything written here is data -- inputs and the reference's outputs -- never source.
+
+  g1/   60 kbp, 3 sequences; index files written by the reference 2bwt-builder (the 512 MiB .lkt is not kept: it is
+        a pure function of .pac, LTConstruct.c:44-105, and both the oracle and the product rebuild it)
+        reads_{a,b,c}_{1,2}.fq + expected_{a,b,c}.fq = stdout of `soap4 pair ... -F -nc` (sorted is not needed: -T 1)
+  fm_vectors.npz   BWTOccValue / BWTSaValue / LKT answers of the reference on g1
+  dp_vectors.npz   callDP inputs and outputs (score, hitLoc, tie count, decoded special CIGAR)
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from megapath_amd import synth  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+INI = "/root/reference/soap4/soap4-nt2.ini"
+
+
+def run_ref(prefix, fq1, fq2, L, out, extra=()):
+    cmd = [os.path.join(REF, "soap4"), "pair", prefix, fq1, fq2, "-o", out + ".tmp", "-C", INI, "-L", str(L), "-T", "1",
+           "-u", "750", "-F", "-nc", *extra]
+    with open(out, "wb") as fo, open(os.devnull, "wb") as fe:
+        subprocess.check_call(cmd, stdout=fo, stderr=fe)
+
+
+def main():
+    subprocess.check_call(["make", "-s", "-f", "oracle/Makefile.ref", "-j8"], cwd=ROOT)
+    g1 = os.path.join(HERE, "g1")
+    os.makedirs(g1, exist_ok=True)
+    genome = synth.random_genome(60000, 101, n_seqs=3, repeat_frac=0.08)
+    fa = os.path.join(g1, "ref.fa")
+    synth.write_fasta(fa, genome)
+    subprocess.check_call([os.path.join(REF, "2bwt-builder"), fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    prefix = fa + ".index"
+    sets = {
+        "a": dict(n_pairs=240, read_len=150, seed=102, sub=0.02, ins=0.002, dele=0.002, random_frac=0.05,
+                  broken_mate_frac=0.12, n_frac=0.002, L=151),
+        "b": dict(n_pairs=120, read_len=150, seed=103, sub=0.01, random_frac=0.05, broken_mate_frac=0.1, L=150),
+        "c": dict(n_pairs=120, read_len=150, seed=104, sub=0.02, ins=0.002, dele=0.002, random_frac=0.05,
+                  broken_mate_frac=0.3, len_range=(75, 300), frag_mean=450, frag_sd=60, frag_max=700, L=301),
+    }
+    for k, cfg in sets.items():
+        L = cfg.pop("L")
+        names, r1, r2 = synth.simulate_pairs(genome, **cfg)
+        f1, f2 = os.path.join(g1, "reads_%s_1.fq" % k), os.path.join(g1, "reads_%s_2.fq" % k)
+        synth.write_fastq_pair(f1, f2, names, r1, r2)
+        run_ref(prefix, f1, f2, L, os.path.join(g1, "expected_%s.fq" % k))
+        with open(os.path.join(g1, "expected_%s.L" % k), "w") as f:
+            f.write("%d\n" % L)
+
+    # ---- FM-index vectors from the real BWT.c
+    R = O.ref_bwt()
+    rx = R.ref_index_open(prefix.encode(), 1)
+    n = R.ref_text_length(rx)
+    rng = np.random.default_rng(7)
+    idx = rng.integers(0, n + 2, size=4000).astype(np.uint64)
+    idx[:4] = [0, 1, n, n + 1]
+    idx[4] = R.ref_inverse_sa0(rx)
+    idx[5] = R.ref_inverse_sa0(rx) + 1
+    cs = rng.integers(0, 4, size=4000).astype(np.uint32)
+    occ = np.zeros(4000, dtype=np.uint64)
+    R.ref_occ_many(rx, idx.ctypes.data, cs.ctypes.data, 4000, occ.ctypes.data)
+    sidx = rng.integers(0, n + 1, size=2000).astype(np.uint64)
+    sidx[:3] = [0, n, R.ref_inverse_sa0(rx)]
+    sav = np.zeros(2000, dtype=np.uint64)
+    R.ref_sa_many(rx, sidx.ctypes.data, 2000, sav.ctypes.data)
+    keys = rng.integers(0, 4 ** 13, size=3000).astype(np.uint32)
+    # make a third of the keys real 13-mers of the text so that non-empty ranges are exercised
+    text = np.concatenate([np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), s[1]) for s in genome]).astype(np.uint64)
+    for j in range(0, 3000, 3):
+        p = int(rng.integers(0, n - 13))
+        keys[j] = int(sum(int(text[p + t]) << (2 * (12 - t)) for t in range(13)))
+    import ctypes as C
+    lk = np.zeros((3000, 2), dtype=np.uint64)
+    for j, k in enumerate(keys):
+        a, b = C.c_uint64(), C.c_uint64()
+        R.ref_lkt_range(rx, int(k), C.byref(a), C.byref(b))
+        lk[j] = (a.value, b.value)
+    np.savez_compressed(os.path.join(HERE, "fm_vectors.npz"), occ_idx=idx, occ_c=cs, occ=occ, sa_idx=sidx, sa=sav,
+                        lkt_key=keys, lkt_range=lk, text_length=np.uint64(n), inverse_sa0=np.uint64(R.ref_inverse_sa0(rx)))
+    os.remove(prefix + ".lkt")
+
+    # ---- DP vectors from the real callDP
+    refs, reads, clips, outs = [], [], [], []
+    for clip in [(130, 130), (100, 100), (20, 5), (5, 40), (0, 0)]:
+        for alpha in (4, 2):
+            batch_refs, batch_reads = [], []
+            for t in range(40):
+                m = int(rng.integers(150, 221))
+                L = int(rng.integers(60, 150))
+                ref = rng.integers(0, alpha, size=m).astype(np.uint8)
+                if rng.random() < 0.9 and m > L:
+                    s = int(rng.integers(0, m - L))
+                    rd = ref[s:s + L].copy()
+                    k = rng.random(L) < 0.06
+                    rd[k] = rng.integers(0, alpha, size=int(k.sum()))
+                    if rng.random() < 0.5:
+                        p = int(rng.integers(10, L - 10))
+                        g = int(rng.integers(1, 4))
+                        if rng.random() < 0.5:
+                            rd = np.concatenate([rd[:p], rd[p + g:], rng.integers(0, alpha, size=g).astype(np.uint8)])
+                        else:
+                            rd = np.concatenate([rd[:p], rng.integers(0, alpha, size=g).astype(np.uint8), rd[p:L - g]])
+                else:
+                    rd = rng.integers(0, alpha, size=L).astype(np.uint8)
+                batch_refs.append(ref)
+                batch_reads.append(rd.astype(np.uint8))
+            res = O.ref_call_dp(batch_refs, batch_reads, *clip)
+            refs += batch_refs
+            reads += batch_reads
+            clips += [clip] * len(batch_refs)
+            outs += res
+    # long windows (mate rescue shape) and long reads
+    for clip, (mlo, mhi), (llo, lhi) in [((130, 130), (700, 752), (120, 150)), ((130, 130), (300, 321), (240, 251))]:
+        batch_refs, batch_reads = [], []
+        for t in range(24):
+            m = int(rng.integers(mlo, mhi))
+            L = int(rng.integers(llo, lhi))
+            ref = rng.integers(0, 4, size=m).astype(np.uint8)
+            s = int(rng.integers(0, m - L))
+            rd = ref[s:s + L].copy()
+            k = rng.random(L) < 0.05
+            rd[k] = rng.integers(0, 4, size=int(k.sum()))
+            batch_refs.append(ref)
+            batch_reads.append(rd)
+        res = O.ref_call_dp(batch_refs, batch_reads, *clip)
+        refs += batch_refs
+        reads += batch_reads
+        clips += [clip] * len(batch_refs)
+        outs += res
+    np.savez_compressed(
+        os.path.join(HERE, "dp_vectors.npz"),
+        ref_cat=np.concatenate(refs), ref_len=np.array([len(r) for r in refs], dtype=np.int32),
+        read_cat=np.concatenate(reads), read_len=np.array([len(r) for r in reads], dtype=np.int32),
+        clip=np.array(clips, dtype=np.int32), score=np.array([o[0] for o in outs], dtype=np.int32),
+        hit_loc=np.array([o[1] for o in outs], dtype=np.int32), count=np.array([o[2] for o in outs], dtype=np.int32),
+        cigar=np.array([o[3] for o in outs]))
+    print("golden fixtures written under", HERE)
+
+
+if __name__ == "__main__":
+    main()

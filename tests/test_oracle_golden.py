@@ -1,0 +1,67 @@
+"""CPU tests: the oracle (oracle/*.c) against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py) -- SURVEY.md section 8(c).  No GPU, no /root/reference needed."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import fastq_records
+
+
+@pytest.fixture(scope="module")
+def g1(g1_prefix):
+    lib = O.oracle()
+    ix = lib.mpo_index_open(g1_prefix.encode())
+    yield ix
+    lib.mpo_index_close(ix)
+
+
+def test_fm_primitives_match_reference_vectors(g1, golden_dir):
+    lib = O.oracle()
+    v = np.load(os.path.join(golden_dir, "fm_vectors.npz"))
+    assert lib.mpo_text_length(g1) == int(v["text_length"])
+    assert lib.mpo_inverse_sa0(g1) == int(v["inverse_sa0"])
+    occ = [lib.mpo_occ(g1, int(i), int(c)) for i, c in zip(v["occ_idx"], v["occ_c"])]
+    assert np.array_equal(np.array(occ, dtype=np.uint64), v["occ"])
+    sa = [lib.mpo_sa_value(g1, int(i)) for i in v["sa_idx"]]
+    assert np.array_equal(np.array(sa, dtype=np.uint64), v["sa"])
+    a, b = C.c_uint64(), C.c_uint64()
+    for k, (l, r) in zip(v["lkt_key"], v["lkt_range"]):
+        lib.mpo_lkt_range(g1, int(k), C.byref(a), C.byref(b))
+        assert (a.value, b.value) == (int(l), int(r))
+
+
+def test_dp_matches_reference_vectors(golden_dir):
+    v = np.load(os.path.join(golden_dir, "dp_vectors.npz"))
+    ro = np.concatenate([[0], np.cumsum(v["ref_len"])])
+    qo = np.concatenate([[0], np.cumsum(v["read_len"])])
+    n_pass = 0
+    for t in range(len(v["score"])):
+        ref = v["ref_cat"][ro[t]:ro[t + 1]]
+        read = v["read_cat"][qo[t]:qo[t + 1]]
+        got = O.sgdp(ref, read, int(v["clip"][t][0]), int(v["clip"][t][1]))
+        want = (int(v["score"][t]), int(v["hit_loc"][t]), int(v["count"][t]), str(v["cigar"][t]))
+        assert got == want, t
+        n_pass += want[0] > 0
+    assert n_pass > 100
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_whole_path_matches_reference_stdout(g1, golden_dir, tmp_path, tag):
+    lib = O.oracle()
+    d = os.path.join(golden_dir, "g1")
+    L = int(open(os.path.join(d, "expected_%s.L" % tag)).read())
+    p = O.default_params(L=L, insert_high=750, mode=1, top=95)
+    st = O.AlignStats()
+    out = tmp_path / "out.fq"
+    rc = lib.mpo_align_fastq(g1, C.byref(p), os.path.join(d, "reads_%s_1.fq" % tag).encode(),
+                             os.path.join(d, "reads_%s_2.fq" % tag).encode(), str(out).encode(), None, C.byref(st))
+    assert rc == 0
+    got = fastq_records(str(out))
+    want = fastq_records(os.path.join(d, "expected_%s.fq" % tag))
+    assert len(got) == len(want) == 2 * st.n_pairs
+    assert got == want
+    # every stage of the path must have been exercised by the fixture
+    assert st.n_deep_dp_pairs > 0 and st.n_default_dp_pairs > 0 and st.n_unpaired_pairs > 0

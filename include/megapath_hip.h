@@ -1,0 +1,166 @@
+/*
+ * include/megapath_hip.h -- the C ABI of the MI355X-native soap4 hot path (libmegapath_hip.so).
+ *
+ * The reference has no plugin/FFI surface: its boundary is the `soap4` process plus two internal
+ * seams.  This header exports those seams as plain-C entry points (pointers and sizes only, no C++/torch types) so that
+ * a soap4-compatible host front end -- ours in megapath_amd/csrc/host/, or the reference's own SOAP4.cpp with the
+ * binding shown in INTEGRATION.md -- can drive the HIP kernels.  Every function returns 0 on success or a negative
+ * MP_E* code; nothing throws across the boundary; all buffers named `out_*` are caller-owned.
+ *
+ * One mp_index per GPU (read-only, shared); one mp_ctx per host thread / HIP stream.
+ */
+#ifndef MEGAPATH_HIP_H
+#define MEGAPATH_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_OK 0
+#define MP_EINVAL (-22)   /* bad argument                                   */
+#define MP_ENOMEM (-12)   /* host or device allocation failed               */
+#define MP_EIO (-5)       /* index file missing / malformed                 */
+#define MP_ENODEV (-19)   /* no HIP device / HIP runtime error              */
+#define MP_ERANGE (-34)   /* input outside what the kernels support         */
+
+typedef struct mp_index mp_index;
+typedef struct mp_ctx mp_ctx;
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Index.  Replaces INDEXLoad (reference soap4/IndexHandler.cpp:49-137: BWTLoad 2bwt-lib/BWT.c:100, HSPLoad HSP.c:57,
+ * LTLoad 2bwt-flex/LT.c:37).  Reads <prefix>.{bwt,fmv,sa,pac,ann,tra} (+ .lkt when present, else rebuilt from .pac as
+ * LTConstruct.c:44-105 does) and re-lays them out in HBM for coalesced access (DESIGN.md "Data layout").
+ * Text length must be < 2^32 - 2 (the reference itself needs index chunks < 4 Gbp: DV-DPfunctions.cpp:1516). */
+int mp_index_open(const char *prefix, int device, mp_index **out);
+/* Same, from arrays already in host memory (used by the in-repo index builder; layouts as in the index files):
+ * bwt_words = 2-bit BWT, 16 symbols per word MSB-first, '$' omitted; sa_samples[k] = SA[k * sa_interval] with
+ * sa_samples[0] ignored; pac_bytes = 4 bases per byte, first base in bits 7-6.  lkt may be NULL (rebuilt). */
+int mp_index_from_arrays(int device, uint64_t text_length, uint64_t inverse_sa0, const uint64_t cum_freq[5],
+                         const uint32_t *bwt_words, const uint64_t *sa_samples, uint32_t sa_interval,
+                         const uint8_t *pac_bytes, const uint64_t *lkt,
+                         uint32_t num_seq, const char *const *seq_names, const uint64_t *seq_starts, const uint64_t *seq_lengths,
+                         mp_index **out);
+int mp_index_close(mp_index *ix);
+
+typedef struct {
+    uint64_t text_length, inverse_sa0;
+    uint64_t cum_freq[5];
+    uint32_t sa_interval, num_seq;
+    uint64_t device_bytes;          /* HBM held by the index */
+} mp_index_info;
+int mp_index_get_info(const mp_index *ix, mp_index_info *out);
+const char *mp_index_seq_name(const mp_index *ix, uint32_t seq_id_1based);
+/* getChrAndPos (BGS-IO.cpp:163-188): packed position -> (1-based position in sequence, 1-based sequence id) */
+int mp_index_chr_and_pos(const mp_index *ix, uint64_t amb_pos, uint64_t *out_pos, uint32_t *out_seq_id);
+
+/* Unit-level device queries (tests; mirror BWTOccValue BWT.c:597, BWTSaValue BWT.c:968, LKT use at
+ * DV-DPfunctions.cpp:2245-2246). All arrays are host pointers; n entries each. */
+int mp_index_occ(const mp_index *ix, const uint64_t *idx, const uint32_t *sym, uint64_t n, uint64_t *out);
+int mp_index_sa(const mp_index *ix, const uint64_t *idx, uint64_t n, uint64_t *out);
+int mp_index_lkt(const mp_index *ix, const uint32_t *key, uint64_t n, uint64_t *out_l, uint64_t *out_r);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Context and reads. */
+int mp_ctx_create(mp_index *ix, mp_ctx **out);
+int mp_ctx_destroy(mp_ctx *ctx);
+
+/* Reads of one batch, 2 per pair (read 2p, mate 2p+1), as the reference stores them after appendToQueryArrays
+ * (QueryParser.cpp:184-234) except that each read's words are contiguous: base i of read r at bits 2*(i%16) of
+ * word r*words_per_read + i/16 (codes A0 C1 G2 T3).  Lengths already truncated to maxReadLength-1. */
+int mp_set_reads(mp_ctx *ctx, const uint32_t *packed, uint32_t words_per_read, const uint32_t *lengths, uint32_t n_reads);
+/* Same, but the arrays are already in this GPU's memory (device pointers) -- no PCIe copy. */
+int mp_set_reads_device(mp_ctx *ctx, const uint32_t *d_packed, uint32_t words_per_read, const uint32_t *d_lengths, uint32_t n_reads,
+                        uint32_t max_length);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Seeding.  Replaces PairEndSeedingBatch::mmpSeeding (DV-DPfunctions.cpp:2404-2615): mmp<0>/mmp<2> (:2224-2377),
+ * SA locate (:2481-2495), merge/filter (:2499-2553).  Parameters = MmpProperties (PEAlgnmt.h:374-384, ini [MMP]). */
+typedef struct {
+    int32_t sa_size_threshold, seed_min_length, uniq_threshold, indel_fuzz, good_seed_len, reseed_len;
+    double reseed_rlt_ratio;
+    int32_t reseed_abs_diff;
+    double short_seed_ratio;
+} mp_mmp_params;
+
+typedef struct {              /* DeepDP_Space::SeedPos (SeedPool.h:52-57) */
+    uint64_t pos;
+    uint32_t strand_read_id;  /* bit31 = reverse strand, low 31 = even read id of the pair */
+    uint32_t paired_seed_length;
+} mp_seedpos;
+
+typedef struct {
+    uint64_t n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos;   /* event counts for the roofline */
+    float ms_seed, ms_locate, ms_merge;                        /* HIP-event kernel times of this call */
+} mp_seed_stats;
+
+int mp_seed_batch(mp_ctx *ctx, const mp_mmp_params *params, mp_seed_stats *out_stats);
+/* Copies the kept seeds of the last mp_seed_batch to the host: out_offsets has n_reads+1 entries; read r owns
+ * out_seeds[out_offsets[r] .. out_offsets[r+1]), '+' strand seeds first then '-', each in ascending pos. */
+int mp_get_seeds(mp_ctx *ctx, mp_seedpos *out_seeds, uint64_t cap, uint64_t *out_offsets);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Semi-global DP + traceback.  Replaces SemiGlobalAligner::performAlignment -> callDP (CPU_DPfunctions.h:127-135,
+ * CPU_DP.h:10-24, CPU_DP.cpp:122-978).  An instance names a read of the current batch, the strand it is aligned in
+ * (1 = as is, 2 = reverse complement) and a window of the indexed text; the gather (packRead/repackDNA,
+ * DV-DPfunctions.cpp:3009-3073) happens on the device from the resident reads and .pac. */
+typedef struct {
+    uint32_t read_id;
+    uint32_t strand;
+    uint64_t win_start;
+    uint32_t win_len;
+    uint32_t reserved;
+} mp_dp_task;
+
+typedef struct {
+    int32_t score;            /* best score if >= cutoff and traceback valid, else 0 */
+    uint32_t hit_loc;         /* 0-based start of the alignment inside the window     */
+    uint32_t max_score_count; /* ties of the best score, saturating at 255            */
+    uint32_t n_ops;           /* ops written (traceback order, alphabet "MmIDS")      */
+} mp_dp_result;
+
+/* cutoff = (int)max(0.2*len, 30) is applied per read as the reference hard-wires it (definitions.h:166-167).
+ * out_ops may be NULL (scores/positions only); otherwise instance t owns out_ops[t*ops_stride ..). */
+int mp_sgdp_batch(mp_ctx *ctx, const mp_dp_task *tasks, uint32_t n_tasks, int clip_left, int clip_right,
+                  mp_dp_result *out_results, uint8_t *out_ops, uint32_t ops_stride, float *out_ms_fill, float *out_ms_trace);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The deep-DP round for all pairs of the batch.  Replaces DPForUnalignPairs2 (DV-DPForBothUnalign.cpp:242) =
+ * performMmpSeeding (:2617) + mergeAndPairPairedEnd (:2088) + PairEndAlignmentEngine::performAlignment (:3147). */
+typedef struct {
+    int32_t insert_low, insert_high;     /* after the SOAP4.cpp:465-474 adjustment */
+    int32_t clip_left, clip_right;       /* ini MaxFrontLenClipped / MaxEndLenClipped */
+    mp_mmp_params mmp;
+} mp_align_params;
+
+typedef struct {              /* one DeepDPAlignResult (PEAlgnmt.h:509-541), both mates passed the cutoff */
+    uint32_t pair_id;
+    uint32_t left_is_mate;    /* readIDLeft & 1 */
+    uint64_t algnmt_1, algnmt_2;
+    int32_t score_1, score_2;
+    uint32_t start_1, start_2;        /* window starts (dpInfoForReads) */
+    uint16_t dplen_1, dplen_2;
+    uint16_t count_1, count_2;
+} mp_pair_hit;
+
+typedef struct {
+    mp_seed_stats seed;
+    uint64_t n_candidates, n_dp_left, n_dp_right, n_pair_hits;
+    uint64_t dp_cells;
+    float ms_pair, ms_dp_fill, ms_dp_trace, ms_total;
+} mp_round_stats;
+
+/* Runs seeding (unless already done for this batch), pairing and both DP legs on the device.  The hits are kept in the
+ * context until the next call; *out_n_hits receives their number. */
+int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n_hits, mp_round_stats *out_stats);
+int mp_get_pair_hits(mp_ctx *ctx, mp_pair_hit *out_hits, uint64_t cap);
+
+/* Library / device probe: fails loudly (MP_ENODEV) when no gfx950 device is usable. */
+int mp_device_check(int device, char *out_name, size_t name_cap);
+const char *mp_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

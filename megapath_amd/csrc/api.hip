@@ -1,0 +1,561 @@
+// megapath_amd/csrc/api.hip -- product code: the C ABI of libmegapath_hip (include/megapath_hip.h), HBM residency and
+// stage orchestration.  One translation unit: the kernels are #included so that hipcc sees a single code object.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include "mp_internal.h"
+#include "kernels_seed.hip"
+#include "kernels_dp.hip"
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    fprintf(stderr, "[megapath_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MP_ENODEV; } } while (0)
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;       // elements
+    int reserve(size_t n)
+    {
+        if (n <= cap) return MP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 64;
+        if (hipMalloc((void **)&p, want * sizeof(T)) != hipSuccess) { p = nullptr; return MP_ENOMEM; }
+        cap = want;
+        return MP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace
+
+struct mp_ctx {
+    mp_index *ix = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    // reads
+    DevBuf<uint32_t> reads, lens, scan;
+    const uint32_t *d_reads = nullptr, *d_lens = nullptr;   // either our buffers or caller-owned device memory
+    uint32_t n_reads = 0, W = 0, max_len = 0;
+    bool seeded = false;
+    // seeding
+    DevBuf<mp_sa_seed> seeds;
+    DevBuf<mp_hit_task> hit_tasks;
+    DevBuf<mp_seed_hit> hits;
+    DevBuf<mp_seedpos> seedpos;
+    DevBuf<uint32_t> hits_per_read, read_base, cursor, n_pos, n_neg;
+    DevBuf<uint8_t> cub_tmp;
+    DevBuf<mp_counters> ctr;
+    mp_seed_stats last_seed{};
+    uint64_t n_hits_total = 0;
+    // pairing + DP
+    DevBuf<mp_candidate> cands;
+    DevBuf<mp_dp_task> tasks_l, tasks_r, tasks_tmp;
+    DevBuf<mp_fill_result> fill;
+    DevBuf<mp_dp_result> res_l, res_r, res_tmp;
+    DevBuf<uint8_t> flags, ops;
+    DevBuf<mp_pair_hit> pair_hits;
+    DevBuf<unsigned long long> n_pair_hits;
+    uint64_t n_pair_hits_host = 0;
+};
+
+// ------------------------------------------------------------------------------------------------ misc
+extern "C" const char *mp_strerror(int code)
+{
+    switch (code) {
+        case MP_OK: return "ok";
+        case MP_EINVAL: return "invalid argument";
+        case MP_ENOMEM: return "out of host or device memory";
+        case MP_EIO: return "index file missing or malformed";
+        case MP_ENODEV: return "no usable HIP device / HIP runtime error";
+        case MP_ERANGE: return "input outside the supported range";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int mp_device_check(int device, char *out_name, size_t name_cap)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device || device < 0) return MP_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MP_ENODEV;
+    if (out_name && name_cap) snprintf(out_name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MP_ENODEV;   // this library carries gfx950 code only
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ index
+static int upload_index(int device, mp_host_index &h, mp_index **out)
+{
+    HIPCHK(hipSetDevice(device));
+    mp_index *ix = new (std::nothrow) mp_index();
+    if (!ix) return MP_ENOMEM;
+    ix->device = device;
+    ix->n = h.n; ix->inv_sa0 = h.inv_sa0; ix->sa_interval = h.sa_interval;
+    for (int i = 0; i < 5; i++) ix->cum[i] = h.cum[i];
+    ix->seq_names = std::move(h.seq_names); ix->seq_start = std::move(h.seq_start); ix->seq_len = std::move(h.seq_len);
+    ix->grid = std::move(h.grid); ix->translate = std::move(h.translate);
+    struct { void **dst; const void *src; size_t bytes; } parts[4] = {
+        {&ix->d_occ, h.occ.data(), h.occ.size() * sizeof(mp_occ_block)},
+        {&ix->d_lkt, h.lkt.data(), h.lkt.size() * 4},
+        {&ix->d_sa, h.sa.data(), h.sa.size() * 4},
+        {&ix->d_text, h.text.data(), h.text.size() * 4}};
+    for (auto &pt : parts) {
+        if (hipMalloc(pt.dst, pt.bytes) != hipSuccess) { mp_index_close(ix); return MP_ENOMEM; }
+        if (hipMemcpy(*pt.dst, pt.src, pt.bytes, hipMemcpyHostToDevice) != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
+        ix->device_bytes += pt.bytes;
+    }
+    ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt;
+    ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text;
+    ix->d.n = (uint32_t)h.n; ix->d.inv_sa0 = (uint32_t)h.inv_sa0; ix->d.sa_interval = h.sa_interval;
+    for (int i = 0; i < 5; i++) ix->d.cum[i] = (uint32_t)h.cum[i];
+    *out = ix;
+    return MP_OK;
+}
+
+extern "C" int mp_index_open(const char *prefix, int device, mp_index **out)
+{
+    if (!prefix || !out) return MP_EINVAL;
+    int rc = mp_device_check(device, nullptr, 0);
+    if (rc) { fprintf(stderr, "[megapath_hip] no gfx950 device %d: the HIP path cannot run (there is no CPU fallback)\n", device); return rc; }
+    mp_host_index h;
+    std::string err;
+    rc = mp_host_index_load(prefix, h, err);
+    if (rc) { fprintf(stderr, "[megapath_hip] %s\n", err.c_str()); return rc; }
+    return upload_index(device, h, out);
+}
+
+extern "C" int mp_index_from_arrays(int device, uint64_t text_length, uint64_t inverse_sa0, const uint64_t cum_freq[5],
+                                    const uint32_t *bwt_words, const uint64_t *sa_samples, uint32_t sa_interval,
+                                    const uint8_t *pac_bytes, const uint64_t *lkt, uint32_t num_seq, const char *const *seq_names,
+                                    const uint64_t *seq_starts, const uint64_t *seq_lengths, mp_index **out)
+{
+    if (!out) return MP_EINVAL;
+    int rc = mp_device_check(device, nullptr, 0);
+    if (rc) { fprintf(stderr, "[megapath_hip] no gfx950 device %d: the HIP path cannot run (there is no CPU fallback)\n", device); return rc; }
+    mp_host_index h;
+    std::string err;
+    rc = mp_host_index_from_arrays(text_length, inverse_sa0, cum_freq, bwt_words, sa_samples, sa_interval, pac_bytes, lkt,
+                                   num_seq, seq_names, seq_starts, seq_lengths, h, err);
+    if (rc) { fprintf(stderr, "[megapath_hip] %s\n", err.c_str()); return rc; }
+    return upload_index(device, h, out);
+}
+
+extern "C" int mp_index_close(mp_index *ix)
+{
+    if (!ix) return MP_OK;
+    (void)hipSetDevice(ix->device);
+    if (ix->d_occ) (void)hipFree(ix->d_occ);
+    if (ix->d_lkt) (void)hipFree(ix->d_lkt);
+    if (ix->d_sa) (void)hipFree(ix->d_sa);
+    if (ix->d_text) (void)hipFree(ix->d_text);
+    delete ix;
+    return MP_OK;
+}
+
+extern "C" int mp_index_get_info(const mp_index *ix, mp_index_info *out)
+{
+    if (!ix || !out) return MP_EINVAL;
+    out->text_length = ix->n; out->inverse_sa0 = ix->inv_sa0;
+    for (int i = 0; i < 5; i++) out->cum_freq[i] = ix->cum[i];
+    out->sa_interval = ix->sa_interval; out->num_seq = (uint32_t)ix->seq_names.size();
+    out->device_bytes = ix->device_bytes;
+    return MP_OK;
+}
+
+extern "C" const char *mp_index_seq_name(const mp_index *ix, uint32_t id)
+{
+    if (!ix || id == 0 || id > ix->seq_names.size()) return "";
+    return ix->seq_names[id - 1].c_str();
+}
+
+extern "C" int mp_index_chr_and_pos(const mp_index *ix, uint64_t amb_pos, uint64_t *out_pos, uint32_t *out_seq)
+{
+    if (!ix || !out_pos || !out_seq || ix->grid.empty()) return MP_EINVAL;
+    uint64_t g = amb_pos >> 18;                         // GRID_SAMPLING_FACTOR_2_POWER (HSP.h:68)
+    if (g >= ix->grid.size()) g = ix->grid.size() - 1;
+    uint32_t v = ix->grid[g];
+    while (v > 0 && ix->translate[v].start > amb_pos) v--;
+    *out_pos = amb_pos - ix->translate[v].corr;
+    *out_seq = ix->translate[v].chr;
+    return MP_OK;
+}
+
+template <typename F>
+static int run_query(const mp_index *ix, uint64_t n, F &&body)
+{
+    if (!ix) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    int rc = body();
+    HIPCHK(hipDeviceSynchronize());
+    return rc;
+}
+
+extern "C" int mp_index_occ(const mp_index *ix, const uint64_t *idx, const uint32_t *sym, uint64_t n, uint64_t *out)
+{
+    if (!ix || !idx || !sym || !out) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    uint64_t *d_idx, *d_out; uint32_t *d_sym;
+    HIPCHK(hipMalloc((void **)&d_idx, n * 8 + 8)); HIPCHK(hipMalloc((void **)&d_out, n * 8 + 8)); HIPCHK(hipMalloc((void **)&d_sym, n * 4 + 8));
+    HIPCHK(hipMemcpy(d_idx, idx, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_sym, sym, n * 4, hipMemcpyHostToDevice));
+    if (n) hipLaunchKernelGGL(occ_query_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, ix->d, d_idx, d_sym, n, d_out);
+    HIPCHK(hipMemcpy(out, d_out, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_idx); (void)hipFree(d_out); (void)hipFree(d_sym);
+    return MP_OK;
+}
+
+extern "C" int mp_index_sa(const mp_index *ix, const uint64_t *idx, uint64_t n, uint64_t *out)
+{
+    if (!ix || !idx || !out) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    uint64_t *d_idx, *d_out;
+    HIPCHK(hipMalloc((void **)&d_idx, n * 8 + 8)); HIPCHK(hipMalloc((void **)&d_out, n * 8 + 8));
+    HIPCHK(hipMemcpy(d_idx, idx, n * 8, hipMemcpyHostToDevice));
+    if (n) hipLaunchKernelGGL(sa_query_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, ix->d, d_idx, n, d_out);
+    HIPCHK(hipMemcpy(out, d_out, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_idx); (void)hipFree(d_out);
+    return MP_OK;
+}
+
+extern "C" int mp_index_lkt(const mp_index *ix, const uint32_t *key, uint64_t n, uint64_t *out_l, uint64_t *out_r)
+{
+    if (!ix || !key || !out_l || !out_r) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    uint32_t *d_key; uint64_t *d_l, *d_r;
+    HIPCHK(hipMalloc((void **)&d_key, n * 4 + 8)); HIPCHK(hipMalloc((void **)&d_l, n * 8 + 8)); HIPCHK(hipMalloc((void **)&d_r, n * 8 + 8));
+    HIPCHK(hipMemcpy(d_key, key, n * 4, hipMemcpyHostToDevice));
+    if (n) hipLaunchKernelGGL(lkt_query_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, ix->d, d_key, n, d_l, d_r);
+    HIPCHK(hipMemcpy(out_l, d_l, n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_r, d_r, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_key); (void)hipFree(d_l); (void)hipFree(d_r);
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ context
+extern "C" int mp_ctx_create(mp_index *ix, mp_ctx **out)
+{
+    if (!ix || !out) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    mp_ctx *c = new (std::nothrow) mp_ctx();
+    if (!c) return MP_ENOMEM;
+    c->ix = ix;
+    HIPCHK(hipStreamCreate(&c->stream));
+    for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    if (c->ctr.reserve(1) || c->n_pair_hits.reserve(1)) { mp_ctx_destroy(c); return MP_ENOMEM; }
+    *out = c;
+    return MP_OK;
+}
+
+extern "C" int mp_ctx_destroy(mp_ctx *c)
+{
+    if (!c) return MP_OK;
+    (void)hipSetDevice(c->ix->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    c->reads.release(); c->lens.release(); c->scan.release(); c->seeds.release(); c->hit_tasks.release(); c->hits.release();
+    c->seedpos.release(); c->hits_per_read.release(); c->read_base.release(); c->cursor.release(); c->n_pos.release();
+    c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
+    c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
+    c->ops.release(); c->pair_hits.release(); c->n_pair_hits.release();
+    delete c;
+    return MP_OK;
+}
+
+extern "C" int mp_set_reads(mp_ctx *c, const uint32_t *packed, uint32_t W, const uint32_t *lengths, uint32_t n_reads)
+{
+    if (!c || !packed || !lengths || W == 0 || (n_reads & 1)) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < n_reads; i++) { if (lengths[i] > mx) mx = lengths[i]; if (lengths[i] > W * 16) return MP_EINVAL; }
+    if (c->reads.reserve((size_t)n_reads * W + 16) || c->lens.reserve(n_reads + 16)) return MP_ENOMEM;
+    HIPCHK(hipMemcpyAsync(c->reads.p, packed, (size_t)n_reads * W * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->lens.p, lengths, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->d_reads = c->reads.p; c->d_lens = c->lens.p;
+    c->n_reads = n_reads; c->W = W; c->max_len = mx; c->seeded = false;
+    return MP_OK;
+}
+
+extern "C" int mp_set_reads_device(mp_ctx *c, const uint32_t *d_packed, uint32_t W, const uint32_t *d_lengths, uint32_t n_reads, uint32_t max_length)
+{
+    if (!c || !d_packed || !d_lengths || W == 0 || (n_reads & 1) || max_length > W * 16) return MP_EINVAL;
+    c->d_reads = d_packed; c->d_lens = d_lengths;
+    c->n_reads = n_reads; c->W = W; c->max_len = max_length; c->seeded = false;
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ seeding
+static mp_dev_mmp to_dev(const mp_mmp_params *p)
+{
+    mp_dev_mmp d;
+    d.sa_size_threshold = p->sa_size_threshold; d.seed_min_length = p->seed_min_length; d.uniq_threshold = p->uniq_threshold;
+    d.indel_fuzz = p->indel_fuzz; d.good_seed_len = p->good_seed_len; d.reseed_len = p->reseed_len; d.reseed_abs_diff = p->reseed_abs_diff;
+    d.reseed_rlt_ratio = p->reseed_rlt_ratio; d.short_seed_ratio = p->short_seed_ratio;
+    return d;
+}
+
+extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_stats *out_stats)
+{
+    if (!c || !params || c->n_reads == 0 || !c->d_reads) return MP_EINVAL;
+    if (params->seed_min_length < MP_LKT_K || params->sa_size_threshold < 1 || params->sa_size_threshold > 1000) return MP_ERANGE;
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t n_reads = c->n_reads, W = c->W;
+    const mp_dev_mmp P = to_dev(params);
+    hipStream_t s = c->stream;
+    if (c->scan.reserve((size_t)n_reads * 2 * (W + 1) + 16) || c->hits_per_read.reserve(n_reads + 1) || c->read_base.reserve(n_reads + 2) ||
+        c->cursor.reserve(n_reads + 1) || c->n_pos.reserve(n_reads + 1) || c->n_neg.reserve(n_reads + 1)) return MP_ENOMEM;
+    hipLaunchKernelGGL(prep_scan_kernel, dim3(grid_for((uint64_t)n_reads * 2 * (W + 1), 256)), dim3(256), 0, s, c->d_reads, c->d_lens, n_reads, W, c->scan.p);
+
+    size_t seed_cap = std::max<size_t>(c->seeds.cap, (size_t)n_reads * 8 + 1024);
+    size_t hit_cap = std::max<size_t>(c->hit_tasks.cap, (size_t)n_reads * 24 + 4096);
+    mp_counters h{};
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if (c->seeds.reserve(seed_cap) || c->hit_tasks.reserve(hit_cap)) return MP_ENOMEM;
+        HIPCHK(hipMemsetAsync(c->ctr.p, 0, sizeof(mp_counters), s));
+        HIPCHK(hipMemsetAsync(c->hits_per_read.p, 0, (size_t)(n_reads + 1) * 4, s));
+        HIPCHK(hipEventRecord(c->ev[0], s));
+        hipLaunchKernelGGL(seed_kernel, dim3(grid_for((uint64_t)n_reads * 2, 256)), dim3(256), 0, s, c->ix->d, c->scan.p, c->d_lens, n_reads, W, P,
+                           c->seeds.p, (uint32_t)c->seeds.cap, c->hit_tasks.p, (uint32_t)c->hit_tasks.cap, c->hits_per_read.p, c->ctr.p);
+        HIPCHK(hipEventRecord(c->ev[1], s));
+        HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h.overflow == 0) break;
+        seed_cap = (size_t)h.n_seeds + 1024; hit_cap = (size_t)h.n_hits + 4096;   // exact needs are known now: retry once
+        if (attempt == 2) return MP_ERANGE;
+    }
+    const uint32_t n_hits = (uint32_t)h.n_hits;
+    // per-read segments of the hit array
+    size_t tmp_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->hits_per_read.p, c->read_base.p, (int)(n_reads + 1), s);
+    if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+    (void)hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->hits_per_read.p, c->read_base.p, (int)(n_reads + 1), s);
+    if (c->hits.reserve((size_t)n_hits + 64) || c->seedpos.reserve((size_t)n_hits + 64)) return MP_ENOMEM;
+    HIPCHK(hipMemsetAsync(c->cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
+    HIPCHK(hipEventRecord(c->ev[2], s));
+    if (n_hits)
+        hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, c->ix->d, c->seeds.p, c->hit_tasks.p, n_hits, c->d_lens, P,
+                           c->read_base.p, c->cursor.p, c->hits.p, c->ctr.p);
+    HIPCHK(hipEventRecord(c->ev[3], s));
+    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, 128)), dim3(128), 0, s, c->hits.p, c->read_base.p, n_reads, P, c->seedpos.p, c->n_pos.p,
+                       c->n_neg.p, c->ctr.p);
+    HIPCHK(hipEventRecord(c->ev[4], s));
+    HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    mp_seed_stats st{};
+    st.n_occ = h.n_occ; st.n_lkt = h.n_lkt; st.n_sa = h.n_sa; st.n_seeds = h.n_seeds; st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
+    (void)hipEventElapsedTime(&st.ms_seed, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&st.ms_locate, c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&st.ms_merge, c->ev[3], c->ev[4]);
+    c->last_seed = st; c->n_hits_total = n_hits; c->seeded = true;
+    if (out_stats) *out_stats = st;
+    return MP_OK;
+}
+
+extern "C" int mp_get_seeds(mp_ctx *c, mp_seedpos *out_seeds, uint64_t cap, uint64_t *out_offsets)
+{
+    if (!c || !c->seeded || !out_offsets) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t n = c->n_reads;
+    std::vector<uint32_t> base(n + 1), np(n), nn(n);
+    HIPCHK(hipMemcpy(base.data(), c->read_base.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(np.data(), c->n_pos.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nn.data(), c->n_neg.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::vector<mp_seedpos> all(c->n_hits_total + 1);
+    if (c->n_hits_total) HIPCHK(hipMemcpy(all.data(), c->seedpos.p, (size_t)c->n_hits_total * sizeof(mp_seedpos), hipMemcpyDeviceToHost));
+    uint64_t w = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        out_offsets[r] = w;
+        uint32_t k = np[r] + nn[r];
+        if (out_seeds) {
+            if (w + k > cap) return MP_ERANGE;
+            for (uint32_t j = 0; j < k; j++) out_seeds[w + j] = all[base[r] + j];
+        }
+        w += k;
+    }
+    out_offsets[n] = w;
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ DP
+namespace {
+
+struct DpShape { int lpi, c; bool wide; };
+
+inline int pick_shape(uint32_t max_len, DpShape &s)
+{
+    // 32 lanes per instance; C columns per lane; 5 bits per cell -> 32-bit flag words up to C = 6
+    static const int cs[] = {3, 4, 5, 6, 8, 10, 12};
+    for (int c : cs) if ((uint32_t)(32 * c) >= max_len) { s.lpi = 32; s.c = c; s.wide = c > 6; return MP_OK; }
+    return MP_ERANGE;   // reads longer than 384 bases (the reference's DP limit is ~312)
+}
+
+template <int C, typename FlagT>
+void launch_fill(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, void *flags, uint32_t flag_rows, mp_fill_result *fill)
+{
+    constexpr int LPI = 32;
+    hipLaunchKernelGGL((dp_fill_kernel<LPI, C, FlagT>), dim3(grid_for(n, MP_DP_BLOCK / LPI)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens,
+                       c->W, tasks, n, cl, cr, (FlagT *)flags, flag_rows, fill);
+}
+template <int C, typename FlagT>
+void launch_trace(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, const void *flags, uint32_t flag_rows,
+                  const mp_fill_result *fill, mp_dp_result *res, uint8_t *ops, uint32_t ops_stride)
+{
+    constexpr int LPI = 32;
+    hipLaunchKernelGGL((dp_trace_kernel<LPI, C, FlagT>), dim3(grid_for(n, 64)), dim3(64), 0, s, tasks, c->d_lens, n, cl, cr, (const FlagT *)flags, flag_rows,
+                       fill, res, ops, ops_stride);
+}
+
+#define MP_DP_DISPATCH(FN, ...)                                                       \
+    switch (shape.c) {                                                                \
+        case 3: FN<3, uint32_t>(__VA_ARGS__); break;                                  \
+        case 4: FN<4, uint32_t>(__VA_ARGS__); break;                                  \
+        case 5: FN<5, uint32_t>(__VA_ARGS__); break;                                  \
+        case 6: FN<6, uint32_t>(__VA_ARGS__); break;                                  \
+        case 8: FN<8, unsigned long long>(__VA_ARGS__); break;                        \
+        case 10: FN<10, unsigned long long>(__VA_ARGS__); break;                      \
+        default: FN<12, unsigned long long>(__VA_ARGS__); break;                      \
+    }
+
+// Runs fill + traceback for device-resident tasks, chunked so that the flag slab stays bounded.
+int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res, uint8_t *d_ops,
+           uint32_t ops_stride, float *ms_fill, float *ms_trace, uint64_t *cells)
+{
+    if (n == 0) return MP_OK;
+    DpShape shape;
+    if (pick_shape(c->max_len, shape)) return MP_ERANGE;
+    if (max_win > MP_DP_MAX_WIN) return MP_ERANGE;
+    hipStream_t s = c->stream;
+    const uint32_t flag_rows = max_win + 32;
+    const size_t word = shape.wide ? 8 : 4;
+    const size_t per_inst = (size_t)flag_rows * 32 * word;
+    uint32_t chunk = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1024, (3ull << 30) / per_inst));   // <= 3 GiB of flags
+    if (c->flags.reserve((size_t)chunk * per_inst) || c->fill.reserve(chunk)) return MP_ENOMEM;
+    float tf = 0, tt = 0;
+    for (uint32_t off = 0; off < n; off += chunk) {
+        uint32_t cnt = std::min(chunk, n - off);
+        HIPCHK(hipEventRecord(c->ev[5], s));
+        MP_DP_DISPATCH(launch_fill, s, c, d_tasks + off, cnt, cl, cr, c->flags.p, flag_rows, c->fill.p);
+        HIPCHK(hipEventRecord(c->ev[6], s));
+        uint8_t *ops_here = d_ops ? d_ops + (size_t)off * ops_stride : nullptr;
+        MP_DP_DISPATCH(launch_trace, s, c, d_tasks + off, cnt, cl, cr, c->flags.p, flag_rows, c->fill.p, d_res + off, ops_here, ops_stride);
+        if (ops_here)
+            hipLaunchKernelGGL(dp_ops_fix_kernel, dim3(grid_for(cnt, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks + off, cnt,
+                               c->fill.p, d_res + off, ops_here, ops_stride);
+        HIPCHK(hipEventRecord(c->ev[7], s));
+        HIPCHK(hipStreamSynchronize(s));
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, c->ev[5], c->ev[6]);
+        (void)hipEventElapsedTime(&b, c->ev[6], c->ev[7]);
+        tf += a; tt += b;
+    }
+    if (ms_fill) *ms_fill += tf;
+    if (ms_trace) *ms_trace += tt;
+    (void)cells;
+    return MP_OK;
+}
+
+}  // namespace
+
+extern "C" int mp_sgdp_batch(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int clip_left, int clip_right, mp_dp_result *out_results,
+                             uint8_t *out_ops, uint32_t ops_stride, float *out_ms_fill, float *out_ms_trace)
+{
+    if (!c || !tasks || !out_results || !c->d_reads) return MP_EINVAL;
+    if (n == 0) return MP_OK;
+    HIPCHK(hipSetDevice(c->ix->device));
+    uint32_t max_win = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        if (tasks[t].read_id >= c->n_reads || (tasks[t].strand != 1 && tasks[t].strand != 2)) return MP_EINVAL;
+        if (tasks[t].win_len > MP_DP_MAX_WIN || tasks[t].win_start + tasks[t].win_len > c->ix->n) return MP_ERANGE;
+        max_win = std::max(max_win, tasks[t].win_len);
+    }
+    if (c->tasks_tmp.reserve(n) || c->res_tmp.reserve(n)) return MP_ENOMEM;
+    if (out_ops && c->ops.reserve((size_t)n * ops_stride + 64)) return MP_ENOMEM;
+    HIPCHK(hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, c->stream));
+    if (out_ops) HIPCHK(hipMemsetAsync(c->ops.p, 0, (size_t)n * ops_stride, c->stream));
+    float f = 0, t = 0;
+    int rc = run_dp(c, c->tasks_tmp.p, n, max_win, clip_left, clip_right, c->res_tmp.p, out_ops ? c->ops.p : nullptr, ops_stride, &f, &t, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out_results, c->res_tmp.p, (size_t)n * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
+    if (out_ops) HIPCHK(hipMemcpy(out_ops, c->ops.p, (size_t)n * ops_stride, hipMemcpyDeviceToHost));
+    if (out_ms_fill) *out_ms_fill = f;
+    if (out_ms_trace) *out_ms_trace = t;
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ deep-DP round
+extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *out_n_hits, mp_round_stats *out_stats)
+{
+    if (!c || !ap || !c->d_reads || c->n_reads == 0) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    hipStream_t s = c->stream;
+    mp_round_stats st{};
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, s));
+    int rc = MP_OK;
+    if (!c->seeded) { rc = mp_seed_batch(c, &ap->mmp, nullptr); if (rc) return rc; }
+    st.seed = c->last_seed;
+    const uint32_t n_pairs = c->n_reads / 2;
+    // ---- pairing (retry once with the exact size on overflow)
+    size_t cand_cap = std::max<size_t>(c->cands.cap, (size_t)n_pairs * 4 + 1024);
+    mp_counters h{};
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if (c->cands.reserve(cand_cap)) return MP_ENOMEM;
+        HIPCHK(hipMemsetAsync(&c->ctr.p->n_cand, 0, 2 * sizeof(unsigned long long), s));   // n_cand + overflow
+        HIPCHK(hipEventRecord(c->ev[0], s));
+        hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n_pairs, 128)), dim3(128), 0, s, c->seedpos.p, c->read_base.p, c->n_pos.p, c->n_neg.p, c->d_lens, n_pairs,
+                           ap->insert_low, ap->insert_high, c->cands.p, (uint32_t)c->cands.cap, c->ctr.p);
+        HIPCHK(hipEventRecord(c->ev[1], s));
+        HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h.overflow == 0) break;
+        cand_cap = (size_t)h.n_cand + 1024;
+        if (attempt == 2) return MP_ERANGE;
+    }
+    (void)hipEventElapsedTime(&st.ms_pair, c->ev[0], c->ev[1]);
+    const uint32_t nc = (uint32_t)h.n_cand;
+    st.n_candidates = nc; st.n_dp_left = nc;
+    c->n_pair_hits_host = 0;
+    if (nc) {
+        if (c->tasks_l.reserve(nc) || c->tasks_r.reserve(nc) || c->res_l.reserve(nc) || c->res_r.reserve(nc) || c->pair_hits.reserve(nc)) return MP_ENOMEM;
+        const uint32_t margin2 = 60;
+        const uint32_t max_win = c->max_len + margin2;
+        hipLaunchKernelGGL(build_left_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, c->tasks_l.p);
+        rc = run_dp(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(build_right_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, ap->insert_high,
+                           c->tasks_l.p, c->res_l.p, c->tasks_r.p);
+        rc = run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(c->n_pair_hits.p, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(collect_pair_hits_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,
+                           c->res_r.p, c->pair_hits.p, c->n_pair_hits.p, (uint32_t)c->pair_hits.cap);
+        unsigned long long nh = 0;
+        HIPCHK(hipMemcpyAsync(&nh, c->n_pair_hits.p, sizeof nh, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        c->n_pair_hits_host = nh;
+    }
+    st.n_pair_hits = c->n_pair_hits_host;
+    HIPCHK(hipEventRecord(t1, s));
+    HIPCHK(hipEventSynchronize(t1));
+    (void)hipEventElapsedTime(&st.ms_total, t0, t1);
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    if (out_n_hits) *out_n_hits = c->n_pair_hits_host;
+    if (out_stats) *out_stats = st;
+    return MP_OK;
+}
+
+extern "C" int mp_get_pair_hits(mp_ctx *c, mp_pair_hit *out_hits, uint64_t cap)
+{
+    if (!c || !out_hits) return MP_EINVAL;
+    if (cap < c->n_pair_hits_host) return MP_ERANGE;
+    HIPCHK(hipSetDevice(c->ix->device));
+    if (c->n_pair_hits_host) HIPCHK(hipMemcpy(out_hits, c->pair_hits.p, (size_t)c->n_pair_hits_host * sizeof(mp_pair_hit), hipMemcpyDeviceToHost));
+    return MP_OK;
+}

@@ -1,0 +1,93 @@
+// megapath_amd/csrc/mp_internal.h -- shared host/device definitions of libmegapath_hip (product code).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/megapath_hip.h"
+
+// ------------------------------------------------------------------------------------------------ HBM index layout
+// One 64-byte block per 192 BWT symbols: running counts of A,C,G,T before the block, then the symbols themselves,
+// 2 bits each, LSB-first (symbol s of the block at bits 2*(s%16) of word s/16).  One rank query = one aligned 64 B
+// load.  Counts are 32-bit: a text is < 2^32-2 bases (the reference's own per-chunk limit).
+#define MP_OCC_SYMS 192u
+struct mp_occ_block {
+    uint32_t cnt[4];
+    uint32_t bwt[12];
+};
+static_assert(sizeof(mp_occ_block) == 64, "occ block must be one 64-byte sector");
+
+#define MP_LKT_K 13
+#define MP_LKT_ENTRIES (1u << (2 * MP_LKT_K))
+
+struct mp_dev_index {          // passed by value to kernels
+    const mp_occ_block *occ;   // ceil((n+2)/192)+1 blocks
+    const uint32_t *lkt;       // 4^13 inclusive right SA bounds
+    const uint32_t *sa;        // SA[k*interval]; entry 0 unused (handled as -1, BWT.c:242)
+    const uint32_t *text;      // 2-bit text, LSB-first, 16 bases per word
+    uint32_t n;                // text length
+    uint32_t inv_sa0;
+    uint32_t cum[5];
+    uint32_t sa_interval;
+};
+
+struct mp_translate_row { uint64_t start; uint32_t chr; uint64_t corr; };
+
+struct mp_index {
+    int device = 0;
+    mp_dev_index d{};
+    void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr;
+    uint64_t device_bytes = 0;
+    uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};
+    uint32_t sa_interval = 0;
+    std::vector<std::string> seq_names;
+    std::vector<uint64_t> seq_start, seq_len;
+    std::vector<uint32_t> grid;
+    std::vector<mp_translate_row> translate;
+};
+
+// host-side staging of an index before upload
+struct mp_host_index {
+    uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};
+    uint32_t sa_interval = 0;
+    std::vector<mp_occ_block> occ;
+    std::vector<uint32_t> lkt, sa, text;
+    std::vector<std::string> seq_names;
+    std::vector<uint64_t> seq_start, seq_len;
+    std::vector<uint32_t> grid;
+    std::vector<mp_translate_row> translate;
+};
+
+// index_host.cpp
+int mp_host_index_load(const char *prefix, mp_host_index &out, std::string &err);
+int mp_host_index_from_arrays(uint64_t n, uint64_t inv_sa0, const uint64_t cum[5], const uint32_t *bwt_words,
+                              const uint64_t *sa_samples, uint32_t sa_interval, const uint8_t *pac, const uint64_t *lkt,
+                              uint32_t num_seq, const char *const *names, const uint64_t *starts, const uint64_t *lens,
+                              mp_host_index &out, std::string &err);
+
+// ------------------------------------------------------------------------------------------------ seeding records
+struct mp_sa_seed {            // SeedSAalign (DV-DPfunctions.cpp:2162-2172) + owner
+    uint32_t read_strand;      // read_id*2 + strand
+    uint32_t sa_l;
+    uint16_t query_offset;
+    uint16_t seed_len;
+    uint32_t sa_diff;
+};
+
+struct mp_seed_hit {           // SeedAlign (DV-DPfunctions.cpp:2144-2160), strand folded into the sort key
+    uint64_t offset;
+    uint16_t mult, length, qo, strand;
+};
+
+struct mp_dev_mmp {
+    int32_t sa_size_threshold, seed_min_length, uniq_threshold, indel_fuzz, good_seed_len, reseed_len, reseed_abs_diff;
+    double reseed_rlt_ratio, short_seed_ratio;
+};
+
+struct mp_counters {           // device-side event counters (one cache line)
+    unsigned long long n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos, n_cand, overflow;
+};
+
+struct mp_hit_task { uint32_t seed_slot; uint32_t k; };                         // one SA row to locate
+struct mp_candidate { uint32_t read_id_left; uint32_t pad; uint64_t pos0, pos1; }; // CandidateInfo (DV-DPfunctions.h:1233-1241)
+struct mp_fill_result { int32_t score; uint16_t row, col; uint32_t count; };    // best cell of one DP instance

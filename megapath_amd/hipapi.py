@@ -1,0 +1,283 @@
+"""ctypes mirror of include/megapath_hip.h.  No CPU fallback: if the library or a gfx950 device is missing, every
+entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmegapath_hip.so")
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class MpError(RuntimeError):
+    pass
+
+
+class MmpParams(C.Structure):
+    _fields_ = [("sa_size_threshold", C.c_int32), ("seed_min_length", C.c_int32), ("uniq_threshold", C.c_int32),
+                ("indel_fuzz", C.c_int32), ("good_seed_len", C.c_int32), ("reseed_len", C.c_int32),
+                ("reseed_rlt_ratio", C.c_double), ("reseed_abs_diff", C.c_int32), ("short_seed_ratio", C.c_double)]
+
+    @classmethod
+    def nt2(cls):
+        """[MMP] section of soap4-nt2.ini (reference soap4/soap4-nt2.ini:114-123)."""
+        return cls(30, 17, 6, 5, 27, 18, 0.7, 4, 0.5)
+
+    @classmethod
+    def human(cls):
+        """[MMP] section of soap4.ini (seed min length 22, reseed length 23)."""
+        return cls(30, 22, 6, 5, 27, 23, 0.7, 4, 0.5)
+
+
+class SeedPos(C.Structure):
+    _fields_ = [("pos", C.c_uint64), ("strand_read_id", C.c_uint32), ("paired_seed_length", C.c_uint32)]
+
+
+class SeedStats(C.Structure):
+    _fields_ = [("n_occ", C.c_uint64), ("n_lkt", C.c_uint64), ("n_sa", C.c_uint64), ("n_seeds", C.c_uint64),
+                ("n_hits", C.c_uint64), ("n_seedpos", C.c_uint64), ("ms_seed", C.c_float), ("ms_locate", C.c_float),
+                ("ms_merge", C.c_float)]
+
+
+class DpTask(C.Structure):
+    _fields_ = [("read_id", C.c_uint32), ("strand", C.c_uint32), ("win_start", C.c_uint64), ("win_len", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class DpResult(C.Structure):
+    _fields_ = [("score", C.c_int32), ("hit_loc", C.c_uint32), ("max_score_count", C.c_uint32), ("n_ops", C.c_uint32)]
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("insert_low", C.c_int32), ("insert_high", C.c_int32), ("clip_left", C.c_int32), ("clip_right", C.c_int32),
+                ("mmp", MmpParams)]
+
+
+class PairHit(C.Structure):
+    _fields_ = [("pair_id", C.c_uint32), ("left_is_mate", C.c_uint32), ("algnmt_1", C.c_uint64), ("algnmt_2", C.c_uint64),
+                ("score_1", C.c_int32), ("score_2", C.c_int32), ("start_1", C.c_uint32), ("start_2", C.c_uint32),
+                ("dplen_1", C.c_uint16), ("dplen_2", C.c_uint16), ("count_1", C.c_uint16), ("count_2", C.c_uint16)]
+
+
+class RoundStats(C.Structure):
+    _fields_ = [("seed", SeedStats), ("n_candidates", C.c_uint64), ("n_dp_left", C.c_uint64), ("n_dp_right", C.c_uint64),
+                ("n_pair_hits", C.c_uint64), ("dp_cells", C.c_uint64), ("ms_pair", C.c_float), ("ms_dp_fill", C.c_float),
+                ("ms_dp_trace", C.c_float), ("ms_total", C.c_float)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("text_length", C.c_uint64), ("inverse_sa0", C.c_uint64), ("cum_freq", C.c_uint64 * 5),
+                ("sa_interval", C.c_uint32), ("num_seq", C.c_uint32), ("device_bytes", C.c_uint64)]
+
+
+EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
+           "mp_index_chr_and_pos", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_ctx_create", "mp_ctx_destroy",
+           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
+           "mp_get_pair_hits", "mp_device_check", "mp_strerror"]
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", src])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u64p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    lib.mp_index_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.mp_index_from_arrays.argtypes = [C.c_int, C.c_uint64, C.c_uint64, u64p, vp, vp, C.c_uint32, vp, vp, C.c_uint32,
+                                         C.POINTER(C.c_char_p), vp, vp, C.POINTER(vp)]
+    lib.mp_index_close.argtypes = [vp]
+    lib.mp_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    lib.mp_index_seq_name.restype = C.c_char_p
+    lib.mp_index_seq_name.argtypes = [vp, C.c_uint32]
+    lib.mp_index_chr_and_pos.argtypes = [vp, C.c_uint64, u64p, u32p]
+    lib.mp_index_occ.argtypes = [vp, vp, vp, C.c_uint64, vp]
+    lib.mp_index_sa.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.mp_index_lkt.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    lib.mp_ctx_create.argtypes = [vp, C.POINTER(vp)]
+    lib.mp_ctx_destroy.argtypes = [vp]
+    lib.mp_set_reads.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
+    lib.mp_set_reads_device.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32]
+    lib.mp_seed_batch.argtypes = [vp, C.POINTER(MmpParams), C.POINTER(SeedStats)]
+    lib.mp_get_seeds.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.mp_sgdp_batch.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.mp_deep_dp_round.argtypes = [vp, C.POINTER(AlignParams), u64p, C.POINTER(RoundStats)]
+    lib.mp_get_pair_hits.argtypes = [vp, vp, C.c_uint64]
+    lib.mp_device_check.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    lib.mp_strerror.restype = C.c_char_p
+    lib.mp_strerror.argtypes = [C.c_int]
+    _lib = lib
+    return lib
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise MpError("%s failed: %s (%d)" % (what, load_library().mp_strerror(rc).decode(), rc))
+
+
+_CODE = np.zeros(256, dtype=np.uint8)           # INDEXFillCharMap (IndexHandler.cpp:26-46): others -> A, N -> G
+for _i, _ch in enumerate(b"ACGT"):
+    _CODE[_ch] = _i
+    _CODE[_ch + 32] = _i
+_CODE[ord("U")] = _CODE[ord("u")] = 3
+_CODE[ord("N")] = _CODE[ord("n")] = 2
+
+
+def pack_reads(seqs, max_read_length: int):
+    """Host-side read packing as appendToQueryArrays (QueryParser.cpp:184-234): truncate to max_read_length-1, map
+    characters, 2 bits per base LSB-first; each read's words contiguous.  Returns (packed[u32 n x W], lengths, W)."""
+    n = len(seqs)
+    W = (max_read_length + 15) // 16
+    packed = np.zeros((n, W), dtype=np.uint32)
+    lens = np.zeros(n, dtype=np.uint32)
+    for r, s in enumerate(seqs):
+        a = np.frombuffer(s, dtype=np.uint8)[: max_read_length - 1]
+        codes = _CODE[a].astype(np.uint32)
+        lens[r] = len(codes)
+        pad = np.zeros(W * 16, dtype=np.uint32)
+        pad[: len(codes)] = codes
+        packed[r] = (pad.reshape(W, 16) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+    return packed, lens, W
+
+
+class Index:
+    def __init__(self, prefix: str, device: int = 0):
+        lib = load_library()
+        self._h = C.c_void_p()
+        _chk(lib.mp_index_open(prefix.encode(), device, C.byref(self._h)), "mp_index_open")
+        self.info = IndexInfo()
+        _chk(lib.mp_index_get_info(self._h, C.byref(self.info)), "mp_index_get_info")
+
+    @classmethod
+    def from_arrays(cls, device, n, inv_sa0, cum, bwt_words, sa_samples, sa_interval, pac, names, starts, lengths):
+        lib = load_library()
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        cumv = (C.c_uint64 * 5)(*[int(x) for x in cum])
+        bwt_words = np.ascontiguousarray(bwt_words, dtype=np.uint32)
+        sa_samples = np.ascontiguousarray(sa_samples, dtype=np.uint64)
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+        cn = (C.c_char_p * len(names))(*[x.encode() for x in names])
+        _chk(lib.mp_index_from_arrays(device, int(n), int(inv_sa0), cumv, bwt_words.ctypes.data, sa_samples.ctypes.data,
+                                      int(sa_interval), pac.ctypes.data, None, len(names), cn, starts.ctypes.data,
+                                      lengths.ctypes.data, C.byref(self._h)), "mp_index_from_arrays")
+        self.info = IndexInfo()
+        _chk(lib.mp_index_get_info(self._h, C.byref(self.info)), "mp_index_get_info")
+        return self
+
+    def close(self):
+        if self._h:
+            load_library().mp_index_close(self._h)
+            self._h = None
+
+    def seq_name(self, seq_id: int) -> str:
+        return load_library().mp_index_seq_name(self._h, seq_id).decode()
+
+    def chr_and_pos(self, amb_pos: int):
+        p, c = C.c_uint64(), C.c_uint32()
+        _chk(load_library().mp_index_chr_and_pos(self._h, int(amb_pos), C.byref(p), C.byref(c)), "mp_index_chr_and_pos")
+        return p.value, c.value
+
+    def occ(self, idx, sym):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        sym = np.ascontiguousarray(sym, dtype=np.uint32)
+        out = np.zeros(len(idx), dtype=np.uint64)
+        _chk(load_library().mp_index_occ(self._h, idx.ctypes.data, sym.ctypes.data, len(idx), out.ctypes.data), "mp_index_occ")
+        return out
+
+    def sa(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.zeros(len(idx), dtype=np.uint64)
+        _chk(load_library().mp_index_sa(self._h, idx.ctypes.data, len(idx), out.ctypes.data), "mp_index_sa")
+        return out
+
+    def lkt(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        l = np.zeros(len(keys), dtype=np.uint64)
+        r = np.zeros(len(keys), dtype=np.uint64)
+        _chk(load_library().mp_index_lkt(self._h, keys.ctypes.data, len(keys), l.ctypes.data, r.ctypes.data), "mp_index_lkt")
+        return l, r
+
+
+class Context:
+    def __init__(self, index: Index):
+        self.index = index
+        self._h = C.c_void_p()
+        _chk(load_library().mp_ctx_create(index._h, C.byref(self._h)), "mp_ctx_create")
+        self.n_reads = 0
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            load_library().mp_ctx_destroy(self._h)
+            self._h = None
+
+    def set_reads(self, packed: np.ndarray, lens: np.ndarray):
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        self.n_reads = len(lens)
+        _chk(load_library().mp_set_reads(self._h, packed.ctypes.data, packed.shape[1], lens.ctypes.data, len(lens)), "mp_set_reads")
+
+    def set_reads_device(self, d_packed_ptr: int, W: int, d_lens_ptr: int, n_reads: int, max_len: int, keep=None):
+        self.n_reads = n_reads
+        self._keep = keep
+        _chk(load_library().mp_set_reads_device(self._h, d_packed_ptr, W, d_lens_ptr, n_reads, max_len), "mp_set_reads_device")
+
+    def seed_batch(self, params: MmpParams) -> SeedStats:
+        st = SeedStats()
+        _chk(load_library().mp_seed_batch(self._h, C.byref(params), C.byref(st)), "mp_seed_batch")
+        return st
+
+    def get_seeds(self):
+        lib = load_library()
+        off = np.zeros(self.n_reads + 1, dtype=np.uint64)
+        _chk(lib.mp_get_seeds(self._h, None, 0, off.ctypes.data), "mp_get_seeds")
+        n = int(off[-1])
+        arr = (SeedPos * max(n, 1))()
+        _chk(lib.mp_get_seeds(self._h, arr, n, off.ctypes.data), "mp_get_seeds")
+        return arr, off
+
+    def sgdp_batch(self, tasks, clip_left: int, clip_right: int, want_ops: bool = True, ops_stride: int = 0):
+        n = len(tasks)
+        arr = (DpTask * max(n, 1))(*tasks)
+        res = (DpResult * max(n, 1))()
+        ops = None
+        if want_ops:
+            if not ops_stride:
+                ops_stride = max(t.win_len for t in tasks) + 400
+            ops = np.zeros(n * ops_stride, dtype=np.uint8)
+        f, t = C.c_float(), C.c_float()
+        _chk(load_library().mp_sgdp_batch(self._h, arr, n, clip_left, clip_right, res, ops.ctypes.data if want_ops else None,
+                                          ops_stride, C.byref(f), C.byref(t)), "mp_sgdp_batch")
+        return res, ops, ops_stride, (f.value, t.value)
+
+    def deep_dp_round(self, params: AlignParams):
+        nh = C.c_uint64()
+        st = RoundStats()
+        _chk(load_library().mp_deep_dp_round(self._h, C.byref(params), C.byref(nh), C.byref(st)), "mp_deep_dp_round")
+        hits = (PairHit * max(nh.value, 1))()
+        if nh.value:
+            _chk(load_library().mp_get_pair_hits(self._h, hits, nh.value), "mp_get_pair_hits")
+        return hits, nh.value, st

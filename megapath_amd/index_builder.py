@@ -1,0 +1,186 @@
+"""2BWT index construction (the builder side of 2bwt-lib, off the hot path).
+
+Builds, from sequences of base codes, the arrays the reference's `2bwt-builder` writes to disk
+(2BWT-Builder.c:199-393, BWTConstruct.c, file layouts in SURVEY App. A): suffix array by prefix doubling with
+device-wide radix sorts (torch.sort -- plumbing, on the GPU when one is present), BWT with '$' omitted, cumulative
+frequencies, sampled SA, packed text.  The result can be handed to the HIP library directly
+(`mp_index_from_arrays`) or written out as reference-format index files (`write_index_files`), which the reference
+soap4 and this repo's loaders both read.
+
+Limits: ACGT only ('N' and other letters map to G/A as the read path does; runs of >= 10 non-ACGT letters are not
+removed as HSPParseFASTAToPacked does, HSP.c:486-527); text length < 2^31 - 2.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+
+def _device():
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def suffix_array(codes: torch.Tensor) -> torch.Tensor:
+    """Suffix array of codes + '$' ('$' smallest), length n+1, int64, on codes.device.  Prefix doubling."""
+    dev = codes.device
+    n = codes.numel()
+    assert n + 2 < 2 ** 31
+    K = 20                                              # 5^20 < 2^63: first pass ranks by 20-mers
+    sym = torch.zeros(n + 1 + K, dtype=torch.int64, device=dev)
+    sym[:n] = codes.to(torch.int64) + 1                 # '$' and everything past the end = 0
+    key = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    for t in range(K):
+        key = key * 5 + sym[t:t + n + 1]
+    del sym
+    h = K
+    while True:
+        order = torch.argsort(key, stable=False)
+        sk = key[order]
+        newgrp = torch.ones(n + 1, dtype=torch.int64, device=dev)
+        newgrp[1:] = (sk[1:] != sk[:-1]).to(torch.int64)
+        rank_sorted = torch.cumsum(newgrp, 0) - 1
+        del sk, newgrp
+        rank = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        rank[order] = rank_sorted
+        done = int(rank_sorted[-1].item()) == n
+        del rank_sorted
+        if done:
+            return order
+        del order
+        nxt = torch.zeros(n + 1, dtype=torch.int64, device=dev)      # rank of suffix i+h, 0 when it runs off the end
+        if h <= n:
+            nxt[: n + 1 - h] = rank[h:] + 1
+        key = rank * (n + 2) + nxt
+        del rank, nxt
+        h *= 2
+
+
+def build_index_arrays(seqs, sa_interval: int = 16, device=None):
+    """seqs: list of (name, uint8 array of base codes 0..3 or ASCII letters).  Returns the keyword arguments of
+    `megapath_amd.hipapi.Index.from_arrays` (host numpy arrays in the reference's file layouts)."""
+    dev = device or _device()
+    names, starts, lengths, parts = [], [], [], []
+    pos = 0
+    for name, arr in seqs:
+        a = np.asarray(arr, dtype=np.uint8)
+        if a.size and a.max() > 3:                       # ASCII
+            lut = np.zeros(256, dtype=np.uint8)
+            for i, ch in enumerate(b"ACGT"):
+                lut[ch] = i
+                lut[ch + 32] = i
+            lut[ord("U")] = lut[ord("u")] = 3
+            lut[ord("N")] = lut[ord("n")] = 2
+            a = lut[a]
+        names.append(name)
+        starts.append(pos)
+        lengths.append(len(a))
+        parts.append(a)
+        pos += len(a)
+    text = np.concatenate(parts)
+    n = len(text)
+    codes = torch.from_numpy(text).to(dev)
+    sa = suffix_array(codes)                            # n+1 entries, sa[0] == n
+    inv_sa0 = int(torch.nonzero(sa == 0)[0].item())
+    # BWT with the '$' row removed (BWT.c:605)
+    prev = sa - 1
+    keep = prev >= 0
+    bwt = codes[prev[keep]].to(torch.uint8)
+    del prev, keep
+    cnt = torch.bincount(codes.to(torch.int64), minlength=4).cpu().numpy()
+    cum = np.zeros(5, dtype=np.uint64)
+    cum[1:] = np.cumsum(cnt)
+    # 16 symbols per word, MSB first
+    nb = (n + 15) // 16 * 16
+    pad = torch.zeros(nb, dtype=torch.int64, device=dev)
+    pad[:n] = bwt.to(torch.int64)
+    shifts = (2 * (15 - torch.arange(16, device=dev, dtype=torch.int64)))
+    bwt_words = (pad.view(-1, 16) << shifts).sum(dim=1).to(torch.int64).cpu().numpy().astype(np.uint32)
+    del pad, bwt
+    samples = sa[::sa_interval].cpu().numpy().astype(np.uint64)
+    del sa
+    # .pac: 4 bases per byte, first base in bits 7-6
+    nb4 = (n + 3) // 4 * 4
+    p4 = torch.zeros(nb4, dtype=torch.int64, device=dev)
+    p4[:n] = codes.to(torch.int64)
+    sh4 = (2 * (3 - torch.arange(4, device=dev, dtype=torch.int64)))
+    pac = (p4.view(-1, 4) << sh4).sum(dim=1).to(torch.uint8).cpu().numpy()
+    pac = np.concatenate([pac, np.zeros(8, dtype=np.uint8)])
+    return dict(n=n, inv_sa0=inv_sa0, cum=cum, bwt_words=bwt_words, sa_samples=samples, sa_interval=sa_interval, pac=pac,
+                names=names, starts=np.asarray(starts, dtype=np.uint64), lengths=np.asarray(lengths, dtype=np.uint64))
+
+
+def write_index_files(prefix: str, arrs, write_lkt: bool = False) -> None:
+    """Write <prefix>.{bwt,fmv,sa,pac,ann,amb,tra} in the reference's formats so that the reference
+    soap4, the oracle and mp_index_open can all load the index.  The 512 MiB .lkt is optional (every loader in this
+    repo rebuilds it from .pac; the reference soap4 needs the file)."""
+    n = int(arrs["n"])
+    hdr = np.zeros(5, dtype=np.uint64)
+    hdr[0] = arrs["inv_sa0"]
+    hdr[1:] = arrs["cum"][1:]
+    with open(prefix + ".bwt", "wb") as f:
+        f.write(hdr.tobytes())
+        f.write(np.asarray(arrs["bwt_words"], dtype=np.uint32).tobytes())
+    # explicit occurrences (BWTConstruct.c:1229-1233; read side BWT.c:783-797)
+    bw = np.asarray(arrs["bwt_words"], dtype=np.uint32)
+    syms = ((bw[:, None] >> (2 * (15 - np.arange(16, dtype=np.uint32)))) & 3).reshape(-1)[:n].astype(np.uint8)
+    n_occ = (n + 255) // 256 + 1
+    occ = np.zeros((n_occ, 4), dtype=np.uint64)
+    for c in range(4):
+        cs = np.concatenate([[0], np.cumsum(syms == c, dtype=np.uint64)])
+        idx = np.minimum(np.arange(n_occ, dtype=np.int64) * 256, n)
+        occ[:, c] = cs[idx]
+    n_major = (n_occ + 255) // 256
+    major = occ[::256][:n_major].copy()
+    rel = (occ - np.repeat(major, 256, axis=0)[:n_occ]).astype(np.uint32)
+    n_pairs = (n_occ + 1) // 2
+    minor = np.zeros((n_pairs, 4), dtype=np.uint32)
+    relp = np.zeros((n_pairs * 2, 4), dtype=np.uint32)
+    relp[:n_occ] = rel
+    minor[:] = (relp[0::2] << 16) + (relp[1::2] & 0xFFFF)
+    with open(prefix + ".fmv", "wb") as f:
+        f.write(hdr.tobytes())
+        f.write(minor.tobytes())
+        f.write(major.astype(np.uint64).tobytes())
+    with open(prefix + ".sa", "wb") as f:
+        f.write(hdr.tobytes())
+        f.write(np.uint64(arrs["sa_interval"]).tobytes())
+        f.write(np.asarray(arrs["sa_samples"], dtype=np.uint64).tobytes())
+    pac = np.asarray(arrs["pac"], dtype=np.uint8)[: (n + 3) // 4]
+    with open(prefix + ".pac", "wb") as f:
+        f.write(pac.tobytes())
+        if n % 4 == 0:
+            f.write(b"\0")
+        f.write(bytes([n % 4]))
+    names, starts, lengths = arrs["names"], arrs["starts"], arrs["lengths"]
+    with open(prefix + ".ann", "w") as f:
+        f.write("%d %d %d\n" % (n, len(names), 11))
+        for nm, s, l in zip(names, starts, lengths):
+            f.write("0 %s\n%d %d 0\n" % (nm, int(s), int(l)))
+    with open(prefix + ".amb", "w") as f:
+        f.write("%d %d 0\n" % (n, len(names)))
+    grid = (n >> 18) + 1
+    with open(prefix + ".tra", "w") as f:
+        f.write("%d %d 0 %d\n" % (n, len(names), grid))
+        for g in range(grid):
+            last = (g << 18) + (1 << 18) - 1
+            v = 0
+            while v + 1 < len(names) and int(starts[v + 1]) <= last:
+                v += 1
+            f.write("%d\n" % v)
+        for i, s in enumerate(starts):
+            f.write("%d %d %d\n" % (int(s), i + 1, (int(s) - 1) % (1 << 64)))
+        for s, l in zip(starts, lengths):
+            f.write("%d %d\n" % (int(s), int(l)))
+    if write_lkt:
+        text = np.concatenate([((pac[:, None] >> (2 * (3 - np.arange(4, dtype=np.uint8)))) & 3).reshape(-1)[:n],
+                               np.zeros(12, dtype=np.uint8)]).astype(np.uint64)
+        key = np.zeros(n, dtype=np.uint64)
+        for t in range(13):
+            key = (key << np.uint64(2)) | text[t:t + n]
+        cnt = np.bincount(key.astype(np.int64), minlength=4 ** 13).astype(np.uint64)
+        table = np.cumsum(cnt, dtype=np.uint64)
+        with open(prefix + ".lkt", "wb") as f:
+            f.write(np.int32(13).tobytes())
+            f.write(table.tobytes())

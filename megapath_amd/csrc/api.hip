@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <new>
 #include "mp_internal.h"
@@ -39,18 +40,19 @@ inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + bl
 struct mp_ctx {
     mp_index *ix = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     // reads
     DevBuf<uint32_t> reads, lens, scan;
     const uint32_t *d_reads = nullptr, *d_lens = nullptr;   // either our buffers or caller-owned device memory
     uint32_t n_reads = 0, W = 0, max_len = 0;
     bool seeded = false;
     // seeding
-    DevBuf<mp_sa_seed> seeds;
-    DevBuf<mp_hit_task> hit_tasks;
+    DevBuf<mp_seed_rec> slabs, big_slabs;
+    DevBuf<mp_sa_seed> seeds;             // one per located hit
+    DevBuf<uint32_t> hit_row, seeds_per_rs, hits_per_rs, rs_base, overflow_rs, over_slot, n_pos, n_neg;
+    DevBuf<unsigned int> queue;
     DevBuf<mp_seed_hit> hits;
     DevBuf<mp_seedpos> seedpos;
-    DevBuf<uint32_t> hits_per_read, read_base, cursor, n_pos, n_neg;
     DevBuf<uint8_t> cub_tmp;
     DevBuf<mp_counters> ctr;
     mp_seed_stats last_seed{};
@@ -258,9 +260,9 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     (void)hipSetDevice(c->ix->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
-    c->reads.release(); c->lens.release(); c->scan.release(); c->seeds.release(); c->hit_tasks.release(); c->hits.release();
-    c->seedpos.release(); c->hits_per_read.release(); c->read_base.release(); c->cursor.release(); c->n_pos.release();
-    c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
+    c->reads.release(); c->lens.release(); c->scan.release(); c->seeds.release(); c->slabs.release(); c->big_slabs.release(); c->hits.release();
+    c->seedpos.release(); c->hit_row.release(); c->seeds_per_rs.release(); c->hits_per_rs.release(); c->rs_base.release(); c->overflow_rs.release(); c->over_slot.release();
+    c->queue.release(); c->n_pos.release(); c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
     c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
     c->ops.release(); c->pair_hits.release(); c->n_pair_hits.release();
     delete c;
@@ -304,52 +306,68 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
 {
     if (!c || !params || c->n_reads == 0 || !c->d_reads) return MP_EINVAL;
     if (params->seed_min_length < MP_LKT_K || params->sa_size_threshold < 1 || params->sa_size_threshold > 1000) return MP_ERANGE;
+    if (c->max_len > MP_SEED_BIG) return MP_ERANGE;
     HIPCHK(hipSetDevice(c->ix->device));
-    const uint32_t n_reads = c->n_reads, W = c->W;
+    const uint32_t n_reads = c->n_reads, W = c->W, n_items = 2 * n_reads;
     const mp_dev_mmp P = to_dev(params);
     hipStream_t s = c->stream;
-    if (c->scan.reserve((size_t)n_reads * 2 * (W + 1) + 16) || c->hits_per_read.reserve(n_reads + 1) || c->read_base.reserve(n_reads + 2) ||
-        c->cursor.reserve(n_reads + 1) || c->n_pos.reserve(n_reads + 1) || c->n_neg.reserve(n_reads + 1)) return MP_ENOMEM;
-    hipLaunchKernelGGL(prep_scan_kernel, dim3(grid_for((uint64_t)n_reads * 2 * (W + 1), 256)), dim3(256), 0, s, c->d_reads, c->d_lens, n_reads, W, c->scan.p);
-
-    size_t seed_cap = std::max<size_t>(c->seeds.cap, (size_t)n_reads * 8 + 1024);
-    size_t hit_cap = std::max<size_t>(c->hit_tasks.cap, (size_t)n_reads * 24 + 4096);
+    const uint32_t overflow_cap = n_items;
+    if (c->scan.reserve((size_t)n_items * (W + 1) + 16) || c->slabs.reserve((size_t)n_items * MP_SEED_SLAB) || c->seeds_per_rs.reserve(n_items + 2) ||
+        c->hits_per_rs.reserve(n_items + 2) || c->rs_base.reserve(n_items + 2) || c->overflow_rs.reserve(overflow_cap) || c->over_slot.reserve(n_items + 1) || c->queue.reserve(1) ||
+        c->n_pos.reserve(n_reads + 1) || c->n_neg.reserve(n_reads + 1)) return MP_ENOMEM;
+    hipLaunchKernelGGL(prep_scan_kernel, dim3(grid_for((uint64_t)n_items * (W + 1), 256)), dim3(256), 0, s, c->d_reads, c->d_lens, n_reads, W, c->scan.p);
+    HIPCHK(hipMemsetAsync(c->ctr.p, 0, sizeof(mp_counters), s));
+    HIPCHK(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), s));
+    HIPCHK(hipMemsetAsync(c->hits_per_rs.p + n_items, 0, 2 * sizeof(uint32_t), s));
+    // persistent grid: at most 8 blocks of 256 lanes per CU (seed_kernel holds 8 waves per SIMD)
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
+    const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * 8u);
+    HIPCHK(hipEventRecord(c->ev[0], s));
+    hipLaunchKernelGGL(seed_kernel, dim3(blocks), dim3(256), 0, s, c->ix->d, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
+                       c->hits_per_rs.p, c->overflow_rs.p, c->over_slot.p, overflow_cap, c->queue.p, c->ctr.p);
+    HIPCHK(hipEventRecord(c->ev[1], s));
     mp_counters h{};
-    for (int attempt = 0; attempt < 3; attempt++) {
-        if (c->seeds.reserve(seed_cap) || c->hit_tasks.reserve(hit_cap)) return MP_ENOMEM;
-        HIPCHK(hipMemsetAsync(c->ctr.p, 0, sizeof(mp_counters), s));
-        HIPCHK(hipMemsetAsync(c->hits_per_read.p, 0, (size_t)(n_reads + 1) * 4, s));
-        HIPCHK(hipEventRecord(c->ev[0], s));
-        hipLaunchKernelGGL(seed_kernel, dim3(grid_for((uint64_t)n_reads * 2, 256)), dim3(256), 0, s, c->ix->d, c->scan.p, c->d_lens, n_reads, W, P,
-                           c->seeds.p, (uint32_t)c->seeds.cap, c->hit_tasks.p, (uint32_t)c->hit_tasks.cap, c->hits_per_read.p, c->ctr.p);
-        HIPCHK(hipEventRecord(c->ev[1], s));
-        HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (h.overflow == 0) break;
-        seed_cap = (size_t)h.n_seeds + 1024; hit_cap = (size_t)h.n_hits + 4096;   // exact needs are known now: retry once
-        if (attempt == 2) return MP_ERANGE;
-    }
-    const uint32_t n_hits = (uint32_t)h.n_hits;
-    // per-read segments of the hit array
+    HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
+    // per-item segments of the hit array (exclusive scan; entry n_items = total)
     size_t tmp_bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->hits_per_read.p, c->read_base.p, (int)(n_reads + 1), s);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->hits_per_rs.p, c->rs_base.p, (int)(n_items + 1), s);
     if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
-    (void)hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->hits_per_read.p, c->read_base.p, (int)(n_reads + 1), s);
-    if (c->hits.reserve((size_t)n_hits + 64) || c->seedpos.reserve((size_t)n_hits + 64)) return MP_ENOMEM;
-    HIPCHK(hipMemsetAsync(c->cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
+    (void)hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->hits_per_rs.p, c->rs_base.p, (int)(n_items + 1), s);
+    uint32_t n_hits = 0;
+    HIPCHK(hipMemcpyAsync(&n_hits, c->rs_base.p + n_items, sizeof n_hits, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint32_t n_over = (uint32_t)h.overflow;
+    if (n_over > overflow_cap) return MP_ERANGE;
+    if (getenv("MP_DEBUG")) fprintf(stderr, "[megapath_hip] seed: %u items, %u overflowed the %d-seed slab, %u hits\n", n_items, n_over, MP_SEED_SLAB, n_hits);
+    HIPCHK(hipEventRecord(c->ev[8], s));
+    if (n_over) {
+        if (c->big_slabs.reserve((size_t)n_over * MP_SEED_BIG)) return MP_ENOMEM;
+        hipLaunchKernelGGL(seed_overflow_kernel, dim3(grid_for(n_over, 64)), dim3(64), 0, s, c->ix->d, c->scan.p, c->d_lens, W, P, c->overflow_rs.p, n_over,
+                           c->big_slabs.p);
+    }
+    if (c->seeds.reserve((size_t)n_hits + 64) || c->hit_row.reserve((size_t)n_hits + 64) || c->hits.reserve((size_t)n_hits + 64) ||
+        c->seedpos.reserve((size_t)n_hits + 64)) return MP_ENOMEM;
+    HIPCHK(hipEventRecord(c->ev[9], s));
     HIPCHK(hipEventRecord(c->ev[2], s));
+    hipLaunchKernelGGL(expand_hits_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, c->slabs.p, c->seeds_per_rs.p, c->rs_base.p, n_items,
+                       c->over_slot.p, c->big_slabs.p, c->seeds.p, c->hit_row.p, c->ctr.p);
     if (n_hits)
-        hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, c->ix->d, c->seeds.p, c->hit_tasks.p, n_hits, c->d_lens, P,
-                           c->read_base.p, c->cursor.p, c->hits.p, c->ctr.p);
+        hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, c->ix->d, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
+                           c->ctr.p);
     HIPCHK(hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, 128)), dim3(128), 0, s, c->hits.p, c->read_base.p, n_reads, P, c->seedpos.p, c->n_pos.p,
+    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, 128)), dim3(128), 0, s, c->hits.p, c->rs_base.p, n_reads, P, c->seedpos.p, c->n_pos.p,
                        c->n_neg.p, c->ctr.p);
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     mp_seed_stats st{};
-    st.n_occ = h.n_occ; st.n_lkt = h.n_lkt; st.n_sa = h.n_sa; st.n_seeds = h.n_seeds; st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
+    st.n_occ = h.n_occ; st.n_lkt = h.n_lkt; st.n_sa = h.n_sa; st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
+    st.n_seeds = h.n_seeds;
+    float ms_over = 0;
     (void)hipEventElapsedTime(&st.ms_seed, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&ms_over, c->ev[8], c->ev[9]);     // items redone with the full-size slab belong to K1
+    st.ms_seed += ms_over;
     (void)hipEventElapsedTime(&st.ms_locate, c->ev[2], c->ev[3]);
     (void)hipEventElapsedTime(&st.ms_merge, c->ev[3], c->ev[4]);
     c->last_seed = st; c->n_hits_total = n_hits; c->seeded = true;
@@ -362,8 +380,8 @@ extern "C" int mp_get_seeds(mp_ctx *c, mp_seedpos *out_seeds, uint64_t cap, uint
     if (!c || !c->seeded || !out_offsets) return MP_EINVAL;
     HIPCHK(hipSetDevice(c->ix->device));
     const uint32_t n = c->n_reads;
-    std::vector<uint32_t> base(n + 1), np(n), nn(n);
-    HIPCHK(hipMemcpy(base.data(), c->read_base.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> base(2 * (size_t)n + 1), np(n), nn(n);
+    HIPCHK(hipMemcpy(base.data(), c->rs_base.p, (2 * (size_t)n + 1) * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(np.data(), c->n_pos.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nn.data(), c->n_neg.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     std::vector<mp_seedpos> all(c->n_hits_total + 1);
@@ -374,7 +392,7 @@ extern "C" int mp_get_seeds(mp_ctx *c, mp_seedpos *out_seeds, uint64_t cap, uint
         uint32_t k = np[r] + nn[r];
         if (out_seeds) {
             if (w + k > cap) return MP_ERANGE;
-            for (uint32_t j = 0; j < k; j++) out_seeds[w + j] = all[base[r] + j];
+            for (uint32_t j = 0; j < k; j++) out_seeds[w + j] = all[base[2 * (size_t)r] + j];
         }
         w += k;
     }
@@ -509,7 +527,7 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         if (c->cands.reserve(cand_cap)) return MP_ENOMEM;
         HIPCHK(hipMemsetAsync(&c->ctr.p->n_cand, 0, 2 * sizeof(unsigned long long), s));   // n_cand + overflow
         HIPCHK(hipEventRecord(c->ev[0], s));
-        hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n_pairs, 128)), dim3(128), 0, s, c->seedpos.p, c->read_base.p, c->n_pos.p, c->n_neg.p, c->d_lens, n_pairs,
+        hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n_pairs, 128)), dim3(128), 0, s, c->seedpos.p, c->rs_base.p, c->n_pos.p, c->n_neg.p, c->d_lens, n_pairs,
                            ap->insert_low, ap->insert_high, c->cands.p, (uint32_t)c->cands.cap, c->ctr.p);
         HIPCHK(hipEventRecord(c->ev[1], s));
         HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));

@@ -123,124 +123,249 @@ __global__ void prep_scan_kernel(const uint32_t *reads, const uint32_t *lens, ui
 }
 
 // ------------------------------------------------------------------------------------------------ K1
-__global__ void __launch_bounds__(256)
-seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t n_reads,
-            uint32_t W, mp_dev_mmp P, mp_sa_seed *__restrict__ seeds, uint32_t seed_cap, mp_hit_task *__restrict__ hit_tasks,
-            uint32_t hit_cap, uint32_t *__restrict__ hits_per_read, mp_counters *ctr)
+// Persistent lanes: every lane pulls (read, strand) items from one queue until it is empty, so a wavefront never idles
+// behind its slowest read.  One trip of the loop issues at most one LKT lookup and one pair of rank queries per lane,
+// whatever mix of states the 64 lanes are in, which keeps the number of serialised memory waits per trip at two.
+// Seeds go to a fixed slab of MP_SEED_SLAB records per (read, strand) -- no atomics on the hot path; the rare item with
+// more seeds is listed in `overflow_rs` and redone by seed_overflow_kernel with a full-size slab.
+#define MP_SEED_SLAB 8
+
+struct mp_seed_rec { uint32_t sa_l; uint16_t query_offset, seed_len; uint32_t sa_diff; };   // 12 bytes
+
+// rank_c at k1 and k2 with a single block load when both fall into the same 64-byte block (narrow SA ranges do)
+__device__ __forceinline__ void mp_occ_pair(const mp_dev_index &ix, uint32_t k1, uint32_t k2, uint32_t c, uint32_t &o1, uint32_t &o2)
 {
-    const uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
+    k1 -= (k1 > ix.inv_sa0);
+    k2 -= (k2 > ix.inv_sa0);
+    const uint32_t b1 = k1 / MP_OCC_SYMS, off1 = k1 - b1 * MP_OCC_SYMS;
+    const uint32_t b2 = k2 / MP_OCC_SYMS, off2 = k2 - b2 * MP_OCC_SYMS;
+    const uint32_t pat = c * 0x55555555u;
+    const uint4 *p = reinterpret_cast<const uint4 *>(ix.occ + b1);
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    uint32_t w[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    uint32_t cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
+    uint32_t a = cnt;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { int ns = (int)off1 - 16 * i; if (ns > 0) a += mp_popc_sym(w[i], pat, ns); }
+    o1 = a;
+    if (b2 != b1) {
+        const uint4 *pp = reinterpret_cast<const uint4 *>(ix.occ + b2);
+        q0 = pp[0]; q1 = pp[1]; q2 = pp[2]; q3 = pp[3];
+        w[0] = q1.x; w[1] = q1.y; w[2] = q1.z; w[3] = q1.w; w[4] = q2.x; w[5] = q2.y; w[6] = q2.z; w[7] = q2.w;
+        w[8] = q3.x; w[9] = q3.y; w[10] = q3.z; w[11] = q3.w;
+        cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
+    }
+    uint32_t bsum = cnt;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { int ns = (int)off2 - 16 * i; if (ns > 0) bsum += mp_popc_sym(w[i], pat, ns); }
+    o2 = bsum;
+}
+
+// State of one (read, strand) backward search -- the variables of mmp<0>/mmp<2> (DV-DPfunctions.cpp:2224-2377)
+struct mp_mmp_state {
+    const uint32_t *sc;     // scan-order bases of this item
+    uint32_t rs;
+    int len, strand, i, seed_len;
+    uint32_t l, r, last_l, last_r, last_seed_len;
+    uint32_t cur_w, cur_word;
+    uint32_t n_seeds, n_hits;
+};
+
+template <int SLAB>
+__device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp &P, uint32_t n, int x, mp_seed_rec *slab)
+{
+    // CHECK_AND_ADD_RANGE (DV-DPfunctions.cpp:2197-2219)
+    int diff = 0;
+    if (s.seed_len >= P.seed_min_length) {
+        // reseed to the last shorter seed whose SA range was larger; comparisons unsigned as in the reference
+        if (s.seed_len >= P.reseed_len && (uint64_t)s.last_r - s.last_l + 1 <= (uint64_t)P.sa_size_threshold &&
+            ((uint64_t)(uint32_t)s.seed_len - s.last_seed_len <= (uint64_t)P.reseed_abs_diff ||
+             s.seed_len * P.reseed_rlt_ratio < (double)s.last_seed_len)) {
+            diff = s.seed_len - (int)s.last_seed_len;
+            s.l = s.last_l; s.r = s.last_r; s.seed_len = (int)s.last_seed_len;
+        }
+        const uint32_t sa_diff = (s.r - s.l) < (uint32_t)P.sa_size_threshold ? (s.r - s.l) : (uint32_t)P.sa_size_threshold;
+        if (s.n_seeds < (uint32_t)SLAB) {
+            mp_seed_rec rec;
+            rec.sa_l = s.l; rec.query_offset = (uint16_t)(x & 1023); rec.seed_len = (uint16_t)s.seed_len; rec.sa_diff = sa_diff;
+            slab[s.n_seeds] = rec;
+        }
+        s.n_seeds++;
+        s.n_hits += sa_diff + 1;
+    }
+    s.i -= diff;
+    s.i -= s.seed_len < P.seed_min_length ? s.seed_len : P.seed_min_length;
+    s.l = 0; s.r = n; s.seed_len = 0;
+    s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
+}
+
+// Runs one item to completion or for one trip.  Returns true when the item is finished.
+template <int SLAB>
+__device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev_mmp &P, mp_mmp_state &s, mp_seed_rec *slab,
+                                            uint32_t &my_occ, uint32_t &my_lkt)
+{
+    const uint32_t n = ix.n;
+    bool finished = false;
+    // ---- at most one LKT (re)start
+    if (s.seed_len == 0) {
+        if (s.len - s.i < P.seed_min_length) {
+            finished = true;                                  // `break` of the scan loop
+        } else {
+            const uint32_t wq = (uint32_t)s.i >> 4, sh = 2 * ((uint32_t)s.i & 15);
+            const uint64_t two = ((uint64_t)s.sc[wq + 1] << 32) | s.sc[wq];
+            const uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
+            const uint32_t nextl = key ? ix.lkt[key - 1] + 1 : 1;
+            const uint32_t nextr = ix.lkt[key];
+            my_lkt++;
+            s.i += MP_LKT_K - 1;
+            s.seed_len = MP_LKT_K - 1;
+            if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
+            else mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
+            ++s.i;
+            if (s.i >= s.len) finished = true;
+        }
+    }
+    // ---- at most one backward extension
+    if (!finished && s.seed_len > 0) {
+        const uint32_t wq = (uint32_t)s.i >> 4;
+        if (wq != s.cur_w) { s.cur_w = wq; s.cur_word = s.sc[wq]; }
+        const uint32_t c = (s.cur_word >> (2 * ((uint32_t)s.i & 15))) & 3u;
+        uint32_t o1, o2;
+        mp_occ_pair(ix, s.l, s.r + 1, c, o1, o2);
+        my_occ += 2;
+        const uint32_t nextl = ix.cum[c] + o1 + 1, nextr = ix.cum[c] + o2;
+        if (nextl <= nextr) {
+            if (s.seed_len >= P.seed_min_length && nextr - nextl < s.r - s.l) { s.last_r = s.r; s.last_l = s.l; s.last_seed_len = (uint32_t)s.seed_len; }
+            s.l = nextl; s.r = nextr; ++s.seed_len;
+        } else {
+            mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
+        }
+        ++s.i;
+        if (s.i >= s.len) finished = true;
+    }
+    if (finished) mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? 0 : s.len - s.seed_len, slab);
+    return finished;
+}
+
+__device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *scan, const uint32_t *lens, uint32_t W, uint32_t rs, uint32_t n)
+{
+    s.sc = scan + (uint64_t)rs * (W + 1);
+    s.rs = rs; s.len = (int)lens[rs >> 1]; s.strand = (int)(rs & 1);
+    s.i = 0; s.seed_len = 0; s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
+    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0;
+}
+
+__global__ void __launch_bounds__(256)
+seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t n_items, uint32_t W, mp_dev_mmp P,
+            mp_seed_rec *__restrict__ slabs, uint32_t *__restrict__ seeds_per_rs, uint32_t *__restrict__ hits_per_rs,
+            uint32_t *__restrict__ overflow_rs, uint32_t *__restrict__ over_slot, uint32_t overflow_cap, unsigned int *queue, mp_counters *ctr)
+{
+    const int lane = threadIdx.x & (MP_WAVE - 1);
     uint32_t my_occ = 0, my_lkt = 0;
-    if (rs < n_reads * 2) {
-        const uint32_t W2 = W + 1;
-        const uint32_t *sc = scan + (uint64_t)rs * W2;
-        const int len = (int)lens[rs >> 1];
-        const int strand = (int)(rs & 1);
-        const uint32_t n = ix.n;
-        int i, seed_len = 0;
-        uint32_t l = 0, r = n, nextl = 0, nextr = 0;
-        uint32_t last_l = 0, last_r = n, last_seed_len = 0;
-        uint32_t cur_w = 0xFFFFFFFFu, cur_word = 0;
-
-        auto close_seed = [&](int x) {
-            int diff = 0;
-            if (seed_len >= P.seed_min_length) {
-                // reseed to the last shorter seed whose SA range was larger (DV-DPfunctions.cpp:2200-2205); all
-                // comparisons are unsigned as in the reference (int vs unsigned long long operands)
-                if (seed_len >= P.reseed_len && (uint64_t)last_r - last_l + 1 <= (uint64_t)P.sa_size_threshold &&
-                    ((uint64_t)(uint32_t)seed_len - last_seed_len <= (uint64_t)P.reseed_abs_diff ||
-                     seed_len * P.reseed_rlt_ratio < (double)last_seed_len)) {
-                    diff = seed_len - (int)last_seed_len;
-                    l = last_l; r = last_r; seed_len = (int)last_seed_len;
-                }
-                uint32_t sa_diff = (r - l) < (uint32_t)P.sa_size_threshold ? (r - l) : (uint32_t)P.sa_size_threshold;
-                uint32_t nh = sa_diff + 1;
-                if ((uint32_t)P.sa_size_threshold + 1 < nh) nh = (uint32_t)P.sa_size_threshold + 1;
-                uint32_t slot = (uint32_t)atomicAdd(&ctr->n_seeds, 1ull);
-                uint32_t hbase = (uint32_t)atomicAdd(&ctr->n_hits, (unsigned long long)nh);
-                if (slot < seed_cap && hbase + nh <= hit_cap) {
-                    mp_sa_seed s;
-                    s.read_strand = rs; s.sa_l = l; s.query_offset = (uint16_t)(x & 1023); s.seed_len = (uint16_t)seed_len; s.sa_diff = sa_diff;
-                    seeds[slot] = s;
-                    for (uint32_t j = 0; j < nh; j++) { mp_hit_task t; t.seed_slot = slot; t.k = l + j; hit_tasks[hbase + j] = t; }
-                    atomicAdd(&hits_per_read[rs >> 1], nh);
-                } else {
-                    atomicAdd(&ctr->overflow, 1ull);
-                }
-            }
-            i -= diff;
-            i -= seed_len < P.seed_min_length ? seed_len : P.seed_min_length;
-            l = 0; r = n; seed_len = 0;
-            last_l = 0; last_r = n; last_seed_len = 0;
-        };
-
-        for (i = 0; i < len; ++i) {
-            if (seed_len == 0) {
-                if (len - i < P.seed_min_length) break;
-                // 13-mer key: scan position i in the low bits, i+12 (the leftmost text base) in bits 25:24
-                uint32_t wq = (uint32_t)i >> 4, sh = 2 * ((uint32_t)i & 15);
-                uint64_t two = ((uint64_t)sc[wq + 1] << 32) | sc[wq];
-                uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
-                nextl = key ? ix.lkt[key - 1] + 1 : 1;
-                nextr = ix.lkt[key];
-                my_lkt++;
-                i += MP_LKT_K - 1;
-                seed_len = MP_LKT_K - 1;
-            } else {
-                uint32_t wq = (uint32_t)i >> 4;
-                if (wq != cur_w) { cur_w = wq; cur_word = sc[wq]; }
-                uint32_t c = (cur_word >> (2 * ((uint32_t)i & 15))) & 3u;
-                nextl = ix.cum[c] + mp_occ(ix, l, c) + 1;
-                nextr = ix.cum[c] + mp_occ(ix, r + 1, c);
-                my_occ += 2;
-            }
-            if (nextl <= nextr) {
-                if (seed_len >= P.seed_min_length && nextr - nextl < r - l) { last_r = r; last_l = l; last_seed_len = (uint32_t)seed_len; }
-                l = nextl; r = nextr; ++seed_len;
-            } else {
-                close_seed(strand == 0 ? len - i : i - seed_len);
+    mp_mmp_state s;
+    bool have = false;
+    for (;;) {
+        // ---- refill: lanes without an item take the next ones from the queue, one atomic per wavefront
+        const unsigned long long need = __ballot(!have);
+        if (need) {
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)need) - 1;
+            if (lane == leader) base = atomicAdd(queue, (unsigned int)__popcll(need));
+            base = __shfl(base, leader);
+            if (!have) {
+                const uint32_t rs = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (rs < n_items) { mp_mmp_begin(s, scan, lens, W, rs, ix.n); have = true; }
             }
         }
-        close_seed(strand == 0 ? 0 : len - seed_len);
+        if (!__any(have)) break;                              // queue drained and every lane idle
+        if (have) {
+            mp_seed_rec *slab = slabs + (uint64_t)s.rs * MP_SEED_SLAB;
+            if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, my_occ, my_lkt)) {
+                seeds_per_rs[s.rs] = s.n_seeds;
+                hits_per_rs[s.rs] = s.n_hits;
+                if (s.n_seeds > MP_SEED_SLAB) {
+                    uint32_t slot = (uint32_t)atomicAdd(&ctr->overflow, 1ull);
+                    if (slot < overflow_cap) { overflow_rs[slot] = s.rs; over_slot[s.rs] = slot; }
+                }
+                have = false;
+            }
+        }
     }
-    // one counter update per wave
     for (int o = MP_WAVE / 2; o > 0; o >>= 1) { my_occ += __shfl_down(my_occ, o); my_lkt += __shfl_down(my_lkt, o); }
-    if ((threadIdx.x & (MP_WAVE - 1)) == 0) {
+    if (lane == 0) {
         if (my_occ) atomicAdd(&ctr->n_occ, (unsigned long long)my_occ);
         if (my_lkt) atomicAdd(&ctr->n_lkt, (unsigned long long)my_lkt);
     }
 }
 
+// Items with more than MP_SEED_SLAB seeds (repeat-rich or heavily mutated reads): redone with a slab that can hold the
+// theoretical maximum of one seed per scan position.  Their rank queries were already counted by seed_kernel.
+#define MP_SEED_BIG 320
+__global__ void __launch_bounds__(64)
+seed_overflow_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t W, mp_dev_mmp P,
+                     const uint32_t *__restrict__ overflow_rs, uint32_t n_over, mp_seed_rec *__restrict__ big_slabs)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_over) return;
+    mp_mmp_state s;
+    mp_mmp_begin(s, scan, lens, W, overflow_rs[t], ix.n);
+    uint32_t a = 0, b = 0;
+    mp_seed_rec *slab = big_slabs + (uint64_t)t * MP_SEED_BIG;
+    while (!mp_mmp_trip<MP_SEED_BIG>(ix, P, s, slab, a, b)) {}
+}
+
 // ------------------------------------------------------------------------------------------------ K2
+// expand: one lane per (read, strand) lists the SA rows of its seeds as locate tasks at rs_base[rs]..  (no atomics:
+// every hit has a fixed, input-determined slot, so the whole seed stage is run-to-run deterministic)
 __global__ void __launch_bounds__(256)
-locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const mp_hit_task *__restrict__ tasks, uint32_t n_tasks,
-              const uint32_t *__restrict__ lens, mp_dev_mmp P, const uint32_t *__restrict__ read_base, uint32_t *__restrict__ cursor,
-              mp_seed_hit *__restrict__ hits, mp_counters *ctr)
+expand_hits_kernel(const mp_seed_rec *__restrict__ slabs, const uint32_t *__restrict__ seeds_per_rs, const uint32_t *__restrict__ rs_base,
+                   uint32_t n_items, const uint32_t *__restrict__ over_slot, const mp_seed_rec *__restrict__ big_slabs,
+                   mp_sa_seed *__restrict__ seeds_out /* one per hit */, uint32_t *__restrict__ hit_row, mp_counters *ctr)
+{
+    const uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ns = rs < n_items ? seeds_per_rs[rs] : 0;
+    uint32_t tot = ns;
+    for (int o = MP_WAVE / 2; o > 0; o >>= 1) tot += __shfl_down(tot, o);
+    if ((threadIdx.x & (MP_WAVE - 1)) == 0 && tot) atomicAdd(&ctr->n_seeds, (unsigned long long)tot);
+    if (ns == 0) return;
+    const mp_seed_rec *src = slabs + (uint64_t)rs * MP_SEED_SLAB;
+    if (ns > MP_SEED_SLAB) src = big_slabs + (uint64_t)over_slot[rs] * MP_SEED_BIG;
+    uint32_t w = rs_base[rs];
+    for (uint32_t j = 0; j < ns; j++) {
+        const mp_seed_rec rec = src[j];
+        mp_sa_seed s;
+        s.read_strand = rs; s.sa_l = rec.sa_l; s.query_offset = rec.query_offset; s.seed_len = rec.seed_len; s.sa_diff = rec.sa_diff;
+        for (uint32_t k = 0; k <= rec.sa_diff; k++) { seeds_out[w] = s; hit_row[w] = rec.sa_l + k; w++; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint32_t *__restrict__ hit_row, uint32_t n_tasks,
+              const uint32_t *__restrict__ lens, mp_dev_mmp P, mp_seed_hit *__restrict__ hits, mp_counters *ctr)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t my_occ = 0;
     if (t < n_tasks) {
-        mp_hit_task task = tasks[t];
-        mp_sa_seed s = seeds[task.seed_slot];
-        uint32_t read = s.read_strand >> 1, strand = s.read_strand & 1;
-        uint32_t len = lens[read];
+        const mp_sa_seed s = seeds[t];
+        const uint32_t read = s.read_strand >> 1, strand = s.read_strand & 1;
+        const uint32_t len = lens[read];
         uint32_t steps;
-        uint64_t sav = mp_sa_value(ix, task.k, &steps);
+        const uint64_t sav = mp_sa_value(ix, hit_row[t], &steps);
         my_occ = steps;
-        uint32_t off = s.query_offset, seedlen = s.seed_len;
+        const uint32_t off = s.query_offset, seedlen = s.seed_len;
         // unsigned 64-bit arithmetic: the projection may wrap exactly as in the reference (DV-DPfunctions.cpp:2489)
-        uint64_t target = strand == 0 ? sav - off : sav - ((uint64_t)len - seedlen - off);
+        const uint64_t target = strand == 0 ? sav - off : sav - ((uint64_t)len - seedlen - off);
         mp_seed_hit h;
         h.offset = target;
         h.length = (uint16_t)seedlen;
         h.qo = (uint16_t)off;
         h.strand = (uint16_t)strand;
         h.mult = (seedlen >= (uint32_t)P.good_seed_len || seedlen >= len / 2) ? (uint16_t)1 : (uint16_t)(s.sa_diff + 1);
-        uint32_t slot = read_base[read] + atomicAdd(&cursor[read], 1u);
-        hits[slot] = h;
+        hits[t] = h;
     }
     for (int o = MP_WAVE / 2; o > 0; o >>= 1) my_occ += __shfl_down(my_occ, o);
     if ((threadIdx.x & (MP_WAVE - 1)) == 0 && my_occ) atomicAdd(&ctr->n_occ, (unsigned long long)my_occ);
-    if (t == 0) atomicAdd(&ctr->n_sa, (unsigned long long)n_tasks);
+    if (t == 0) { atomicAdd(&ctr->n_sa, (unsigned long long)n_tasks); atomicAdd(&ctr->n_hits, (unsigned long long)n_tasks); }
 }
 
 // ------------------------------------------------------------------------------------------------ K3
@@ -289,13 +414,13 @@ __device__ void sort_hits(mp_seed_hit *a, int n)
 
 // Output: seedpos[read_base[r] .. ) holds the kept seeds of read r, '+' first; n_pos[r], n_neg[r] their counts.
 __global__ void __launch_bounds__(128)
-merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ read_base, uint32_t n_reads, mp_dev_mmp P,
+merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P,
              mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    const uint32_t base = read_base[r];
-    const int n = (int)(read_base[r + 1] - base);
+    const uint32_t base = rs_base[2 * r];
+    const int n = (int)(rs_base[2 * r + 2] - base);
     mp_seed_hit *h = hits + base;
     mp_seedpos *out = seedpos + base;
     sort_hits(h, n);
@@ -358,7 +483,7 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ read_b
 __device__ __forceinline__ int mp_margin(int l) { return l > 100 ? 30 : 25; }
 
 __global__ void __launch_bounds__(128)
-pair_kernel(const mp_seedpos *__restrict__ seedpos, const uint32_t *__restrict__ read_base, const uint32_t *__restrict__ n_pos,
+pair_kernel(const mp_seedpos *__restrict__ seedpos, const uint32_t *__restrict__ rs_base, const uint32_t *__restrict__ n_pos,
             const uint32_t *__restrict__ n_neg, const uint32_t *__restrict__ lens, uint32_t n_pairs, int insert_low, int insert_high,
             mp_candidate *__restrict__ cands, uint32_t cand_cap, mp_counters *ctr)
 {
@@ -367,9 +492,9 @@ pair_kernel(const mp_seedpos *__restrict__ seedpos, const uint32_t *__restrict__
     for (int leg = 0; leg < 2; leg++) {
         // leg 0: read '+' with mate '-' (readIDLeft even); leg 1: mate '+' with read '-' (readIDLeft odd)
         const uint32_t lft = 2 * p + (uint32_t)leg, rgt = lft ^ 1u;
-        const mp_seedpos *L = seedpos + read_base[lft];
+        const mp_seedpos *L = seedpos + rs_base[2 * lft];
         const int nl = (int)n_pos[lft];
-        const mp_seedpos *R = seedpos + read_base[rgt] + n_pos[rgt];
+        const mp_seedpos *R = seedpos + rs_base[2 * rgt] + n_pos[rgt];
         const int nr = (int)n_neg[rgt];
         if (nl == 0 || nr == 0) continue;
         const int rlen = (int)lens[rgt];                     // length of the right-leg read (DV-DPfunctions.cpp:2030)

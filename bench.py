@@ -179,6 +179,10 @@ def main():
         log("[bench] genome %.0f Mbp: suffix sort + BWT %.1fs, HBM re-layout + upload %.1fs, index %.2f GB in HBM"
             % (args.genome_mbp, t1 - t0, t2 - t1, gix.info.device_bytes / 1e9))
     torch.cuda.empty_cache()
+    g_ms, g_bytes = gix.bench_gather64()
+    gather_gbs = g_bytes / (g_ms * 1e-3) / 1e9
+    if rank == 0:
+        log("[bench] random 64-B gather ceiling over the rank blocks: %.0f GB/s" % gather_gbs)
 
     P = args.pairs_per_step
     W = (args.read_len + 1 + 15) // 16
@@ -240,6 +244,7 @@ def main():
                        "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750},
             "roofline": {"bound": "hbm", "kernel": "seed_kernel+locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "random64_gather_ceiling_gbs": gather_gbs, "frac_of_gather_ceiling": achieved / gather_gbs,
                          "algorithmic_bytes_per_pair": b_seed / (K * P), "launch_ms": (acc["seed"] + acc["locate"]) / K},
             "kernel_ms_per_step": kernel_ms,
             "events_per_pair": {"occ": acc["occ"] / (K * P), "lkt": acc["lkt"] / (K * P), "sa": acc["sa"] / (K * P),

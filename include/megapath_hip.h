@@ -54,6 +54,7 @@ int mp_index_get_info(const mp_index *ix, mp_index_info *out);
 const char *mp_index_seq_name(const mp_index *ix, uint32_t seq_id_1based);
 /* getChrAndPos (BGS-IO.cpp:163-188): packed position -> (1-based position in sequence, 1-based sequence id) */
 int mp_index_chr_and_pos(const mp_index *ix, uint64_t amb_pos, uint64_t *out_pos, uint32_t *out_seq_id);
+int mp_index_chr_and_pos_batch(const mp_index *ix, const uint64_t *amb_pos, uint64_t n, uint64_t *out_pos, uint32_t *out_seq_id);
 
 /* Unit-level device queries (tests; mirror BWTOccValue BWT.c:597, BWTSaValue BWT.c:968, LKT use at
  * DV-DPfunctions.cpp:2245-2246). All arrays are host pointers; n entries each. */
@@ -155,6 +156,11 @@ typedef struct {
  * context until the next call; *out_n_hits receives their number. */
 int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n_hits, mp_round_stats *out_stats);
 int mp_get_pair_hits(mp_ctx *ctx, mp_pair_hit *out_hits, uint64_t cap);
+
+/* Measurement aid: `lanes` lanes each load `per_lane` random 64-byte rank blocks (independent loads); reports the mean
+ * launch time and the exact bytes one launch requests.  This is the random-64 B-gather ceiling the seed stage is priced
+ * against and the calibration workload for the FETCH_SIZE counter. */
+int mp_bench_gather64(const mp_index *ix, uint32_t lanes, uint32_t per_lane, uint32_t repeats, float *out_ms, uint64_t *out_bytes);
 
 /* Library / device probe: fails loudly (MP_ENODEV) when no gfx950 device is usable. */
 int mp_device_check(int device, char *out_name, size_t name_cap);

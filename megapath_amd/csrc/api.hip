@@ -190,6 +190,16 @@ extern "C" int mp_index_chr_and_pos(const mp_index *ix, uint64_t amb_pos, uint64
     return MP_OK;
 }
 
+extern "C" int mp_index_chr_and_pos_batch(const mp_index *ix, const uint64_t *amb_pos, uint64_t n, uint64_t *out_pos, uint32_t *out_seq)
+{
+    if (!ix || !amb_pos || !out_pos || !out_seq) return MP_EINVAL;
+    for (uint64_t i = 0; i < n; i++) {
+        int rc = mp_index_chr_and_pos(ix, amb_pos[i], &out_pos[i], &out_seq[i]);
+        if (rc) return rc;
+    }
+    return MP_OK;
+}
+
 template <typename F>
 static int run_query(const mp_index *ix, uint64_t n, F &&body)
 {
@@ -236,6 +246,25 @@ extern "C" int mp_index_lkt(const mp_index *ix, const uint32_t *key, uint64_t n,
     if (n) hipLaunchKernelGGL(lkt_query_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, ix->d, d_key, n, d_l, d_r);
     HIPCHK(hipMemcpy(out_l, d_l, n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_r, d_r, n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_key); (void)hipFree(d_l); (void)hipFree(d_r);
+    return MP_OK;
+}
+
+extern "C" int mp_bench_gather64(const mp_index *ix, uint32_t lanes, uint32_t per_lane, uint32_t repeats, float *out_ms, uint64_t *out_bytes)
+{
+    if (!ix || !out_ms || !out_bytes || lanes == 0 || per_lane == 0 || repeats == 0) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    uint32_t *sink; hipEvent_t a, b;
+    HIPCHK(hipMalloc((void **)&sink, 64)); HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    const uint32_t n_blocks = (uint32_t)((ix->n + 2) / MP_OCC_SYMS + 1);
+    hipLaunchKernelGGL(gather64_kernel, dim3(grid_for(lanes, 256)), dim3(256), 0, 0, ix->d, n_blocks, per_lane, 1u, sink);   // warm-up
+    HIPCHK(hipEventRecord(a, 0));
+    for (uint32_t r = 0; r < repeats; r++)
+        hipLaunchKernelGGL(gather64_kernel, dim3(grid_for(lanes, 256)), dim3(256), 0, 0, ix->d, n_blocks, per_lane, 77u + r, sink);
+    HIPCHK(hipEventRecord(b, 0)); HIPCHK(hipEventSynchronize(b));
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+    *out_ms = ms / repeats;
+    *out_bytes = (uint64_t)grid_for(lanes, 256) * 256ull * per_lane * 64ull;
+    (void)hipFree(sink); (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     return MP_OK;
 }
 

@@ -93,6 +93,25 @@ __global__ void lkt_query_kernel(mp_dev_index ix, const uint32_t *key, uint64_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ calibration
+// Random 64-byte gathers over the rank blocks with a known byte count: the ceiling the seed stage is priced against
+// ("measured random-64 B-gather ceiling") and the calibration of the FETCH_SIZE counter for this access shape.
+// Each lane issues `per_lane` independent block loads (4 x dwordx4 each, like a rank query) at hashed block indices.
+__global__ void __launch_bounds__(256)
+gather64_kernel(mp_dev_index ix, uint32_t n_blocks, uint32_t per_lane, uint32_t seed, uint32_t *sink)
+{
+    uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + seed;
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < per_lane; i++) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        const uint32_t b = (uint32_t)(((uint64_t)x * n_blocks) >> 32);
+        const uint4 *p = reinterpret_cast<const uint4 *>(ix.occ + b);
+        uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        acc += q0.x ^ q1.y ^ q2.z ^ q3.w;
+    }
+    if (acc == 0x12345u) sink[0] = acc;      // keeps the loads alive
+}
+
 // ------------------------------------------------------------------------------------------------ scan-order reads
 // scan[(read*2+strand)*W2 + w]: the read's bases in the order the strand's backward search consumes them
 // (strand 0: right-to-left; strand 1: left-to-right, complemented), LSB-first, zero padded.  W2 = W + 1 words so that a

@@ -78,9 +78,9 @@ class IndexInfo(C.Structure):
 
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
-           "mp_index_chr_and_pos", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_ctx_create", "mp_ctx_destroy",
+           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_ctx_create", "mp_ctx_destroy",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
-           "mp_get_pair_hits", "mp_device_check", "mp_strerror"]
+           "mp_get_pair_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
 
 
 def build_library(force: bool = False) -> str:
@@ -111,6 +111,7 @@ def load_library():
     lib.mp_index_seq_name.restype = C.c_char_p
     lib.mp_index_seq_name.argtypes = [vp, C.c_uint32]
     lib.mp_index_chr_and_pos.argtypes = [vp, C.c_uint64, u64p, u32p]
+    lib.mp_index_chr_and_pos_batch.argtypes = [vp, vp, C.c_uint64, vp, vp]
     lib.mp_index_occ.argtypes = [vp, vp, vp, C.c_uint64, vp]
     lib.mp_index_sa.argtypes = [vp, vp, C.c_uint64, vp]
     lib.mp_index_lkt.argtypes = [vp, vp, C.c_uint64, vp, vp]
@@ -123,6 +124,7 @@ def load_library():
     lib.mp_sgdp_batch.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mp_deep_dp_round.argtypes = [vp, C.POINTER(AlignParams), u64p, C.POINTER(RoundStats)]
     lib.mp_get_pair_hits.argtypes = [vp, vp, C.c_uint64]
+    lib.mp_bench_gather64.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]
     lib.mp_device_check.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     lib.mp_strerror.restype = C.c_char_p
     lib.mp_strerror.argtypes = [C.c_int]
@@ -200,6 +202,14 @@ class Index:
         _chk(load_library().mp_index_chr_and_pos(self._h, int(amb_pos), C.byref(p), C.byref(c)), "mp_index_chr_and_pos")
         return p.value, c.value
 
+    def chr_and_pos_batch(self, amb_pos):
+        amb_pos = np.ascontiguousarray(amb_pos, dtype=np.uint64)
+        p = np.zeros(len(amb_pos), dtype=np.uint64)
+        c = np.zeros(len(amb_pos), dtype=np.uint32)
+        _chk(load_library().mp_index_chr_and_pos_batch(self._h, amb_pos.ctypes.data, len(amb_pos), p.ctypes.data, c.ctypes.data),
+             "mp_index_chr_and_pos_batch")
+        return p, c
+
     def occ(self, idx, sym):
         idx = np.ascontiguousarray(idx, dtype=np.uint64)
         sym = np.ascontiguousarray(sym, dtype=np.uint32)
@@ -212,6 +222,11 @@ class Index:
         out = np.zeros(len(idx), dtype=np.uint64)
         _chk(load_library().mp_index_sa(self._h, idx.ctypes.data, len(idx), out.ctypes.data), "mp_index_sa")
         return out
+
+    def bench_gather64(self, lanes=1 << 21, per_lane=64, repeats=5):
+        ms, nb = C.c_float(), C.c_uint64()
+        _chk(load_library().mp_bench_gather64(self._h, lanes, per_lane, repeats, C.byref(ms), C.byref(nb)), "mp_bench_gather64")
+        return ms.value, nb.value
 
     def lkt(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint32)

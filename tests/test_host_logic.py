@@ -1,0 +1,108 @@
+"""CPU tests of the product's host side: C-ABI surface, read packing, host bookkeeping, and the N>1 path over gloo."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from megapath_amd import hipapi as H
+from megapath_amd import pipeline, taxcount
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "megapath_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(mp_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "megapath_amd", "csrc")])
+    lib = C.CDLL(H.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(H.EXPORTS) == declared
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    """Without a GPU the product must refuse to run: there is no CPU path behind the ABI."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = H.load_library()
+    assert lib.mp_device_check(0, None, 0) == -19
+    with pytest.raises(H.MpError):
+        H.Index(os.path.join(ROOT, "tests", "golden", "g1", "ref.fa.index"), 0)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "megapath_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle_lib" not in src and "mp_oracle" not in src and "libmp_oracle" not in src, fn
+
+
+def test_pack_reads_matches_reference_packing_rules():
+    # QueryParser.cpp:184-234 + IndexHandler.cpp:26-46: truncate to L-1, N->G, other letters->A, LSB-first 2 bits
+    packed, lens, W = H.pack_reads([b"ACGTNRacgtu", b"T" * 40], 21)
+    assert W == 2 and lens.tolist() == [11, 20]
+    codes = [(int(packed[0, i // 16]) >> (2 * (i % 16))) & 3 for i in range(11)]
+    assert codes == [0, 1, 2, 3, 2, 0, 0, 1, 2, 3, 3]
+    assert all(((int(packed[1, i // 16]) >> (2 * (i % 16))) & 3) == 3 for i in range(20))
+
+
+def test_single_candidate_merge_rules():
+    # singleMerge (DV-DPfunctions.cpp:295-342): drop < 17, merge within 5 bp on the same strand keeping the longer,
+    # longest first, drop < 0.6 x best
+    c = pipeline._single_candidates([(100, 1, 20), (103, 1, 40), (104, 2, 30), (500, 1, 16), (900, 1, 23), (2000, 2, 60)])
+    assert c == [(2000, 2, 60), (103, 1, 40)]
+    assert pipeline.dp_cutoff(150) == 30 and pipeline.dp_cutoff(300) == 60 and pipeline.margin(100) == 25 and pipeline.margin(101) == 30
+
+
+def test_header_mapping_quirks():
+    sc, v = pipeline._mapping_from_header(b"SCORE:300;300,seq1;290,seq2;", 0.95, 0.0)
+    assert sc == 300 and v == [(300, b"300,seq1"), (290, b"290,seq2")]
+    assert pipeline._mapping_from_header(b"IGNORE", 0.95, 0.0) == (0, [])
+    assert pipeline._mapping_from_header(None, 0.95, 0.0) == (0, [])
+    assert pipeline._mapping_from_header(b"SCORE:100;100,a;", 0.95, 200.0) == (100, [])
+
+
+def test_shard_bounds_cover_all_pairs():
+    for n, w in [(10, 3), (1 << 20, 8), (5, 8)]:
+        cuts = [taxcount.shard_bounds(n, w, r) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch.distributed as dist
+from megapath_amd import taxcount
+from conftest import fastq_records
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+lines = [l for l in open(os.path.join(sys.argv[1], "tests", "golden", "g1", "expected_a.fq"), "rb") if l.startswith(b"@r")]
+pairs = len(lines) // 2
+lo, hi = taxcount.shard_bounds(pairs, world, rank)
+idx = {"seq1": 0, "seq2": 1, "seq3": 2}
+c, u = taxcount.counts_from_fastq(lines[2 * lo:2 * hi], idx, 3)
+gc, gu = taxcount.all_reduce_counts(c, u)
+fc, fu = taxcount.counts_from_fastq(lines, idx, 3)
+assert np.array_equal(gc, fc) and np.array_equal(gu, fu), (gc, fc)
+assert gc.sum() > 0
+dist.destroy_process_group()
+print("rank", rank, "ok", gc.tolist())
+'''
+
+
+def test_two_rank_sharding_and_count_allreduce_over_gloo(tmp_path):
+    """N>1: shard the pairs over 2 ranks, count hits per reference on each shard, all-reduce; must equal 1-rank counts."""
+    w = tmp_path / "worker.py"
+    w.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29577", str(w), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2

@@ -133,6 +133,9 @@ typedef struct {
     int32_t insert_low, insert_high;     /* after the SOAP4.cpp:465-474 adjustment */
     int32_t clip_left, clip_right;       /* ini MaxFrontLenClipped / MaxEndLenClipped */
     mp_mmp_params mmp;
+    int32_t want_tie_counts;             /* 1: fill mp_pair_hit.count_* (num_sameScore, used only by the BAM MAPQ,
+                                            BGS-IO.cpp:679-979); 0: MegaPath -F/-P text mode, counters left 0 */
+    int32_t reserved;
 } mp_align_params;
 
 typedef struct {              /* one DeepDPAlignResult (PEAlgnmt.h:509-541), both mates passed the cutoff */

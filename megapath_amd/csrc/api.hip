@@ -432,65 +432,68 @@ extern "C" int mp_get_seeds(mp_ctx *c, mp_seedpos *out_seeds, uint64_t cap, uint
 // ------------------------------------------------------------------------------------------------ DP
 namespace {
 
-struct DpShape { int lpi, c; bool wide; };
+struct DpShape { int c, nw; };
 
 inline int pick_shape(uint32_t max_len, DpShape &s)
 {
-    // 32 lanes per instance; C columns per lane; 5 bits per cell -> 32-bit flag words up to C = 6
-    static const int cs[] = {3, 4, 5, 6, 8, 10, 12};
-    for (int c : cs) if ((uint32_t)(32 * c) >= max_len) { s.lpi = 32; s.c = c; s.wide = c > 6; return MP_OK; }
+    // 32 lanes per instance pair; C columns per lane; 5 bits per cell, 3 cells per 16-bit half of a flag word
+    static const int cs[] = {3, 5, 6, 8, 10, 12};
+    for (int c : cs) if ((uint32_t)(32 * c) >= max_len) { s.c = c; s.nw = (c + 2) / 3; return MP_OK; }
     return MP_ERANGE;   // reads longer than 384 bases (the reference's DP limit is ~312)
 }
 
-template <int C, typename FlagT>
-void launch_fill(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, void *flags, uint32_t flag_rows, mp_fill_result *fill)
+template <int C>
+void launch_fill(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, uint32_t *flags, uint32_t flag_rows,
+                 mp_fill_result *fill, bool count)
 {
-    constexpr int LPI = 32;
-    hipLaunchKernelGGL((dp_fill_kernel<LPI, C, FlagT>), dim3(grid_for(n, MP_DP_BLOCK / LPI)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens,
-                       c->W, tasks, n, cl, cr, (FlagT *)flags, flag_rows, fill);
+    const unsigned pairs = (n + 1) / 2, groups = MP_DP_BLOCK / MP_DP_LPI;
+    if (count)
+        hipLaunchKernelGGL((dp_fill_kernel<C, true>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                           tasks, n, cl, cr, flags, flag_rows, fill);
+    else
+        hipLaunchKernelGGL((dp_fill_kernel<C, false>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                           tasks, n, cl, cr, flags, flag_rows, fill);
 }
-template <int C, typename FlagT>
-void launch_trace(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, const void *flags, uint32_t flag_rows,
+template <int C>
+void launch_trace(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, const uint32_t *flags, uint32_t flag_rows,
                   const mp_fill_result *fill, mp_dp_result *res, uint8_t *ops, uint32_t ops_stride)
 {
-    constexpr int LPI = 32;
-    hipLaunchKernelGGL((dp_trace_kernel<LPI, C, FlagT>), dim3(grid_for(n, 64)), dim3(64), 0, s, tasks, c->d_lens, n, cl, cr, (const FlagT *)flags, flag_rows,
-                       fill, res, ops, ops_stride);
+    hipLaunchKernelGGL((dp_trace_kernel<C>), dim3(grid_for(n, 64)), dim3(64), 0, s, tasks, c->d_lens, n, cl, cr, flags, flag_rows, fill, res, ops, ops_stride);
 }
 
-#define MP_DP_DISPATCH(FN, ...)                                                       \
-    switch (shape.c) {                                                                \
-        case 3: FN<3, uint32_t>(__VA_ARGS__); break;                                  \
-        case 4: FN<4, uint32_t>(__VA_ARGS__); break;                                  \
-        case 5: FN<5, uint32_t>(__VA_ARGS__); break;                                  \
-        case 6: FN<6, uint32_t>(__VA_ARGS__); break;                                  \
-        case 8: FN<8, unsigned long long>(__VA_ARGS__); break;                        \
-        case 10: FN<10, unsigned long long>(__VA_ARGS__); break;                      \
-        default: FN<12, unsigned long long>(__VA_ARGS__); break;                      \
+#define MP_DP_DISPATCH(FN, ...)                      \
+    switch (shape.c) {                               \
+        case 3: FN<3>(__VA_ARGS__); break;           \
+        case 5: FN<5>(__VA_ARGS__); break;           \
+        case 6: FN<6>(__VA_ARGS__); break;           \
+        case 8: FN<8>(__VA_ARGS__); break;           \
+        case 10: FN<10>(__VA_ARGS__); break;         \
+        default: FN<12>(__VA_ARGS__); break;         \
     }
 
 // Runs fill + traceback for device-resident tasks, chunked so that the flag slab stays bounded.
 int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res, uint8_t *d_ops,
-           uint32_t ops_stride, float *ms_fill, float *ms_trace, uint64_t *cells)
+           uint32_t ops_stride, float *ms_fill, float *ms_trace, bool count)
 {
     if (n == 0) return MP_OK;
     DpShape shape;
     if (pick_shape(c->max_len, shape)) return MP_ERANGE;
     if (max_win > MP_DP_MAX_WIN) return MP_ERANGE;
     hipStream_t s = c->stream;
-    const uint32_t flag_rows = max_win + 32;
-    const size_t word = shape.wide ? 8 : 4;
-    const size_t per_inst = (size_t)flag_rows * 32 * word;
-    uint32_t chunk = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1024, (3ull << 30) / per_inst));   // <= 3 GiB of flags
-    if (c->flags.reserve((size_t)chunk * per_inst) || c->fill.reserve(chunk)) return MP_ENOMEM;
+    const uint32_t flag_rows = max_win + MP_DP_LPI;
+    const size_t per_pair = (size_t)flag_rows * MP_DP_LPI * shape.nw * 4;
+    uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 2 * std::max<uint64_t>(512, (3ull << 30) / per_pair));   // <= 3 GiB of flags, even
+    chunk &= ~1u;
+    if (chunk < 2) chunk = 2;
+    if (c->flags.reserve(((size_t)chunk / 2 + 1) * per_pair) || c->fill.reserve(chunk + 2)) return MP_ENOMEM;
     float tf = 0, tt = 0;
     for (uint32_t off = 0; off < n; off += chunk) {
         uint32_t cnt = std::min(chunk, n - off);
         HIPCHK(hipEventRecord(c->ev[5], s));
-        MP_DP_DISPATCH(launch_fill, s, c, d_tasks + off, cnt, cl, cr, c->flags.p, flag_rows, c->fill.p);
+        MP_DP_DISPATCH(launch_fill, s, c, d_tasks + off, cnt, cl, cr, (uint32_t *)c->flags.p, flag_rows, c->fill.p, count);
         HIPCHK(hipEventRecord(c->ev[6], s));
         uint8_t *ops_here = d_ops ? d_ops + (size_t)off * ops_stride : nullptr;
-        MP_DP_DISPATCH(launch_trace, s, c, d_tasks + off, cnt, cl, cr, c->flags.p, flag_rows, c->fill.p, d_res + off, ops_here, ops_stride);
+        MP_DP_DISPATCH(launch_trace, s, c, d_tasks + off, cnt, cl, cr, (const uint32_t *)c->flags.p, flag_rows, c->fill.p, d_res + off, ops_here, ops_stride);
         if (ops_here)
             hipLaunchKernelGGL(dp_ops_fix_kernel, dim3(grid_for(cnt, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks + off, cnt,
                                c->fill.p, d_res + off, ops_here, ops_stride);
@@ -503,7 +506,6 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
     }
     if (ms_fill) *ms_fill += tf;
     if (ms_trace) *ms_trace += tt;
-    (void)cells;
     return MP_OK;
 }
 
@@ -526,7 +528,7 @@ extern "C" int mp_sgdp_batch(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int
     HIPCHK(hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, c->stream));
     if (out_ops) HIPCHK(hipMemsetAsync(c->ops.p, 0, (size_t)n * ops_stride, c->stream));
     float f = 0, t = 0;
-    int rc = run_dp(c, c->tasks_tmp.p, n, max_win, clip_left, clip_right, c->res_tmp.p, out_ops ? c->ops.p : nullptr, ops_stride, &f, &t, nullptr);
+    int rc = run_dp(c, c->tasks_tmp.p, n, max_win, clip_left, clip_right, c->res_tmp.p, out_ops ? c->ops.p : nullptr, ops_stride, &f, &t, true);
     if (rc) return rc;
     HIPCHK(hipMemcpy(out_results, c->res_tmp.p, (size_t)n * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
     if (out_ops) HIPCHK(hipMemcpy(out_ops, c->ops.p, (size_t)n * ops_stride, hipMemcpyDeviceToHost));
@@ -574,11 +576,11 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         const uint32_t margin2 = 60;
         const uint32_t max_win = c->max_len + margin2;
         hipLaunchKernelGGL(build_left_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, c->tasks_l.p);
-        rc = run_dp(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, nullptr);
+        rc = run_dp(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         hipLaunchKernelGGL(build_right_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, ap->insert_high,
                            c->tasks_l.p, c->res_l.p, c->tasks_r.p);
-        rc = run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, nullptr);
+        rc = run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(c->n_pair_hits.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(collect_pair_hits_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,

@@ -38,140 +38,295 @@ __device__ __forceinline__ uint32_t mp_text_base(const uint32_t *text, uint64_t 
     return (text[p >> 4] >> (2 * (p & 15))) & 3u;
 }
 
-template <int LPI, int C, typename FlagT>
+// Packed 16-bit arithmetic: every lane computes the same cell of TWO instances at once (low / high half of a VGPR) with
+// v_pk_add_i16 / v_pk_max_i16 / v_pk_min_u16 / v_pk_mad_u16.  There is no packed compare on gfx950, so every decision
+// bit is formed arithmetically: for x >= 0, min_u16(x, 1) is "x != 0".  Stored bits are therefore the *negations*
+// nD, nE, nEO, nFO next to Z; the traceback inverts them.
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+#define TBP_Z 1u
+#define TBP_ND 2u
+#define TBP_NE 4u
+#define TBP_NEO 8u
+#define TBP_NFO 16u
+#define MP_DP_LPI 32
+#define MP_DP_NEG16 ((short)-16000)
+
+// One instruction each, opaque to the optimiser (it would otherwise turn min_u16(x,1) into an unpacked compare+select)
+#define MP_PKOP2(name, ins) \
+    __device__ __forceinline__ v2s name(v2s a, v2s b) { v2s r; asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+MP_PKOP2(pk_add, "v_pk_add_i16")
+MP_PKOP2(pk_sub, "v_pk_sub_i16")
+MP_PKOP2(pk_max, "v_pk_max_i16")
+MP_PKOP2(pk_min, "v_pk_min_i16")
+MP_PKOP2(pk_minu, "v_pk_min_u16")
+__device__ __forceinline__ v2s pk_mad(v2s a, v2s b, v2s c) { v2s r; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ v2s pk_xor(v2s a, v2s b) { return a ^ b; }
+// lane k receives lane k-1's value (wavefront shift right by one; the first lane of each 32-lane group is overridden by the caller)
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+
+// constants the cell update needs in registers (VOP3P operands)
+struct dp_consts { v2s open, ext, one, zero, neg3, k2, k4, k8, k16; };
+
+// One DP cell of two instances in ONE asm statement (hipcc pads every separate asm with s_nop).
+//   in : Hup/Eup (row above), Hl/Fl (cell to the left), diag, base (window bases), rb (read bases), floorv, elig
+//   out: e, f, h for this cell; fw (flag accumulator); COUNT=false: rowcode = max over the row of (eligible H << 4 | 15-cc)
+//        so that the first maximum of the row wins; COUNT=true: exact per-cell first-maximum tracking with tie counts.
+// Decision bits are arithmetic: x != 0  <=>  min_u16(x, 1) (x taken as unsigned); differences are formed with v_xor_b32
+// (full rate on gfx950; v_pk_* and v_max run at half rate -- scripts/valu_rate.hip) and stored negated (see TBP_*).
+template <bool COUNT>
+__device__ __forceinline__ void dp_cell(const dp_consts &K, v2s Hup, v2s Eup, v2s Hl, v2s Fl, v2s diag, v2s base, v2s rb, v2s floorv, v2s elig,
+                                        v2s gate, v2s shiftk, v2s colk, v2s &e, v2s &f, v2s &h, v2s &fw, v2s &best, v2s &bpos, v2s &pos, v2s &cnt,
+                                        v2s &rowcode)
+{
+    v2s eo, fo, dg, t1, bits;
+    asm("v_pk_add_i16 %[eo], %[Hup], %[kopen]\n\t"
+        "v_pk_add_i16 %[e], %[Eup], %[kext]\n\t"
+        "v_pk_max_i16 %[e], %[eo], %[e]\n\t"
+        "v_pk_add_i16 %[fo], %[Hl], %[kopen]\n\t"
+        "v_pk_add_i16 %[f], %[Fl], %[kext]\n\t"
+        "v_pk_max_i16 %[f], %[fo], %[f]\n\t"
+        "v_xor_b32 %[t1], %[base], %[rb]\n\t"
+        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
+        "v_pk_mad_i16 %[t1], %[t1], %[kneg3], %[kone]\n\t"          // +1 match / -2 mismatch
+        "v_pk_add_i16 %[dg], %[diag], %[t1]\n\t"
+        "v_pk_max_i16 %[t1], %[dg], %[e]\n\t"
+        "v_pk_max_i16 %[t1], %[t1], %[f]\n\t"                       // H before the left-clip floor
+        "v_pk_max_i16 %[h], %[t1], %[floorv]\n\t"                   // H
+        "v_xor_b32 %[bits], %[h], %[t1]\n\t"
+        "v_pk_min_u16 %[bits], %[bits], %[kone]\n\t"                // Z
+        "v_xor_b32 %[t1], %[h], %[dg]\n\t"
+        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
+        "v_pk_mad_i16 %[bits], %[t1], %[k2], %[bits]\n\t"           // nD
+        "v_xor_b32 %[t1], %[h], %[e]\n\t"
+        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
+        "v_pk_mad_i16 %[bits], %[t1], %[k4], %[bits]\n\t"           // nE
+        "v_xor_b32 %[t1], %[e], %[eo]\n\t"
+        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
+        "v_pk_mad_i16 %[bits], %[t1], %[k8], %[bits]\n\t"           // nEO
+        "v_xor_b32 %[t1], %[f], %[fo]\n\t"
+        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
+        "v_pk_mad_i16 %[bits], %[t1], %[k16], %[bits]\n\t"          // nFO
+        "v_pk_mad_i16 %[fw], %[bits], %[shiftk], %[fw]\n\t"
+        "v_pk_min_i16 %[t1], %[h], %[elig]"                         // eligible H (<= -1 in columns that cannot end an alignment)
+        : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [bits] "=&v"(bits), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h),
+          [fw] "+&v"(fw)
+        : [Hup] "v"(Hup), [Eup] "v"(Eup), [Hl] "v"(Hl), [Fl] "v"(Fl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
+          [elig] "v"(elig), [shiftk] "v"(shiftk), [kopen] "v"(K.open), [kext] "v"(K.ext), [kone] "v"(K.one),
+          [kneg3] "v"(K.neg3), [k2] "v"(K.k2), [k4] "v"(K.k4), [k8] "v"(K.k8), [k16] "v"(K.k16));
+    if (!COUNT) {
+        // (H << 4) | (15 - cc): one max per cell keeps the row's best score and, among equals, its first column
+        asm("v_pk_mad_i16 %[t1], %[t1], %[k16], %[colk]\n\t"
+            "v_pk_max_i16 %[rowcode], %[rowcode], %[t1]"
+            : [t1] "+&v"(t1), [rowcode] "+&v"(rowcode) : [k16] "v"(K.k16), [colk] "v"(colk));
+    } else {
+        v2s eq, ng;
+        asm("v_pk_min_i16 %[t1], %[t1], %[gate]\n\t"                    // rows past this instance's window: <= 0
+            "v_pk_sub_i16 %[bits], %[t1], %[best]\n\t"
+            "v_pk_max_i16 %[bits], %[bits], %[kzero]\n\t"
+            "v_pk_min_u16 %[bits], %[bits], %[kone]\n\t"                // gt: strictly better than the best so far
+            "v_pk_max_i16 %[best], %[best], %[t1]\n\t"
+            "v_pk_sub_i16 %[dg], %[pos], %[bpos]\n\t"
+            "v_pk_mad_i16 %[bpos], %[bits], %[dg], %[bpos]\n\t"
+            "v_pk_add_i16 %[pos], %[pos], %[kone]\n\t"
+            "v_pk_sub_i16 %[eq], %[best], %[t1]\n\t"                    // cnt = gt ? 1 : cnt + (eligible H == best)
+            "v_pk_min_u16 %[eq], %[eq], %[kone]\n\t"
+            "v_pk_sub_i16 %[eq], %[kone], %[eq]\n\t"
+            "v_pk_sub_i16 %[ng], %[kone], %[bits]\n\t"
+            "v_pk_mad_i16 %[cnt], %[cnt], %[ng], %[eq]"
+            : [t1] "+&v"(t1), [bits] "=&v"(bits), [dg] "=&v"(dg), [eq] "=&v"(eq), [ng] "=&v"(ng), [best] "+&v"(best), [bpos] "+&v"(bpos),
+              [pos] "+&v"(pos), [cnt] "+&v"(cnt)
+            : [gate] "v"(gate), [kzero] "v"(K.zero), [kone] "v"(K.one));
+    }
+}
+
+__device__ __forceinline__ v2s pk(short a, short b) { v2s r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2s pk1(short a) { v2s r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2u nz(v2s x) { return __builtin_elementwise_min(__builtin_bit_cast(v2u, x), (v2u){1, 1}); }   // x >= 0: (x != 0)
+__device__ __forceinline__ int as_int(v2s v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ v2s as_v2s(int v) { return __builtin_bit_cast(v2s, v); }
+
+// flag words per lane-step for C columns: 3 cells (15 bits) per 16-bit half
+#define MP_DP_NW(C) (((C) + 2) / 3)
+
+template <int C, bool COUNT>
 __global__ void __launch_bounds__(MP_DP_BLOCK)
 dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t W,
                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, int clip_left, int clip_right,
-               FlagT *__restrict__ flags, uint32_t flag_rows /* rows of LPI words reserved per instance */,
+               uint32_t *__restrict__ flags, uint32_t flag_rows /* rows of 32 x NW words reserved per instance PAIR */,
                mp_fill_result *__restrict__ out)
 {
-    constexpr int GROUPS = MP_DP_BLOCK / LPI;
-    __shared__ uint32_t s_win[GROUPS][MP_DP_MAX_WIN / 16 + 1];
-    const int g = threadIdx.x / LPI;              // instance slot inside the block
-    const int k = threadIdx.x % LPI;              // lane inside the instance
-    const uint32_t inst = blockIdx.x * GROUPS + g;
-    const bool live = inst < n_tasks;
-    mp_dp_task task; task.read_id = 0; task.strand = 1; task.win_start = 0; task.win_len = 0; task.reserved = 0;
-    if (live) task = tasks[inst];
-    const int L = live ? (int)lens[task.read_id] : 0;
-    int m = (int)task.win_len;
-    if (m > MP_DP_MAX_WIN) m = MP_DP_MAX_WIN;
-    if (L > LPI * C) m = 0;                        // host guarantees the template covers the longest read
-    const int clipL = task.strand == 1 ? clip_left : clip_right;     // soft clips follow the strand (:2908-2911)
-    const int clipR = task.strand == 1 ? clip_right : clip_left;
-    const int cutoff = mp_dp_cutoff(L);
-
-    // ---- stage the window into LDS: word q holds bases 16q..16q+15 of the window, LSB-first
-    for (int q = k; q * 16 < m; q += LPI) {
-        uint64_t p = task.win_start + 16ull * (uint64_t)q;
-        uint32_t sh = 2 * (uint32_t)(p & 15);
-        uint64_t two = (uint64_t)text[p >> 4];
-        if (sh) two |= (uint64_t)text[(p >> 4) + 1] << 32;
-        s_win[g][q] = (uint32_t)(two >> sh);
+    constexpr int LPI = MP_DP_LPI;
+    constexpr int GROUPS = MP_DP_BLOCK / LPI;          // lane groups per block, two instances each
+    constexpr int NW = MP_DP_NW(C);
+    __shared__ uint32_t s_win[GROUPS][2][MP_DP_MAX_WIN / 16 + 1];
+    const int g = threadIdx.x / LPI;
+    const int k = threadIdx.x % LPI;
+    const uint32_t pair = blockIdx.x * GROUPS + g;
+    int L[2], m[2], clipL[2], clipR[2], cutoff[2], strand[2];
+    uint32_t rid[2];
+    uint64_t wstart[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t inst = 2 * pair + q;
+        mp_dp_task task; task.read_id = 0; task.strand = 1; task.win_start = 0; task.win_len = 0; task.reserved = 0;
+        const bool live = inst < n_tasks;
+        if (live) task = tasks[inst];
+        L[q] = live ? (int)lens[task.read_id] : 0;
+        m[q] = (int)task.win_len;
+        if (m[q] > MP_DP_MAX_WIN) m[q] = MP_DP_MAX_WIN;
+        if (L[q] > LPI * C) m[q] = 0;                  // host guarantees the template covers the longest read
+        strand[q] = (int)task.strand; rid[q] = task.read_id; wstart[q] = task.win_start;
+        clipL[q] = task.strand == 1 ? clip_left : clip_right;      // soft clips follow the strand (:2908-2911)
+        clipR[q] = task.strand == 1 ? clip_right : clip_left;
+        cutoff[q] = mp_dp_cutoff(L[q]);
+        for (int w = k; w * 16 < m[q]; w += LPI) {     // stage the window: word w = bases 16w..16w+15, LSB-first
+            uint64_t p = task.win_start + 16ull * (uint64_t)w;
+            uint32_t sh = 2 * (uint32_t)(p & 15);
+            uint64_t two = (uint64_t)text[p >> 4];
+            if (sh) two |= (uint64_t)text[(p >> 4) + 1] << 32;
+            s_win[g][q][w] = (uint32_t)(two >> sh);
+        }
     }
-    // ---- this lane's read bases (reverse-complemented for strand 2) and row-0 boundary
-    int rb[C], Hup[C], Eup[C];
-    const uint32_t *rd = reads + (uint64_t)task.read_id * W;
+    // per-column constants and row-0 boundary, both instances packed
+    v2s rb[C], Hup[C], Eup[C], floorv[C], elig[C];
 #pragma unroll
     for (int cc = 0; cc < C; cc++) {
-        int j = k * C + cc + 1;
-        int b = 4;                                 // never matches
-        if (j <= L) {
-            int p = task.strand == 1 ? j - 1 : L - j;
-            b = (int)((rd[p >> 4] >> (2 * (p & 15))) & 3u);
-            if (task.strand != 1) b = 3 - b;
+        const int j = k * C + cc + 1;
+        short b2[2], h2[2], fl2[2], el2[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            int b = 4 + q;                              // never matches a window base (0..3)
+            if (j <= L[q]) {
+                const uint32_t *rd = reads + (uint64_t)rid[q] * W;
+                int p = strand[q] == 1 ? j - 1 : L[q] - j;
+                b = (int)((rd[p >> 4] >> (2 * (p & 15))) & 3u);
+                if (strand[q] != 1) b = 3 - b;
+            }
+            b2[q] = (short)b;
+            h2[q] = (short)(j <= clipL[q] ? 0 : MP_DP_OPEN + (j - clipL[q] - 1) * MP_DP_EXT);   // CPU_DP.cpp:394-432
+            fl2[q] = (short)(j <= clipL[q] ? 0 : -32768);                                      // floor inside the left clip (:505-510)
+            int mc = L[q] - clipR[q]; if (mc < 0) mc = 0;
+            el2[q] = (short)((j >= mc && j <= L[q]) ? 32767 : -1);                             // best-cell columns (:538-591)
         }
-        rb[cc] = b;
-        Hup[cc] = j <= clipL ? 0 : MP_DP_OPEN + (j - clipL - 1) * MP_DP_EXT;   // CPU_DP.cpp:394-432
-        Eup[cc] = MP_DP_NEG;
+        rb[cc] = pk(b2[0], b2[1]); Hup[cc] = pk(h2[0], h2[1]); Eup[cc] = pk1(MP_DP_NEG16);
+        floorv[cc] = pk(fl2[0], fl2[1]); elig[cc] = pk(el2[0], el2[1]);
     }
-    int diag_carry;                                // H[i-1][j0-1]
+    v2s diag_carry;
     {
-        int j0m1 = k * C;
-        diag_carry = j0m1 <= clipL ? 0 : MP_DP_OPEN + (j0m1 - clipL - 1) * MP_DP_EXT;
+        const int j0 = k * C;
+        diag_carry = pk((short)(j0 <= clipL[0] ? 0 : MP_DP_OPEN + (j0 - clipL[0] - 1) * MP_DP_EXT),
+                        (short)(j0 <= clipL[1] ? 0 : MP_DP_OPEN + (j0 - clipL[1] - 1) * MP_DP_EXT));
     }
     __syncthreads();
 
-    int min_col = L - clipR; if (min_col < 0) min_col = 0;
-    int best = 0, best_row = 0, best_col = 0, cnt = 0;
-    int outH = 0, outF = MP_DP_NEG, outB = 0;      // what this lane hands to lane k+1
-    FlagT *frow = flags + (uint64_t)inst * flag_rows * LPI;
-
-    // the wavefront may hold two instances with different window lengths: run to the longest
-    int steps = m > 0 ? m + LPI - 1 : 0;
+    dp_consts K;
+    K.open = pk1(MP_DP_OPEN); K.ext = pk1(MP_DP_EXT); K.one = pk1(1); K.zero = pk1(0); K.neg3 = pk1(-3);
+    K.k2 = pk1(2); K.k4 = pk1(4); K.k8 = pk1(8); K.k16 = pk1(16);
+    const v2s kShift[3] = {pk1(1), pk1(32), pk1(1024)};
+    const v2s kZero = pk1(0);
+    v2s best = kZero, bpos = kZero;
+    v2s cnt = kZero;
+    v2s outH = kZero, outF = pk1(MP_DP_NEG16);
+    int outB = 0;
+    uint32_t *frow = flags + (uint64_t)pair * flag_rows * (LPI * NW);
+    const int mmax = m[0] > m[1] ? m[0] : m[1];
+    int steps = mmax > 0 ? mmax + LPI - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(steps, o); steps = v > steps ? v : steps; }
+    const v2s mrow = pk((short)m[0], (short)m[1]);
+    uint32_t wq0 = 0, wq1 = 0;                     // 16 window bases of each instance, consumed two bits per step
 
     for (int t = 1; t <= steps; t++) {
-        int inH = __shfl_up(outH, 1, LPI);
-        int inF = __shfl_up(outF, 1, LPI);
-        int inB = __shfl_up(outB, 1, LPI);
+        int inHi = wave_shr1(as_int(outH));
+        int inFi = wave_shr1(as_int(outF));
+        int inB = wave_shr1(outB);
+        // the first lane of a group handles row t: its window bases come from LDS, one word per 16 steps (uniform in t)
+        if (((t - 1) & 15) == 0) { wq0 = s_win[g][0][(t - 1) >> 4]; wq1 = s_win[g][1][(t - 1) >> 4]; }
+        const int r0 = t <= m[0] ? (int)(wq0 & 3u) : 6, r1 = t <= m[1] ? (int)(wq1 & 3u) : 7;
+        wq0 >>= 2; wq1 >>= 2;
+        if (k == 0) { inHi = 0; inFi = as_int(pk1(MP_DP_NEG16)); inB = r0 | (r1 << 16); }   // column 0: H = 0, no insertion state
         const int i = t - k;                       // row handled now
-        const bool row_ok = i >= 1 && i <= m;
-        int base;
-        if (k == 0) {
-            inH = 0; inF = MP_DP_NEG;              // column 0: H = 0 on every row, no insertion state
-            base = row_ok ? (int)((s_win[g][(i - 1) >> 4] >> (2 * ((i - 1) & 15))) & 3u) : 0;
-        } else base = inB;
-        if (row_ok) {
-            int Hl = inH, Fl = inF, diag = diag_carry;
-            FlagT fw = 0;
+        if (i >= 1 && i <= mmax) {
+            const v2s base = as_v2s(inB);
+            // rows past an instance's own window must not count: cap 32767 while i <= m, 0 afterwards (best starts at 0
+            // and only a strictly greater value replaces it)
+            const v2s g2 = vmax(vmin(kZero, mrow - pk1((short)i)), pk1(-1));            // 0 or -1
+            const v2s gatecap = g2 * pk1(32767) + pk1(32767);
+            const v2s gatecode = (g2 + pk1(1)) * pk1(32735);                            // large in range, 0 past the window
+            v2s Hl = as_v2s(inHi), Fl = as_v2s(inFi), diag = diag_carry;
+            v2s pos = pk1((short)(i * 16));
+            v2s rowcode = pk1(-32768);
+            v2s fw[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) fw[w] = kZero;
 #pragma unroll
             for (int cc = 0; cc < C; cc++) {
-                const int j = k * C + cc + 1;
-                const int eo = Hup[cc] + MP_DP_OPEN, ee = Eup[cc] + MP_DP_EXT;
-                const int e = eo >= ee ? eo : ee;
-                const int fo = Hl + MP_DP_OPEN, fe = Fl + MP_DP_EXT;
-                const int f = fo >= fe ? fo : fe;
-                const int dg = diag + (base == rb[cc] ? 1 : MP_DP_MISMATCH);
-                int h = dg > e ? dg : e;
-                h = h > f ? h : f;
-                uint32_t bits = 0;
-                if (j <= clipL && h < 0) { h = 0; bits = TB_Z; }             // CPU_DP.cpp:505-510
-                else if (e == h) bits = TB_E;
-                if (h == dg) bits |= TB_D;
-                if (eo >= ee) bits |= TB_EO;
-                if (fo >= fe) bits |= TB_FO;
-                fw |= (FlagT)bits << (5 * cc);
+                v2s e, f, h;
+                dp_cell<COUNT>(K, Hup[cc], Eup[cc], Hl, Fl, diag, base, rb[cc], floorv[cc], elig[cc], gatecap, kShift[cc % 3], pk1((short)(15 - cc)),
+                               e, f, h, fw[cc / 3], best, bpos, pos, cnt, rowcode);
                 diag = Hup[cc];
                 Hup[cc] = h; Eup[cc] = e; Hl = h; Fl = f;
-                // best cell: rows <= refLen, columns in [L - clipR, L], strict '>' in row-major order (CPU_DP.cpp:538-591)
-                if (j >= min_col && j <= L && h >= cutoff) {
-                    if (h > best) { best = h; best_row = i; best_col = j; cnt = 1; }
-                    else if (h == best) cnt++;
-                }
             }
-            diag_carry = inH;
+            if (!COUNT) {
+                // once per row: does this row beat the best so far?  (strictly: code > best code with its column bits saturated)
+                const v2s rc = vmin(rowcode, gatecode);                        // rows past the instance's window never win
+                const v2s gt = __builtin_bit_cast(v2s, nz(vmax(rc - (best | pk1(15)), kZero)));
+                best += gt * (rc - best);
+                bpos += gt * (pk1((short)i) - bpos);
+            }
+            diag_carry = as_v2s(inHi);
             outH = Hl; outF = Fl;
-            frow[(uint64_t)(t - 1) * LPI + k] = fw;
+#pragma unroll
+            for (int w = 0; w < NW; w++) frow[((uint64_t)(t - 1) * LPI + k) * NW + w] = __builtin_bit_cast(uint32_t, fw[w]);
         }
-        outB = base;
+        outB = inB;
     }
 
-    // ---- reduce over the LPI lanes: max score, then smallest row, then smallest column; ties counted
-    unsigned long long key = best > 0 ? ((unsigned long long)(uint32_t)best << 32) | ((uint32_t)(0xFFFF - best_row) << 16) | (uint32_t)(0xFFFF - best_col) : 0ull;
-    unsigned long long kmax = key;
-    for (int o = LPI / 2; o > 0; o >>= 1) { unsigned long long v = __shfl_xor(kmax, o, LPI); kmax = v > kmax ? v : kmax; }
-    const int gbest = (int)(kmax >> 32);
-    int c2 = (best == gbest && gbest > 0) ? cnt : 0;
-    for (int o = LPI / 2; o > 0; o >>= 1) c2 += __shfl_xor(c2, o, LPI);
-    if (live && k == 0) {
-        mp_fill_result r;
-        r.score = gbest;
-        r.row = (uint16_t)(0xFFFF - ((kmax >> 16) & 0xFFFF));
-        r.col = (uint16_t)(0xFFFF - (kmax & 0xFFFF));
-        r.count = c2 > 255 ? 255u : (uint32_t)c2;
-        if (gbest == 0) { r.row = 0; r.col = 0; r.count = 0; }
-        out[inst] = r;
+    // ---- per instance: reduce over the 32 lanes -- max score, then smallest row, then smallest column; ties counted
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        int b, brow, bcol;
+        if (COUNT) {
+            const int pos = q == 0 ? bpos.x : bpos.y;
+            b = q == 0 ? best.x : best.y; brow = pos >> 4; bcol = k * C + (pos & 15) + 1;
+        } else {
+            const int code = q == 0 ? best.x : best.y;      // (score << 4) | (15 - cc)
+            b = code >> 4; brow = q == 0 ? bpos.x : bpos.y; bcol = k * C + (15 - (code & 15)) + 1;
+        }
+        unsigned long long key = b >= cutoff[q] && b > 0 ? ((unsigned long long)(uint32_t)b << 32) | ((uint32_t)(0xFFFF - brow) << 16) | (uint32_t)(0xFFFF - bcol) : 0ull;
+        unsigned long long kmax = key;
+        for (int o = LPI / 2; o > 0; o >>= 1) { unsigned long long v = __shfl_xor(kmax, o, LPI); kmax = v > kmax ? v : kmax; }
+        const int gbest = (int)(kmax >> 32);
+        int c2 = 0;
+        if (COUNT) {
+            c2 = (b == gbest && gbest > 0) ? (int)(unsigned short)(q == 0 ? cnt.x : cnt.y) : 0;
+            for (int o = LPI / 2; o > 0; o >>= 1) c2 += __shfl_xor(c2, o, LPI);
+        }
+        const uint32_t inst = 2 * pair + q;
+        if (inst < n_tasks && k == 0) {
+            mp_fill_result r;
+            r.score = gbest;
+            r.row = (uint16_t)(0xFFFF - ((kmax >> 16) & 0xFFFF));
+            r.col = (uint16_t)(0xFFFF - (kmax & 0xFFFF));
+            r.count = c2 > 255 ? 255u : (uint32_t)c2;
+            if (gbest == 0) { r.row = 0; r.col = 0; r.count = 0; }
+            out[inst] = r;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ traceback
-template <int LPI, int C, typename FlagT>
+template <int C>
 __global__ void __launch_bounds__(64)
 dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, uint32_t n_tasks, int clip_left, int clip_right,
-                const FlagT *__restrict__ flags, uint32_t flag_rows, const mp_fill_result *__restrict__ fill,
+                const uint32_t *__restrict__ flags, uint32_t flag_rows, const mp_fill_result *__restrict__ fill,
                 mp_dp_result *__restrict__ out, uint8_t *__restrict__ ops, uint32_t ops_stride)
 {
+    constexpr int LPI = MP_DP_LPI;
+    constexpr int NW = MP_DP_NW(C);
     const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
     if (inst >= n_tasks) return;
     const mp_dp_task task = tasks[inst];
@@ -182,16 +337,19 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
     mp_dp_result res; res.score = 0; res.hit_loc = 0; res.max_score_count = 0; res.n_ops = 0;
     if (fr.score < cutoff || fr.score <= 0 || task.win_len == 0) { out[inst] = res; return; }
     res.max_score_count = fr.count;
-    const FlagT *frow = flags + (uint64_t)inst * flag_rows * LPI;
+    const uint32_t *frow = flags + (uint64_t)(inst >> 1) * flag_rows * (LPI * NW);
+    const int half = (int)(inst & 1u) * 16;
     uint8_t *op = ops ? ops + (uint64_t)inst * ops_stride : nullptr;
     uint32_t n = 0;
     auto emit = [&](uint8_t ch, int rep) { for (int q = 0; q < rep; q++) { if (op && n < ops_stride) op[n] = ch; n++; } };
-    auto cell = [&](int r, int c) -> uint32_t {      // traceback bits of (row r, column c)
+    // traceback bits of (row r, column c) as TB_* (positive logic)
+    auto cell = [&](int r, int c) -> uint32_t {
         if (c == 0) return TB_Z;
         if (r == 0) return c <= clipL ? TB_Z : 0u;
-        int lane = (c - 1) / C, cc = (c - 1) % C;
-        FlagT w = frow[(uint64_t)(r + lane - 1) * LPI + lane];
-        return (uint32_t)(w >> (5 * cc)) & 31u;
+        const int lane = (c - 1) / C, cc = (c - 1) % C;
+        const uint32_t w = frow[((uint64_t)(r + lane - 1) * LPI + lane) * NW + cc / 3];
+        const uint32_t b = (w >> (half + 5 * (cc % 3))) & 31u;
+        return (b & TBP_Z) | ((b ^ 30u) & 30u);       // invert nD, nE, nEO, nFO
     };
     bool valid = true;
     int hit = 0;

@@ -57,7 +57,7 @@ class DpResult(C.Structure):
 
 class AlignParams(C.Structure):
     _fields_ = [("insert_low", C.c_int32), ("insert_high", C.c_int32), ("clip_left", C.c_int32), ("clip_right", C.c_int32),
-                ("mmp", MmpParams)]
+                ("mmp", MmpParams), ("want_tie_counts", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PairHit(C.Structure):

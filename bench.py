@@ -195,9 +195,12 @@ def main():
     lib = H.load_library()
 
     def one_step():
-        # a new batch arrives: forget the seeds of the previous one, then run the whole deep-DP round on the device
+        # a new batch arrives: forget the seeds of the previous one, then run the whole path on the device:
+        # deep-DP round (seed, locate, merge, pair, both DP legs) and the rescue passes of the pairs it left unaligned
         ctx.set_reads_device(packed.data_ptr(), W, lens_i.data_ptr(), 2 * P, args.read_len, keep=(packed, lens_i))
-        return ctx.deep_dp_round(params)
+        hits, nh, st = ctx.deep_dp_round(params)
+        _, _, rst = ctx.rescue_round(params, False, fetch=False)
+        return hits, nh, st, rst
 
     for _ in range(args.warmup):
         one_step()
@@ -205,9 +208,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     tstart = time.perf_counter()
-    acc = dict(seed=0.0, locate=0.0, merge=0.0, pair=0.0, fill=0.0, trace=0.0, occ=0, lkt=0, sa=0, seedpos=0, cand=0, hits=0)
+    acc = dict(seed=0.0, locate=0.0, merge=0.0, pair=0.0, fill=0.0, trace=0.0, occ=0, lkt=0, sa=0, seedpos=0, cand=0, hits=0,
+               rescue_fill=0.0, rescue_trace=0.0, rescue_tasks=0.0, failed=0, stasks=0, rtasks=0)
     for _ in range(args.steps):
-        hits, nh, st = one_step()
+        hits, nh, st, rst = one_step()
+        acc["rescue_fill"] += rst.ms_dp_fill; acc["rescue_trace"] += rst.ms_dp_trace; acc["rescue_tasks"] += rst.ms_tasks
+        acc["failed"] += rst.n_failed_pairs; acc["stasks"] += rst.n_single_tasks; acc["rtasks"] += rst.n_rescue_tasks
         acc["seed"] += st.seed.ms_seed; acc["locate"] += st.seed.ms_locate; acc["merge"] += st.seed.ms_merge
         acc["pair"] += st.ms_pair; acc["fill"] += st.ms_dp_fill; acc["trace"] += st.ms_dp_trace
         acc["occ"] += st.seed.n_occ; acc["lkt"] += st.seed.n_lkt; acc["sa"] += st.seed.n_sa; acc["seedpos"] += st.seed.n_seedpos
@@ -229,7 +235,9 @@ def main():
         b_seed = 64 * acc["occ"] + 16 * acc["lkt"] + 8 * acc["sa"] + 0.25 * (2 * P * K * args.read_len) + 16 * acc["seedpos"]
         t_seed_s = (acc["seed"] + acc["locate"]) / 1e3
         achieved = b_seed / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
-        kernel_ms = {k: acc[k] / K for k in ("seed", "locate", "merge", "pair", "fill", "trace")}
+        kernel_ms = {k: acc[k] / K for k in ("seed", "locate", "merge", "pair", "fill", "trace", "rescue_tasks", "rescue_fill", "rescue_trace")}
+        n_inst = 2 * acc["cand"] + acc["stasks"] + acc["rtasks"]
+        cells = (2 * acc["cand"] + acc["stasks"]) * (args.read_len + 61) * args.read_len + acc["rtasks"] * (750 - args.read_len + args.read_len + 1) * args.read_len
         out = {
             "metric": "paired 150bp reads aligned/sec vs 2BWT index",
             "value": total_pairs / elapsed,
@@ -239,7 +247,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "2x%dbp synthetic pairs vs synthetic %.0f Mbp genome (GRCh38 human-filter stage scaled), %d pairs/step/GPU, "
-                                   "deep-DP round: MMP seeding + pairing + both DP legs with traceback" % (args.read_len, args.genome_mbp, P),
+                                   "whole path on the device: deep-DP round (MMP seeding, pairing, both DP legs + traceback) and rescue passes (single-end DP, mate rescue)" % (args.read_len, args.genome_mbp, P),
                        "index_replicated_per_gpu": True, "pairs_per_step_per_gpu": P, "genome_mbp": args.genome_mbp,
                        "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750},
             "roofline": {"bound": "hbm", "kernel": "seed_kernel+locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -247,8 +255,11 @@ def main():
                          "random64_gather_ceiling_gbs": gather_gbs, "frac_of_gather_ceiling": achieved / gather_gbs,
                          "algorithmic_bytes_per_pair": b_seed / (K * P), "launch_ms": (acc["seed"] + acc["locate"]) / K},
             "kernel_ms_per_step": kernel_ms,
+            "dp": {"bound": "valu", "unit": "Gcells/s", "achieved": cells / ((acc["fill"] + acc["rescue_fill"]) / 1e3) / 1e9 if acc["fill"] else 0.0,
+                   "instances_per_step": n_inst / K, "note": "integer max/add recurrences: VALU-bound, no MFMA, not an HBM roofline (SURVEY 8d)"},
             "events_per_pair": {"occ": acc["occ"] / (K * P), "lkt": acc["lkt"] / (K * P), "sa": acc["sa"] / (K * P),
-                                "candidates": acc["cand"] / (K * P), "pair_hits": acc["hits"] / (K * P)},
+                                "candidates": acc["cand"] / (K * P), "pair_hits": acc["hits"] / (K * P),
+                                "failed_pairs": acc["failed"] / (K * P), "single_dp_tasks": acc["stasks"] / (K * P), "rescue_dp_tasks": acc["rtasks"] / (K * P)},
         }
         cb = None
         if world == 1 and not args.no_cpu_baseline:

@@ -160,6 +160,37 @@ typedef struct {
 int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n_hits, mp_round_stats *out_stats);
 int mp_get_pair_hits(mp_ctx *ctx, mp_pair_hit *out_hits, uint64_t cap);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Rescue passes for the pairs the deep-DP round left without a hit.  Replaces DPForUnalignSingle2
+ * (DV-DPForSingleReads.cpp:321, alignment.cpp:182) and semiGlobalDPForSingleEndDpAlignment (DV-SemiDP.cpp:197,
+ * alignment.cpp:250): candidate selection, window arithmetic and both DP batches run on the device; the per-pair
+ * bookkeeping that turns the hits into output records stays with the caller.  Call after mp_deep_dp_round. */
+typedef struct {              /* SingleAlgnmtResult (PEAlgnmt.h) of a read whose pair failed the deep-DP round */
+    uint32_t read_id;
+    uint32_t strand;          /* 1 '+', 2 '-' */
+    uint64_t algnmt;
+    int32_t score;
+    uint32_t count;           /* num_sameScore */
+    uint64_t win_start;       /* startPos: orders the hits for mate rescue (DV-SemiDP.cpp:37-44) */
+} mp_single_hit;
+
+typedef struct {              /* one successful mate rescue: the aligned mate's single hit + the DP hit of the other mate */
+    uint32_t pair_id;
+    uint32_t aligned_read;    /* read id (2p or 2p+1) of the mate that had the single-end hit */
+    uint64_t aligned_pos, dp_pos;
+    int32_t aligned_score, dp_score;
+    uint32_t aligned_strand, dp_strand;
+} mp_rescue_hit;
+
+typedef struct {
+    uint64_t n_failed_pairs, n_single_tasks, n_single_hits, n_rescue_tasks, n_rescue_hits;
+    float ms_tasks, ms_dp_fill, ms_dp_trace, ms_total;
+} mp_rescue_stats;
+
+int mp_rescue_round(mp_ctx *ctx, const mp_align_params *params, int skip_default_dp, mp_rescue_stats *out_stats);
+int mp_get_single_hits(mp_ctx *ctx, mp_single_hit *out_hits, uint64_t cap, uint64_t *out_n);
+int mp_get_rescue_hits(mp_ctx *ctx, mp_rescue_hit *out_hits, uint64_t cap, uint64_t *out_n);
+
 /* Measurement aid: `lanes` lanes each load `per_lane` random 64-byte rank blocks (independent loads); reports the mean
  * launch time and the exact bytes one launch requests.  This is the random-64 B-gather ceiling the seed stage is priced
  * against and the calibration workload for the FETCH_SIZE counter. */

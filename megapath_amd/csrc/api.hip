@@ -10,6 +10,7 @@
 #include "mp_internal.h"
 #include "kernels_seed.hip"
 #include "kernels_dp.hip"
+#include "kernels_rescue.hip"
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     fprintf(stderr, "[megapath_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MP_ENODEV; } } while (0)
@@ -41,6 +42,7 @@ struct mp_ctx {
     mp_index *ix = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};
+    std::vector<hipEvent_t> ev_pool;       // per-chunk DP timing without per-chunk host syncs
     // reads
     DevBuf<uint32_t> reads, lens, scan;
     const uint32_t *d_reads = nullptr, *d_lens = nullptr;   // either our buffers or caller-owned device memory
@@ -66,6 +68,13 @@ struct mp_ctx {
     DevBuf<mp_pair_hit> pair_hits;
     DevBuf<unsigned long long> n_pair_hits;
     uint64_t n_pair_hits_host = 0;
+    // rescue passes
+    DevBuf<uint32_t> pair_done, failed_flag, failed_off, failed_reads, n_scand, s_off, rsrc;
+    DevBuf<mp_single_cand> scand;
+    DevBuf<mp_dp_task> stasks, rtasks;
+    DevBuf<mp_dp_result> sres, rres;
+    uint32_t n_failed_reads = 0, n_stasks = 0;
+    bool rescued = false;
 };
 
 // ------------------------------------------------------------------------------------------------ misc
@@ -289,11 +298,14 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     (void)hipSetDevice(c->ix->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     c->reads.release(); c->lens.release(); c->scan.release(); c->seeds.release(); c->slabs.release(); c->big_slabs.release(); c->hits.release();
     c->seedpos.release(); c->hit_row.release(); c->seeds_per_rs.release(); c->hits_per_rs.release(); c->rs_base.release(); c->overflow_rs.release(); c->over_slot.release();
     c->queue.release(); c->n_pos.release(); c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
     c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
     c->ops.release(); c->pair_hits.release(); c->n_pair_hits.release();
+    c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
+    c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release();
     delete c;
     return MP_OK;
 }
@@ -487,21 +499,26 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
     if (chunk < 2) chunk = 2;
     if (c->flags.reserve(((size_t)chunk / 2 + 1) * per_pair) || c->fill.reserve(chunk + 2)) return MP_ENOMEM;
     float tf = 0, tt = 0;
-    for (uint32_t off = 0; off < n; off += chunk) {
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    while (c->ev_pool.size() < 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    size_t ci = 0;
+    for (uint32_t off = 0; off < n; off += chunk, ci++) {
         uint32_t cnt = std::min(chunk, n - off);
-        HIPCHK(hipEventRecord(c->ev[5], s));
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci], s));
         MP_DP_DISPATCH(launch_fill, s, c, d_tasks + off, cnt, cl, cr, (uint32_t *)c->flags.p, flag_rows, c->fill.p, count);
-        HIPCHK(hipEventRecord(c->ev[6], s));
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
         uint8_t *ops_here = d_ops ? d_ops + (size_t)off * ops_stride : nullptr;
         MP_DP_DISPATCH(launch_trace, s, c, d_tasks + off, cnt, cl, cr, (const uint32_t *)c->flags.p, flag_rows, c->fill.p, d_res + off, ops_here, ops_stride);
         if (ops_here)
             hipLaunchKernelGGL(dp_ops_fix_kernel, dim3(grid_for(cnt, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks + off, cnt,
                                c->fill.p, d_res + off, ops_here, ops_stride);
-        HIPCHK(hipEventRecord(c->ev[7], s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t q = 0; q < n_chunks; q++) {
         float a = 0, b = 0;
-        (void)hipEventElapsedTime(&a, c->ev[5], c->ev[6]);
-        (void)hipEventElapsedTime(&b, c->ev[6], c->ev[7]);
+        (void)hipEventElapsedTime(&a, c->ev_pool[3 * q], c->ev_pool[3 * q + 1]);
+        (void)hipEventElapsedTime(&b, c->ev_pool[3 * q + 1], c->ev_pool[3 * q + 2]);
         tf += a; tt += b;
     }
     if (ms_fill) *ms_fill += tf;
@@ -606,5 +623,143 @@ extern "C" int mp_get_pair_hits(mp_ctx *c, mp_pair_hit *out_hits, uint64_t cap)
     if (cap < c->n_pair_hits_host) return MP_ERANGE;
     HIPCHK(hipSetDevice(c->ix->device));
     if (c->n_pair_hits_host) HIPCHK(hipMemcpy(out_hits, c->pair_hits.p, (size_t)c->n_pair_hits_host * sizeof(mp_pair_hit), hipMemcpyDeviceToHost));
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ rescue passes
+static int exclusive_scan_u32(mp_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    size_t tmp_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, (int)n, c->stream);
+    if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+    (void)hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, in, out, (int)n, c->stream);
+    return MP_OK;
+}
+
+extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_default_dp, mp_rescue_stats *out_stats)
+{
+    if (!c || !ap || !c->seeded || c->n_reads == 0) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    hipStream_t s = c->stream;
+    const uint32_t n_reads = c->n_reads, n_pairs = n_reads / 2;
+    mp_rescue_stats st{};
+    hipEvent_t t0, t1, t2;
+    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1)); HIPCHK(hipEventCreate(&t2));
+    HIPCHK(hipEventRecord(t0, s));
+    if (c->pair_done.reserve(n_pairs + 1) || c->failed_flag.reserve(n_reads + 2) || c->failed_off.reserve(n_reads + 2)) return MP_ENOMEM;
+    HIPCHK(hipMemsetAsync(c->pair_done.p, 0, (size_t)(n_pairs + 1) * 4, s));
+    if (c->n_pair_hits_host)
+        hipLaunchKernelGGL(mark_done_kernel, dim3(grid_for(c->n_pair_hits_host, 256)), dim3(256), 0, s, c->pair_hits.p, (uint32_t)c->n_pair_hits_host, c->pair_done.p);
+    hipLaunchKernelGGL(failed_flag_kernel, dim3(grid_for(n_reads + 1, 256)), dim3(256), 0, s, c->pair_done.p, n_reads, c->failed_flag.p);
+    int rc = exclusive_scan_u32(c, c->failed_flag.p, c->failed_off.p, n_reads + 1);
+    if (rc) return rc;
+    uint32_t nf = 0;
+    HIPCHK(hipMemcpyAsync(&nf, c->failed_off.p + n_reads, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->n_failed_reads = nf; c->n_stasks = 0; c->rescued = true;
+    st.n_failed_pairs = nf / 2;
+    if (nf) {
+        if (c->failed_reads.reserve(nf + 1) || c->n_scand.reserve(nf + 2) || c->s_off.reserve(nf + 2) || c->scand.reserve(c->n_hits_total + 64)) return MP_ENOMEM;
+        hipLaunchKernelGGL(list_failed_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, s, c->failed_flag.p, c->failed_off.p, n_reads, c->failed_reads.p);
+        hipLaunchKernelGGL(single_cand_kernel, dim3(grid_for(nf + 1, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->seedpos.p, c->rs_base.p, c->n_pos.p,
+                           c->n_neg.p, c->scand.p, c->n_scand.p);
+        rc = exclusive_scan_u32(c, c->n_scand.p, c->s_off.p, nf + 1);
+        if (rc) return rc;
+        uint32_t nst = 0;
+        HIPCHK(hipMemcpyAsync(&nst, c->s_off.p + nf, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        c->n_stasks = nst;
+        st.n_single_tasks = nst;
+        if (c->stasks.reserve(nst + 2) || c->sres.reserve(nst + 2) || c->rtasks.reserve(4 * (size_t)nf + 2) || c->rres.reserve(4 * (size_t)nf + 2) ||
+            c->rsrc.reserve(4 * (size_t)nf + 2)) return MP_ENOMEM;
+        hipLaunchKernelGGL(single_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->scand.p, c->rs_base.p, c->n_scand.p,
+                           c->s_off.p, c->d_lens, c->ix->n, c->stasks.p);
+        HIPCHK(hipEventRecord(t1, s));
+        const uint32_t max_win = c->max_len + 60;
+        rc = run_dp(c, c->stasks.p, nst, max_win, ap->clip_left, ap->clip_right, c->sres.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
+        if (rc) return rc;
+        if (!skip_default_dp) {
+            hipLaunchKernelGGL(mate_rescue_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->s_off.p, c->stasks.p, c->sres.p,
+                               c->d_lens, c->ix->n, ap->insert_low, ap->insert_high, c->rtasks.p, c->rsrc.p);
+            const uint32_t rwin = (uint32_t)(ap->insert_high - ap->insert_low) + c->max_len + 1;   // HalfEnd maxDNALength (DV-DPfunctions.cpp:1340)
+            if (rwin > MP_DP_MAX_WIN) return MP_ERANGE;
+            rc = run_dp(c, c->rtasks.p, 4 * nf, rwin, ap->clip_left, ap->clip_right, c->rres.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace,
+                        ap->want_tie_counts != 0);
+            if (rc) return rc;
+            st.n_rescue_tasks = 4ull * nf;
+        }
+    }
+    HIPCHK(hipEventRecord(t2, s));
+    HIPCHK(hipEventSynchronize(t2));
+    (void)hipEventElapsedTime(&st.ms_total, t0, t2);
+    if (nf) (void)hipEventElapsedTime(&st.ms_tasks, t0, t1);
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(t2);
+    c->seeded = c->seeded;   // seeds stay valid for mp_get_seeds
+    if (out_stats) *out_stats = st;
+    return MP_OK;
+}
+
+extern "C" int mp_get_single_hits(mp_ctx *c, mp_single_hit *out, uint64_t cap, uint64_t *out_n)
+{
+    if (!c || !c->rescued || !out_n) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t n = c->n_stasks;
+    std::vector<mp_dp_task> tasks(n + 1);
+    std::vector<mp_dp_result> res(n + 1);
+    std::vector<uint32_t> lens(c->n_reads);
+    if (n) {
+        HIPCHK(hipMemcpy(tasks.data(), c->stasks.p, (size_t)n * sizeof(mp_dp_task), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(res.data(), c->sres.p, (size_t)n * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lens.data(), c->d_lens, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
+    }
+    uint64_t w = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        if (res[t].score <= 0 || res[t].score < mp_dp_cutoff((int)lens[tasks[t].read_id])) continue;
+        if (out) {
+            if (w >= cap) return MP_ERANGE;
+            mp_single_hit h;
+            h.read_id = tasks[t].read_id; h.strand = tasks[t].strand; h.algnmt = tasks[t].win_start + res[t].hit_loc; h.score = res[t].score;
+            h.count = res[t].max_score_count; h.win_start = tasks[t].win_start;
+            out[w] = h;
+        }
+        w++;
+    }
+    *out_n = w;
+    return MP_OK;
+}
+
+extern "C" int mp_get_rescue_hits(mp_ctx *c, mp_rescue_hit *out, uint64_t cap, uint64_t *out_n)
+{
+    if (!c || !c->rescued || !out_n) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t nf = c->n_failed_reads, n = c->n_stasks;
+    *out_n = 0;
+    if (nf == 0 || n == 0) return MP_OK;
+    std::vector<mp_dp_task> stasks(n), rtasks(4 * (size_t)nf);
+    std::vector<mp_dp_result> sres(n), rres(4 * (size_t)nf);
+    std::vector<uint32_t> rsrc(4 * (size_t)nf), lens(c->n_reads);
+    HIPCHK(hipMemcpy(stasks.data(), c->stasks.p, (size_t)n * sizeof(mp_dp_task), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sres.data(), c->sres.p, (size_t)n * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rtasks.data(), c->rtasks.p, rtasks.size() * sizeof(mp_dp_task), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rres.data(), c->rres.p, rres.size() * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rsrc.data(), c->rsrc.p, rsrc.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lens.data(), c->d_lens, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
+    uint64_t w = 0;
+    for (size_t q = 0; q < rtasks.size(); q++) {
+        const uint32_t src = rsrc[q];
+        if (src == 0xFFFFFFFFu) continue;
+        const uint32_t un = rtasks[q].read_id;
+        if (rres[q].score <= 0 || rres[q].score < mp_dp_cutoff((int)lens[un])) continue;
+        if (out) {
+            if (w >= cap) return MP_ERANGE;
+            mp_rescue_hit h;
+            h.aligned_read = stasks[src].read_id; h.pair_id = h.aligned_read >> 1;
+            h.aligned_pos = stasks[src].win_start + sres[src].hit_loc; h.aligned_score = sres[src].score; h.aligned_strand = stasks[src].strand;
+            h.dp_pos = rtasks[q].win_start + rres[q].hit_loc; h.dp_score = rres[q].score; h.dp_strand = rtasks[q].strand;
+            out[w] = h;
+        }
+        w++;
+    }
+    *out_n = w;
     return MP_OK;
 }

@@ -72,6 +72,21 @@ class RoundStats(C.Structure):
                 ("ms_dp_trace", C.c_float), ("ms_total", C.c_float)]
 
 
+class SingleHit(C.Structure):
+    _fields_ = [("read_id", C.c_uint32), ("strand", C.c_uint32), ("algnmt", C.c_uint64), ("score", C.c_int32), ("count", C.c_uint32),
+                ("win_start", C.c_uint64)]
+
+
+class RescueHit(C.Structure):
+    _fields_ = [("pair_id", C.c_uint32), ("aligned_read", C.c_uint32), ("aligned_pos", C.c_uint64), ("dp_pos", C.c_uint64),
+                ("aligned_score", C.c_int32), ("dp_score", C.c_int32), ("aligned_strand", C.c_uint32), ("dp_strand", C.c_uint32)]
+
+
+class RescueStats(C.Structure):
+    _fields_ = [("n_failed_pairs", C.c_uint64), ("n_single_tasks", C.c_uint64), ("n_single_hits", C.c_uint64), ("n_rescue_tasks", C.c_uint64),
+                ("n_rescue_hits", C.c_uint64), ("ms_tasks", C.c_float), ("ms_dp_fill", C.c_float), ("ms_dp_trace", C.c_float), ("ms_total", C.c_float)]
+
+
 class IndexInfo(C.Structure):
     _fields_ = [("text_length", C.c_uint64), ("inverse_sa0", C.c_uint64), ("cum_freq", C.c_uint64 * 5),
                 ("sa_interval", C.c_uint32), ("num_seq", C.c_uint32), ("device_bytes", C.c_uint64)]
@@ -80,7 +95,7 @@ class IndexInfo(C.Structure):
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_ctx_create", "mp_ctx_destroy",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
-           "mp_get_pair_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
+           "mp_get_pair_hits", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
 
 
 def build_library(force: bool = False) -> str:
@@ -124,6 +139,9 @@ def load_library():
     lib.mp_sgdp_batch.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mp_deep_dp_round.argtypes = [vp, C.POINTER(AlignParams), u64p, C.POINTER(RoundStats)]
     lib.mp_get_pair_hits.argtypes = [vp, vp, C.c_uint64]
+    lib.mp_rescue_round.argtypes = [vp, C.POINTER(AlignParams), C.c_int, C.POINTER(RescueStats)]
+    lib.mp_get_single_hits.argtypes = [vp, vp, C.c_uint64, u64p]
+    lib.mp_get_rescue_hits.argtypes = [vp, vp, C.c_uint64, u64p]
     lib.mp_bench_gather64.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]
     lib.mp_device_check.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     lib.mp_strerror.restype = C.c_char_p
@@ -287,6 +305,22 @@ class Context:
         _chk(load_library().mp_sgdp_batch(self._h, arr, n, clip_left, clip_right, res, ops.ctypes.data if want_ops else None,
                                           ops_stride, C.byref(f), C.byref(t)), "mp_sgdp_batch")
         return res, ops, ops_stride, (f.value, t.value)
+
+    def rescue_round(self, params: AlignParams, skip_default_dp: bool = False, fetch: bool = True):
+        lib = load_library()
+        st = RescueStats()
+        _chk(lib.mp_rescue_round(self._h, C.byref(params), 1 if skip_default_dp else 0, C.byref(st)), "mp_rescue_round")
+        if not fetch:
+            return None, None, st
+        n = C.c_uint64()
+        _chk(lib.mp_get_single_hits(self._h, None, 0, C.byref(n)), "mp_get_single_hits")
+        singles = (SingleHit * max(n.value, 1))()
+        _chk(lib.mp_get_single_hits(self._h, singles, n.value, C.byref(n)), "mp_get_single_hits")
+        ns = n.value
+        _chk(lib.mp_get_rescue_hits(self._h, None, 0, C.byref(n)), "mp_get_rescue_hits")
+        resc = (RescueHit * max(n.value, 1))()
+        _chk(lib.mp_get_rescue_hits(self._h, resc, n.value, C.byref(n)), "mp_get_rescue_hits")
+        return (singles, ns), (resc, n.value), st
 
     def deep_dp_round(self, params: AlignParams):
         nh = C.c_uint64()

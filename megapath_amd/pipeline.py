@@ -3,8 +3,8 @@
 Mirrors `soap3_dp_pair_align` (reference soap4/alignment.cpp:29-355): the deep-DP round runs entirely on the GPU
 (`mp_deep_dp_round`); pairs it leaves unaligned go through single-end DP on their pooled seeds
 (DV-DPForSingleReads.cpp:121-215, DV-DPfunctions.cpp:295-342) and mate rescue inside the insert window
-(DV-SemiDP.cpp, DV-DPfunctions.cpp:1048-1231) -- both as batches of DP instances handed to `mp_sgdp_batch` -- and
-everything is written as the annotated interleaved FASTQ of `-F` / `-P` mode (BGS-IO.cpp:1384-1446, 1966-2091).
+(DV-SemiDP.cpp, DV-DPfunctions.cpp:1048-1231) -- candidate selection, windows and both DP batches on the device
+(`mp_rescue_round`) -- and everything is written as the annotated interleaved FASTQ of `-F` / `-P` mode (BGS-IO.cpp:1384-1446, 1966-2091).
 Host work here is per-pair bookkeeping only; every DP cell and every FM-index step happens in the HIP kernels.
 """
 from __future__ import annotations
@@ -18,7 +18,6 @@ import numpy as np
 from . import hipapi as H
 
 NOT_ALIGNED = (1 << 64) - 1
-DIVIDE_GAP = 5
 
 
 def dp_cutoff(length: int) -> int:
@@ -197,45 +196,6 @@ def _target_chr(index, positions, read_lens):
     return out
 
 
-def _window(pos, read_len, text_len):
-    m = margin(read_len)
-    s = (pos - m) & 0xFFFFFFFFFFFFFFFF
-    if s >= text_len:
-        s = 0                                              # DV-DPfunctions.cpp:2871-2874
-    ln = read_len + 2 * m
-    if s + ln > text_len:
-        ln = text_len - s
-    return s, ln
-
-
-def _single_candidates(seeds_of_read):
-    """transferSeed + singleMerge (DV-DPForSingleReads.cpp:121-215, DV-DPfunctions.cpp:295-342).
-    seeds_of_read: list of (pos, strand(1|2), seedlen).  Returns [(pos, strand, seedlen)] in DP order."""
-    c = sorted(seeds_of_read, key=lambda t: (t[1], t[0], t[2]))
-    m = []
-    i, n = 0, len(c)
-    while i < n:
-        if c[i][2] < 17:
-            i += 1
-            continue
-        cur = c[i]
-        while i + 1 < n:
-            nx = c[i + 1]
-            if nx[0] < cur[0] + DIVIDE_GAP and cur[1] == nx[1]:
-                if nx[2] > cur[2]:
-                    cur = nx
-            else:
-                break
-            i += 1
-        m.append(cur)
-        i += 1
-    # sort by seed length descending; stable insertion order is what std::sort does below 16 elements
-    m.sort(key=lambda t: -t[2])
-    while m and m[-1][2] < m[0][2] * 0.6:
-        m.pop()
-    return m[:200]                                         # DV-DPForSingleReads.cpp:200
-
-
 class PairAligner:
     """One GPU, one index, batches of pairs -> annotated FASTQ."""
 
@@ -304,76 +264,30 @@ class PairAligner:
         self.stats.n_deep_pairs += int(done.sum())
         failed = np.flatnonzero(~done)
         if len(failed):
-            self._rescue(failed, out_recs, lens_l, w)
+            self._rescue(failed, out_recs, lens_l, w, ap)
 
     # ------------------------------------------------------------------ rescue passes for pairs the deep-DP round left
-    def _rescue(self, failed, out_recs, lens, w):
-        p, ctx, text_len = self.p, self.ctx, self.text_len
-        seeds, off = ctx.get_seeds()
-        sview = np.frombuffer(seeds, dtype=np.dtype([("pos", "<u8"), ("sid", "<u4"), ("len", "<u4")]), count=int(off[-1])) if int(off[-1]) else None
-        # ---- single-end DP on the pooled seeds of both mates
-        tasks, owner = [], []
-        for q in failed.tolist():
-            for r in (2 * q, 2 * q + 1):
-                lo, hi = int(off[r]), int(off[r + 1])
-                if hi == lo:
-                    continue
-                pool = [(int(sview["pos"][i]), 2 if (int(sview["sid"][i]) >> 31) else 1, int(sview["len"][i]) & 0x7FFFFFFF) for i in range(lo, hi)]
-                for pos, strand, slen in _single_candidates(pool):
-                    ws, wl = _window(pos, lens[r], text_len)
-                    tasks.append(H.DpTask(r, strand, ws, wl, 0))
-                    owner.append((r, strand))
-        single = {}                                          # read id -> list of (algnmt, score, strand, start)
-        if tasks:
-            res, _, _, _ = ctx.sgdp_batch(tasks, p.clip_left, p.clip_right, want_ops=False)
-            self.stats.n_dp_instances += len(tasks)
-            for t, (r, strand) in enumerate(owner):
-                if res[t].score >= dp_cutoff(lens[r]) and res[t].score > 0:
-                    single.setdefault(r, []).append((tasks[t].win_start + res[t].hit_loc, res[t].score, strand, tasks[t].win_start))
-        # ---- mate rescue from the last four hits per read in (score desc, window start asc) order
-        rtasks, rinfo = [], []
-        if not p.skip_default_dp:
-            for q in failed.tolist():
-                for r in (2 * q, 2 * q + 1):
-                    hs = single.get(r)
-                    if not hs:
-                        continue
-                    hs_sorted = sorted(hs, key=lambda t: (-t[1], t[3]))
-                    for algn, score, strand, _ in hs_sorted[-4:]:
-                        un = r ^ 1
-                        alen, ulen = lens[r], lens[un]
-                        if strand == 1:                         # aligned mate is the left leg (DV-DPfunctions.cpp:1182-1205)
-                            r_end = algn + p.insert_high
-                            r_start = (algn + p.insert_low - ulen) & 0xFFFFFFFFFFFFFFFF
-                            if r_start < algn:
-                                r_start = algn
-                            if r_start < text_len and r_end <= text_len:
-                                rtasks.append(H.DpTask(un, 2, r_start, r_end - r_start, 0))
-                                rinfo.append((q, r, algn, score, strand))
-                        else:                                   # aligned mate is the right leg (:1207-1230)
-                            l_start = (algn + alen - p.insert_high) & 0xFFFFFFFFFFFFFFFF
-                            l_end = (algn + alen - p.insert_low + ulen) & 0xFFFFFFFFFFFFFFFF
-                            if l_end >= algn + alen:
-                                l_end = algn + alen - 1
-                            if l_start < text_len and l_end <= text_len:
-                                rtasks.append(H.DpTask(un, 1, l_start, l_end - l_start, 0))
-                                rinfo.append((q, r, algn, score, strand))
+    def _rescue(self, failed, out_recs, lens, w, ap):
+        """Single-end DP on the pooled seeds and mate rescue run on the device (`mp_rescue_round`); here only the
+        per-pair bookkeeping of alignment.cpp:137-352: which pairs were rescued, which go out unpaired."""
+        p = self.p
+        (singles, ns), (resc, nr), rst = self.ctx.rescue_round(ap, p.skip_default_dp)
+        self.stats.n_dp_instances += int(rst.n_single_tasks + rst.n_rescue_tasks)
+        single = {}
+        for i in range(ns):
+            h = singles[i]
+            single.setdefault(h.read_id, set()).add((h.algnmt, h.score))
         rescued = {}
-        if rtasks:
-            res, _, _, _ = ctx.sgdp_batch(rtasks, p.clip_left, p.clip_right, want_ops=False)
-            self.stats.n_dp_instances += len(rtasks)
-            for t, (q, r, algn, score, strand) in enumerate(rinfo):
-                un = r ^ 1
-                if res[t].score >= dp_cutoff(lens[un]) and res[t].score > 0:
-                    dp_pos = rtasks[t].win_start + res[t].hit_loc
-                    if r & 1 == 0:
-                        rescued.setdefault(q, set()).add((algn, dp_pos, score, res[t].score))
-                    else:
-                        rescued.setdefault(q, set()).add((dp_pos, algn, res[t].score, score))
-        # ---- output
+        for i in range(nr):
+            h = resc[i]
+            if h.aligned_read & 1 == 0:
+                rescued.setdefault(h.pair_id, set()).add((h.aligned_pos, h.dp_pos, h.aligned_score, h.dp_score))
+            else:
+                rescued.setdefault(h.pair_id, set()).add((h.dp_pos, h.aligned_pos, h.dp_score, h.aligned_score))
         for q in failed.tolist():
             r1, r2 = 2 * q, 2 * q + 1
             if q in rescued:
+                # OutputBuffer::ready(1): sorted by (pos1, pos2, score1, score2), duplicates and failed rescues dropped
                 res = [list(x) for x in sorted(rescued[q])]
                 c1 = _target_chr(self.ix, [x[0] for x in res], [lens[r1]] * len(res)).tolist()
                 c2 = _target_chr(self.ix, [x[1] for x in res], [lens[r2]] * len(res)).tolist()
@@ -381,7 +295,7 @@ class PairAligner:
                 self.stats.n_rescued_pairs += 1
             else:
                 for r in (r1, r2):
-                    hs = sorted(set((h[0], h[1]) for h in single.get(r, [])))
+                    hs = sorted(single.get(r, ()))
                     chrs = _target_chr(self.ix, [h[0] for h in hs], [lens[r]] * len(hs)).tolist()
                     w.single(out_recs[r], [(c, h[1]) for c, h in zip(chrs, hs)])
                 self.stats.n_unpaired_pairs += 1

@@ -52,11 +52,7 @@ def test_pack_reads_matches_reference_packing_rules():
     assert all(((int(packed[1, i // 16]) >> (2 * (i % 16))) & 3) == 3 for i in range(20))
 
 
-def test_single_candidate_merge_rules():
-    # singleMerge (DV-DPfunctions.cpp:295-342): drop < 17, merge within 5 bp on the same strand keeping the longer,
-    # longest first, drop < 0.6 x best
-    c = pipeline._single_candidates([(100, 1, 20), (103, 1, 40), (104, 2, 30), (500, 1, 16), (900, 1, 23), (2000, 2, 60)])
-    assert c == [(2000, 2, 60), (103, 1, 40)]
+def test_cutoff_and_margin_rules():
     assert pipeline.dp_cutoff(150) == 30 and pipeline.dp_cutoff(300) == 60 and pipeline.margin(100) == 25 and pipeline.margin(101) == 30
 
 

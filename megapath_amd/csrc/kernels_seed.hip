@@ -148,6 +148,7 @@ __global__ void prep_scan_kernel(const uint32_t *reads, const uint32_t *lens, ui
 // Seeds go to a fixed slab of MP_SEED_SLAB records per (read, strand) -- no atomics on the hot path; the rare item with
 // more seeds is listed in `overflow_rs` and redone by seed_overflow_kernel with a full-size slab.
 #define MP_SEED_SLAB 8
+#define MP_SEED_CHUNK 64
 
 struct mp_seed_rec { uint32_t sa_l; uint16_t query_offset, seed_len; uint32_t sa_diff; };   // 12 bytes
 
@@ -283,20 +284,30 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
     uint32_t my_occ = 0, my_lkt = 0;
     mp_mmp_state s;
     bool have = false;
+    // Work queue: one global counter, but a wavefront takes MP_SEED_CHUNK items per atomic into a private range and hands
+    // them to its lanes as they finish (a single word sustains only ~90 returning atomics per microsecond chip-wide).
+    uint32_t pool_next = 0, pool_end = 0;       // wave-uniform
+    bool drained = false;
     for (;;) {
-        // ---- refill: lanes without an item take the next ones from the queue, one atomic per wavefront
         const unsigned long long need = __ballot(!have);
         if (need) {
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)need) - 1;
-            if (lane == leader) base = atomicAdd(queue, (unsigned int)__popcll(need));
-            base = __shfl(base, leader);
-            if (!have) {
-                const uint32_t rs = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (rs < n_items) { mp_mmp_begin(s, scan, lens, W, rs, ix.n); have = true; }
+            if (pool_next == pool_end && !drained) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)need) - 1;
+                if (lane == leader) base = atomicAdd(queue, (unsigned int)MP_SEED_CHUNK);
+                base = __shfl(base, leader);
+                if (base >= n_items) drained = true;
+                else { pool_next = base; pool_end = base + MP_SEED_CHUNK < n_items ? base + MP_SEED_CHUNK : n_items; }
+            }
+            const uint32_t avail = pool_end - pool_next;
+            if (avail) {
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (!have && rank < avail) { mp_mmp_begin(s, scan, lens, W, pool_next + rank, ix.n); have = true; }
+                const uint32_t want = (uint32_t)__popcll(need);
+                pool_next += want < avail ? want : avail;
             }
         }
-        if (!__any(have)) break;                              // queue drained and every lane idle
+        if (!__any(have)) { if (drained && pool_next == pool_end) break; else continue; }   // nothing to do this trip
         if (have) {
             mp_seed_rec *slab = slabs + (uint64_t)s.rs * MP_SEED_SLAB;
             if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, my_occ, my_lkt)) {

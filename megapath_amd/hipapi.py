@@ -326,7 +326,9 @@ class Context:
         nh = C.c_uint64()
         st = RoundStats()
         _chk(load_library().mp_deep_dp_round(self._h, C.byref(params), C.byref(nh), C.byref(st)), "mp_deep_dp_round")
-        hits = (PairHit * max(nh.value, 1))()
+        # uninitialised host buffer (a ctypes array would be zero-filled first: ~150 MB per 1 Mi-pair batch)
+        buf = np.empty(max(nh.value, 1) * C.sizeof(PairHit), dtype=np.uint8)
         if nh.value:
-            _chk(load_library().mp_get_pair_hits(self._h, hits, nh.value), "mp_get_pair_hits")
+            _chk(load_library().mp_get_pair_hits(self._h, buf.ctypes.data, nh.value), "mp_get_pair_hits")
+        hits = (PairHit * max(nh.value, 1)).from_buffer(buf)
         return hits, nh.value, st

@@ -261,6 +261,16 @@ def main():
                                 "candidates": acc["cand"] / (K * P), "pair_hits": acc["hits"] / (K * P),
                                 "failed_pairs": acc["failed"] / (K * P), "single_dp_tasks": acc["stasks"] / (K * P), "rescue_dp_tasks": acc["rtasks"] / (K * P)},
         }
+        # HBM traffic of the seed stage from the committed PMC passes (separate rocprofv3 --pmc runs of this very command,
+        # profiles/r01_pmc_seed_stage.json); only quoted when the workload is the one those passes measured
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_seed_stage.json")))
+            wl = pmc["workload"]
+            if wl["genome_mbp"] == args.genome_mbp and wl["pairs_per_step"] == P and wl["read_len"] == args.read_len:
+                out["roofline"]["traffic"] = pmc["seed_stage_hbm_bytes_per_launch"]
+                out["roofline"]["algorithmic_bytes_per_launch"] = b_seed / K
+        except Exception:  # noqa: BLE001
+            pass
         cb = None
         if world == 1 and not args.no_cpu_baseline:
             tmpdir = tempfile.mkdtemp(prefix="mpbench_")

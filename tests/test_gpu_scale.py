@@ -61,6 +61,18 @@ def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg):
     assert len(got) == len(want) == 2 * cfg["n_pairs"]
     assert got == want
     assert pst.n_deep_pairs == st.n_deep_dp_pairs
+    # the C++ driver (bin/soap4-mi355x) on the same inputs, again in several batches
+    import subprocess
+    from conftest import ROOT
+    cxx_out = tmp_path / "cxx.fq"
+    env = dict(os.environ, MP_BATCH_PAIRS="1300")
+    env.pop("MP_SOAP4_PYTHON", None)
+    with open(cxx_out, "wb") as fo:
+        r = subprocess.run([os.path.join(ROOT, "bin", "soap4"), "pair", prefix, f1, f2, "-o", str(tmp_path / "o"), "-C",
+                            os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(cfg["L"]), "-T", "1", "-u", "750", "-F", "-nc"],
+                           stdout=fo, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert fastq_records(str(cxx_out)) == want
 
 
 def test_batch_scale_properties():

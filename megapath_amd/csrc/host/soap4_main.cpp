@@ -36,7 +36,7 @@ struct Params {
     int clip_left = 130, clip_right = 130;
     int mode = 0;                 // 1 = -F, 2 = -P
     double top = 0.95;
-    bool skip_default_dp = false, want_bam = false;
+    bool skip_default_dp = false, want_bam = false, ignore_comments = false;   // -nc: SOAP4.cpp:537-547
     mp_mmp_params mmp = {30, 17, 6, 5, 27, 18, 0.85, 4, 0.5};       // defaults of ParseIniFile (IniParam.cpp:427-435)
     size_t batch_pairs = 1u << 20;                                   // SOAP4.cpp:206
 };
@@ -153,6 +153,7 @@ bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out)
                 r.seq[i] = "ACGT"[c];
             }
             if (r.qual.size() > keep) r.qual.resize(keep);
+            if (p.ignore_comments) { r.has_comment = false; r.comment.clear(); }
             out.lens.push_back((uint32_t)keep);
             out.recs.push_back(r);
         }
@@ -382,7 +383,7 @@ int main(int argc, char **argv)
         else if (a == "-F") p.mode = 1;
         else if (a == "-P") p.mode = 2;
         else if (a == "-b") p.want_bam = true;
-        else if (a == "-nc") {}
+        else if (a == "-nc") p.ignore_comments = true;
     }
     if (p.mode == 0) { fprintf(stderr, "[soap4-mi355x] only MegaPath modes -F / -P are implemented (plain mode segfaults in the reference, SURVEY App. D15)\n"); return 1; }
     if (ini_path.empty()) ini_path = std::string(argv[0]) + ".ini";       // SOAP4.cpp:150-154

@@ -38,6 +38,7 @@ class Soap4Params:
     megapath_mode: int = 1                                # 1 = -F, 2 = -P
     top_percentage: float = 0.95                          # -top N
     skip_default_dp: bool = False
+    ignore_comments: bool = False                         # -nc (SOAP4.cpp:537-547)
     mmp: H.MmpParams = field(default_factory=H.MmpParams.nt2)
 
 
@@ -224,7 +225,7 @@ class PairAligner:
         for r, rec in enumerate(recs):
             ln = lens_l[r]
             codes = H._CODE[np.frombuffer(rec[2], dtype=np.uint8)[:ln]]
-            out_recs.append((rec[0], rec[1], lut[codes].tobytes(), rec[3][:ln]))
+            out_recs.append((rec[0], None if p.ignore_comments else rec[1], lut[codes].tobytes(), rec[3][:ln]))
         if self._first_batch:
             # SOAP4.cpp:465-474 / QueryParser.cpp:2253-2277: insert_low >= detected read lengths (first 10^6 samples)
             d1 = int(lens[0::2][:999999].max()) if n_pairs else 100

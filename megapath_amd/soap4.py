@@ -95,7 +95,7 @@ def main(argv=None) -> int:
         elif a == "-P":
             mode = 2
         elif a == "-nc":
-            pass                                   # "no comment": the first chunk has no SCORE: header to merge
+            p.ignore_comments = True               # drop FASTA/Q comments before alignment (SOAP4.cpp:537-547)
         elif a == "-b":
             want_bam = True
         i += 1

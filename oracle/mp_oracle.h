@@ -120,6 +120,7 @@ typedef struct {
     int quality_constant;    /* 33 */
     int skip_default_dp;     /* ini SkipDefaultDP */
     mpo_mmp_params mmp;
+    int ignore_comments;     /* -nc: drop every FASTQ comment before alignment (SOAP4.cpp:537-547) */
 } mpo_align_params;
 
 typedef struct {

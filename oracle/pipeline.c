@@ -435,6 +435,8 @@ int mpo_align_fastq(const mpo_index *ix, const mpo_align_params *Pin, const char
     fill_char_map();
     read_set rs;
     if (load_fastq_pair(fq1, fq2, P->max_read_length, P->quality_constant, &rs)) return -1;
+    if (P->ignore_comments)                                   /* SOAP4.cpp:537-547 */
+        for (int i = 0; i < rs.n; i++) { free(rs.comment[i]); rs.comment[i] = NULL; }
     FILE *out = fopen(out_fastq, "wb");
     FILE *rec = out_records ? fopen(out_records, "wb") : NULL;
     if (!out) { fprintf(stderr, "[oracle] cannot write %s\n", out_fastq); return -1; }

@@ -57,6 +57,38 @@ def main():
         with open(os.path.join(g1, "expected_%s.L" % k), "w") as f:
             f.write("%d\n" % L)
 
+    # ---- "d": -P mode with IGNORE comments (BGS-IO.cpp:1393-1402, 2003-2011, 2046-2048)
+    src1 = open(os.path.join(g1, "reads_a_1.fq"), "rb").read().split(b"\n")
+    src2 = open(os.path.join(g1, "reads_a_2.fq"), "rb").read().split(b"\n")
+    for i in range(0, len(src1) - 3, 4):
+        k = i // 4
+        if k % 7 == 0:
+            src1[i] = src1[i] + b" IGNORE"
+        if k % 11 == 0:
+            src1[i] = src1[i].split(b" ")[0] + b" IGNORE"
+            src2[i] = src2[i] + b" IGNORE"
+    d1, d2 = os.path.join(g1, "reads_d_1.fq"), os.path.join(g1, "reads_d_2.fq")
+    open(d1, "wb").write(b"\n".join(src1))
+    open(d2, "wb").write(b"\n".join(src2))
+    for tag, extra in (("d", []), ("f", ["-nc"])):       # "f": -nc drops the comments first (SOAP4.cpp:537-547)
+        cmd = [os.path.join(REF, "soap4"), "pair", prefix, d1, d2, "-o", os.path.join(g1, "d.tmp"), "-C", INI, "-L", "151", "-T", "1", "-u", "750", "-P"] + extra
+        with open(os.path.join(g1, "expected_%s.fq" % tag), "wb") as fo, open(os.devnull, "wb") as fe:
+            subprocess.check_call(cmd, stdout=fo, stderr=fe)
+    # ---- "e": second chunk of the NT loop (runMegaPath.sh:191-227): the reference's own stdout of set "a", de-interleaved,
+    # goes back in WITHOUT -nc so that the SCORE: comments are merged (BGS-IO.cpp:1348-1371), -top 95
+    lines = open(os.path.join(g1, "expected_a.fq"), "rb").read().split(b"\n")
+    e1, e2 = os.path.join(g1, "reads_e_1.fq"), os.path.join(g1, "reads_e_2.fq")
+    with open(e1, "wb") as a, open(e2, "wb") as b:
+        for i in range(0, len(lines) - 7, 8):
+            a.write(b"\n".join(lines[i:i + 4]) + b"\n")
+            b.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
+    cmd = [os.path.join(REF, "soap4"), "pair", prefix, e1, e2, "-o", os.path.join(g1, "e.tmp"), "-C", INI, "-L", "151", "-T", "1", "-u", "750", "-F", "-top", "95"]
+    with open(os.path.join(g1, "expected_e.fq"), "wb") as fo, open(os.devnull, "wb") as fe:
+        subprocess.check_call(cmd, stdout=fo, stderr=fe)
+    for f in os.listdir(g1):
+        if ".tmp" in f:
+            os.remove(os.path.join(g1, f))
+
     # ---- FM-index vectors from the real BWT.c
     R = O.ref_bwt()
     rx = R.ref_index_open(prefix.encode(), 1)

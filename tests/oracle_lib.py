@@ -45,7 +45,7 @@ class AlignParams(C.Structure):
     _fields_ = [("max_read_length", C.c_int), ("insert_low", C.c_int), ("insert_high", C.c_int),
                 ("clip_left", C.c_int), ("clip_right", C.c_int), ("megapath_mode", C.c_int),
                 ("top_percentage", C.c_double), ("quality_constant", C.c_int), ("skip_default_dp", C.c_int),
-                ("mmp", MmpParams)]
+                ("mmp", MmpParams), ("ignore_comments", C.c_int)]
 
 
 class AlignStats(C.Structure):
@@ -104,13 +104,14 @@ def oracle():
     return _oracle
 
 
-def default_params(L=151, insert_high=750, mode=1, top=95) -> AlignParams:
+def default_params(L=151, insert_high=750, mode=1, top=95, nc=False) -> AlignParams:
     p = AlignParams()
     oracle().mpo_default_params(C.byref(p))
     p.max_read_length = L
     p.insert_high = insert_high
     p.megapath_mode = mode
     p.top_percentage = top / 100.0
+    p.ignore_comments = 1 if nc else 0
     return p
 
 

@@ -67,3 +67,51 @@ def test_chained_chunks_merge_header_scores(golden_dir, tmp_path, driver):
     assert lib.mpo_align_fastq(ix, C.byref(p), str(f1).encode(), str(f2).encode(), str(ref_out).encode(), None, C.byref(st)) == 0
     assert fastq_records(str(out)) == fastq_records(str(ref_out))
     lib.mpo_index_close(ix)
+
+
+@pytest.mark.parametrize("driver", ["cxx", "py"])
+def test_paired_only_mode_gz_input_and_ignore_comments(golden_dir, tmp_path, driver):
+    """-P ("not paired == not aligned", BGS-IO.cpp:1393-1396, 2003-2011), gzip'ed inputs (kseq/zlib in the reference), and
+    reads carrying the IGNORE comment (BGS-IO.cpp:1400-1402, 2046-2048).  Expected output: the oracle in mode 2."""
+    import gzip
+    d = os.path.join(golden_dir, "g1")
+    src1 = open(os.path.join(d, "reads_a_1.fq"), "rb").read().split(b"\n")
+    src2 = open(os.path.join(d, "reads_a_2.fq"), "rb").read().split(b"\n")
+    # every 7th pair is marked IGNORE on read 1, every 11th on both mates
+    for i in range(0, len(src1) - 3, 4):
+        k = i // 4
+        if k % 7 == 0:
+            src1[i] = src1[i] + b" IGNORE"
+        if k % 11 == 0:
+            src1[i] = src1[i].split(b" ")[0] + b" IGNORE"
+            src2[i] = src2[i] + b" IGNORE"
+    f1, f2 = tmp_path / "p_1.fq", tmp_path / "p_2.fq"
+    f1.write_bytes(b"\n".join(src1))
+    f2.write_bytes(b"\n".join(src2))
+    g1, g2 = tmp_path / "p_1.fq.gz", tmp_path / "p_2.fq.gz"
+    for a, b in ((f1, g1), (f2, g2)):
+        with gzip.open(b, "wb") as z:
+            z.write(a.read_bytes())
+    out = tmp_path / "out.fq"
+    _run_cli(["pair", os.path.join(d, "ref.fa.index"), str(g1), str(g2), "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
+              "-L", "151", "-T", "1", "-u", "750", "-P"], out, driver=driver)
+    lib = O.oracle()
+    ix = lib.mpo_index_open(os.path.join(d, "ref.fa.index").encode())
+    p = O.default_params(L=151, mode=2)
+    st = O.AlignStats()
+    ref_out = tmp_path / "oracle.fq"
+    assert lib.mpo_align_fastq(ix, C.byref(p), str(f1).encode(), str(f2).encode(), str(ref_out).encode(), None, C.byref(st)) == 0
+    lib.mpo_index_close(ix)
+    got, want = fastq_records(str(out)), fastq_records(str(ref_out))
+    assert got == want
+    assert any(b"IGNORE" in h.encode() for _, _, h, _, _ in got)
+
+
+@pytest.mark.parametrize("driver", ["cxx", "py"])
+@pytest.mark.parametrize("tag,reads,flags", [("d", "d", ["-P"]), ("f", "d", ["-P", "-nc"]), ("e", "e", ["-F", "-top", "95"])])
+def test_cli_equals_reference_paired_only_and_chained(golden_dir, tmp_path, tag, reads, flags, driver):
+    d = os.path.join(golden_dir, "g1")
+    out = tmp_path / "out.fq"
+    _run_cli(["pair", os.path.join(d, "ref.fa.index"), os.path.join(d, "reads_%s_1.fq" % reads), os.path.join(d, "reads_%s_2.fq" % reads),
+              "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "1", "-u", "750"] + flags, out, driver=driver)
+    assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_%s.fq" % tag))

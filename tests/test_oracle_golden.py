@@ -65,3 +65,18 @@ def test_whole_path_matches_reference_stdout(g1, golden_dir, tmp_path, tag):
     assert got == want
     # every stage of the path must have been exercised by the fixture
     assert st.n_deep_dp_pairs > 0 and st.n_default_dp_pairs > 0 and st.n_unpaired_pairs > 0
+
+
+@pytest.mark.parametrize("tag,reads,mode,nc", [("d", "d", 2, False), ("f", "d", 2, True), ("e", "e", 1, False)])
+def test_paired_only_ignore_and_chained_chunk_goldens(g1, golden_dir, tmp_path, tag, reads, mode, nc):
+    """"d": -P with IGNORE comments; "f": the same with -nc (comments dropped first); "e": the second chunk of the NT loop, header scores of the first chunk merged.
+    Expected files are the real reference's stdout (tests/golden/make_golden.py)."""
+    lib = O.oracle()
+    d = os.path.join(golden_dir, "g1")
+    p = O.default_params(L=151, insert_high=750, mode=mode, top=95, nc=nc)
+    st = O.AlignStats()
+    out = tmp_path / "out.fq"
+    rc = lib.mpo_align_fastq(g1, C.byref(p), os.path.join(d, "reads_%s_1.fq" % reads).encode(), os.path.join(d, "reads_%s_2.fq" % reads).encode(),
+                             str(out).encode(), None, C.byref(st))
+    assert rc == 0
+    assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_%s.fq" % tag))

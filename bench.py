@@ -154,12 +154,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # rehearsal knobs (1-GPU boxes): MP_BENCH_SHARE_GPU=1 puts every rank on device 0, MP_BENCH_BACKEND=gloo avoids RCCL
+    if os.environ.get("MP_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from megapath_amd import hipapi as H
     from megapath_amd import index_builder, simulate
@@ -223,7 +230,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - tstart
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

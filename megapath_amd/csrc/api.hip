@@ -492,7 +492,7 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
     if (pick_shape(c->max_len, shape)) return MP_ERANGE;
     if (max_win > MP_DP_MAX_WIN) return MP_ERANGE;
     hipStream_t s = c->stream;
-    const uint32_t flag_rows = max_win + MP_DP_LPI;
+    const uint32_t flag_rows = (max_win + MP_DP_LPI + MP_DP_FLUSH - 1) / MP_DP_FLUSH * MP_DP_FLUSH;   // whole 8-step runs
     const size_t per_pair = (size_t)flag_rows * MP_DP_LPI * shape.nw * 4;
     uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 2 * std::max<uint64_t>(512, (3ull << 30) / per_pair));   // <= 3 GiB of flags, even
     chunk &= ~1u;

@@ -151,6 +151,7 @@ __device__ __forceinline__ v2s as_v2s(int v) { return __builtin_bit_cast(v2s, v)
 
 // flag words per lane-step for C columns: 3 cells (15 bits) per 16-bit half
 #define MP_DP_NW(C) (((C) + 2) / 3)
+#define MP_DP_FLUSH 8          // steps of flag words staged per lane before one contiguous global write
 
 template <int C, bool COUNT>
 __global__ void __launch_bounds__(MP_DP_BLOCK)
@@ -163,6 +164,9 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     constexpr int GROUPS = MP_DP_BLOCK / LPI;          // lane groups per block, two instances each
     constexpr int NW = MP_DP_NW(C);
     __shared__ uint32_t s_win[GROUPS][2][MP_DP_MAX_WIN / 16 + 1];
+    // per-lane staging of 8 steps of flag words (odd row stride: conflict-free ds_write_b32); a lane only ever reads its
+    // own row, so no barrier is involved -- LDS is used as a transposing scratchpad
+    __shared__ uint32_t s_fl[GROUPS][LPI][MP_DP_FLUSH * NW + 1];
     const int g = threadIdx.x / LPI;
     const int k = threadIdx.x % LPI;
     const uint32_t pair = blockIdx.x * GROUPS + g;
@@ -232,7 +236,8 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     v2s cnt = kZero;
     v2s outH = kZero, outF = pk1(MP_DP_NEG16);
     int outB = 0;
-    uint32_t *frow = flags + (uint64_t)pair * flag_rows * (LPI * NW);
+    // slab of one instance pair: [lane][step][word] -- the traceback walks a lane's steps, 8 of them per 64-byte line
+    uint32_t *frow = flags + (uint64_t)pair * flag_rows * (LPI * NW) + (uint64_t)k * flag_rows * NW;
     const int mmax = m[0] > m[1] ? m[0] : m[1];
     int steps = mmax > 0 ? mmax + LPI - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(steps, o); steps = v > steps ? v : steps; }
@@ -280,9 +285,19 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             diag_carry = as_v2s(inHi);
             outH = Hl; outF = Fl;
 #pragma unroll
-            for (int w = 0; w < NW; w++) frow[((uint64_t)(t - 1) * LPI + k) * NW + w] = __builtin_bit_cast(uint32_t, fw[w]);
+            for (int w = 0; w < NW; w++) s_fl[g][k][((t - 1) & (MP_DP_FLUSH - 1)) * NW + w] = __builtin_bit_cast(uint32_t, fw[w]);
         }
         outB = inB;
+        if ((t & (MP_DP_FLUSH - 1)) == 0 || t == steps) {
+            // flush this lane's last (up to) 8 steps as one contiguous run
+            uint32_t *dst = frow + (uint64_t)((t - 1) & ~(MP_DP_FLUSH - 1)) * NW;
+#pragma unroll
+            for (int w = 0; w < MP_DP_FLUSH * NW; w += 4) {
+                uint4 v;
+                v.x = s_fl[g][k][w]; v.y = s_fl[g][k][w + 1]; v.z = s_fl[g][k][w + 2]; v.w = s_fl[g][k][w + 3];
+                *reinterpret_cast<uint4 *>(dst + w) = v;
+            }
+        }
     }
 
     // ---- per instance: reduce over the 32 lanes -- max score, then smallest row, then smallest column; ties counted
@@ -337,7 +352,7 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
     mp_dp_result res; res.score = 0; res.hit_loc = 0; res.max_score_count = 0; res.n_ops = 0;
     if (fr.score < cutoff || fr.score <= 0 || task.win_len == 0) { out[inst] = res; return; }
     res.max_score_count = fr.count;
-    const uint32_t *frow = flags + (uint64_t)(inst >> 1) * flag_rows * (LPI * NW);
+    const uint32_t *fpair = flags + (uint64_t)(inst >> 1) * flag_rows * (LPI * NW);
     const int half = (int)(inst & 1u) * 16;
     uint8_t *op = ops ? ops + (uint64_t)inst * ops_stride : nullptr;
     uint32_t n = 0;
@@ -347,7 +362,7 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
         if (c == 0) return TB_Z;
         if (r == 0) return c <= clipL ? TB_Z : 0u;
         const int lane = (c - 1) / C, cc = (c - 1) % C;
-        const uint32_t w = frow[((uint64_t)(r + lane - 1) * LPI + lane) * NW + cc / 3];
+        const uint32_t w = fpair[((uint64_t)lane * flag_rows + (uint32_t)(r + lane - 1)) * NW + cc / 3];
         const uint32_t b = (w >> (half + 5 * (cc % 3))) & 31u;
         return (b & TBP_Z) | ((b ^ 30u) & 30u);       // invert nD, nE, nEO, nFO
     };

@@ -506,19 +506,20 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_bas
     }
     n_pos[r] = (uint32_t)np;
     n_neg[r] = (uint32_t)nn;
-    if (w) atomicAdd(&ctr->n_seedpos, (unsigned long long)w);
+    if (w) atomicAdd(&ctr->n_seedpos, (unsigned long long)w);      // no-return atomic; rare enough after the early exits
 }
 
 // ------------------------------------------------------------------------------------------------ K4
 __device__ __forceinline__ int mp_margin(int l) { return l > 100 ? 30 : 25; }
 
-__global__ void __launch_bounds__(128)
-pair_kernel(const mp_seedpos *__restrict__ seedpos, const uint32_t *__restrict__ rs_base, const uint32_t *__restrict__ n_pos,
-            const uint32_t *__restrict__ n_neg, const uint32_t *__restrict__ lens, uint32_t n_pairs, int insert_low, int insert_high,
-            mp_candidate *__restrict__ cands, uint32_t cand_cap, mp_counters *ctr)
+// Emits (EMIT) or only counts the candidates of one pair: pairEndMerge for both legs.
+template <bool EMIT>
+__device__ __forceinline__ uint32_t pair_candidates(const mp_seedpos *__restrict__ seedpos, const uint32_t *__restrict__ rs_base,
+                                                    const uint32_t *__restrict__ n_pos, const uint32_t *__restrict__ n_neg,
+                                                    const uint32_t *__restrict__ lens, uint32_t p, int insert_low, int insert_high,
+                                                    mp_candidate *__restrict__ out)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
+    uint32_t n = 0;
     for (int leg = 0; leg < 2; leg++) {
         // leg 0: read '+' with mate '-' (readIDLeft even); leg 1: mate '+' with read '-' (readIDLeft odd)
         const uint32_t lft = 2 * p + (uint32_t)leg, rgt = lft ^ 1u;
@@ -543,14 +544,35 @@ pair_kernel(const mp_seedpos *__restrict__ seedpos, const uint32_t *__restrict__
                 const uint64_t mate_loc = R[b].pos;
                 if (read_loc + (uint64_t)(int64_t)length_high < mate_loc) break;
                 else if (read_loc + (uint64_t)(int64_t)length_low <= mate_loc) {
-                    uint32_t slot = (uint32_t)atomicAdd(&ctr->n_cand, 1ull);
-                    if (slot < cand_cap) {
-                        mp_candidate c; c.read_id_left = lft; c.pad = 0; c.pos0 = read_loc; c.pos1 = mate_loc;
-                        cands[slot] = c;
-                    } else atomicAdd(&ctr->overflow, 1ull);
+                    if (EMIT) { mp_candidate c; c.read_id_left = lft; c.pad = 0; c.pos0 = read_loc; c.pos1 = mate_loc; out[n] = c; }
+                    n++;
                     pre_start = b;                           // App. D7: overwritten at every match
                 }
             }
         }
     }
+    return n;
+}
+
+// One lane per pair.  Count, reserve a contiguous range with ONE atomic per wavefront (a single counter word sustains
+// only ~90 returning atomics per microsecond), then emit.
+__global__ void __launch_bounds__(128)
+pair_kernel(const mp_seedpos *__restrict__ seedpos, const uint32_t *__restrict__ rs_base, const uint32_t *__restrict__ n_pos,
+            const uint32_t *__restrict__ n_neg, const uint32_t *__restrict__ lens, uint32_t n_pairs, int insert_low, int insert_high,
+            mp_candidate *__restrict__ cands, uint32_t cand_cap, mp_counters *ctr)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & (MP_WAVE - 1);
+    const uint32_t mine = p < n_pairs ? pair_candidates<false>(seedpos, rs_base, n_pos, n_neg, lens, p, insert_low, insert_high, nullptr) : 0u;
+    // inclusive prefix sum over the wavefront
+    uint32_t incl = mine;
+    for (int o = 1; o < MP_WAVE; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const uint32_t total = __shfl(incl, MP_WAVE - 1);
+    uint32_t base = 0;
+    if (lane == MP_WAVE - 1 && total) base = (uint32_t)atomicAdd(&ctr->n_cand, (unsigned long long)total);
+    base = __shfl(base, MP_WAVE - 1);
+    if (mine == 0) return;
+    const uint32_t at = base + incl - mine;
+    if (at + mine <= cand_cap) pair_candidates<true>(seedpos, rs_base, n_pos, n_neg, lens, p, insert_low, insert_high, cands + at);
+    else atomicAdd(&ctr->overflow, 1ull);
 }

@@ -159,6 +159,8 @@ typedef struct {
  * context until the next call; *out_n_hits receives their number. */
 int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n_hits, mp_round_stats *out_stats);
 int mp_get_pair_hits(mp_ctx *ctx, mp_pair_hit *out_hits, uint64_t cap);
+/* Same without a pageable copy: the hits land in a pinned buffer owned by the context (valid until the next call). */
+int mp_get_pair_hits_view(mp_ctx *ctx, const mp_pair_hit **out_hits, uint64_t *out_n);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Rescue passes for the pairs the deep-DP round left without a hit.  Replaces DPForUnalignSingle2

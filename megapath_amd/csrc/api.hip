@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <new>
 #include "mp_internal.h"
+#include "kernels_index.hip"
 #include "kernels_seed.hip"
 #include "kernels_dp.hip"
 #include "kernels_rescue.hip"
@@ -68,6 +69,8 @@ struct mp_ctx {
     DevBuf<mp_pair_hit> pair_hits;
     DevBuf<unsigned long long> n_pair_hits;
     uint64_t n_pair_hits_host = 0;
+    mp_pair_hit *h_pair_hits = nullptr;    // pinned staging for mp_get_pair_hits_view
+    size_t h_pair_hits_cap = 0;
     // rescue passes
     DevBuf<uint32_t> pair_done, failed_flag, failed_off, failed_reads, n_scand, s_off, rsrc;
     DevBuf<mp_single_cand> scand;
@@ -103,6 +106,7 @@ extern "C" int mp_device_check(int device, char *out_name, size_t name_cap)
 }
 
 // ------------------------------------------------------------------------------------------------ index
+// Uploads the raw index arrays and builds the HBM layouts with streaming kernels (kernels_index.hip).
 static int upload_index(int device, mp_host_index &h, mp_index **out)
 {
     HIPCHK(hipSetDevice(device));
@@ -113,19 +117,51 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
     for (int i = 0; i < 5; i++) ix->cum[i] = h.cum[i];
     ix->seq_names = std::move(h.seq_names); ix->seq_start = std::move(h.seq_start); ix->seq_len = std::move(h.seq_len);
     ix->grid = std::move(h.grid); ix->translate = std::move(h.translate);
-    struct { void **dst; const void *src; size_t bytes; } parts[4] = {
-        {&ix->d_occ, h.occ.data(), h.occ.size() * sizeof(mp_occ_block)},
-        {&ix->d_lkt, h.lkt.data(), h.lkt.size() * 4},
-        {&ix->d_sa, h.sa.data(), h.sa.size() * 4},
-        {&ix->d_text, h.text.data(), h.text.size() * 4}};
-    for (auto &pt : parts) {
-        if (hipMalloc(pt.dst, pt.bytes) != hipSuccess) { mp_index_close(ix); return MP_ENOMEM; }
-        if (hipMemcpy(*pt.dst, pt.src, pt.bytes, hipMemcpyHostToDevice) != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
-        ix->device_bytes += pt.bytes;
+    const uint64_t n = h.n;
+    const uint32_t n_blocks = (uint32_t)((n + 2) / MP_OCC_SYMS + 2);   // ranks are asked up to n+1: one spare block keeps loads in bounds
+    const uint64_t text_words = n / 16 + 4;
+    const size_t occ_bytes = (size_t)n_blocks * sizeof(mp_occ_block), lkt_bytes = (size_t)MP_LKT_ENTRIES * 4, sa_bytes = h.sa.size() * 4,
+                 text_bytes = (size_t)text_words * 4;
+    void *d_bwt = nullptr, *d_pac = nullptr, *d_cnt = nullptr, *d_run = nullptr, *d_tmp = nullptr;
+    auto fail = [&](int rc) { (void)hipFree(d_bwt); (void)hipFree(d_pac); (void)hipFree(d_cnt); (void)hipFree(d_run); (void)hipFree(d_tmp); mp_index_close(ix); return rc; };
+    if (hipMalloc(&ix->d_occ, occ_bytes) != hipSuccess || hipMalloc(&ix->d_lkt, lkt_bytes) != hipSuccess || hipMalloc(&ix->d_sa, sa_bytes) != hipSuccess ||
+        hipMalloc(&ix->d_text, text_bytes) != hipSuccess) return fail(MP_ENOMEM);
+    ix->device_bytes = occ_bytes + lkt_bytes + sa_bytes + text_bytes;
+    const size_t bwt_in = ((size_t)n_blocks * 12 + 16) * 4, pac_in = (size_t)text_words * 4 + 16;
+    if (hipMalloc(&d_bwt, bwt_in) != hipSuccess || hipMalloc(&d_pac, pac_in) != hipSuccess || hipMalloc(&d_cnt, (size_t)n_blocks * 16) != hipSuccess ||
+        hipMalloc(&d_run, (size_t)n_blocks * 16) != hipSuccess) return fail(MP_ENOMEM);
+    if (hipMemset(d_bwt, 0, bwt_in) != hipSuccess || hipMemset(d_pac, 0, pac_in) != hipSuccess) return fail(MP_ENODEV);
+    if (hipMemcpy(d_bwt, h.bwt_words.data(), std::min(bwt_in, h.bwt_words.size() * 4), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_pac, h.pac.data(), std::min(pac_in, h.pac.size()), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ix->d_sa, h.sa.data(), sa_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(MP_ENODEV);
+    // rank blocks: per-block symbol counts -> exclusive scans -> blocks with running counts and LSB-first payload
+    hipLaunchKernelGGL(occ_count_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, 0, (const uint32_t *)d_bwt, n, n_blocks, (uint32_t *)d_cnt);
+    size_t tmp_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint32_t *)d_cnt, (uint32_t *)d_run, (int)n_blocks, 0);
+    size_t tmp2 = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp2, (uint32_t *)ix->d_lkt, (uint32_t *)ix->d_lkt, (int)MP_LKT_ENTRIES, 0);
+    tmp_bytes = std::max(tmp_bytes, tmp2) + 256;
+    if (hipMalloc(&d_tmp, tmp_bytes) != hipSuccess) return fail(MP_ENOMEM);
+    for (int c = 0; c < 4; c++)
+        (void)hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, (uint32_t *)d_cnt + (size_t)c * n_blocks, (uint32_t *)d_run + (size_t)c * n_blocks, (int)n_blocks, 0);
+    hipLaunchKernelGGL(occ_build_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, 0, (const uint32_t *)d_bwt, n, n_blocks, (const uint32_t *)d_run,
+                       (mp_occ_block *)ix->d_occ);
+    hipLaunchKernelGGL(text_build_kernel, dim3(grid_for(text_words, 256)), dim3(256), 0, 0, (const uint8_t *)d_pac, n, text_words, (uint32_t *)ix->d_text);
+    if (!h.lkt.empty()) {
+        if (hipMemcpy(ix->d_lkt, h.lkt.data(), lkt_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(MP_ENODEV);
+    } else {
+        // LTConstruct.c:44-105: count every 13-mer window of (text + 12 x 'A'), then an inclusive prefix sum
+        if (hipMemset(ix->d_lkt, 0, lkt_bytes) != hipSuccess) return fail(MP_ENODEV);
+        if (n) hipLaunchKernelGGL(lkt_hist_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, (uint32_t *)ix->d_lkt);
+        (void)hipcub::DeviceScan::InclusiveSum(d_tmp, tmp_bytes, (uint32_t *)ix->d_lkt, (uint32_t *)ix->d_lkt, (int)MP_LKT_ENTRIES, 0);
     }
+    if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
+    (void)hipFree(d_bwt); (void)hipFree(d_pac); (void)hipFree(d_cnt); (void)hipFree(d_run); (void)hipFree(d_tmp);
     ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt;
     ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text;
     ix->d.n = (uint32_t)h.n; ix->d.inv_sa0 = (uint32_t)h.inv_sa0; ix->d.sa_interval = h.sa_interval;
+    ix->d.sa_shift = 0xFFFFFFFFu;
+    for (uint32_t b = 0; b < 31; b++) if ((1u << b) == h.sa_interval) ix->d.sa_shift = b;
     for (int i = 0; i < 5; i++) ix->d.cum[i] = (uint32_t)h.cum[i];
     *out = ix;
     return MP_OK;
@@ -304,6 +340,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->queue.release(); c->n_pos.release(); c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
     c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
     c->ops.release(); c->pair_hits.release(); c->n_pair_hits.release();
+    if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
     c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
     c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release();
     delete c;
@@ -623,6 +660,26 @@ extern "C" int mp_get_pair_hits(mp_ctx *c, mp_pair_hit *out_hits, uint64_t cap)
     if (cap < c->n_pair_hits_host) return MP_ERANGE;
     HIPCHK(hipSetDevice(c->ix->device));
     if (c->n_pair_hits_host) HIPCHK(hipMemcpy(out_hits, c->pair_hits.p, (size_t)c->n_pair_hits_host * sizeof(mp_pair_hit), hipMemcpyDeviceToHost));
+    return MP_OK;
+}
+
+extern "C" int mp_get_pair_hits_view(mp_ctx *c, const mp_pair_hit **out_hits, uint64_t *out_n)
+{
+    if (!c || !out_hits || !out_n) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    const size_t n = c->n_pair_hits_host;
+    if (n > c->h_pair_hits_cap) {
+        if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
+        c->h_pair_hits = nullptr; c->h_pair_hits_cap = 0;
+        const size_t want = n + n / 4 + 1024;
+        if (hipHostMalloc((void **)&c->h_pair_hits, want * sizeof(mp_pair_hit), hipHostMallocDefault) != hipSuccess) return MP_ENOMEM;
+        c->h_pair_hits_cap = want;
+    }
+    if (n) {
+        HIPCHK(hipMemcpyAsync(c->h_pair_hits, c->pair_hits.p, n * sizeof(mp_pair_hit), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *out_hits = c->h_pair_hits; *out_n = n;
     return MP_OK;
 }
 

@@ -285,8 +285,9 @@ void align_batch(mp_index *ix, mp_ctx *ctx, Params &p, Batch &b, bool &first, Wr
     uint64_t nh = 0;
     mp_round_stats rs;
     die(mp_deep_dp_round(ctx, &ap, &nh, &rs), "mp_deep_dp_round");
-    std::vector<mp_pair_hit> hits(nh);
-    if (nh) die(mp_get_pair_hits(ctx, hits.data(), nh), "mp_get_pair_hits");
+    const mp_pair_hit *view = nullptr;
+    die(mp_get_pair_hits_view(ctx, &view, &nh), "mp_get_pair_hits_view");
+    std::vector<mp_pair_hit> hits(view, view + nh);
     st.pairs += n_pairs; st.dp += 2 * rs.n_candidates;
     // OutputBuffer::ready: per pair sort by (pos1, pos2, score1, score2) and drop duplicates (DV-DPfunctions.h:165-196)
     std::sort(hits.begin(), hits.end(), [](const mp_pair_hit &x, const mp_pair_hit &y) {

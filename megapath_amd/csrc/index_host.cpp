@@ -5,8 +5,9 @@
 //   DNALoadPacked      soap4/2bwt-lib/TextConverter.c:427-499 (.pac)
 //   HSPLoad            soap4/2bwt-lib/HSP.c:57-300       (.ann, .tra)
 //   LTLoad             soap4/2bwt-flex/LT.c:37-57        (.lkt; rebuilt from the text as LTConstruct.c:44-105 when absent)
-// The explicit-occurrence file (.fmv) is only header-checked: the 64-byte blocks carry their own running counts,
-// recomputed here in one pass over the BWT.
+// The explicit-occurrence file (.fmv) is only header-checked: the 64-byte rank blocks carry their own running counts,
+// recomputed on the device (api.hip: upload_index) together with the LSB-first text and, when no .lkt file exists,
+// the 13-mer table.  This file only parses; no per-base loop runs on the host.
 #include "mp_internal.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,63 +23,14 @@ struct File {
     bool read(void *dst, size_t sz, size_t cnt) { return cnt == 0 || fread(dst, sz, cnt, f) == cnt; }
 };
 
-// symbol k of a reference-format BWT / text word array (16 per word, MSB first)
-inline uint32_t msb_sym(const uint32_t *w, uint64_t k) { return (w[k >> 4] >> (2 * (15 - (k & 15)))) & 3u; }
-
-void build_occ_blocks(const uint32_t *bwt_words, uint64_t n, std::vector<mp_occ_block> &occ)
-{
-    // ranks are asked for indices 0..n+1 (after the '$' adjustment 0..n): one spare block keeps every load in bounds
-    uint64_t n_blocks = (n + 2) / MP_OCC_SYMS + 2;
-    occ.assign(n_blocks, mp_occ_block{});
-    uint32_t run[4] = {0, 0, 0, 0};
-    for (uint64_t b = 0; b < n_blocks; b++) {
-        mp_occ_block &blk = occ[b];
-        for (int c = 0; c < 4; c++) blk.cnt[c] = run[c];
-        uint64_t base = b * MP_OCC_SYMS;
-        for (uint32_t s = 0; s < MP_OCC_SYMS; s++) {
-            uint64_t k = base + s;
-            if (k >= n) break;
-            uint32_t c = msb_sym(bwt_words, k);
-            blk.bwt[s >> 4] |= c << (2 * (s & 15));
-            run[c]++;
-        }
-    }
-}
-
-void build_text(const uint8_t *pac, uint64_t n, std::vector<uint32_t> &text)
-{
-    text.assign(n / 16 + 4, 0u);
-    for (uint64_t p = 0; p < n; p++) {
-        uint32_t c = (pac[p >> 2] >> (6 - 2 * (p & 3))) & 3u;
-        text[p >> 4] |= c << (2 * (p & 15));
-    }
-}
-
-void build_lkt_from_text(const std::vector<uint32_t> &text, uint64_t n, std::vector<uint32_t> &lkt)
-{
-    // LTConstruct.c:44-105: every 13-mer window of (text + 12 x 'A'), then an inclusive prefix sum
-    lkt.assign(MP_LKT_ENTRIES, 0u);
-    const uint64_t mask = MP_LKT_ENTRIES - 1;
-    uint64_t w = 0;
-    for (uint64_t i = 0; i < n + MP_LKT_K - 1; i++) {
-        uint32_t c = i < n ? (text[i >> 4] >> (2 * (i & 15))) & 3u : 0u;
-        w = ((w << 2) | c) & mask;
-        if (i >= MP_LKT_K - 1) lkt[w]++;
-    }
-    uint64_t acc = 0;
-    for (uint64_t k = 0; k < MP_LKT_ENTRIES; k++) { acc += lkt[k]; lkt[k] = (uint32_t)acc; }
-}
-
-int finish(mp_host_index &out, const uint32_t *bwt_words, const uint8_t *pac, const uint64_t *lkt64, std::string &err)
+int finish(mp_host_index &out, std::vector<uint32_t> &bwt_words, std::vector<uint8_t> &pac, const uint64_t *lkt64, std::string &err)
 {
     if (out.n >= 0xFFFFFFF0ull) { err = "text length must be below 2^32 (split the database into chunks as the reference does)"; return MP_ERANGE; }
-    build_occ_blocks(bwt_words, out.n, out.occ);
-    build_text(pac, out.n, out.text);
+    out.bwt_words.swap(bwt_words);
+    out.pac.swap(pac);
     if (lkt64) {
         out.lkt.resize(MP_LKT_ENTRIES);
         for (uint64_t k = 0; k < MP_LKT_ENTRIES; k++) out.lkt[k] = (uint32_t)lkt64[k];
-    } else {
-        build_lkt_from_text(out.text, out.n, out.lkt);
     }
     return MP_OK;
 }
@@ -162,7 +114,7 @@ int mp_host_index_load(const char *prefix_c, mp_host_index &out, std::string &er
             if (!f.read(&k, 4, 1) || k != MP_LKT_K || !f.read(lkt64.get(), 8, MP_LKT_ENTRIES)) { err = "bad " + prefix + ".lkt (lookup table size must be 13)"; return MP_EIO; }
         }
     }
-    return finish(out, bwt_words.data(), pac.data(), lkt64.get(), err);
+    return finish(out, bwt_words, pac, lkt64.get(), err);
 }
 
 int mp_host_index_from_arrays(uint64_t n, uint64_t inv_sa0, const uint64_t cum[5], const uint32_t *bwt_words,
@@ -193,5 +145,9 @@ int mp_host_index_from_arrays(uint64_t n, uint64_t inv_sa0, const uint64_t cum[5
         while (v + 1 < num_seq && starts[v + 1] <= pos) v++;
         out.grid[g] = v;
     }
-    return finish(out, bwt_words, pac, lkt, err);
+    std::vector<uint32_t> bw(bwt_words, bwt_words + (n + 15) / 16);
+    bw.resize(bw.size() + 16, 0u);
+    std::vector<uint8_t> pc(pac, pac + (n + 3) / 4);
+    pc.resize(pc.size() + 8, 0);
+    return finish(out, bw, pc, lkt, err);
 }

@@ -1,0 +1,87 @@
+// megapath_amd/csrc/kernels_index.hip -- product code: builds the HBM index layouts on the device from the reference's
+// file layouts: rank blocks from the MSB-first .bwt words, LSB-first text from .pac bytes, and the
+// 13-mer lookup table from the text when no .lkt file is shipped (LTConstruct.c:44-105).  Streaming kernels: every
+// input byte is read once, coalesced; no per-base loop runs on the host.
+#include <hip/hip_runtime.h>
+#include "mp_internal.h"
+
+// reverse the order of the sixteen 2-bit symbols of a word (MSB-first <-> LSB-first)
+__device__ __forceinline__ uint32_t mp_rev2(uint32_t x)
+{
+    uint32_t r = __brev(x);
+    return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+
+// symbols of block b that exist: the first `valid` of its 192
+__device__ __forceinline__ uint32_t mp_block_word(const uint32_t *__restrict__ bwt_msb, uint64_t n, uint32_t b, int w)
+{
+    const uint64_t first = (uint64_t)b * MP_OCC_SYMS + 16ull * (uint64_t)w;
+    if (first >= n) return 0u;
+    uint32_t v = mp_rev2(bwt_msb[first >> 4]);
+    const uint64_t left = n - first;
+    if (left < 16) v &= (1u << (2 * (uint32_t)left)) - 1u;
+    return v;
+}
+
+__global__ void occ_count_kernel(const uint32_t *__restrict__ bwt_msb, uint64_t n, uint32_t n_blocks, uint32_t *__restrict__ cnt /* [4][n_blocks] */)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint32_t c[4] = {0, 0, 0, 0};
+    for (int w = 0; w < 12; w++) {
+        const uint64_t first = (uint64_t)b * MP_OCC_SYMS + 16ull * (uint64_t)w;
+        if (first >= n) break;
+        const uint32_t v = mp_block_word(bwt_msb, n, b, w);
+        const uint64_t left = n - first;
+        const int ns = left < 16 ? (int)left : 16;
+        const uint32_t mask = ns < 16 ? ((1u << (2 * ns)) - 1u) & 0x55555555u : 0x55555555u;
+        for (uint32_t s = 1; s < 4; s++) {
+            const uint32_t x = v ^ (s * 0x55555555u);
+            c[s] += (uint32_t)__popc(~(x | (x >> 1)) & mask);
+        }
+        c[0] += (uint32_t)ns;
+    }
+    c[0] -= c[1] + c[2] + c[3];
+    for (int s = 0; s < 4; s++) cnt[(uint64_t)s * n_blocks + b] = c[s];
+}
+
+__global__ void occ_build_kernel(const uint32_t *__restrict__ bwt_msb, uint64_t n, uint32_t n_blocks, const uint32_t *__restrict__ run /* [4][n_blocks] exclusive */,
+                                 mp_occ_block *__restrict__ out)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    mp_occ_block blk;
+    for (int s = 0; s < 4; s++) blk.cnt[s] = run[(uint64_t)s * n_blocks + b];
+    for (int w = 0; w < 12; w++) blk.bwt[w] = mp_block_word(bwt_msb, n, b, w);
+    out[b] = blk;
+}
+
+__global__ void text_build_kernel(const uint8_t *__restrict__ pac, uint64_t n, uint64_t n_words, uint32_t *__restrict__ text)
+{
+    const uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (q >= n_words) return;
+    const uint64_t first = q * 16;
+    uint32_t v = 0;
+    if (first < n) {
+        const uint8_t *p = pac + q * 4;
+        v = mp_rev2(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]);
+        const uint64_t left = n - first;
+        if (left < 16) v &= (1u << (2 * (uint32_t)left)) - 1u;
+    }
+    text[q] = v;
+}
+
+// one lane per text position s: the 13-mer starting at s, the text continued with 'A's past its end, leftmost base in
+// the most significant bits of the key
+__global__ void lkt_hist_kernel(const uint32_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ lkt)
+{
+    const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    // 26 bits starting at base s (LSB-first words, zero = 'A' beyond n because the text buffer is zero padded)
+    const uint64_t q = s >> 4;
+    const uint32_t sh = 2 * (uint32_t)(s & 15);
+    const uint64_t two = ((uint64_t)text[q + 1] << 32) | text[q];
+    const uint32_t lsb = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);     // base s in bits 1:0
+    const uint32_t key = mp_rev2(lsb) >> 6;                                // base s in bits 25:24
+    atomicAdd(&lkt[key], 1u);
+}

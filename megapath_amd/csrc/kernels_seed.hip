@@ -47,16 +47,30 @@ __device__ __forceinline__ uint32_t mp_occ(const mp_dev_index &ix, uint32_t k, u
     return mp_occ_raw(ix, k, c);
 }
 
-// LF step (BWTPsiMinusValue, BWT.c:915-938): one 64-byte block gives both the symbol and its rank
+// LF step (BWTPsiMinusValue, BWT.c:915-938): ONE 64-byte block load gives both the symbol BWT[k-1] and its rank at k
+// (k-1 and k share the block unless k is a block boundary, where the rank is the next block's running count: the
+// symbol's own occurrence is then added by hand).
 __device__ __forceinline__ uint32_t mp_lf(const mp_dev_index &ix, uint32_t idx)
 {
     if (idx == ix.inv_sa0) return 0;
     uint32_t k = idx + 1;
     k -= (k > ix.inv_sa0);
-    uint32_t s = k - 1;
-    uint32_t b = s / MP_OCC_SYMS, so = s - b * MP_OCC_SYMS;
-    uint32_t c = (ix.occ[b].bwt[so >> 4] >> (2 * (so & 15))) & 3u;
-    return ix.cum[c] + mp_occ_raw(ix, k, c);
+    const uint32_t s = k - 1;
+    const uint32_t b = s / MP_OCC_SYMS, so = s - b * MP_OCC_SYMS;       // block of the symbol; rank wanted at offset so+1
+    const uint4 *p = reinterpret_cast<const uint4 *>(ix.occ + b);
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const uint32_t w[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    const uint32_t wi = so >> 4;
+    uint32_t word = w[0];
+#pragma unroll
+    for (int i = 1; i < 12; i++) word = wi == (uint32_t)i ? w[i] : word;
+    const uint32_t c = (word >> (2 * (so & 15))) & 3u;
+    uint32_t cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
+    const uint32_t pat = c * 0x55555555u;
+    const int off = (int)so + 1;                                         // symbols of this block counted: [0, so]
+#pragma unroll
+    for (int i = 0; i < 12; i++) { int ns = off - 16 * i; if (ns > 0) cnt += mp_popc_sym(w[i], pat, ns); }
+    return ix.cum[c] + cnt;
 }
 
 __global__ void occ_query_kernel(mp_dev_index ix, const uint64_t *idx, const uint32_t *sym, uint64_t n, uint64_t *out)
@@ -67,9 +81,15 @@ __global__ void occ_query_kernel(mp_dev_index ix, const uint64_t *idx, const uin
 
 __device__ __forceinline__ uint64_t mp_sa_value(const mp_dev_index &ix, uint32_t idx, uint32_t *steps_out)
 {
-    uint32_t steps = 0;
-    while (idx % ix.sa_interval != 0) { idx = mp_lf(ix, idx); steps++; }
-    uint32_t q = idx / ix.sa_interval;
+    uint32_t steps = 0, q;
+    if (ix.sa_shift != 0xFFFFFFFFu) {             // power-of-two sampling: mask and shift instead of integer division
+        const uint32_t mask = ix.sa_interval - 1;
+        while (idx & mask) { idx = mp_lf(ix, idx); steps++; }
+        q = idx >> ix.sa_shift;
+    } else {
+        while (idx % ix.sa_interval != 0) { idx = mp_lf(ix, idx); steps++; }
+        q = idx / ix.sa_interval;
+    }
     *steps_out = steps;
     // SA[0] is kept as -1 so that walking through the '$' row yields text position `steps - 1` (BWT.c:242,994-996)
     uint64_t base = q == 0 ? ~0ull : (uint64_t)ix.sa[q];

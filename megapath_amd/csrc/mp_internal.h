@@ -29,6 +29,7 @@ struct mp_dev_index {          // passed by value to kernels
     uint32_t inv_sa0;
     uint32_t cum[5];
     uint32_t sa_interval;
+    uint32_t sa_shift;         // log2(sa_interval) when it is a power of two (the builder default 16), else 0xFFFFFFFF
 };
 
 struct mp_translate_row { uint64_t start; uint32_t chr; uint64_t corr; };
@@ -50,8 +51,12 @@ struct mp_index {
 struct mp_host_index {
     uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};
     uint32_t sa_interval = 0;
-    std::vector<mp_occ_block> occ;
-    std::vector<uint32_t> lkt, sa, text;
+    // raw arrays in the reference's file layouts; the HBM layouts (rank blocks, LSB-first text, LKT when no .lkt file
+    // is present) are built on the device by upload_index (api.hip)
+    std::vector<uint32_t> bwt_words;   // 16 symbols per word, MSB first, '$' omitted
+    std::vector<uint8_t> pac;          // 4 bases per byte, first base in bits 7-6
+    std::vector<uint32_t> lkt;         // 4^13 inclusive right bounds, or empty -> rebuilt from the text
+    std::vector<uint32_t> sa;
     std::vector<std::string> seq_names;
     std::vector<uint64_t> seq_start, seq_len;
     std::vector<uint32_t> grid;

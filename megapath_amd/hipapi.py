@@ -95,7 +95,7 @@ class IndexInfo(C.Structure):
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_ctx_create", "mp_ctx_destroy",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
-           "mp_get_pair_hits", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
+           "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
 
 
 def build_library(force: bool = False) -> str:
@@ -139,6 +139,7 @@ def load_library():
     lib.mp_sgdp_batch.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mp_deep_dp_round.argtypes = [vp, C.POINTER(AlignParams), u64p, C.POINTER(RoundStats)]
     lib.mp_get_pair_hits.argtypes = [vp, vp, C.c_uint64]
+    lib.mp_get_pair_hits_view.argtypes = [vp, C.POINTER(vp), u64p]
     lib.mp_rescue_round.argtypes = [vp, C.POINTER(AlignParams), C.c_int, C.POINTER(RescueStats)]
     lib.mp_get_single_hits.argtypes = [vp, vp, C.c_uint64, u64p]
     lib.mp_get_rescue_hits.argtypes = [vp, vp, C.c_uint64, u64p]
@@ -326,9 +327,8 @@ class Context:
         nh = C.c_uint64()
         st = RoundStats()
         _chk(load_library().mp_deep_dp_round(self._h, C.byref(params), C.byref(nh), C.byref(st)), "mp_deep_dp_round")
-        # uninitialised host buffer (a ctypes array would be zero-filled first: ~150 MB per 1 Mi-pair batch)
-        buf = np.empty(max(nh.value, 1) * C.sizeof(PairHit), dtype=np.uint8)
-        if nh.value:
-            _chk(load_library().mp_get_pair_hits(self._h, buf.ctypes.data, nh.value), "mp_get_pair_hits")
-        hits = (PairHit * max(nh.value, 1)).from_buffer(buf)
+        # view of the context's pinned staging buffer: one DMA, no pageable copy, valid until the next round
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _chk(load_library().mp_get_pair_hits_view(self._h, C.byref(ptr), C.byref(n)), "mp_get_pair_hits_view")
+        hits = (PairHit * max(n.value, 1)).from_address(ptr.value) if n.value else (PairHit * 1)()
         return hits, nh.value, st

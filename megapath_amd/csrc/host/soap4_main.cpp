@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 #include <algorithm>
 #include <condition_variable>
 #include <map>
@@ -371,13 +372,19 @@ int main(int argc, char **argv)
     }
     Params p;
     std::string ini_path;
+    int cli_device = -1;
     const char *prefix = argv[2], *fq1 = argv[3], *fq2 = argv[4];
     for (int i = 5; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return argv[++i]; };
-        if (a == "-o" || a == "-T" || a == "-h" || a == "-p" || a == "-c" || a == "-s") (void)val();
+        // arities follow parseInputArgs (IniParam.cpp:651-896)
+        if (a == "-o" || a == "-T" || a == "-D" || a == "-A" || a == "-R" || a == "-e") (void)val();
+        else if (a == "-h") { int t = atoi(val()); if (t < 1 || t > 4) { fprintf(stderr, "The output option should be 1, 2, 3 or 4\n"); return 1; } }
+        else if (a == "-s") { if (i + 1 < argc && isdigit((unsigned char)argv[i + 1][0])) i++; }   // IniParam.cpp:738-757
+        else if (a == "-c") { cli_device = atoi(val()); if (cli_device < 0) { fprintf(stderr, "The GPU device ID should not be less than 0\n"); return 1; } }
+        else if (a == "-p" || a == "-I") {}                                                          // flags without a value
         else if (a == "-C") ini_path = val();
-        else if (a == "-L") p.max_read_length = atoi(val());
+        else if (a == "-L" || a == "-l") p.max_read_length = atoi(val());
         else if (a == "-u") p.insert_high = atoi(val());
         else if (a == "-v") p.insert_low = atoi(val());
         else if (a == "-top") p.top = atoi(val()) / 100.0;
@@ -386,6 +393,7 @@ int main(int argc, char **argv)
         else if (a == "-b") p.want_bam = true;
         else if (a == "-nc") p.ignore_comments = true;
     }
+    if (p.insert_low > p.insert_high) { fprintf(stderr, "The minimum value of insert size should not be greater than the maximum value of insert size.\n"); return 1; }
     if (p.mode == 0) { fprintf(stderr, "[soap4-mi355x] only MegaPath modes -F / -P are implemented (plain mode segfaults in the reference, SURVEY App. D15)\n"); return 1; }
     if (ini_path.empty()) ini_path = std::string(argv[0]) + ".ini";       // SOAP4.cpp:150-154
     Ini ini;
@@ -405,7 +413,8 @@ int main(int argc, char **argv)
     if (const char *e = getenv("MP_BATCH_PAIRS")) p.batch_pairs = (size_t)atol(e);
     if (p.want_bam) fprintf(stderr, "[soap4-mi355x] -b: BAM output is not written by this build (annotated FASTQ only)\n");
     int device = 0;
-    if (const char *e = getenv("MP_DEVICE")) device = atoi(e); else if (const char *e2 = getenv("LOCAL_RANK")) device = atoi(e2);
+    if (cli_device >= 0) device = cli_device;                              // -c <GPU device id>, IniParam.cpp:822-838
+    else if (const char *e = getenv("MP_DEVICE")) device = atoi(e); else if (const char *e2 = getenv("LOCAL_RANK")) device = atoi(e2);
     fill_char_map();
 
     mp_index *ix = nullptr;

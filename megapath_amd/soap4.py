@@ -73,12 +73,25 @@ def main(argv=None) -> int:
     i = 4
     while i < len(argv):
         a = argv[i]
-        if a in ("-o", "-T", "-h", "-p", "-c", "-s"):
+        if a in ("-o", "-T", "-D", "-A", "-R", "-e"):   # arities follow parseInputArgs (IniParam.cpp:651-896)
             i += 1                                 # value consumed, not used on this path
+        elif a == "-h":
+            i += 1
+            if not (1 <= int(argv[i]) <= 4):
+                sys.stderr.write("The output option should be 1, 2, 3 or 4\n")
+                return 1
+        elif a == "-s":
+            if i + 1 < len(argv) and argv[i + 1][:1].isdigit():
+                i += 1
+        elif a == "-c":
+            i += 1
+            device = int(argv[i])                  # GPU device id (IniParam.cpp:822-838)
+        elif a in ("-p", "-I"):
+            pass
         elif a == "-C":
             i += 1
             ini = argv[i]
-        elif a == "-L":
+        elif a in ("-L", "-l"):
             i += 1
             p.max_read_length = int(argv[i])
         elif a == "-u":
@@ -99,6 +112,9 @@ def main(argv=None) -> int:
         elif a == "-b":
             want_bam = True
         i += 1
+    if p.insert_low > p.insert_high:
+        sys.stderr.write("The minimum value of insert size should not be greater than the maximum value of insert size.\n")
+        return 1
     if mode == 0:
         sys.stderr.write("[soap4-mi355x] only MegaPath modes -F / -P are implemented (plain mode segfaults in the reference, SURVEY App. D15)\n")
         return 1

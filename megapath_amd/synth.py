@@ -65,11 +65,12 @@ def _mutate(frag: np.ndarray, rng, sub: float, ins: float, dele: float) -> np.nd
 def simulate_pairs(seqs, n_pairs: int, read_len: int, seed: int, frag_mean: float = 350.0, frag_sd: float = 40.0,
                    frag_min: int = 200, frag_max: int = 600, sub: float = 0.01, ins: float = 0.0005,
                    dele: float = 0.0005, random_frac: float = 0.0, len_range=None, n_frac: float = 0.0,
-                   broken_mate_frac: float = 0.0):
+                   broken_mate_frac: float = 0.0, noisy_mate_frac: float = 0.0, noisy_sub: float = 0.2):
     """Return (names, reads1, reads2) with reads as ASCII byte strings; FR orientation.
 
     `len_range=(lo,hi)` draws each mate's length uniformly (config C5); `random_frac` replaces whole
-    pairs by random sequence; `broken_mate_frac` replaces one mate by random sequence.
+    pairs by random sequence; `broken_mate_frac` replaces one mate by random sequence; `noisy_mate_frac` gives one
+    mate extra substitutions at rate `noisy_sub` (too few exact seeds: only mate rescue can place it).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     lens = np.asarray([len(s[1]) for s in seqs], dtype=np.int64)
@@ -101,6 +102,15 @@ def simulate_pairs(seqs, n_pairs: int, read_len: int, seed: int, frag_mean: floa
                     a = _BASES[rng.integers(0, 4, size=l1)]
                 else:
                     b = _BASES[rng.integers(0, 4, size=l2)]
+            if noisy_mate_frac > 0 and rng.random() < noisy_mate_frac:
+                pick_a = rng.random() < 0.5
+                tgt = (a if pick_a else b).copy()
+                hit = rng.random(len(tgt)) < noisy_sub
+                tgt[hit] = _BASES[(np.searchsorted(_BASES, tgt[hit]) + 1 + rng.integers(0, 3, size=int(hit.sum()))) & 3]
+                if pick_a:
+                    a = tgt
+                else:
+                    b = tgt
         if n_frac > 0:
             a = a.copy(); b = b.copy()
             a[rng.random(len(a)) < n_frac] = ord("N")

@@ -36,6 +36,8 @@ struct mpo_index {
     int num_seq;
     char **seq_name;
     uint64_t *seq_start, *seq_len;
+    uint64_t *seq_actual_len; /* .tra tail: length with the removed N-runs (SAM header LN, SAM.cpp:117) */
+    uint64_t n_removed;       /* .tra header: numOfRemovedSegment */
     /* translate (.tra) */
     uint32_t n_grid;
     uint32_t *grid;
@@ -168,6 +170,13 @@ mpo_index *mpo_index_open(const char *prefix)
             if (fscanf(f, "%llu %u %llu\n", &a, &b, &c) != 3) { fprintf(stderr, "[oracle] bad .tra row\n"); exit(1); }
             ix->tr_start[t] = a; ix->tr_chr[t] = b; ix->tr_corr[t] = c;
         }
+        ix->n_removed = rem;
+        ix->seq_actual_len = (uint64_t *)xmalloc(8 * (size_t)ns);
+        for (int t = 0; t < ns; t++) {
+            unsigned long long a, b;
+            /* HSP.c:286-302: older indexes lack these rows; the packed lengths are used then */
+            if (fscanf(f, "%llu %llu\n", &a, &b) == 2) ix->seq_actual_len[t] = b; else ix->seq_actual_len[t] = ix->seq_len[t];
+        }
     }
     fclose(f);
 
@@ -190,7 +199,7 @@ void mpo_index_close(mpo_index *ix)
     if (!ix) return;
     free(ix->bwt); free(ix->occ_minor); free(ix->occ_major); free(ix->sa); free(ix->pac); free(ix->lkt);
     for (int i = 0; i < ix->num_seq; i++) free(ix->seq_name[i]);
-    free(ix->seq_name); free(ix->seq_start); free(ix->seq_len);
+    free(ix->seq_name); free(ix->seq_start); free(ix->seq_len); free(ix->seq_actual_len);
     free(ix->grid); free(ix->tr_start); free(ix->tr_corr); free(ix->tr_chr);
     free(ix);
 }
@@ -263,3 +272,23 @@ void mpo_chr_and_pos(const mpo_index *ix, uint64_t ambPos, uint64_t *tp, unsigne
     *tp = ambPos - ix->tr_corr[v];
     *chr = ix->tr_chr[v];
 }
+
+/* getChrAndPos with its return value (BGS-IO.cpp:163-188): the last packed position of the translate segment, computed
+ * as the reference does -- `row < numOfRemovedSegment - 1 ? next row's start - 1 : dnaLength` in unsigned 64-bit, so that
+ * with no removed segment every row takes the first branch.  For the last row that branch reads one element past the
+ * reference's array (undefined there); the text length is returned here, which gives the same trimming decisions
+ * unless that stray value happened to fall inside the read. */
+uint64_t mpo_chr_and_pos_seg(const mpo_index *ix, uint64_t ambPos, uint64_t *tp, unsigned *chr)
+{
+    uint64_t g = ambPos >> 18;
+    if (g >= ix->n_grid) g = ix->n_grid - 1;
+    uint32_t v = ix->grid[g];
+    while (v > 0 && ix->tr_start[v] > ambPos) v--;
+    *tp = ambPos - ix->tr_corr[v];
+    *chr = ix->tr_chr[v];
+    if ((uint64_t)v < ix->n_removed - 1 && v + 1 < ix->n_trans) return ix->tr_start[v + 1] - 1;
+    return ix->n;
+}
+uint64_t mpo_seq_start(const mpo_index *ix, int i) { return ix->seq_start[i]; }
+uint64_t mpo_seq_length(const mpo_index *ix, int i) { return ix->seq_len[i]; }
+uint64_t mpo_seq_actual_length(const mpo_index *ix, int i) { return ix->seq_actual_len[i]; }

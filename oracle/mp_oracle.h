@@ -45,6 +45,11 @@ unsigned mpo_text_base(const mpo_index *ix, uint64_t p);
 /* packed-position -> (1-based position in sequence, 1-based sequence id); getChrAndPos (BGS-IO.cpp:163-188) */
 void mpo_chr_and_pos(const mpo_index *ix, uint64_t ambPos, uint64_t *tp, unsigned *chr);
 const uint64_t *mpo_lkt_table(const mpo_index *ix);
+/* getChrAndPos including its return value: last packed position of the translate segment (BGS-IO.cpp:163-188) */
+uint64_t mpo_chr_and_pos_seg(const mpo_index *ix, uint64_t ambPos, uint64_t *tp, unsigned *chr);
+uint64_t mpo_seq_start(const mpo_index *ix, int i);          /* seqOffset[i].startPos (.ann) */
+uint64_t mpo_seq_length(const mpo_index *ix, int i);         /* packed length (.ann) */
+uint64_t mpo_seq_actual_length(const mpo_index *ix, int i);  /* seqActualOffset length (.tra tail) = SAM header LN */
 
 /* ------------------------------------------------------------------ DP (rows a9, a10) */
 typedef struct {
@@ -140,6 +145,13 @@ typedef struct {
  * for the best alignment (what the BAM record would carry).  Returns 0 on success. */
 int mpo_align_fastq(const mpo_index *ix, const mpo_align_params *p, const char *fq1, const char *fq2,
                     const char *out_fastq, const char *out_records, mpo_align_stats *stats);
+
+/* Same with the BAM side of `-b` (row a15) restated as text: writes <bam_text_prefix>.dpout.txt / .gout.txt / .unpair.txt,
+ * one line per BAM record in the form tests/bamtext.py prints for a decoded BAM file, and <bam_text_prefix>.header.txt
+ * (SAMOutputHeaderConstruct, SAM.cpp:83-132).  print_mdnm = -p; read_group = -D or the first read file as given. */
+int mpo_align_fastq_bam(const mpo_index *ix, const mpo_align_params *p, const char *fq1, const char *fq2,
+                        const char *out_fastq, const char *out_records, const char *bam_text_prefix, int print_mdnm,
+                        const char *read_group, mpo_align_stats *stats);
 
 /* stage-level access used by tests: seed + pair one batch of reads given as codes */
 typedef struct {

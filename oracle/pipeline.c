@@ -173,7 +173,29 @@ typedef struct {
     char *cigar_1, *cigar_2;
     uint64_t start_1, start_2;     /* window starts (dpInfoForReads) */
     int dplen_1, dplen_2;
+    int editdist_1, editdist_2;    /* XA edit distance */
+    int count_1, count_2;          /* num_sameScore */
+    long long insert;              /* insertSize: only its sign reaches the BAM record */
 } deep_result;
+
+/* edit distance from the score identity (DV-DPfunctions.cpp:733-737, 1545-1548, 3466-3469); `len` is the read length the
+ * reference happens to use there (the right leg's for both mates of a deep-DP pair).  Also returns D - I - S. */
+static int edit_dist(const char *sp, int len, int score, int *dis)
+{
+    int nI = 0, nD = 0, nS = 0, gap = 0, cur = 0;
+    for (const char *p = sp; *p; p++) {
+        if (*p >= '0' && *p <= '9') { cur = cur * 10 + (*p - '0'); continue; }
+        if (cur > 0) {
+            if (*p == 'I') { nI += cur; gap += -3 + (cur - 1) * -1; }
+            else if (*p == 'D') { nD += cur; gap += -3 + (cur - 1) * -1; }
+            else if (*p == 'S') nS += cur;
+        }
+        cur = 0;
+    }
+    if (dis) *dis = nD - nI - nS;
+    int L = len - nI - nS;
+    return nI + nD + (L * 1 + gap - score) / (1 - -2);
+}
 
 static int cmp_deep(const void *a, const void *b)
 {
@@ -301,6 +323,7 @@ typedef struct {
     int strand, score, seed_len;
     uint64_t algnmt;
     char *cigar;
+    int editdist, count;
 } single_result;
 
 /* unproperlypairDPOutputFastqAPI (BGS-IO.cpp:1384-1446) */
@@ -424,10 +447,18 @@ void mpo_default_params(mpo_align_params *p)
     p->mmp.short_seed_ratio = 0.5;
 }
 
+#include "samout.inc"
 #include "rescue.inc"
 
 int mpo_align_fastq(const mpo_index *ix, const mpo_align_params *Pin, const char *fq1, const char *fq2,
                     const char *out_fastq, const char *out_records, mpo_align_stats *stats)
+{
+    return mpo_align_fastq_bam(ix, Pin, fq1, fq2, out_fastq, out_records, NULL, 0, NULL, stats);
+}
+
+int mpo_align_fastq_bam(const mpo_index *ix, const mpo_align_params *Pin, const char *fq1, const char *fq2,
+                        const char *out_fastq, const char *out_records, const char *bam_text_prefix, int print_mdnm,
+                        const char *read_group, mpo_align_stats *stats)
 {
     mpo_align_params Pv = *Pin, *P = &Pv;
     mpo_align_stats local; if (!stats) stats = &local;
@@ -440,6 +471,24 @@ int mpo_align_fastq(const mpo_index *ix, const mpo_align_params *Pin, const char
     FILE *out = fopen(out_fastq, "wb");
     FILE *rec = out_records ? fopen(out_records, "wb") : NULL;
     if (!out) { fprintf(stderr, "[oracle] cannot write %s\n", out_fastq); return -1; }
+    sam_ctx sam_store, *sam = NULL;
+    if (bam_text_prefix) {
+        static const char *ext[3] = {".dpout.txt", ".gout.txt", ".unpair.txt"};
+        char path[4096];
+        sam = &sam_store; sam_ctx_init(sam);
+        sam->print_mdnm = print_mdnm; sam->read_group = read_group ? read_group : fq1;
+        for (int k = 0; k < 3; k++) {
+            snprintf(path, sizeof path, "%s%s", bam_text_prefix, ext[k]);
+            if (!(sam->f[k] = fopen(path, "wb"))) { fprintf(stderr, "[oracle] cannot write %s\n", path); return -1; }
+        }
+        /* SAMOutputHeaderConstruct (SAM.cpp:83-132); sample name and read-group option default to "default" and "" */
+        snprintf(path, sizeof path, "%s.header.txt", bam_text_prefix);
+        FILE *h = fopen(path, "wb");
+        if (!h) return -1;
+        fprintf(h, "@HD\tVN:1.3\tSO:unsorted\n@RG\tID:%s\tSM:%s\t%s\n", sam->read_group, "default", "");
+        for (int i = 0; i < mpo_num_seqs(ix); i++) fprintf(h, "@SQ\tSN:%s\tLN:%u\n", mpo_seq_name(ix, i), (unsigned)mpo_seq_actual_length(ix, i));
+        fclose(h);
+    }
     const uint64_t text_len = mpo_text_length(ix);
     const int n_pairs = rs.n / 2;
     stats->n_pairs = (uint64_t)n_pairs;
@@ -510,6 +559,14 @@ int mpo_align_fastq(const mpo_index *ix, const mpo_align_params *Pin, const char
             d->cigar_1 = o[read_side].cigar; d->cigar_2 = o[mate_side].cigar;
             d->start_1 = ws[read_side]; d->start_2 = ws[mate_side];
             d->dplen_1 = wl[read_side]; d->dplen_2 = wl[mate_side];
+            {
+                int ed[2], dis[2];
+                for (int k = 0; k < 2; k++) ed[k] = edit_dist(o[k].cigar, rs.len[right], o[k].score, &dis[k]);   /* batch->lengths[i]: the right read's */
+                d->editdist_1 = ed[read_side]; d->editdist_2 = ed[mate_side];
+                d->count_1 = o[read_side].count; d->count_2 = o[mate_side].count;
+                if (d->algnmt_1 < d->algnmt_2) d->insert = (long long)(d->algnmt_2 - d->algnmt_1) + rs.len[right] + dis[1];
+                else d->insert = (long long)(d->algnmt_1 - d->algnmt_2) + rs.len[right] + dis[1];
+            }
         }
         if (results.n > 0) {
             deep_result *res = (deep_result *)results.p;
@@ -535,6 +592,7 @@ int mpo_align_fastq(const mpo_index *ix, const mpo_align_params *Pin, const char
                 }
             }
             output_pair_fastq(out, ix, &rs, P, res, (int)nres);
+            if (sam) { sam->stage = 1; sam_output_pair(sam, 0, ix, &rs, res, (int)nres, (int)best); }
             for (size_t i = 0; i < nres; i++) { free(res[i].cigar_1); free(res[i].cigar_2); }
             /* freeSeedAlignmentsOfReadWithReadId for properly paired reads (OutputDPResult.cpp:123-127) */
             vec_free(&pool.pool[r]); vec_free(&pool.pool[m]);
@@ -544,7 +602,8 @@ int mpo_align_fastq(const mpo_index *ix, const mpo_align_params *Pin, const char
         vec_free(&results); vec_free(&cands);
     }
 
-    rescue_and_output(ix, P, &rs, &pool, pair_done, out, rec, stats);
+    rescue_and_output(ix, P, &rs, &pool, pair_done, out, rec, sam, stats);
+    if (sam) for (int k = 0; k < 3; k++) fclose(sam->f[k]);
 
     for (int i = 0; i < rs.n; i++) { vec_free(&pool.pool[i]); vec_free(&pos_list[i]); vec_free(&neg_list[i]); }
     free(pool.pool); free(pos_list); free(neg_list); free(sp_pos); free(pair_done);

@@ -38,3 +38,17 @@ def fastq_records(path):
         out.append((name, seen[name], h, lines[i + 1], lines[i + 3]))
         i += 4
     return sorted(out)
+
+
+def bam_golden(path):
+    """Parses tests/golden/**/expected_*.bam.txt -> {"header": str, "dpout": [...], "gout": [...], "unpair": [...]}."""
+    out = {"header": "", "dpout": [], "gout": [], "unpair": []}
+    cur = None
+    for line in open(path).read().splitlines():
+        if line.startswith("#") and line[1:] in out:
+            cur = line[1:]
+        elif cur == "header":
+            out["header"] += line + "\n"
+        else:
+            out[cur].append(line)
+    return out

@@ -100,8 +100,24 @@ def oracle():
         lib.mpo_default_params.argtypes = [C.POINTER(AlignParams)]
         lib.mpo_align_fastq.argtypes = [C.c_void_p, C.POINTER(AlignParams), C.c_char_p, C.c_char_p, C.c_char_p,
                                         C.c_char_p, C.POINTER(AlignStats)]
+        lib.mpo_align_fastq_bam.argtypes = [C.c_void_p, C.POINTER(AlignParams), C.c_char_p, C.c_char_p, C.c_char_p,
+                                            C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(AlignStats)]
         _oracle = lib
     return _oracle
+
+
+def align_fastq_bam(index_prefix, params, fq1, fq2, out_fastq, bam_text_prefix, print_mdnm=False, read_group=None):
+    """Whole path with the BAM side as text; returns {"dpout": [...], "gout": [...], "unpair": [...], "header": str}."""
+    lib = oracle()
+    ix = lib.mpo_index_open(index_prefix.encode())
+    st = AlignStats()
+    rc = lib.mpo_align_fastq_bam(ix, C.byref(params), fq1.encode(), fq2.encode(), out_fastq.encode(), None,
+                                 bam_text_prefix.encode(), int(print_mdnm), read_group.encode() if read_group else None, C.byref(st))
+    lib.mpo_index_close(ix)
+    assert rc == 0
+    out = {k: open("%s.%s.txt" % (bam_text_prefix, k)).read().splitlines() for k in ("dpout", "gout", "unpair")}
+    out["header"] = open(bam_text_prefix + ".header.txt").read()
+    return out
 
 
 def default_params(L=151, insert_high=750, mode=1, top=95, nc=False) -> AlignParams:

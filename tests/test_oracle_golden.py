@@ -80,3 +80,25 @@ def test_paired_only_ignore_and_chained_chunk_goldens(g1, golden_dir, tmp_path, 
                              str(out).encode(), None, C.byref(st))
     assert rc == 0
     assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_%s.fq" % tag))
+
+
+# (set, -L, MegaPath mode, -nc, -p): the flags the goldens were made with (tests/golden/make_golden_bam.py)
+BAM_SETS = {"a": (151, 1, True, False), "c": (301, 1, True, False), "d": (151, 2, False, False), "g": (151, 1, False, True),
+            "h": (151, 1, False, False)}
+
+
+@pytest.mark.parametrize("tag", sorted(BAM_SETS))
+def test_bam_records_match_reference_bam(g1_prefix, golden_dir, tmp_path, tag):
+    """Row a15: every BAM record the real `soap4 -b` wrote (.dpout.1 / .gout.1 / .unpair, decoded), field for field:
+    flag, position, MAPQ, CIGAR, mate fields, tlen, sequence, qualities and the RG X0 X1 XM XO XG [NM MD] XA PH tags."""
+    from conftest import bam_golden
+    L, mode, nc, mdnm = BAM_SETS[tag]
+    g = os.path.join(golden_dir, "g1")
+    P = O.default_params(L=L, mode=mode, nc=nc)
+    got = O.align_fastq_bam(g1_prefix, P, os.path.join(g, "reads_%s_1.fq" % tag), os.path.join(g, "reads_%s_2.fq" % tag),
+                            str(tmp_path / "o.fq"), str(tmp_path / "o"), print_mdnm=mdnm, read_group="reads_%s_1.fq" % tag)
+    want = bam_golden(os.path.join(g, "expected_%s.bam.txt" % tag))
+    for k in ("dpout", "gout", "unpair"):
+        assert got[k] == want[k], k
+    assert want["header"].startswith(got["header"])          # the reference appends its own @PG line
+    assert open(tmp_path / "o.fq", "rb").read() == open(os.path.join(g, "expected_%s.fq" % tag), "rb").read()

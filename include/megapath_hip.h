@@ -55,6 +55,14 @@ const char *mp_index_seq_name(const mp_index *ix, uint32_t seq_id_1based);
 /* getChrAndPos (BGS-IO.cpp:163-188): packed position -> (1-based position in sequence, 1-based sequence id) */
 int mp_index_chr_and_pos(const mp_index *ix, uint64_t amb_pos, uint64_t *out_pos, uint32_t *out_seq_id);
 int mp_index_chr_and_pos_batch(const mp_index *ix, const uint64_t *amb_pos, uint64_t n, uint64_t *out_pos, uint32_t *out_seq_id);
+/* Same, also returning getChrAndPos's own return value: the last packed position of the translate segment
+ * (BGS-IO.cpp:186-187), which BoundaryCheckDP (BGS-IO.cpp:219) trims BAM records against. */
+int mp_index_chr_pos_segment(const mp_index *ix, uint64_t amb_pos, uint64_t *out_pos, uint32_t *out_seq_id, uint64_t *out_segment_end);
+/* HSP seqOffset[i].startPos / packed length (.ann) and seqActualOffset length (.tra tail = the BAM header's LN, SAM.cpp:117) */
+int mp_index_seq_info(const mp_index *ix, uint32_t seq_id_1based, uint64_t *out_start, uint64_t *out_packed_len, uint64_t *out_actual_len);
+/* Text bases (codes 0..3) of n_ranges ranges, gathered on the device from the resident .pac: range r lands in
+ * out[r*stride .. r*stride + min(len[r], stride)).  Replaces the host-side hsp->packedDNA reads of getMisInfoForDP (PE.cpp:459). */
+int mp_index_fetch_text(const mp_index *ix, const uint64_t *pos, const uint32_t *len, uint32_t n_ranges, uint8_t *out, uint32_t stride);
 
 /* Unit-level device queries (tests; mirror BWTOccValue BWT.c:597, BWTSaValue BWT.c:968, LKT use at
  * DV-DPfunctions.cpp:2245-2246). All arrays are host pointers; n entries each. */
@@ -174,6 +182,8 @@ typedef struct {              /* SingleAlgnmtResult (PEAlgnmt.h) of a read whose
     int32_t score;
     uint32_t count;           /* num_sameScore */
     uint64_t win_start;       /* startPos: orders the hits for mate rescue (DV-SemiDP.cpp:37-44) */
+    uint32_t win_len;         /* refDpLength: with win_start it names the DP instance again (mp_sgdp_batch gives its ops) */
+    uint32_t reserved;
 } mp_single_hit;
 
 typedef struct {              /* one successful mate rescue: the aligned mate's single hit + the DP hit of the other mate */
@@ -182,6 +192,9 @@ typedef struct {              /* one successful mate rescue: the aligned mate's 
     uint64_t aligned_pos, dp_pos;
     int32_t aligned_score, dp_score;
     uint32_t aligned_strand, dp_strand;
+    uint64_t aligned_win_start, dp_win_start;   /* DP windows of both mates (startPos / refDpLength of the reference) */
+    uint32_t aligned_win_len, dp_win_len;
+    uint32_t aligned_count, dp_count;           /* num_sameScore */
 } mp_rescue_hit;
 
 typedef struct {

@@ -117,6 +117,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
     for (int i = 0; i < 5; i++) ix->cum[i] = h.cum[i];
     ix->seq_names = std::move(h.seq_names); ix->seq_start = std::move(h.seq_start); ix->seq_len = std::move(h.seq_len);
     ix->grid = std::move(h.grid); ix->translate = std::move(h.translate);
+    ix->seq_actual_len = std::move(h.seq_actual_len); ix->n_removed = h.n_removed;
     const uint64_t n = h.n;
     const uint32_t n_blocks = (uint32_t)((n + 2) / MP_OCC_SYMS + 2);   // ranks are asked up to n+1: one spare block keeps loads in bounds
     const uint64_t text_words = n / 16 + 4;
@@ -233,6 +234,64 @@ extern "C" int mp_index_chr_and_pos(const mp_index *ix, uint64_t amb_pos, uint64
     *out_pos = amb_pos - ix->translate[v].corr;
     *out_seq = ix->translate[v].chr;
     return MP_OK;
+}
+
+// getChrAndPos with its return value (BGS-IO.cpp:163-188).  The reference evaluates `row < numOfRemovedSegment - 1` in
+// unsigned 64-bit arithmetic, so with no removed segment every row takes the "next row" branch; for the last row that
+// is a read past its array, for which the text length is returned here.
+extern "C" int mp_index_chr_pos_segment(const mp_index *ix, uint64_t amb_pos, uint64_t *out_pos, uint32_t *out_seq, uint64_t *out_segment_end)
+{
+    if (!ix || !out_pos || !out_seq || !out_segment_end || ix->grid.empty()) return MP_EINVAL;
+    uint64_t g = amb_pos >> 18;
+    if (g >= ix->grid.size()) g = ix->grid.size() - 1;
+    uint32_t v = ix->grid[g];
+    while (v > 0 && ix->translate[v].start > amb_pos) v--;
+    *out_pos = amb_pos - ix->translate[v].corr;
+    *out_seq = ix->translate[v].chr;
+    if ((uint64_t)v < ix->n_removed - 1 && (size_t)v + 1 < ix->translate.size()) *out_segment_end = ix->translate[v + 1].start - 1;
+    else *out_segment_end = ix->n;
+    return MP_OK;
+}
+
+extern "C" int mp_index_seq_info(const mp_index *ix, uint32_t seq_id_1based, uint64_t *out_start, uint64_t *out_packed_len, uint64_t *out_actual_len)
+{
+    if (!ix || seq_id_1based == 0 || seq_id_1based > ix->seq_names.size()) return MP_EINVAL;
+    if (out_start) *out_start = ix->seq_start[seq_id_1based - 1];
+    if (out_packed_len) *out_packed_len = ix->seq_len[seq_id_1based - 1];
+    if (out_actual_len) *out_actual_len = ix->seq_actual_len[seq_id_1based - 1];
+    return MP_OK;
+}
+
+__global__ void fetch_text_kernel(const uint32_t *__restrict__ text, uint64_t n, const uint64_t *__restrict__ pos, const uint32_t *__restrict__ len,
+                                  uint32_t n_ranges, uint8_t *__restrict__ out, uint32_t stride)
+{
+    const uint32_t r = blockIdx.x;
+    if (r >= n_ranges) return;
+    const uint64_t p0 = pos[r];
+    const uint32_t L = len[r] < stride ? len[r] : stride;
+    for (uint32_t i = threadIdx.x; i < L; i += blockDim.x) {
+        const uint64_t p = p0 + i;
+        out[(size_t)r * stride + i] = p < n ? (uint8_t)((text[p >> 4] >> (2 * (p & 15))) & 3u) : (uint8_t)0;
+    }
+}
+
+extern "C" int mp_index_fetch_text(const mp_index *ix, const uint64_t *pos, const uint32_t *len, uint32_t n_ranges, uint8_t *out, uint32_t stride)
+{
+    if (!ix || !pos || !len || !out || stride == 0) return MP_EINVAL;
+    if (n_ranges == 0) return MP_OK;
+    HIPCHK(hipSetDevice(ix->device));
+    uint64_t *d_pos = nullptr; uint32_t *d_len = nullptr; uint8_t *d_out = nullptr;
+    int rc = MP_OK;
+    if (hipMalloc((void **)&d_pos, (size_t)n_ranges * 8) != hipSuccess || hipMalloc((void **)&d_len, (size_t)n_ranges * 4) != hipSuccess ||
+        hipMalloc((void **)&d_out, (size_t)n_ranges * stride) != hipSuccess) rc = MP_ENOMEM;
+    if (!rc && (hipMemcpy(d_pos, pos, (size_t)n_ranges * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_len, len, (size_t)n_ranges * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = MP_ENODEV;
+    if (!rc) {
+        hipLaunchKernelGGL(fetch_text_kernel, dim3(n_ranges), dim3(64), 0, 0, ix->d.text, ix->n, d_pos, d_len, n_ranges, d_out, stride);
+        if (hipMemcpy(out, d_out, (size_t)n_ranges * stride, hipMemcpyDeviceToHost) != hipSuccess) rc = MP_ENODEV;
+    }
+    (void)hipFree(d_pos); (void)hipFree(d_len); (void)hipFree(d_out);
+    return rc;
 }
 
 extern "C" int mp_index_chr_and_pos_batch(const mp_index *ix, const uint64_t *amb_pos, uint64_t n, uint64_t *out_pos, uint32_t *out_seq)
@@ -776,7 +835,7 @@ extern "C" int mp_get_single_hits(mp_ctx *c, mp_single_hit *out, uint64_t cap, u
             if (w >= cap) return MP_ERANGE;
             mp_single_hit h;
             h.read_id = tasks[t].read_id; h.strand = tasks[t].strand; h.algnmt = tasks[t].win_start + res[t].hit_loc; h.score = res[t].score;
-            h.count = res[t].max_score_count; h.win_start = tasks[t].win_start;
+            h.count = res[t].max_score_count; h.win_start = tasks[t].win_start; h.win_len = tasks[t].win_len; h.reserved = 0;
             out[w] = h;
         }
         w++;
@@ -813,6 +872,8 @@ extern "C" int mp_get_rescue_hits(mp_ctx *c, mp_rescue_hit *out, uint64_t cap, u
             h.aligned_read = stasks[src].read_id; h.pair_id = h.aligned_read >> 1;
             h.aligned_pos = stasks[src].win_start + sres[src].hit_loc; h.aligned_score = sres[src].score; h.aligned_strand = stasks[src].strand;
             h.dp_pos = rtasks[q].win_start + rres[q].hit_loc; h.dp_score = rres[q].score; h.dp_strand = rtasks[q].strand;
+            h.aligned_win_start = stasks[src].win_start; h.aligned_win_len = stasks[src].win_len; h.aligned_count = sres[src].max_score_count;
+            h.dp_win_start = rtasks[q].win_start; h.dp_win_len = rtasks[q].win_len; h.dp_count = rres[q].max_score_count;
             out[w] = h;
         }
         w++;

@@ -104,6 +104,13 @@ int mp_host_index_load(const char *prefix_c, mp_host_index &out, std::string &er
             if (fscanf(f.f, "%llu %u %llu\n", &a, &b, &c) != 3) { err = "bad .tra row"; return MP_EIO; }
             row.start = a; row.chr = b; row.corr = c;
         }
+        out.n_removed = rem;
+        out.seq_actual_len = out.seq_len;                       // HSP.c:286-302: older indexes lack the tail rows
+        for (int s = 0; s < ns && s < (int)out.seq_actual_len.size(); s++) {
+            unsigned long long a, b;
+            if (fscanf(f.f, "%llu %llu\n", &a, &b) != 2) break;
+            out.seq_actual_len[s] = b;
+        }
     }
     std::unique_ptr<uint64_t[]> lkt64;
     {
@@ -135,6 +142,7 @@ int mp_host_index_from_arrays(uint64_t n, uint64_t inv_sa0, const uint64_t cum[5
         out.seq_names.emplace_back(names[s]);
         out.seq_start.push_back(starts[s]);
         out.seq_len.push_back(lens[s]);
+        out.seq_actual_len.push_back(lens[s]);
         mp_translate_row row;
         row.start = starts[s]; row.chr = s + 1; row.corr = starts[s] - 1;   // HSP.c:679-690: tp = ambPos - correction, 1-based
         out.translate.push_back(row);

@@ -43,6 +43,8 @@ struct mp_index {
     uint32_t sa_interval = 0;
     std::vector<std::string> seq_names;
     std::vector<uint64_t> seq_start, seq_len;
+    std::vector<uint64_t> seq_actual_len;   // .tra tail: length including removed N-runs (SAM header LN)
+    uint64_t n_removed = 0;                 // .tra header: numOfRemovedSegment
     std::vector<uint32_t> grid;
     std::vector<mp_translate_row> translate;
 };
@@ -59,6 +61,8 @@ struct mp_host_index {
     std::vector<uint32_t> sa;
     std::vector<std::string> seq_names;
     std::vector<uint64_t> seq_start, seq_len;
+    std::vector<uint64_t> seq_actual_len;
+    uint64_t n_removed = 0;
     std::vector<uint32_t> grid;
     std::vector<mp_translate_row> translate;
 };

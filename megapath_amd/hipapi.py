@@ -74,12 +74,14 @@ class RoundStats(C.Structure):
 
 class SingleHit(C.Structure):
     _fields_ = [("read_id", C.c_uint32), ("strand", C.c_uint32), ("algnmt", C.c_uint64), ("score", C.c_int32), ("count", C.c_uint32),
-                ("win_start", C.c_uint64)]
+                ("win_start", C.c_uint64), ("win_len", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class RescueHit(C.Structure):
     _fields_ = [("pair_id", C.c_uint32), ("aligned_read", C.c_uint32), ("aligned_pos", C.c_uint64), ("dp_pos", C.c_uint64),
-                ("aligned_score", C.c_int32), ("dp_score", C.c_int32), ("aligned_strand", C.c_uint32), ("dp_strand", C.c_uint32)]
+                ("aligned_score", C.c_int32), ("dp_score", C.c_int32), ("aligned_strand", C.c_uint32), ("dp_strand", C.c_uint32),
+                ("aligned_win_start", C.c_uint64), ("dp_win_start", C.c_uint64), ("aligned_win_len", C.c_uint32), ("dp_win_len", C.c_uint32),
+                ("aligned_count", C.c_uint32), ("dp_count", C.c_uint32)]
 
 
 class RescueStats(C.Structure):
@@ -93,7 +95,7 @@ class IndexInfo(C.Structure):
 
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
-           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_ctx_create", "mp_ctx_destroy",
+           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_ctx_create", "mp_ctx_destroy",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
 

@@ -285,21 +285,25 @@ class PairAligner:
                 rescued.setdefault(h.pair_id, set()).add((h.aligned_pos, h.dp_pos, h.aligned_score, h.dp_score))
             else:
                 rescued.setdefault(h.pair_id, set()).add((h.dp_pos, h.aligned_pos, h.dp_score, h.aligned_score))
+        # the default-DP stage writes every rescued pair of the batch before the unpaired output starts (alignment.cpp:225-330)
         for q in failed.tolist():
+            if q not in rescued:
+                continue
             r1, r2 = 2 * q, 2 * q + 1
+            # OutputBuffer::ready(1): sorted by (pos1, pos2, score1, score2), duplicates and failed rescues dropped
+            res = [list(x) for x in sorted(rescued[q])]
+            c1 = _target_chr(self.ix, [x[0] for x in res], [lens[r1]] * len(res)).tolist()
+            c2 = _target_chr(self.ix, [x[1] for x in res], [lens[r2]] * len(res)).tolist()
+            w.pair(out_recs[r1], out_recs[r2], res, c1, c2)
+            self.stats.n_rescued_pairs += 1
+        for q in failed.tolist():
             if q in rescued:
-                # OutputBuffer::ready(1): sorted by (pos1, pos2, score1, score2), duplicates and failed rescues dropped
-                res = [list(x) for x in sorted(rescued[q])]
-                c1 = _target_chr(self.ix, [x[0] for x in res], [lens[r1]] * len(res)).tolist()
-                c2 = _target_chr(self.ix, [x[1] for x in res], [lens[r2]] * len(res)).tolist()
-                w.pair(out_recs[r1], out_recs[r2], res, c1, c2)
-                self.stats.n_rescued_pairs += 1
-            else:
-                for r in (r1, r2):
-                    hs = sorted(single.get(r, ()))
-                    chrs = _target_chr(self.ix, [h[0] for h in hs], [lens[r]] * len(hs)).tolist()
-                    w.single(out_recs[r], [(c, h[1]) for c, h in zip(chrs, hs)])
-                self.stats.n_unpaired_pairs += 1
+                continue
+            for r in (2 * q, 2 * q + 1):
+                hs = sorted(single.get(r, ()))
+                chrs = _target_chr(self.ix, [h[0] for h in hs], [lens[r]] * len(hs)).tolist()
+                w.single(out_recs[r], [(c, h[1]) for c, h in zip(chrs, hs)])
+            self.stats.n_unpaired_pairs += 1
 
 
 def align_fastq(index: H.Index, params: Soap4Params, fq1: str, fq2: str, out, batch_pairs: int = 1 << 20) -> PathStats:

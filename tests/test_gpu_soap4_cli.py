@@ -115,3 +115,38 @@ def test_cli_equals_reference_paired_only_and_chained(golden_dir, tmp_path, tag,
     _run_cli(["pair", os.path.join(d, "ref.fa.index"), os.path.join(d, "reads_%s_1.fq" % reads), os.path.join(d, "reads_%s_2.fq" % reads),
               "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "1", "-u", "750"] + flags, out, driver=driver)
     assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_%s.fq" % tag))
+
+
+# (set, -L, mode flag, extra flags): the commands the BAM goldens were made with (tests/golden/make_golden_bam.py)
+BAM_RUNS = {"a": (151, "-F", ["-nc"]), "c": (301, "-F", ["-nc"]), "d": (151, "-P", []), "g": (151, "-F", ["-p"]), "h": (151, "-F", [])}
+
+
+@pytest.mark.parametrize("tag", sorted(BAM_RUNS))
+def test_cli_bam_files_equal_reference(golden_dir, tmp_path, tag):
+    """`soap4 ... -b` (row a15): the three kinds of BAM side files, decoded record by record, against what the REAL
+    reference wrote for the same command (-T 1): flag, position, MAPQ, CIGAR, mate fields, tlen, sequence, qualities and
+    the RG X0 X1 XM XO XG [NM MD] XA PH tags, in the same order; stdout must stay byte-identical too."""
+    import bamtext
+    from conftest import bam_golden
+    d = os.path.join(golden_dir, "g1")
+    L, mode, extra = BAM_RUNS[tag]
+    out = tmp_path / "out.fq"
+    prefix = str(tmp_path / "bam")
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", "ref.fa.index", "reads_%s_1.fq" % tag, "reads_%s_2.fq" % tag, "-o", prefix,
+           "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L), "-T", "2", "-u", "750", mode, "-b"] + extra
+    env = dict(os.environ, MP_BATCH_PAIRS="1048576")
+    with open(out, "wb") as fo:
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, cwd=d, env=env)     # relative names: RG = "reads_<set>_1.fq" as in the golden
+    assert r.returncode == 0, r.stderr.decode()
+    want = bam_golden(os.path.join(d, "expected_%s.bam.txt" % tag))
+    text, refs, dp = bamtext.read_bam(prefix + ".dpout.1")
+    gout = bamtext.read_bam(prefix + ".gout.1")[2]
+    assert bamtext.read_bam(prefix + ".gout.2")[2] == []          # one header-only file per further -T thread
+    unpair = bamtext.read_bam(prefix + ".unpair")[2]
+    assert dp == want["dpout"]
+    assert gout == want["gout"]
+    assert unpair == want["unpair"]
+    sq = [l for l in want["header"].splitlines() if not l.startswith("@PG")]
+    assert [l for l in text.splitlines() if not l.startswith("@PG")] == sq
+    assert [("@SQ\tSN:%s\tLN:%d" % r) for r in refs] == [l for l in sq if l.startswith("@SQ")]
+    assert open(out, "rb").read() == open(os.path.join(d, "expected_%s.fq" % tag), "rb").read()

@@ -127,10 +127,13 @@ def write_index_files(prefix: str, arrs, write_lkt: bool = False) -> None:
     syms = ((bw[:, None] >> (2 * (15 - np.arange(16, dtype=np.uint32)))) & 3).reshape(-1)[:n].astype(np.uint8)
     n_occ = (n + 255) // 256 + 1
     occ = np.zeros((n_occ, 4), dtype=np.uint64)
+    # the reference counts whole 256-symbol intervals after clearing the trailing code (BWTConstruct.c:312-314, 1036-1041):
+    # the sample past the text end includes the zero padding as 'A's, and BWTOccValue subtracts them again when it
+    # decodes backwards from that sample (reachable whenever n mod 256 > 128)
+    padded = np.concatenate([syms, np.zeros((n_occ - 1) * 256 - n, dtype=np.uint8)])
     for c in range(4):
-        cs = np.concatenate([[0], np.cumsum(syms == c, dtype=np.uint64)])
-        idx = np.minimum(np.arange(n_occ, dtype=np.int64) * 256, n)
-        occ[:, c] = cs[idx]
+        cs = np.concatenate([[0], np.cumsum(padded == c, dtype=np.uint64)])
+        occ[:, c] = cs[np.arange(n_occ, dtype=np.int64) * 256]
     n_major = (n_occ + 255) // 256
     major = occ[::256][:n_major].copy()
     rel = (occ - np.repeat(major, 256, axis=0)[:n_occ]).astype(np.uint32)

@@ -49,6 +49,28 @@ def test_fm_primitives_exhaustive_small(gidx, oidx):
     assert np.array_equal(gidx.sa(sidx), want)
 
 
+@pytest.mark.parametrize("n_bases", [256 * 9 + 200, 192 * 25, 4096 + 17])
+def test_fm_primitives_every_index_at_text_tail_shapes(tmp_path, n_bases):
+    """Text lengths that end inside the upper half of an explicit-occurrence interval, on a rank-block boundary and just
+    past a power of two: every rank (all four symbols) and every SA value, device vs oracle, on builder-written files."""
+    from megapath_amd import index_builder, synth
+    genome = synth.random_genome(n_bases, 78, n_seqs=3)
+    prefix = str(tmp_path / "t.index")
+    index_builder.write_index_files(prefix, index_builder.build_index_arrays(genome, sa_interval=16))
+    lib = O.oracle()
+    oix = lib.mpo_index_open(prefix.encode())
+    gix = H.Index(prefix, 0)
+    n = gix.info.text_length
+    idx = np.arange(0, n + 2, dtype=np.uint64)
+    for c in range(4):
+        want = np.array([lib.mpo_occ(oix, int(i), c) for i in idx], dtype=np.uint64)
+        assert np.array_equal(gix.occ(idx, np.full(len(idx), c, dtype=np.uint32)), want), c
+    sidx = np.arange(0, n + 1, dtype=np.uint64)
+    assert np.array_equal(gix.sa(sidx), np.array([lib.mpo_sa_value(oix, int(i)) for i in sidx], dtype=np.uint64))
+    gix.close()
+    lib.mpo_index_close(oix)
+
+
 @pytest.mark.parametrize("tag,mmp", [("a", H.MmpParams.nt2()), ("b", H.MmpParams.human()), ("c", H.MmpParams.nt2())])
 def test_seed_stage_matches_oracle(gidx, oidx, golden_dir, tag, mmp):
     d = os.path.join(golden_dir, "g1")

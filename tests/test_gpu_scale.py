@@ -33,6 +33,9 @@ def _build(tmp_path, genome):
     dict(tag="mixed", n_bases=800000, n_seqs=3, n_pairs=2000, read_len=150, L=301, sim=dict(sub=0.02, ins=0.002, dele=0.002, random_frac=0.05,
                                                                                          broken_mate_frac=0.3, len_range=(75, 300), frag_mean=450,
                                                                                          frag_sd=60, frag_max=700)),
+    dict(tag="noisy", n_bases=600000, n_seqs=40, n_pairs=3000, read_len=150, L=151, sim=dict(sub=0.02, ins=0.002, dele=0.002, random_frac=0.03,
+                                                                                          broken_mate_frac=0.05, noisy_mate_frac=0.4, noisy_sub=0.2,
+                                                                                          n_frac=0.001)),
 ])
 def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg):
     genome = synth.random_genome(cfg["n_bases"], 501, n_seqs=cfg["n_seqs"], repeat_frac=0.12)
@@ -46,7 +49,8 @@ def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg):
     p = O.default_params(L=cfg["L"])
     st = O.AlignStats()
     want_path = str(tmp_path / "oracle.fq")
-    assert lib.mpo_align_fastq(oix, C.byref(p), f1.encode(), f2.encode(), want_path.encode(), None, C.byref(st)) == 0
+    assert lib.mpo_align_fastq_bam(oix, C.byref(p), f1.encode(), f2.encode(), want_path.encode(), None, str(tmp_path / "obam").encode(), 1,
+                                   b"rg1", C.byref(st)) == 0
     lib.mpo_index_close(oix)
     assert st.n_deep_dp_pairs > 0 and st.n_default_dp_pairs > 0 and st.n_unpaired_pairs > 0
     # product
@@ -69,10 +73,22 @@ def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg):
     env.pop("MP_SOAP4_PYTHON", None)
     with open(cxx_out, "wb") as fo:
         r = subprocess.run([os.path.join(ROOT, "bin", "soap4"), "pair", prefix, f1, f2, "-o", str(tmp_path / "o"), "-C",
-                            os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(cfg["L"]), "-T", "1", "-u", "750", "-F", "-nc"],
+                            os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(cfg["L"]), "-T", "1", "-u", "750", "-F", "-nc",
+                            "-b", "-p", "-D", "rg1", "-A", "default"],
                            stdout=fo, stderr=subprocess.PIPE, env=env)
     assert r.returncode == 0, r.stderr.decode()
     assert fastq_records(str(cxx_out)) == want
+    # BAM side files of the same run (row a15) against the oracle's records, NM/MD included; the batches differ, so by content
+    import bamtext
+    n_rec = 0
+    for kind, path in (("dpout", "o.dpout.1"), ("gout", "o.gout.1"), ("unpair", "o.unpair")):
+        got_recs = bamtext.read_bam(str(tmp_path / path))[2]
+        want_recs = open(tmp_path / ("obam.%s.txt" % kind)).read().splitlines()
+        assert sorted(got_recs) == sorted(want_recs), kind
+        n_rec += len(got_recs)
+        if cfg["tag"] == "noisy":
+            assert len(got_recs) > 100, kind
+    assert n_rec == 2 * cfg["n_pairs"]
 
 
 def test_batch_scale_properties():

@@ -30,20 +30,9 @@ def test_builder_matches_reference_files(golden_dir, tmp_path):
         a = open(prefix + ext, "rb").read()
         b = open(os.path.join(d, "ref.fa.index" + ext), "rb").read()
         assert a == b, ext
-    # .fmv: every explicit sample a rank query can reach (nearest-sample index <= (n+127)/256, BWT.c:614-615) and all
-    # major counters must agree; the reference leaves the one sample past the text end undefined
-    n = int(arrs["n"])
-    a = np.frombuffer(open(prefix + ".fmv", "rb").read(), dtype=np.uint32)
-    b = np.frombuffer(open(os.path.join(d, "ref.fa.index.fmv"), "rb").read(), dtype=np.uint32)
-    assert len(a) == len(b) and np.array_equal(a[:10], b[:10])
-    n_occ = (n + 255) // 256 + 1
-    minor_words = (n_occ + 1) // 2 * 4
-    last_used = (n + 127) // 256
-    ma, mb = a[10:10 + minor_words].reshape(-1, 4), b[10:10 + minor_words].reshape(-1, 4)
-    sa_ = np.stack([ma >> 16, ma & 0xFFFF], axis=1).reshape(-1, 4)[:last_used + 1]
-    sb_ = np.stack([mb >> 16, mb & 0xFFFF], axis=1).reshape(-1, 4)[:last_used + 1]
-    assert np.array_equal(sa_, sb_)
-    assert np.array_equal(a[10 + minor_words:], b[10 + minor_words:])
+    # .fmv: byte-identical too, including the sample past the text end, which counts the cleared trailing code as 'A's
+    # (BWTConstruct.c:312-314, 1036-1041) and is what rank queries in the last 128 positions decode backwards from
+    assert open(prefix + ".fmv", "rb").read() == open(os.path.join(d, "ref.fa.index.fmv"), "rb").read()
     # annotation / translation carry the same coordinates (the reference also writes a random seed in .ann)
     mine = open(prefix + ".tra").read().split()
     ref = open(os.path.join(d, "ref.fa.index.tra")).read().split()
@@ -71,3 +60,26 @@ def test_oracle_loads_builder_output(golden_dir, tmp_path):
         assert (pa.value, ca.value) == (pb.value, cb.value)
     lib.mpo_index_close(a)
     lib.mpo_index_close(b)
+
+
+def test_rank_near_text_end_from_builder_files(tmp_path):
+    """n mod 256 > 128: ranks in the tail decode backwards from the explicit sample past the text end (BWT.c:614-634).
+    The oracle reading this builder's .fmv must agree with a direct count over the BWT for every index and symbol."""
+    import oracle_lib as O
+    from megapath_amd import synth
+    genome = synth.random_genome(256 * 9 + 200, 77, n_seqs=2)
+    arrs = build_index_arrays(genome, sa_interval=16)
+    prefix = str(tmp_path / "tail.index")
+    write_index_files(prefix, arrs)
+    n = int(arrs["n"])
+    bw = np.asarray(arrs["bwt_words"], dtype=np.uint32)
+    syms = ((bw[:, None] >> (2 * (15 - np.arange(16, dtype=np.uint32)))) & 3).reshape(-1)[:n]
+    inv = int(arrs["inv_sa0"])
+    lib = O.oracle()
+    ix = lib.mpo_index_open(prefix.encode())
+    for c in range(4):
+        cs = np.concatenate([[0], np.cumsum(syms == c)])
+        for idx in list(range(n - 300, n + 2)) + [0, 1, inv, inv + 1]:
+            k = idx - (1 if idx > inv else 0)           # the '$' row is not part of the stored BWT (BWT.c:605)
+            assert lib.mpo_occ(ix, idx, c) == int(cs[k]), (idx, c)
+    lib.mpo_index_close(ix)

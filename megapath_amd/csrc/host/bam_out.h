@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../../include/megapath_hip.h"
 
@@ -29,29 +30,26 @@ namespace mpbam {
 const uint64_t NOT_ALIGNED = ~0ull;
 
 // ------------------------------------------------------------------------------------------------ BGZF container
+// Blocks are independent deflate streams, so a group of them is compressed by several threads at once and written in
+// order (the reference compresses on its single output thread).
 class Bgzf {
 public:
-    bool open(const std::string &path, int level)
+    bool open(const std::string &path, int level, int threads)
     {
         f_ = fopen(path.c_str(), "wb");
-        level_ = level;
-        buf_.reserve(kBlock);
+        level_ = level; threads_ = threads < 1 ? 1 : threads;
         return f_ != nullptr;
     }
     void write(const void *data, size_t n)
     {
         const uint8_t *p = (const uint8_t *)data;
-        while (n) {
-            size_t take = std::min(n, (size_t)kBlock - buf_.size());
-            buf_.insert(buf_.end(), p, p + take);
-            p += take; n -= take;
-            if (buf_.size() == kBlock) flush_block();
-        }
+        raw_.insert(raw_.end(), p, p + n);
+        if (raw_.size() >= kBlock * kGroup * (size_t)threads_) flush_blocks(false);
     }
     bool close()
     {
         if (!f_) return true;
-        if (!buf_.empty()) flush_block();
+        flush_blocks(true);
         static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool ok = fwrite(eof, 1, sizeof eof, f_) == sizeof eof && !failed_;
         ok = fclose(f_) == 0 && ok;
@@ -61,31 +59,57 @@ public:
     ~Bgzf() { close(); }
 
 private:
-    static const size_t kBlock = 0xff00;
-    void flush_block()
+    static const size_t kBlock = 0xff00, kGroup = 16, kOut = 0x10000 + 64;
+    // one BGZF block: 18-byte header with the BC extra field, raw deflate data, CRC32 and input size
+    static size_t deflate_block(const uint8_t *in, size_t n, uint8_t *out, int level)
     {
-        uint8_t out[0x10000 + 64];
         z_stream z;
         memset(&z, 0, sizeof z);
-        if (deflateInit2(&z, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed_ = true; buf_.clear(); return; }
-        z.next_in = buf_.data(); z.avail_in = (uInt)buf_.size();
-        z.next_out = out + 18; z.avail_out = sizeof out - 18 - 8;
-        int rc = deflate(&z, Z_FINISH);
+        if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+        z.next_in = const_cast<uint8_t *>(in); z.avail_in = (uInt)n;
+        z.next_out = out + 18; z.avail_out = (uInt)(kOut - 18 - 8);
+        const int rc = deflate(&z, Z_FINISH);
         deflateEnd(&z);
-        if (rc != Z_STREAM_END) { failed_ = true; buf_.clear(); return; }      // cannot happen: 0xff00 bytes always fit
+        if (rc != Z_STREAM_END) return 0;                        // cannot happen: 0xff00 bytes always fit
         const size_t clen = z.total_out, total = clen + 26;
         static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
         memcpy(out, hdr, 16);
         out[16] = (uint8_t)((total - 1) & 0xff); out[17] = (uint8_t)((total - 1) >> 8);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size()), isz = (uint32_t)buf_.size();
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n), isz = (uint32_t)n;
         memcpy(out + 18 + clen, &crc, 4); memcpy(out + 22 + clen, &isz, 4);
-        if (fwrite(out, 1, total, f_) != total) failed_ = true;
-        buf_.clear();
+        return total;
+    }
+    void flush_blocks(bool all)
+    {
+        const size_t n_full = raw_.size() / kBlock, n_blocks = all ? (raw_.size() + kBlock - 1) / kBlock : n_full;
+        if (n_blocks == 0) return;
+        out_.resize(n_blocks * kOut);
+        len_.assign(n_blocks, 0);
+        auto work = [&](size_t t, size_t stride) {
+            for (size_t i = t; i < n_blocks; i += stride) {
+                const size_t off = i * kBlock, n = std::min(kBlock, raw_.size() - off);
+                len_[i] = deflate_block(raw_.data() + off, n, out_.data() + i * kOut, level_);
+            }
+        };
+        const size_t nt = std::min((size_t)threads_, n_blocks);
+        if (nt <= 1) work(0, 1);
+        else {
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < nt; t++) pool.emplace_back(work, t, nt);
+            work(0, nt);
+            for (auto &th : pool) th.join();
+        }
+        for (size_t i = 0; i < n_blocks; i++) {
+            if (len_[i] == 0 || fwrite(out_.data() + i * kOut, 1, len_[i], f_) != len_[i]) failed_ = true;
+        }
+        const size_t used = std::min(raw_.size(), n_blocks * kBlock);
+        raw_.erase(raw_.begin(), raw_.begin() + (long)used);
     }
     FILE *f_ = nullptr;
-    int level_ = Z_DEFAULT_COMPRESSION;
+    int level_ = Z_DEFAULT_COMPRESSION, threads_ = 1;
     bool failed_ = false;
-    std::vector<uint8_t> buf_;
+    std::vector<uint8_t> raw_, out_;
+    std::vector<size_t> len_;
 };
 
 // ------------------------------------------------------------------------------------------------ alignment records
@@ -156,7 +180,7 @@ public:
         for (size_t k = 0; k < 2 + (size_t)o_.threads; k++) {
             std::string path = prefix + (k == 0 ? ".dpout.1" : k == 1 ? ".unpair" : ".gout." + std::to_string(k - 1));
             files_.emplace_back(new Bgzf());
-            if (!files_[k]->open(path, o_.level)) { fprintf(stderr, "[soap4-mi355x] cannot write %s\n", path.c_str()); return false; }
+            if (!files_[k]->open(path, o_.level, o_.threads)) { fprintf(stderr, "[soap4-mi355x] cannot write %s\n", path.c_str()); return false; }
             files_[k]->write(hdr.data(), hdr.size());
         }
         return true;
@@ -164,13 +188,15 @@ public:
     bool close() { bool ok = true; for (auto &f : files_) ok = f->close() && ok; return ok; }
 
     enum { FILE_DPOUT = 0, FILE_UNPAIR = 1, FILE_GOUT = 2 };
+    // records built by pair() / unpaired() go to the file in the order the caller appends them
+    void append(int file, const std::string &records) { if (!records.empty()) files_[(size_t)file]->write(records.data(), records.size()); }
 
     // text bases for MD: the caller resolves [pos, pos+len) of the best alignments in bulk (mp_index_fetch_text)
     struct RefText { uint64_t pos = 0; const uint8_t *codes = nullptr; uint32_t len = 0; };
 
     // Properly paired output.  `res` already went through the annotated-FASTQ writer (the reference mutates the
     // results there first, BGS-IO.cpp:2103-2111); `best` was chosen before that (OutputDPResult.cpp:156-232).
-    void pair(int file, int stage, const ReadView rd[2], const std::vector<PairAln> &res, size_t best, const RefText ref[2])
+    void pair(std::string &sink, int stage, const ReadView rd[2], const std::vector<PairAln> &res, size_t best, const RefText ref[2]) const
     {
         const PairAln &b = res[best];
         const bool a[2] = {b.m[0].pos != NOT_ALIGNED, b.m[1].pos != NOT_ALIGNED};
@@ -228,13 +254,13 @@ public:
                 if (tp[k] > tp[o]) isize = -(long long)(tp[k] + (uint64_t)rlen[k] - tp[o]);
                 else isize = (long long)(tp[o] + (uint64_t)rlen[o] - tp[k]);
             }
-            emit(file, stage, rd[k], flag, chr[k], tp[k], chr[o], tp[o], isize, r[k]);
+            emit(sink, stage, rd[k], flag, chr[k], tp[k], chr[o], tp[o], isize, r[k]);
         }
     }
 
     // Unpaired output.  `lst` already went through the annotated-FASTQ writer (BGS-IO.cpp:1406-1411 un-aligns hits that
     // span a sequence boundary, in -F mode only).
-    void unpaired(int stage, const ReadView rd[2], const std::vector<Side> lst[2], const RefText *ref_of_hit[2])
+    void unpaired(std::string &sink, int stage, const ReadView rd[2], const std::vector<Side> lst[2], const RefText *ref_of_hit[2]) const
     {
         int best[2] = {-1, -1}, best_score[2] = {0, 0}, best_num[2] = {0, 0}, x1[2] = {0, 0}, deleted_end[2] = {0, 0};
         uint64_t tp[2] = {0, 0}; uint32_t chr[2] = {0, 0};
@@ -281,7 +307,7 @@ public:
                 if (tp[o] > tp[k]) isize = (long long)(tp[o] - (uint64_t)deleted_end[o] + rd[o].len - tp[k]);
                 else isize = -(long long)(tp[k] - (uint64_t)deleted_end[k] + rd[k].len - tp[o]);
             }
-            emit(FILE_UNPAIR, stage, rd[k], flag, chr[k], tp[k], chr[o], tp[o], isize, r[k]);
+            emit(sink, stage, rd[k], flag, chr[k], tp[k], chr[o], tp[o], isize, r[k]);
         }
     }
 
@@ -339,7 +365,7 @@ private:
     }
     // BoundaryCheckDP (BGS-IO.cpp:219-386) behind getChrAndPosWithBoundaryCheckDP (:412-431):
     // > 0 trimmed on the left, < 0 on the right, 0 none
-    long long chr_pos_boundary(uint32_t read_len, uint64_t amb, const char *cigar, uint64_t &tp, uint32_t &chr, std::string &new_cigar)
+    long long chr_pos_boundary(uint32_t read_len, uint64_t amb, const char *cigar, uint64_t &tp, uint32_t &chr, std::string &new_cigar) const
     {
         uint64_t seg_end = 0, start = 0, plen = 0;
         mp_index_chr_pos_segment(ix_, amb, &tp, &chr, &seg_end);
@@ -500,7 +526,7 @@ private:
     static void tag_z(std::string &b, const char *t, const std::string &v) { b.append(t, 2); b += 'Z'; b += v; b += '\0'; }
 
     // initializeSAMAlgnmt / initializeSAMAlgnmt2 (BGS-IO.cpp:433-675) + the core fields the callers fill in
-    void emit(int file, int stage, const ReadView &rd, int flag, uint32_t c_self, uint64_t t_self, uint32_t c_oth, uint64_t t_oth, long long isize, const Rec &r)
+    void emit(std::string &rec_, int stage, const ReadView &rd, int flag, uint32_t c_self, uint64_t t_self, uint32_t c_oth, uint64_t t_oth, long long isize, const Rec &r) const
     {
         const int32_t tid = c_self == 0 ? (c_oth == 0 ? -1 : (int32_t)c_oth - 1) : (int32_t)c_self - 1;
         const int32_t pos = t_self == 0 ? (t_oth == 0 ? -1 : (int32_t)(t_oth - 1)) : (int32_t)(t_self - 1);
@@ -517,7 +543,7 @@ private:
         }
         const uint32_t l_name = (uint32_t)strlen(rd.name) + 1, L = rd.len;
         const uint32_t mapq = r.mapped ? (uint32_t)(r.mapq & 0xFF) : 0u;
-        rec_.clear();
+        const size_t at = rec_.size();                          // records are appended to the caller's buffer (one per file kind)
         put32(rec_, 0);                                         // block_size, patched below
         put32(rec_, (uint32_t)tid); put32(rec_, (uint32_t)pos);
         put32(rec_, 0u << 16 | mapq << 8 | l_name);             // bin = bam_reg2bin(0, 0) = 0 for every record (BGS-IO.cpp:438)
@@ -545,16 +571,14 @@ private:
             if (!r.xa.empty()) tag_z(rec_, "XA", r.xa);
             if (stage != -1) tag_i(rec_, "PH", stage);
         } else if (!r.xa.empty()) tag_z(rec_, "XA", r.xa);
-        const uint32_t bs = (uint32_t)rec_.size() - 4;
-        memcpy(&rec_[0], &bs, 4);
-        files_[(size_t)file]->write(rec_.data(), rec_.size());
+        const uint32_t bs = (uint32_t)(rec_.size() - at) - 4;
+        memcpy(&rec_[at], &bs, 4);
     }
 
     const mp_index *ix_;
     Options o_;
     int g_log_n_[256];
     std::vector<std::unique_ptr<Bgzf>> files_;
-    std::string rec_;
 };
 
 }  // namespace mpbam

@@ -20,6 +20,7 @@
 #include <string.h>
 #include <ctype.h>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -51,11 +52,27 @@ struct Rec {
     bool has_comment = false;
 };
 
+struct RescueRow { uint32_t pair; uint64_t a1, a2; int s1, s2; uint32_t src; };
+
+// One batch on its way through the three stages: reader threads fill the inputs, the GPU stage the hit lists, the output
+// stage prints.  The objects are recycled, so the strings keep their capacity.
 struct Batch {
-    std::vector<Rec> recs;                  // 2 per pair
-    std::vector<uint32_t> packed, lens;
-    uint32_t W = 0;
+    // ---- stage 1: parsed and packed reads (2 per pair)
+    std::vector<Rec> recs[2];               // per mate file, grown on demand
+    std::vector<uint32_t> packed_m[2], lens_m[2];
+    std::vector<uint32_t> packed, lens;     // interleaved 2q / 2q+1 as the device wants them
+    uint32_t W = 0, n_reads = 0;
     bool last = false;
+    const Rec &rec(uint32_t r) const { return recs[r & 1u][r >> 1]; }
+    // ---- stage 2: what the device found
+    std::vector<mp_pair_hit> hits;          // deep-DP round
+    std::vector<mp_single_hit> singles;     // rescue round: single-end hits of the failed pairs
+    std::vector<mp_rescue_hit> resc;        //               mate rescues
+    std::vector<RescueRow> rows;
+    std::vector<char> done;                 // per pair: 1 deep, 2 rescued
+    std::vector<std::string> cig, rcig, scig;   // -b: special CIGARs of hits / rows / singles, in list order
+    bool lists_ready = false;               // hit lists already sorted and de-duplicated (done early when -b needs CIGARs)
+    uint64_t dp_instances = 0;
 };
 
 unsigned char g_code[256];
@@ -97,73 +114,103 @@ int ini_int(const Ini &ini, const char *key, int dflt) { auto it = ini.find(key)
 double ini_dbl(const Ini &ini, const char *key, double dflt) { auto it = ini.find(key); return it == ini.end() ? dflt : atof(it->second.c_str()); }
 
 // ------------------------------------------------------------------------------------------------ FASTQ (plain or gz)
+// Four-line FASTQ or two-line FASTA records through zlib (as the reference's kseq does), read in 4 MiB gulps.
 struct FqReader {
     gzFile f = nullptr;
     std::vector<char> buf;
-    bool open(const char *path) { f = gzopen(path, "rb"); if (f) gzbuffer(f, 1 << 20); buf.resize(1 << 16); return f != nullptr; }
-    bool line(std::string &out)
+    size_t pos = 0, end = 0;
+    bool eof = false;
+    bool open(const char *path) { f = gzopen(path, "rb"); if (f) gzbuffer(f, 1 << 20); buf.resize(1 << 22); return f != nullptr; }
+    // next line without its terminator; the pointer stays valid until the next call
+    bool line(const char *&p, size_t &n)
     {
-        out.clear();
         for (;;) {
-            if (!gzgets(f, buf.data(), (int)buf.size())) return !out.empty();
-            size_t n = strlen(buf.data());
-            out.append(buf.data(), n);
-            if (n && buf[n - 1] == '\n') break;
+            char *nl = end > pos ? (char *)memchr(buf.data() + pos, '\n', end - pos) : nullptr;
+            if (nl) { p = buf.data() + pos; n = (size_t)(nl - p); pos = (size_t)(nl - buf.data()) + 1; break; }
+            if (eof) { if (pos >= end) return false; p = buf.data() + pos; n = end - pos; pos = end; break; }
+            memmove(buf.data(), buf.data() + pos, end - pos);
+            end -= pos; pos = 0;
+            if (end == buf.size()) buf.resize(buf.size() * 2);
+            const int got = gzread(f, buf.data() + end, (unsigned)std::min(buf.size() - end, (size_t)1 << 30));
+            if (got <= 0) eof = true; else end += (size_t)got;
         }
-        while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
-        return true;
-    }
-    // one record; name loses a trailing /1 /2 (QueryParser.cpp:177), comment = rest of the header line (kseq)
-    bool next(Rec &r, std::string &raw_seq)
-    {
-        std::string h, plus;
-        do { if (!line(h)) return false; } while (h.empty());
-        if (!line(raw_seq)) return false;
-        bool fasta = h[0] == '>';
-        r.qual.clear();
-        if (!fasta) { line(plus); line(r.qual); }
-        size_t cut = h.find_first_of(" \t", 1);
-        r.name = h.substr(1, cut == std::string::npos ? std::string::npos : cut - 1);
-        r.has_comment = cut != std::string::npos && cut + 1 < h.size();
-        r.comment = r.has_comment ? h.substr(cut + 1) : std::string();
-        size_t L = r.name.size();
-        if (L > 2 && r.name[L - 2] == '/' && r.name[L - 1] >= '0' && r.name[L - 1] <= '9') r.name.resize(L - 2);
+        while (n && (p[n - 1] == '\r' || p[n - 1] == '\n')) n--;
         return true;
     }
     ~FqReader() { if (f) gzclose(f); }
 };
 
-// reads the next batch and packs it as appendToQueryArrays does (QueryParser.cpp:184-234), words contiguous per read
-bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out)
+// Parses up to max_pairs records of one file into the slots of mate k and packs them as appendToQueryArrays does
+// (QueryParser.cpp:184-234): length capped to maxReadLength-1, N/other -> G/A through the character map, 2 bits per base
+// LSB-first, words contiguous per read.  The name loses a trailing /1 /2 (QueryParser.cpp:177); the comment is the rest
+// of the header line (kseq).  Returns the number of records read.
+size_t parse_file(FqReader &rd, const Params &p, Batch &out, int k, size_t max_pairs)
 {
-    out.recs.clear(); out.packed.clear(); out.lens.clear(); out.last = false;
-    const uint32_t W = (uint32_t)(p.max_read_length + 15) / 16;
-    out.W = W;
-    std::string sa, sb;
-    Rec ra, rb;
-    while (out.recs.size() < 2 * p.batch_pairs) {
-        bool ga = a.next(ra, sa), gb = b.next(rb, sb);
-        if (ga != gb) { fprintf(stderr, "Error: number of sequences of pair-end files not matched.\n"); exit(1); }
-        if (!ga) { out.last = true; break; }
-        for (int k = 0; k < 2; k++) {
-            Rec &r = k ? rb : ra;
-            const std::string &raw = k ? sb : sa;
-            size_t keep = std::min(raw.size(), (size_t)(p.max_read_length - 1));          // QueryParser.cpp:188
-            size_t base = out.packed.size();
-            out.packed.resize(base + W, 0u);
-            r.seq.resize(keep);
-            for (size_t i = 0; i < keep; i++) {
-                unsigned c = g_code[(unsigned char)raw[i]];
-                out.packed[base + i / 16] |= c << (2 * (i % 16));
+    const uint32_t W = out.W;
+    const size_t cap = (size_t)p.max_read_length - 1;
+    size_t q = 0;
+    const char *h, *sq, *pl, *ql; size_t hn, sn, pn, qn;
+    std::vector<Rec> &recs = out.recs[k];
+    std::vector<uint32_t> &packed = out.packed_m[k], &lens = out.lens_m[k];
+    for (; q < max_pairs; q++) {
+        do { if (!rd.line(h, hn)) return q; } while (hn == 0);
+        if (q >= recs.size()) { const size_t grow = std::max<size_t>(4096, recs.size()); recs.resize(recs.size() + grow); }
+        if ((q + 1) * (size_t)W > packed.size()) { packed.resize(std::max<size_t>(4096 * (size_t)W, 2 * packed.size())); lens.resize(packed.size() / W); }
+        Rec &r = recs[q];
+        const bool fasta = h[0] == '>';
+        size_t cut = 1;
+        while (cut < hn && h[cut] != ' ' && h[cut] != '\t') cut++;
+        size_t nl = cut - 1;
+        if (nl > 2 && h[cut - 2] == '/' && h[cut - 1] >= '0' && h[cut - 1] <= '9') nl -= 2;
+        r.name.assign(h + 1, nl);
+        r.has_comment = !p.ignore_comments && cut + 1 < hn;
+        if (r.has_comment) r.comment.assign(h + cut + 1, hn - cut - 1); else r.comment.clear();
+        if (!rd.line(sq, sn)) return q;
+        const size_t keep = std::min(sn, cap);                                          // QueryParser.cpp:188
+        r.seq.resize(keep);
+        uint32_t *dst = packed.data() + q * (size_t)W;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t v = 0;
+            const size_t lo = (size_t)w * 16, hi = std::min(keep, lo + 16);
+            for (size_t i = lo; i < hi; i++) {
+                const unsigned c = g_code[(unsigned char)sq[i]];
+                v |= c << (2 * (i - lo));
                 r.seq[i] = "ACGT"[c];
             }
-            if (r.qual.size() > keep) r.qual.resize(keep);
-            if (p.ignore_comments) { r.has_comment = false; r.comment.clear(); }
-            out.lens.push_back((uint32_t)keep);
-            out.recs.push_back(r);
+            dst[w] = v;
+        }
+        lens[q] = (uint32_t)keep;
+        if (fasta) r.qual.clear();
+        else {
+            if (!rd.line(pl, pn) || !rd.line(ql, qn)) return q;
+            r.qual.assign(ql, std::min(qn, keep));
         }
     }
-    return !out.recs.empty();
+    return q;
+}
+
+// reads the next batch: the two files are parsed side by side
+bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out)
+{
+    const size_t bp = p.batch_pairs;
+    out.W = (uint32_t)(p.max_read_length + 15) / 16;
+    size_t nb = 0;
+    std::thread second([&]() { nb = parse_file(b, p, out, 1, bp); });
+    const size_t na = parse_file(a, p, out, 0, bp);
+    second.join();
+    if (na != nb) { fprintf(stderr, "Error: number of sequences of pair-end files not matched.\n"); exit(1); }
+    out.n_reads = (uint32_t)(2 * na);
+    out.last = na < bp;
+    const uint32_t W = out.W;
+    out.packed.resize(2 * na * (size_t)W); out.lens.resize(2 * na);
+    for (size_t q = 0; q < na; q++)
+        for (int k = 0; k < 2; k++) {
+            memcpy(out.packed.data() + (2 * q + k) * (size_t)W, out.packed_m[k].data() + q * (size_t)W, (size_t)W * 4);
+            out.lens[2 * q + k] = out.lens_m[k][q];
+        }
+    out.hits.clear(); out.singles.clear(); out.resc.clear(); out.rows.clear(); out.cig.clear(); out.rcig.clear(); out.scig.clear();
+    out.lists_ready = false; out.dp_instances = 0;
+    return na > 0;
 }
 
 // ------------------------------------------------------------------------------------------------ output
@@ -195,9 +242,8 @@ struct Writer {
     const mp_index *ix;
     const Params &p;
     std::string out;
-    Writer(const mp_index *i, const Params &pp) : ix(i), p(pp) { out.reserve(1 << 22); }
-    void flush() { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
-    void seq_qual(const Rec &r) { out += r.seq; out += "\n+\n"; out += r.qual; out += '\n'; if (out.size() > (1u << 22)) flush(); }
+    Writer(const mp_index *i, const Params &pp) : ix(i), p(pp) {}
+    void seq_qual(const Rec &r) { out += r.seq; out += "\n+\n"; out += r.qual; out += '\n'; }
     void score_line(const Rec &r, int best, const std::vector<ChrHit> &hits, const std::vector<HdrMap> &v)
     {
         out += '@'; out += r.name;
@@ -271,11 +317,15 @@ struct Writer {
 
 void die(int rc, const char *what) { if (rc) { fprintf(stderr, "[soap4-mi355x] %s failed: %s (%d)\n", what, mp_strerror(rc), rc); exit(1); } }
 
-struct Stats { uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0; };
+struct Stats {
+    uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0;
+    double t_upload = 0, t_deep = 0, t_sort = 0, t_cigar = 0, t_emit_deep = 0, t_rescue = 0, t_emit_rest = 0;   // seconds (MP_TIMING=1 prints them)
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // -b only: the special CIGAR of each listed DP instance.  The hits name their instance (read, strand, window); the same
 // kernels run it again with the op strings switched on (mp_sgdp_batch), in bounded chunks.
-void resolve_cigars(mp_ctx *ctx, const Params &p, const std::vector<mp_dp_task> &tasks, const std::vector<uint32_t> &lens, std::vector<std::string> &out)
+void resolve_cigars(mp_ctx *ctx, const Params &p, int threads, const std::vector<mp_dp_task> &tasks, const std::vector<uint32_t> &lens, std::vector<std::string> &out)
 {
     out.assign(tasks.size(), std::string());
     const size_t chunk = 1u << 17;
@@ -289,18 +339,26 @@ void resolve_cigars(mp_ctx *ctx, const Params &p, const std::vector<mp_dp_task> 
         ops.assign(cnt * (size_t)stride, 0);
         res.resize(cnt);
         die(mp_sgdp_batch(ctx, tasks.data() + off, (uint32_t)cnt, p.clip_left, p.clip_right, res.data(), ops.data(), stride, nullptr, nullptr), "mp_sgdp_batch");
-        for (size_t t = 0; t < cnt; t++) {
-            if (res[t].score <= 0 || res[t].n_ops == 0) { fprintf(stderr, "[soap4-mi355x] internal error: a reported hit did not align again\n"); exit(1); }
-            // CigarStringEncoder (DV-DPfunctions.h:377-427): runs collected in traceback order, printed from the read's start
-            const uint8_t *o = ops.data() + t * (size_t)stride;
-            std::string &cg = out[off + t];
-            for (int i = (int)res[t].n_ops - 1; i >= 0;) {
-                int j = i;
-                while (j >= 0 && o[j] == o[i]) j--;
-                cg += std::to_string(i - j); cg += (char)o[i];
-                i = j;
+        auto convert = [&](size_t t0, size_t t1) {
+            for (size_t t = t0; t < t1; t++) {
+                if (res[t].score <= 0 || res[t].n_ops == 0) { fprintf(stderr, "[soap4-mi355x] internal error: a reported hit did not align again\n"); exit(1); }
+                // CigarStringEncoder (DV-DPfunctions.h:377-427): runs collected in traceback order, printed from the read's start
+                const uint8_t *o = ops.data() + t * (size_t)stride;
+                std::string &cg = out[off + t];
+                char num[16];
+                for (int i = (int)res[t].n_ops - 1; i >= 0;) {
+                    int j = i;
+                    while (j >= 0 && o[j] == o[i]) j--;
+                    cg.append(num, (size_t)snprintf(num, sizeof num, "%d", i - j)); cg += (char)o[i];
+                    i = j;
+                }
             }
-        }
+        };
+        const size_t nt = (size_t)std::max(1, std::min(threads, (int)(cnt / 4096) + 1));
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; t++) pool.emplace_back(convert, cnt * t / nt, cnt * (t + 1) / nt);
+        convert(0, cnt / nt);
+        for (auto &th : pool) th.join();
     }
 }
 
@@ -329,113 +387,35 @@ struct PairText {
     }
 };
 
-void align_batch(mp_index *ix, mp_ctx *ctx, Params &p, Batch &b, bool &first, Writer &w, BamState *bam, Stats &st)
+// OutputBuffer::ready for the three hit lists of a batch: sorted by (positions, scores), exact duplicates dropped
+// (DV-DPfunctions.h:165-196; :853-866 for the single-end hits; ready(1) also drops failed rescues, which never get here)
+void prepare_lists(Batch &b)
 {
-    const uint32_t n_reads = (uint32_t)b.recs.size(), n_pairs = n_reads / 2;
-    if (first) {
-        // SOAP4.cpp:465-474 / QueryParser.cpp:2253-2277: the minimum insert size is at least the detected read lengths
-        uint32_t d1 = 0, d2 = 0;
-        for (uint32_t q = 0; q < n_pairs && q < 999999; q++) { d1 = std::max(d1, b.lens[2 * q]); d2 = std::max(d2, b.lens[2 * q + 1]); }
-        p.insert_low = std::max(p.insert_low, (int)std::max(d1, d2));
-        first = false;
-    }
-    for (uint32_t l : b.lens) if (l < 30) { fprintf(stderr, "[soap4-mi355x] reads shorter than the DP cutoff (30) are undefined in the reference (CPU_DP.cpp:316-324)\n"); exit(1); }
-    die(mp_set_reads(ctx, b.packed.data(), b.W, b.lens.data(), n_reads), "mp_set_reads");
-    mp_align_params ap;
-    ap.insert_low = p.insert_low; ap.insert_high = p.insert_high; ap.clip_left = p.clip_left; ap.clip_right = p.clip_right; ap.mmp = p.mmp;
-    ap.want_tie_counts = bam ? 1 : 0; ap.reserved = 0;          // num_sameScore only feeds the BAM MAPQ / X0 / X1
-    uint64_t nh = 0;
-    mp_round_stats rs;
-    die(mp_deep_dp_round(ctx, &ap, &nh, &rs), "mp_deep_dp_round");
-    const mp_pair_hit *view = nullptr;
-    die(mp_get_pair_hits_view(ctx, &view, &nh), "mp_get_pair_hits_view");
-    std::vector<mp_pair_hit> hits(view, view + nh);
-    st.pairs += n_pairs; st.dp += 2 * rs.n_candidates;
-    // OutputBuffer::ready: per pair sort by (pos1, pos2, score1, score2) and drop duplicates (DV-DPfunctions.h:165-196)
-    std::sort(hits.begin(), hits.end(), [](const mp_pair_hit &x, const mp_pair_hit &y) {
+    if (b.lists_ready) return;
+    auto &hits = b.hits;
+    auto hit_less = [](const mp_pair_hit &x, const mp_pair_hit &y) {
         if (x.pair_id != y.pair_id) return x.pair_id < y.pair_id;
         if (x.algnmt_1 != y.algnmt_1) return x.algnmt_1 < y.algnmt_1;
         if (x.algnmt_2 != y.algnmt_2) return x.algnmt_2 < y.algnmt_2;
         if (x.score_1 != y.score_1) return x.score_1 < y.score_1;
         return x.score_2 < y.score_2;
-    });
+    };
+    // the device emits the hits in candidate order, i.e. already grouped by pair: then only the few hits of each pair
+    // need ordering
+    if (std::is_sorted(hits.begin(), hits.end(), [](const mp_pair_hit &x, const mp_pair_hit &y) { return x.pair_id < y.pair_id; })) {
+        for (size_t i = 0; i < hits.size();) {
+            size_t j = i + 1;
+            while (j < hits.size() && hits[j].pair_id == hits[i].pair_id) j++;
+            if (j - i > 1) std::sort(hits.begin() + (long)i, hits.begin() + (long)j, hit_less);
+            i = j;
+        }
+    } else std::sort(hits.begin(), hits.end(), hit_less);
     hits.erase(std::unique(hits.begin(), hits.end(), [](const mp_pair_hit &x, const mp_pair_hit &y) {
         return x.pair_id == y.pair_id && x.algnmt_1 == y.algnmt_1 && x.algnmt_2 == y.algnmt_2 && x.score_1 == y.score_1 && x.score_2 == y.score_2; }), hits.end());
-    std::vector<std::string> cig;
-    std::vector<mp_dp_task> tasks;
-    if (bam) {
-        tasks.reserve(2 * hits.size());
-        for (const mp_pair_hit &h : hits) {
-            const uint32_t s1 = h.left_is_mate ? 2u : 1u;       // the left leg is aligned as is, the right leg reverse-complemented
-            tasks.push_back(mp_dp_task{2 * h.pair_id, s1, h.start_1, h.dplen_1, 0});
-            tasks.push_back(mp_dp_task{2 * h.pair_id + 1, 3u - s1, h.start_2, h.dplen_2, 0});
-        }
-        resolve_cigars(ctx, p, tasks, b.lens, cig);
-    }
-    std::vector<char> done(n_pairs, 0);
-    uint32_t n_done = 0;
-    std::vector<PairAln> res;
-    PairText text;
-    auto best_of = [](const std::vector<PairAln> &v) {           // first maximum of score_1 + score_2 (OutputDPResult.cpp:156-232)
-        size_t best = 0;
-        for (size_t i = 1; i < v.size(); i++) if (v[i].m[0].score + v[i].m[1].score > v[best].m[0].score + v[best].m[1].score) best = i;
-        return best;
-    };
-    auto emit_pair = [&](uint32_t q, int file, int stage) {
-        const Rec &r1 = b.recs[2 * q], &r2 = b.recs[2 * q + 1];
-        const size_t best = best_of(res);
-        w.pair(r1, r2, b.lens[2 * q], b.lens[2 * q + 1], res);
-        if (!bam) return;
-        const mpbam::ReadView rd[2] = {view_of(r1, b.lens[2 * q]), view_of(r2, b.lens[2 * q + 1])};
-        if (bam->w->wants_text()) { const Side *bs[2] = {&res[best].m[0], &res[best].m[1]}; text.fetch(ix, bs); }
-        bam->w->pair(file, stage, rd, res, best, text.ref);
-    };
-    for (size_t i = 0; i < hits.size();) {
-        size_t j = i;
-        res.clear();
-        const uint32_t q = hits[i].pair_id;
-        for (; j < hits.size() && hits[j].pair_id == q; j++) {
-            const mp_pair_hit &h = hits[j];
-            PairAln r;
-            r.m[0].pos = h.algnmt_1; r.m[1].pos = h.algnmt_2; r.m[0].score = h.score_1; r.m[1].score = h.score_2;
-            r.m[0].strand = h.left_is_mate ? 2 : 1; r.m[1].strand = 3 - r.m[0].strand;
-            if (bam) {
-                // the reference computes both edit distances with the right leg's read length (DV-DPfunctions.cpp:3466, :2999)
-                const int right_len = (int)b.lens[2 * q + (h.left_is_mate ? 0 : 1)], right_side = h.left_is_mate ? 0 : 1;
-                int dis[2];
-                for (int k = 0; k < 2; k++) {
-                    r.m[k].cigar = cig[2 * j + k].c_str();
-                    r.m[k].editdist = mpbam::edit_dist(r.m[k].cigar, right_len, r.m[k].score, &dis[k]);
-                }
-                r.m[0].count = h.count_1; r.m[1].count = h.count_2;
-                const uint64_t d = h.algnmt_1 < h.algnmt_2 ? h.algnmt_2 - h.algnmt_1 : h.algnmt_1 - h.algnmt_2;
-                r.insert = (long long)d + right_len + dis[right_side];                              // :3520-3525
-            }
-            res.push_back(r);
-        }
-        emit_pair(q, mpbam::Writer::FILE_DPOUT, 1);
-        done[q] = 1; st.deep++; n_done++;
-        i = j;
-    }
-    if (n_done == n_pairs) return;
-    // ---- rescue passes (alignment.cpp:137-352): single-end DP + mate rescue on the device, bookkeeping here
-    mp_rescue_stats rst;
-    die(mp_rescue_round(ctx, &ap, p.skip_default_dp ? 1 : 0, &rst), "mp_rescue_round");
-    st.dp += rst.n_single_tasks + rst.n_rescue_tasks;
-    uint64_t ns = 0, nr = 0;
-    die(mp_get_single_hits(ctx, nullptr, 0, &ns), "mp_get_single_hits");
-    std::vector<mp_single_hit> singles(ns + 1);
-    die(mp_get_single_hits(ctx, singles.data(), ns, &ns), "mp_get_single_hits");
-    singles.resize(ns);
-    die(mp_get_rescue_hits(ctx, nullptr, 0, &nr), "mp_get_rescue_hits");
-    std::vector<mp_rescue_hit> resc(nr + 1);
-    die(mp_get_rescue_hits(ctx, resc.data(), nr, &nr), "mp_get_rescue_hits");
-    resc.resize(nr);
-    // mate rescue results as (read, mate) pairs; OutputBuffer::ready(1): sorted, duplicates and failed rescues dropped
-    struct RescueRow { uint32_t pair; uint64_t a1, a2; int s1, s2; uint32_t src; };
-    std::vector<RescueRow> rows(nr);
-    for (uint64_t i = 0; i < nr; i++) {
-        const mp_rescue_hit &h = resc[i];
+    auto &rows = b.rows;
+    rows.resize(b.resc.size());
+    for (size_t i = 0; i < b.resc.size(); i++) {
+        const mp_rescue_hit &h = b.resc[i];
         if ((h.aligned_read & 1u) == 0) rows[i] = RescueRow{h.pair_id, h.aligned_pos, h.dp_pos, h.aligned_score, h.dp_score, (uint32_t)i};
         else rows[i] = RescueRow{h.pair_id, h.dp_pos, h.aligned_pos, h.dp_score, h.aligned_score, (uint32_t)i};
     }
@@ -448,7 +428,8 @@ void align_batch(mp_index *ix, mp_ctx *ctx, Params &p, Batch &b, bool &first, Wr
     });
     rows.erase(std::unique(rows.begin(), rows.end(), [](const RescueRow &x, const RescueRow &y) {
         return x.pair == y.pair && x.a1 == y.a1 && x.a2 == y.a2 && x.s1 == y.s1 && x.s2 == y.s2; }), rows.end());
-    // single-end hits per read, OutputBuffer::ready(): sorted by (position, score), duplicates dropped (DV-DPfunctions.cpp:853-866)
+    for (const RescueRow &r : rows) b.done[r.pair] = 2;
+    auto &singles = b.singles;
     std::sort(singles.begin(), singles.end(), [](const mp_single_hit &x, const mp_single_hit &y) {
         if (x.read_id != y.read_id) return x.read_id < y.read_id;
         if (x.algnmt != y.algnmt) return x.algnmt < y.algnmt;
@@ -456,67 +437,235 @@ void align_batch(mp_index *ix, mp_ctx *ctx, Params &p, Batch &b, bool &first, Wr
     });
     singles.erase(std::unique(singles.begin(), singles.end(), [](const mp_single_hit &x, const mp_single_hit &y) {
         return x.read_id == y.read_id && x.algnmt == y.algnmt && x.score == y.score; }), singles.end());
-    for (const RescueRow &r : rows) done[r.pair] = 2;
-    std::vector<std::string> rcig, scig;
+    b.lists_ready = true;
+}
+
+// Stage 2: everything that touches the device.  Per batch: upload, deep-DP round, and for the pairs it left without a
+// hit the rescue round (alignment.cpp:29-355); with -b also the CIGARs of every hit that will be written.
+void gpu_stage(mp_ctx *ctx, Params &p, Batch &b, bool &first, bool bam, int threads, Stats &st)
+{
+    const uint32_t n_reads = b.n_reads, n_pairs = n_reads / 2;
+    if (first) {
+        // SOAP4.cpp:465-474 / QueryParser.cpp:2253-2277: the minimum insert size is at least the detected read lengths
+        uint32_t d1 = 0, d2 = 0;
+        for (uint32_t q = 0; q < n_pairs && q < 999999; q++) { d1 = std::max(d1, b.lens[2 * q]); d2 = std::max(d2, b.lens[2 * q + 1]); }
+        p.insert_low = std::max(p.insert_low, (int)std::max(d1, d2));
+        first = false;
+    }
+    for (uint32_t r = 0; r < n_reads; r++) if (b.lens[r] < 30) { fprintf(stderr, "[soap4-mi355x] reads shorter than the DP cutoff (30) are undefined in the reference (CPU_DP.cpp:316-324)\n"); exit(1); }
+    double t0 = now_s();
+    die(mp_set_reads(ctx, b.packed.data(), b.W, b.lens.data(), n_reads), "mp_set_reads");
+    st.t_upload += now_s() - t0; t0 = now_s();
+    mp_align_params ap;
+    ap.insert_low = p.insert_low; ap.insert_high = p.insert_high; ap.clip_left = p.clip_left; ap.clip_right = p.clip_right; ap.mmp = p.mmp;
+    ap.want_tie_counts = bam ? 1 : 0; ap.reserved = 0;          // num_sameScore only feeds the BAM MAPQ / X0 / X1
+    uint64_t nh = 0;
+    mp_round_stats rs;
+    die(mp_deep_dp_round(ctx, &ap, &nh, &rs), "mp_deep_dp_round");
+    const mp_pair_hit *view = nullptr;
+    die(mp_get_pair_hits_view(ctx, &view, &nh), "mp_get_pair_hits_view");
+    b.hits.assign(view, view + nh);
+    b.dp_instances = 2 * rs.n_candidates;
+    b.done.assign(n_pairs, 0);
+    uint32_t n_done = 0;
+    for (const mp_pair_hit &h : b.hits) if (!b.done[h.pair_id]) { b.done[h.pair_id] = 1; n_done++; }
+    st.t_deep += now_s() - t0; t0 = now_s();
+    if (n_done < n_pairs) {
+        // rescue passes (alignment.cpp:137-352): single-end DP + mate rescue on the device
+        mp_rescue_stats rst;
+        die(mp_rescue_round(ctx, &ap, p.skip_default_dp ? 1 : 0, &rst), "mp_rescue_round");
+        b.dp_instances += rst.n_single_tasks + rst.n_rescue_tasks;
+        uint64_t ns = 0, nr = 0;
+        die(mp_get_single_hits(ctx, nullptr, 0, &ns), "mp_get_single_hits");
+        b.singles.resize(ns + 1);
+        die(mp_get_single_hits(ctx, b.singles.data(), ns, &ns), "mp_get_single_hits");
+        b.singles.resize(ns);
+        die(mp_get_rescue_hits(ctx, nullptr, 0, &nr), "mp_get_rescue_hits");
+        b.resc.resize(nr + 1);
+        die(mp_get_rescue_hits(ctx, b.resc.data(), nr, &nr), "mp_get_rescue_hits");
+        b.resc.resize(nr);
+    }
+    st.t_rescue += now_s() - t0; t0 = now_s();
     if (bam) {
+        prepare_lists(b);
+        st.t_sort += now_s() - t0; t0 = now_s();
+        std::vector<mp_dp_task> tasks;
+        tasks.reserve(2 * b.hits.size());
+        for (const mp_pair_hit &h : b.hits) {
+            const uint32_t s1 = h.left_is_mate ? 2u : 1u;       // the left leg is aligned as is, the right leg reverse-complemented
+            tasks.push_back(mp_dp_task{2 * h.pair_id, s1, h.start_1, h.dplen_1, 0});
+            tasks.push_back(mp_dp_task{2 * h.pair_id + 1, 3u - s1, h.start_2, h.dplen_2, 0});
+        }
+        resolve_cigars(ctx, p, threads, tasks, b.lens, b.cig);
         tasks.clear();
-        for (const RescueRow &r : rows) {
-            const mp_rescue_hit &h = resc[r.src];
+        for (const RescueRow &r : b.rows) {
+            const mp_rescue_hit &h = b.resc[r.src];
             tasks.push_back(mp_dp_task{h.aligned_read, h.aligned_strand, h.aligned_win_start, h.aligned_win_len, 0});
             tasks.push_back(mp_dp_task{h.aligned_read ^ 1u, h.dp_strand, h.dp_win_start, h.dp_win_len, 0});
         }
-        resolve_cigars(ctx, p, tasks, b.lens, rcig);
+        resolve_cigars(ctx, p, threads, tasks, b.lens, b.rcig);
         tasks.clear();
-        for (const mp_single_hit &h : singles) if (done[h.read_id >> 1] == 0) tasks.push_back(mp_dp_task{h.read_id, h.strand, h.win_start, h.win_len, 0});
-        resolve_cigars(ctx, p, tasks, b.lens, scig);
+        for (const mp_single_hit &h : b.singles) if (b.done[h.read_id >> 1] == 0) tasks.push_back(mp_dp_task{h.read_id, h.strand, h.win_start, h.win_len, 0});
+        resolve_cigars(ctx, p, threads, tasks, b.lens, b.scig);
+        st.t_cigar += now_s() - t0;
     }
-    // the default-DP stage writes every rescued pair of the batch before the unpaired output starts (alignment.cpp:225-330)
-    for (size_t i = 0; i < rows.size();) {
-        size_t j = i;
-        res.clear();
-        const uint32_t q = rows[i].pair;
-        for (; j < rows.size() && rows[j].pair == q; j++) {
-            const mp_rescue_hit &h = resc[rows[j].src];
-            const int al = (int)(h.aligned_read & 1u), un = 1 - al;
-            PairAln r;
-            r.m[al].pos = h.aligned_pos; r.m[al].score = h.aligned_score; r.m[al].strand = (int)h.aligned_strand;
-            r.m[un].pos = h.dp_pos; r.m[un].score = h.dp_score; r.m[un].strand = (int)h.dp_strand;
-            if (bam) {
-                int dis = 0;
-                r.m[al].cigar = rcig[2 * j].c_str(); r.m[un].cigar = rcig[2 * j + 1].c_str();
-                r.m[al].editdist = mpbam::edit_dist(r.m[al].cigar, (int)b.lens[h.aligned_read], h.aligned_score, nullptr);
-                r.m[un].editdist = mpbam::edit_dist(r.m[un].cigar, (int)b.lens[h.aligned_read ^ 1u], h.dp_score, &dis);
-                r.m[al].count = (int)h.aligned_count; r.m[un].count = (int)h.dp_count;
-                // DV-DPfunctions.cpp:1553-1565
-                if (h.dp_pos < h.aligned_pos) r.insert = (long long)(h.aligned_pos - h.dp_pos) + b.lens[h.aligned_read];
-                else r.insert = (long long)(h.dp_pos - h.aligned_pos) + b.lens[h.aligned_read ^ 1u] + dis;
-            }
-            res.push_back(r);
+}
+
+// Stage 3: per-pair bookkeeping and printing (OutputDPResult.cpp:65-404, BGS-IO.cpp writers).  Order within a batch as in
+// the reference: pairs of the deep-DP round, then every rescued pair, then the unpaired rest (alignment.cpp:105-330).
+// Pairs are independent, so each section is cut into chunks that worker threads format into their own buffers; the
+// buffers go out in chunk order.
+struct Sink { std::string text, bam[3]; uint64_t n = 0; };
+
+template <typename F>
+void for_chunks(size_t n_items, int threads, BamState *bam, F &&body)
+{
+    const size_t chunk = 4096;
+    const size_t n_chunks = (n_items + chunk - 1) / chunk;
+    const size_t wave = (size_t)std::max(1, threads);
+    std::vector<Sink> sinks(wave);
+    for (size_t c0 = 0; c0 < n_chunks; c0 += wave) {
+        const size_t nc = std::min(wave, n_chunks - c0);
+        auto run = [&](size_t t) { Sink &s = sinks[t]; s.text.clear(); for (auto &x : s.bam) x.clear(); body((c0 + t) * chunk, std::min(n_items, (c0 + t + 1) * chunk), s); };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nc; t++) pool.emplace_back(run, t);
+        run(0);
+        for (auto &th : pool) th.join();
+        for (size_t t = 0; t < nc; t++) {
+            fwrite(sinks[t].text.data(), 1, sinks[t].text.size(), stdout);
+            if (bam) for (int k = 0; k < 3; k++) bam->w->append(k, sinks[t].bam[k]);
         }
-        emit_pair(q, mpbam::Writer::FILE_GOUT, bam ? bam->stage_rescue : 0);
-        st.rescued++;
-        i = j;
     }
-    std::vector<Side> lst[2];
-    std::vector<mpbam::Writer::RefText> ref_of[2];
-    std::vector<uint8_t> tbuf[2];
-    size_t si = 0, ci = 0;
-    for (uint32_t q = 0; q < n_pairs; q++) {
-        if (done[q]) { while (si < singles.size() && (singles[si].read_id >> 1) == q) si++; continue; }
-        for (int k = 0; k < 2; k++) {
-            lst[k].clear();
-            const uint32_t r = 2 * q + (uint32_t)k;
-            for (; si < singles.size() && singles[si].read_id == r; si++) {
-                const mp_single_hit &h = singles[si];
-                Side s;
-                s.pos = h.algnmt; s.score = h.score; s.strand = (int)h.strand; s.count = (int)h.count;
-                if (bam) { s.cigar = scig[ci++].c_str(); s.editdist = mpbam::edit_dist(s.cigar, (int)b.lens[r], h.score, nullptr); }
-                lst[k].push_back(s);
+}
+
+void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int threads, Stats &st)
+{
+    const uint32_t n_pairs = b.n_reads / 2;
+    double t0 = now_s();
+    prepare_lists(b);
+    st.t_sort += now_s() - t0; t0 = now_s();
+    st.pairs += n_pairs; st.dp += b.dp_instances;
+    const auto &hits = b.hits;
+    auto best_of = [](const std::vector<PairAln> &v) {           // first maximum of score_1 + score_2 (OutputDPResult.cpp:156-232)
+        size_t best = 0;
+        for (size_t i = 1; i < v.size(); i++) if (v[i].m[0].score + v[i].m[1].score > v[best].m[0].score + v[best].m[1].score) best = i;
+        return best;
+    };
+    auto emit_pair = [&](Writer &w, Sink &sink, PairText &text, std::vector<PairAln> &res, uint32_t q, int file, int stage) {
+        const Rec &r1 = b.rec(2 * q), &r2 = b.rec(2 * q + 1);
+        const size_t best = best_of(res);
+        w.pair(r1, r2, b.lens[2 * q], b.lens[2 * q + 1], res);
+        if (!bam) return;
+        const mpbam::ReadView rd[2] = {view_of(r1, b.lens[2 * q]), view_of(r2, b.lens[2 * q + 1])};
+        if (bam->w->wants_text()) { const Side *bs[2] = {&res[best].m[0], &res[best].m[1]}; text.fetch(ix, bs); }
+        bam->w->pair(sink.bam[file], stage, rd, res, best, text.ref);
+    };
+    // ---- pairs of the deep-DP round: groups of equal pair_id in the sorted hit list
+    std::vector<size_t> grp;
+    for (size_t i = 0; i < hits.size(); i++) if (i == 0 || hits[i].pair_id != hits[i - 1].pair_id) grp.push_back(i);
+    grp.push_back(hits.size());
+    for_chunks(grp.size() - 1, threads, bam, [&](size_t g0, size_t g1, Sink &sink) {
+        Writer w(ix, p);
+        PairText text;
+        std::vector<PairAln> res;
+        for (size_t g = g0; g < g1; g++) {
+            res.clear();
+            const uint32_t q = hits[grp[g]].pair_id;
+            for (size_t j = grp[g]; j < grp[g + 1]; j++) {
+                const mp_pair_hit &h = hits[j];
+                PairAln r;
+                r.m[0].pos = h.algnmt_1; r.m[1].pos = h.algnmt_2; r.m[0].score = h.score_1; r.m[1].score = h.score_2;
+                r.m[0].strand = h.left_is_mate ? 2 : 1; r.m[1].strand = 3 - r.m[0].strand;
+                if (bam) {
+                    // the reference computes both edit distances with the right leg's read length (DV-DPfunctions.cpp:3466, :2999)
+                    const int right_len = (int)b.lens[2 * q + (h.left_is_mate ? 0 : 1)], right_side = h.left_is_mate ? 0 : 1;
+                    int dis[2];
+                    for (int k = 0; k < 2; k++) {
+                        r.m[k].cigar = b.cig[2 * j + k].c_str();
+                        r.m[k].editdist = mpbam::edit_dist(r.m[k].cigar, right_len, r.m[k].score, &dis[k]);
+                    }
+                    r.m[0].count = h.count_1; r.m[1].count = h.count_2;
+                    const uint64_t d = h.algnmt_1 < h.algnmt_2 ? h.algnmt_2 - h.algnmt_1 : h.algnmt_1 - h.algnmt_2;
+                    r.insert = (long long)d + right_len + dis[right_side];                              // :3520-3525
+                }
+                res.push_back(r);
             }
-            w.single(b.recs[r], b.lens[r], lst[k]);
+            emit_pair(w, sink, text, res, q, mpbam::Writer::FILE_DPOUT, 1);
         }
-        if (bam) {
-            const mpbam::ReadView rd[2] = {view_of(b.recs[2 * q], b.lens[2 * q]), view_of(b.recs[2 * q + 1], b.lens[2 * q + 1])};
+        sink.text.swap(w.out);
+    });
+    st.deep += grp.size() - 1;
+    st.t_emit_deep += now_s() - t0; t0 = now_s();
+    // ---- rescued pairs
+    const auto &rows = b.rows;
+    grp.clear();
+    for (size_t i = 0; i < rows.size(); i++) if (i == 0 || rows[i].pair != rows[i - 1].pair) grp.push_back(i);
+    grp.push_back(rows.size());
+    for_chunks(grp.size() - 1, threads, bam, [&](size_t g0, size_t g1, Sink &sink) {
+        Writer w(ix, p);
+        PairText text;
+        std::vector<PairAln> res;
+        for (size_t g = g0; g < g1; g++) {
+            res.clear();
+            const uint32_t q = rows[grp[g]].pair;
+            for (size_t j = grp[g]; j < grp[g + 1]; j++) {
+                const mp_rescue_hit &h = b.resc[rows[j].src];
+                const int al = (int)(h.aligned_read & 1u), un = 1 - al;
+                PairAln r;
+                r.m[al].pos = h.aligned_pos; r.m[al].score = h.aligned_score; r.m[al].strand = (int)h.aligned_strand;
+                r.m[un].pos = h.dp_pos; r.m[un].score = h.dp_score; r.m[un].strand = (int)h.dp_strand;
+                if (bam) {
+                    int dis = 0;
+                    r.m[al].cigar = b.rcig[2 * j].c_str(); r.m[un].cigar = b.rcig[2 * j + 1].c_str();
+                    r.m[al].editdist = mpbam::edit_dist(r.m[al].cigar, (int)b.lens[h.aligned_read], h.aligned_score, nullptr);
+                    r.m[un].editdist = mpbam::edit_dist(r.m[un].cigar, (int)b.lens[h.aligned_read ^ 1u], h.dp_score, &dis);
+                    r.m[al].count = (int)h.aligned_count; r.m[un].count = (int)h.dp_count;
+                    // DV-DPfunctions.cpp:1553-1565
+                    if (h.dp_pos < h.aligned_pos) r.insert = (long long)(h.aligned_pos - h.dp_pos) + b.lens[h.aligned_read];
+                    else r.insert = (long long)(h.dp_pos - h.aligned_pos) + b.lens[h.aligned_read ^ 1u] + dis;
+                }
+                res.push_back(r);
+            }
+            emit_pair(w, sink, text, res, q, mpbam::Writer::FILE_GOUT, bam ? bam->stage_rescue : 0);
+        }
+        sink.text.swap(w.out);
+    });
+    st.rescued += grp.size() - 1;
+    // ---- the unpaired rest: per pair where its single-end hits (and their CIGARs) start
+    const auto &singles = b.singles;
+    struct Rest { uint32_t q; size_t si, ci; };
+    std::vector<Rest> rest;
+    {
+        size_t si = 0, ci = 0;
+        for (uint32_t q = 0; q < n_pairs; q++) {
+            size_t e = si;
+            while (e < singles.size() && (singles[e].read_id >> 1) == q) e++;
+            if (!b.done[q]) { rest.push_back(Rest{q, si, ci}); ci += e - si; }
+            si = e;
+        }
+    }
+    for_chunks(rest.size(), threads, bam, [&](size_t i0, size_t i1, Sink &sink) {
+        Writer w(ix, p);
+        std::vector<Side> lst[2];
+        std::vector<mpbam::Writer::RefText> ref_of[2];
+        std::vector<uint8_t> tbuf[2];
+        for (size_t i = i0; i < i1; i++) {
+            const uint32_t q = rest[i].q;
+            size_t si = rest[i].si, ci = rest[i].ci;
+            for (int k = 0; k < 2; k++) {
+                lst[k].clear();
+                const uint32_t r = 2 * q + (uint32_t)k;
+                for (; si < singles.size() && singles[si].read_id == r; si++) {
+                    const mp_single_hit &h = singles[si];
+                    Side s;
+                    s.pos = h.algnmt; s.score = h.score; s.strand = (int)h.strand; s.count = (int)h.count;
+                    if (bam) { s.cigar = b.scig[ci++].c_str(); s.editdist = mpbam::edit_dist(s.cigar, (int)b.lens[r], h.score, nullptr); }
+                    lst[k].push_back(s);
+                }
+                w.single(b.rec(r), b.lens[r], lst[k]);
+            }
+            if (!bam) continue;
+            const mpbam::ReadView rd[2] = {view_of(b.rec(2 * q), b.lens[2 * q]), view_of(b.rec(2 * q + 1), b.lens[2 * q + 1])};
             const mpbam::Writer::RefText *rp[2] = {nullptr, nullptr};
             if (bam->w->wants_text())
                 for (int k = 0; k < 2; k++) {
@@ -524,20 +673,39 @@ void align_batch(mp_index *ix, mp_ctx *ctx, Params &p, Batch &b, bool &first, Wr
                     ref_of[k].assign(n, mpbam::Writer::RefText());
                     if (!n) continue;
                     std::vector<uint64_t> pos(n); std::vector<uint32_t> len(n); uint32_t stride = 16;
-                    for (size_t i = 0; i < n; i++) {
-                        const bool ok = lst[k][i].pos != NOT_ALIGNED;
-                        pos[i] = ok ? lst[k][i].pos : 0; len[i] = ok ? mpbam::Writer::ref_span(lst[k][i].cigar) + 8 : 0; stride = std::max(stride, len[i]);
+                    for (size_t x = 0; x < n; x++) {
+                        const bool ok = lst[k][x].pos != NOT_ALIGNED;
+                        pos[x] = ok ? lst[k][x].pos : 0; len[x] = ok ? mpbam::Writer::ref_span(lst[k][x].cigar) + 8 : 0; stride = std::max(stride, len[x]);
                     }
                     tbuf[k].assign(n * (size_t)stride, 0);
                     die(mp_index_fetch_text(ix, pos.data(), len.data(), (uint32_t)n, tbuf[k].data(), stride), "mp_index_fetch_text");
-                    for (size_t i = 0; i < n; i++) { ref_of[k][i].pos = pos[i]; ref_of[k][i].codes = tbuf[k].data() + i * (size_t)stride; ref_of[k][i].len = len[i]; }
+                    for (size_t x = 0; x < n; x++) { ref_of[k][x].pos = pos[x]; ref_of[k][x].codes = tbuf[k].data() + x * (size_t)stride; ref_of[k][x].len = len[x]; }
                     rp[k] = ref_of[k].data();
                 }
-            bam->w->unpaired(bam->stage_unpaired, rd, lst, rp);
+            bam->w->unpaired(sink.bam[mpbam::Writer::FILE_UNPAIR], bam->stage_unpaired, rd, lst, rp);
         }
-        st.unpaired++;
-    }
+        sink.text.swap(w.out);
+    });
+    st.unpaired += rest.size();
+    st.t_emit_rest += now_s() - t0;
 }
+
+// hand-over of batches between the stages
+struct BatchQueue {
+    std::mutex mu; std::condition_variable cv;
+    std::vector<Batch *> q;
+    bool closed = false;
+    void push(Batch *b) { { std::lock_guard<std::mutex> lk(mu); q.push_back(b); } cv.notify_all(); }
+    void close() { { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_all(); }
+    Batch *pop()                                                  // nullptr once closed and drained
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !q.empty() || closed; });
+        if (q.empty()) return nullptr;
+        Batch *b = q.front(); q.erase(q.begin());
+        return b;
+    }
+};
 
 }  // namespace
 
@@ -624,23 +792,7 @@ int main(int argc, char **argv)
 
     FqReader ra, rb;
     if (!ra.open(fq1) || !rb.open(fq2)) { fprintf(stderr, "[soap4-mi355x] cannot open read files\n"); return 1; }
-    // double buffer: the reader thread parses + packs batch k+1 while the GPU aligns batch k (aio_thread.cpp:247)
-    Batch bufs[2];
-    std::mutex mu; std::condition_variable cv;
-    int ready[2] = {0, 0};           // 0 = free, 1 = filled
-    bool reader_done = false;
-    std::thread reader([&]() {
-        for (int k = 0;; k ^= 1) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[k] == 0; }); }
-            bool got = fill_batch(ra, rb, p, bufs[k]);
-            { std::lock_guard<std::mutex> lk(mu); if (got) ready[k] = 1; if (!got || bufs[k].last) reader_done = true; }
-            cv.notify_all();
-            if (!got || bufs[k].last) break;
-        }
-    });
-    Writer w(ix, p);
     Stats st;
-    bool first = true;
     BamState bam_state, *bam = nullptr;
     if (p.want_bam) {
         bam_state.w.reset(new mpbam::Writer(ix, bopt));
@@ -648,20 +800,50 @@ int main(int argc, char **argv)
         bam_state.stage_unpaired = p.skip_default_dp ? 2 : 3;
         bam = &bam_state;
     }
-    for (int k = 0;; k ^= 1) {
-        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[k] == 1 || reader_done; }); if (ready[k] != 1) break; }
-        align_batch(ix, ctx, p, bufs[k], first, w, bam, st);
-        bool last = bufs[k].last;
-        { std::lock_guard<std::mutex> lk(mu); ready[k] = 0; }
-        cv.notify_all();
-        if (last) break;
+    // Three stages over three recycled batch objects: the reader threads parse and pack batch k+1 (the reference's IO
+    // thread, aio_thread.cpp:247) and the output thread prints batch k-1 while the device aligns batch k.
+    Batch pool[3];
+    BatchQueue free_q, filled_q, aligned_q;
+    for (Batch &b : pool) free_q.push(&b);
+    const double t_start = now_s();
+    std::thread reader([&]() {
+        for (;;) {
+            Batch *b = free_q.pop();
+            if (!b) break;
+            const bool got = fill_batch(ra, rb, p, *b);
+            if (got) filled_q.push(b);
+            if (!got || b->last) break;
+        }
+        filled_q.close();
+    });
+    std::thread printer([&]() {
+        for (;;) {
+            Batch *b = aligned_q.pop();
+            if (!b) break;
+            output_stage(ix, p, *b, bam, threads, st);
+            free_q.push(b);
+        }
+    });
+    bool first = true;
+    for (;;) {
+        Batch *b = filled_q.pop();
+        if (!b) break;
+        gpu_stage(ctx, p, *b, first, bam != nullptr, threads, st);
+        aligned_q.push(b);
     }
+    aligned_q.close();
+    printer.join();
+    free_q.close();
     reader.join();
-    w.flush();
+    const double t_loop = now_s() - t_start;
     fflush(stdout);
     if (bam && !bam->w->close()) { fprintf(stderr, "[soap4-mi355x] error while writing the BAM files\n"); return 1; }
     fprintf(stderr, "[Main] %llu pairs: %llu aligned by deep DP, %llu by mate rescue, %llu unpaired; %llu DP instances\n", (unsigned long long)st.pairs,
             (unsigned long long)st.deep, (unsigned long long)st.rescued, (unsigned long long)st.unpaired, (unsigned long long)st.dp);
+    fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped)\n", t_loop, st.pairs / std::max(t_loop, 1e-9));
+    if (getenv("MP_TIMING"))
+        fprintf(stderr, "[Main] seconds: upload %.2f, deep-DP round %.2f, sort %.2f, BAM CIGARs %.2f, output of deep pairs %.2f, rescue round %.2f, output of the rest %.2f\n",
+                st.t_upload, st.t_deep, st.t_sort, st.t_cigar, st.t_emit_deep, st.t_rescue, st.t_emit_rest);
     mp_ctx_destroy(ctx);
     mp_index_close(ix);
     return 0;

@@ -43,6 +43,7 @@ struct Params {
     int mode = 0;                 // 1 = -F, 2 = -P
     double top = 0.95;
     bool skip_default_dp = false, want_bam = false, ignore_comments = false;   // -nc: SOAP4.cpp:537-547
+    int lsam = 0;                 // extension: 1 = print LSAM lines instead of annotated FASTQ (what `| fastq2lsam 1` yields), 2 = without sequences
     mp_mmp_params mmp = {30, 17, 6, 5, 27, 18, 0.85, 4, 0.5};       // defaults of ParseIniFile (IniParam.cpp:427-435)
     size_t batch_pairs = 1u << 20;                                   // SOAP4.cpp:206
 };
@@ -243,25 +244,76 @@ struct Writer {
     const Params &p;
     std::string out;
     Writer(const mp_index *i, const Params &pp) : ix(i), p(pp) {}
-    void seq_qual(const Rec &r) { out += r.seq; out += "\n+\n"; out += r.qual; out += '\n'; }
-    void score_line(const Rec &r, int best, const std::vector<ChrHit> &hits, const std::vector<HdrMap> &v)
+    // -lsam: the line cc/fastq2lsam would print for a record (print_lsam_line, cc/fastq2lsam.cpp:28-78)
+    void lsam_line(const std::string &name, const std::string &comm, const std::string &seq, const std::string &qual, int which_end)
     {
-        out += '@'; out += r.name;
-        if (r.has_comment && r.comment == "IGNORE") { out += "\tIGNORE\n"; return; }
-        char tmp[64];
-        snprintf(tmp, sizeof tmp, "\tSCORE:%d;", best); out += tmp;
-        if (best > 0) {
-            for (size_t i = 0; i < hits.size(); i++) {
-                if (i > 0 && hits[i].chr == hits[i - 1].chr) continue;
-                if (-hits[i].neg > 0 && -hits[i].neg >= best * p.top) {
-                    snprintf(tmp, sizeof tmp, "%d,", -hits[i].neg); out += tmp;
-                    out += mp_index_seq_name(ix, (uint32_t)hits[i].chr); out += ';';
+        char tmp[32];
+        out += name;
+        out += which_end == 1 ? "\t64\t" : which_end == 2 ? "\t128\t" : "\t0\t";
+        const bool ignore = comm == "IGNORE";
+        const int score = ignore ? -1 : (comm.size() > 6 ? atoi(comm.c_str() + 6) : 0);
+        snprintf(tmp, sizeof tmp, "%d\t", score); out += tmp;
+        if (p.lsam == 1) { out += seq; out += '\t'; out += qual; out += '\t'; } else out += "*\t*\t";
+        if (score <= 0) out += '*';
+        else {
+            bool first = true;
+            size_t i = comm.find(';');                       // element 0 is the score itself
+            while (i != std::string::npos && i + 1 < comm.size()) {
+                size_t j = comm.find(';', i + 1);
+                if (j == std::string::npos) j = comm.size();
+                // one "score,acc[,acc...]" element
+                size_t c0 = comm.find(',', i + 1);
+                if (c0 == std::string::npos || c0 > j) c0 = j;
+                for (size_t a = c0; a < j;) {
+                    size_t b = comm.find(',', a + 1);
+                    if (b == std::string::npos || b > j) b = j;
+                    if (!first) out += ';';
+                    first = false;
+                    out.append(comm, i + 1, c0 - i - 1); out += ','; out.append(comm, a + 1, b - a - 1);
+                    a = b;
                 }
+                i = j;
             }
         }
-        for (const HdrMap &m : v) if (m.score >= best * p.top) { out += m.text; out += ';'; }
+        if (ignore) out += "\tIGNORE";
         out += '\n';
     }
+    // fastq2lsam's pairing of consecutive records with equal names (cc/fastq2lsam.cpp:92-112); every pair leaves this
+    // writer as two consecutive records, so the state never spans the chunks of the output stage
+    void lsam_record(const Rec &r, const std::string &comm)
+    {
+        if (held_) {
+            if (held_->name == r.name) { lsam_line(held_->name, held_comm_, held_->seq, held_->qual, 1); lsam_line(r.name, comm, r.seq, r.qual, 2); held_ = nullptr; return; }
+            lsam_line(held_->name, held_comm_, held_->seq, held_->qual, 0);
+        }
+        held_ = &r; held_comm_ = comm;
+    }
+    void finish() { if (held_) { lsam_line(held_->name, held_comm_, held_->seq, held_->qual, 0); held_ = nullptr; } }
+    // one output record: the annotated FASTQ header + sequence + qualities, or its LSAM line
+    void record(const Rec &r, int best, const std::vector<ChrHit> &hits, const std::vector<HdrMap> &v)
+    {
+        std::string &o = p.lsam ? comm_ : out;
+        if (p.lsam) comm_.clear(); else { out += '@'; out += r.name; out += '\t'; }
+        if (r.has_comment && r.comment == "IGNORE") o += "IGNORE";
+        else {
+            char tmp[64];
+            snprintf(tmp, sizeof tmp, "SCORE:%d;", best); o += tmp;
+            if (best > 0) {
+                for (size_t i = 0; i < hits.size(); i++) {
+                    if (i > 0 && hits[i].chr == hits[i - 1].chr) continue;
+                    if (-hits[i].neg > 0 && -hits[i].neg >= best * p.top) {
+                        snprintf(tmp, sizeof tmp, "%d,", -hits[i].neg); o += tmp;
+                        o += mp_index_seq_name(ix, (uint32_t)hits[i].chr); o += ';';
+                    }
+                }
+            }
+            for (const HdrMap &m : v) if (m.score >= best * p.top) { o += m.text; o += ';'; }
+        }
+        if (p.lsam) { lsam_record(r, comm_); return; }
+        out += '\n'; out += r.seq; out += "\n+\n"; out += r.qual; out += '\n';
+    }
+    const Rec *held_ = nullptr;
+    std::string held_comm_, comm_;
     // decideTargetChr (BGS-IO.cpp:1312-1341)
     int target_chr(uint64_t pos, uint32_t len) const
     {
@@ -291,13 +343,13 @@ struct Writer {
         std::vector<HdrMap> v1, v2;
         int p1 = mapping_from_header(r1, v1, p.top, best1 * p.top), p2 = mapping_from_header(r2, v2, p.top, best2 * p.top);
         best1 = std::max(best1, p1); best2 = std::max(best2, p2);
-        score_line(r1, best1, h1_, v1); seq_qual(r1);
-        score_line(r2, best2, h2_, v2); seq_qual(r2);
+        record(r1, best1, h1_, v1);
+        record(r2, best2, h2_, v2);
     }
     // unproperlypairDPOutputFastqAPI (BGS-IO.cpp:1384-1446); in -F mode hits that span a sequence boundary are un-aligned in place
     void single(const Rec &r, uint32_t len, std::vector<Side> &hits)
     {
-        if (r.has_comment && r.comment == "IGNORE") { out += '@'; out += r.name; out += "\tIGNORE\n"; seq_qual(r); return; }
+        if (r.has_comment && r.comment == "IGNORE") { h1_.clear(); record(r, 0, h1_, std::vector<HdrMap>()); return; }
         int best = 0;
         h1_.clear();
         if (p.mode != 2)
@@ -310,7 +362,7 @@ struct Writer {
         std::vector<HdrMap> v;
         int prev = mapping_from_header(r, v, p.top, best * p.top);
         best = std::max(best, prev);
-        score_line(r, best, h1_, v); seq_qual(r);
+        record(r, best, h1_, v);
     }
     std::vector<ChrHit> h1_, h2_;
 };
@@ -592,6 +644,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
             }
             emit_pair(w, sink, text, res, q, mpbam::Writer::FILE_DPOUT, 1);
         }
+        w.finish();
         sink.text.swap(w.out);
     });
     st.deep += grp.size() - 1;
@@ -628,6 +681,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
             }
             emit_pair(w, sink, text, res, q, mpbam::Writer::FILE_GOUT, bam ? bam->stage_rescue : 0);
         }
+        w.finish();
         sink.text.swap(w.out);
     });
     st.rescued += grp.size() - 1;
@@ -684,6 +738,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
                 }
             bam->w->unpaired(sink.bam[mpbam::Writer::FILE_UNPAIR], bam->stage_unpaired, rd, lst, rp);
         }
+        w.finish();
         sink.text.swap(w.out);
     });
     st.unpaired += rest.size();
@@ -748,6 +803,8 @@ int main(int argc, char **argv)
         else if (a == "-P") p.mode = 2;
         else if (a == "-b") p.want_bam = true;
         else if (a == "-nc") p.ignore_comments = true;
+        else if (a == "-lsam") p.lsam = 1;                     // not in the reference: stdout = LSAM, saves the fastq2lsam pipe stage
+        else if (a == "-lsam-noseq") p.lsam = 2;
     }
     if (p.insert_low > p.insert_high) { fprintf(stderr, "The minimum value of insert size should not be greater than the maximum value of insert size.\n"); return 1; }
     // IniParam.cpp:918-940: -R needs -D and -A; -A and -D come together

@@ -31,6 +31,29 @@ KERN(k_pk_mad_i16, BODY3, "v_pk_mad_i16")
 KERN(k_max3_i32, BODY3, "v_max3_i32")
 KERN(k_add3_u32, BODY3, "v_add3_u32")
 KERN(k_lshl_or, BODY3, "v_lshl_or_b32")
+KERN(k_sub_u32, BODY, "v_sub_u32")
+KERN(k_and_b32, BODY, "v_and_b32")
+KERN(k_or_b32, BODY, "v_or_b32")
+KERN(k_xor_b32, BODY, "v_xor_b32")
+KERN(k_lshrrev, BODY, "v_lshrrev_b32")
+KERN(k_lshlrev, BODY, "v_lshlrev_b32")
+KERN(k_min_u32, BODY, "v_min_u32")
+KERN(k_max_u32, BODY, "v_max_u32")
+KERN(k_pk_max_u16, BODY, "v_pk_max_u16")
+KERN(k_pk_lshr16, BODY, "v_pk_lshrrev_b16")
+KERN(k_pk_ashr16, BODY, "v_pk_ashrrev_i16")
+KERN(k_pk_mul16, BODY, "v_pk_mul_lo_u16")
+KERN(k_mul_u24, BODY, "v_mul_u32_u24")
+KERN(k_bfi, BODY3, "v_bfi_b32")
+KERN(k_and_or, BODY3, "v_and_or_b32")
+KERN(k_or3, BODY3, "v_or3_b32")
+KERN(k_perm, BODY3, "v_perm_b32")
+KERN(k_alignbit, BODY3, "v_alignbit_b32")
+KERN(k_lshl_add, BODY3, "v_lshl_add_u32")
+KERN(k_mad_u24, BODY3, "v_mad_u32_u24")
+KERN(k_xad, BODY3, "v_xad_u32")
+KERN(k_min3_u32, BODY3, "v_min3_u32")
+KERN(k_med3_i32, BODY3, "v_med3_i32")
 // dependent chain (1 accumulator) to see the latency one wave pays
 __global__ void k_dep_pk(int *out, int k) { int a = threadIdx.x; for (int it = 0; it < ITER * REP; it++) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a) : "v"(k)); out[blockIdx.x * blockDim.x + threadIdx.x] = a; }
 __global__ void k_dep_u32(int *out, int k) { int a = threadIdx.x; for (int it = 0; it < ITER * REP; it++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(k)); out[blockIdx.x * blockDim.x + threadIdx.x] = a; }
@@ -51,6 +74,14 @@ int main() {
         run("v_pk_min_u16", k_pk_min_u16, d, w); run("v_pk_sub_i16", k_pk_sub_i16, d, w); run("v_pk_mad_i16", k_pk_mad_i16, d, w);
         run("v_max3_i32", k_max3_i32, d, w); run("v_add3_u32", k_add3_u32, d, w); run("v_lshl_or_b32", k_lshl_or, d, w);
         run("dep pk_add", k_dep_pk, d, w); run("dep add_u32", k_dep_u32, d, w);
+        if (w == 8) {
+            run("v_sub_u32", k_sub_u32, d, w); run("v_and_b32", k_and_b32, d, w); run("v_or_b32", k_or_b32, d, w); run("v_xor_b32", k_xor_b32, d, w);
+            run("v_lshrrev_b32", k_lshrrev, d, w); run("v_lshlrev_b32", k_lshlrev, d, w); run("v_min_u32", k_min_u32, d, w); run("v_max_u32", k_max_u32, d, w);
+            run("v_pk_max_u16", k_pk_max_u16, d, w); run("v_pk_lshrrev_b16", k_pk_lshr16, d, w); run("v_pk_ashrrev_i16", k_pk_ashr16, d, w);
+            run("v_pk_mul_lo_u16", k_pk_mul16, d, w); run("v_mul_u32_u24", k_mul_u24, d, w); run("v_bfi_b32", k_bfi, d, w); run("v_and_or_b32", k_and_or, d, w);
+            run("v_or3_b32", k_or3, d, w); run("v_perm_b32", k_perm, d, w); run("v_alignbit_b32", k_alignbit, d, w); run("v_lshl_add_u32", k_lshl_add, d, w);
+            run("v_mad_u32_u24", k_mad_u24, d, w); run("v_xad_u32", k_xad, d, w); run("v_min3_u32", k_min3_u32, d, w); run("v_med3_i32", k_med3_i32, d, w);
+        }
     }
     return 0;
 }

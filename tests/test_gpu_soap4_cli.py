@@ -150,3 +150,20 @@ def test_cli_bam_files_equal_reference(golden_dir, tmp_path, tag):
     assert [l for l in text.splitlines() if not l.startswith("@PG")] == sq
     assert [("@SQ\tSN:%s\tLN:%d" % r) for r in refs] == [l for l in sq if l.startswith("@SQ")]
     assert open(out, "rb").read() == open(os.path.join(d, "expected_%s.fq" % tag), "rb").read()
+
+
+@pytest.mark.parametrize("tag,L,mode,extra,reads", [("a", 151, "-F", ["-nc", "-lsam"], "a"), ("a.noseq", 151, "-F", ["-nc", "-lsam-noseq"], "a"),
+                                                    ("d", 151, "-P", ["-lsam"], "d"), ("e", 151, "-F", ["-top", "95", "-lsam"], "e"),
+                                                    ("g", 151, "-F", ["-lsam"], "g"), ("h", 151, "-F", ["-lsam"], "h")])
+def test_cli_direct_lsam_equals_reference_pipe(golden_dir, tmp_path, tag, L, mode, extra, reads):
+    """-lsam (extension): stdout is what `soap4 ... | cc/fastq2lsam 1` gives in the reference pipeline (runMegaPath.sh:136,
+    162,208) -- byte-identical to the real tool run on the real soap4's output, chained-chunk comments and IGNORE included."""
+    d = os.path.join(golden_dir, "g1")
+    out = tmp_path / "out.lsam"
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", os.path.join(d, "ref.fa.index"), os.path.join(d, "reads_%s_1.fq" % reads),
+           os.path.join(d, "reads_%s_2.fq" % reads), "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L),
+           "-T", "3", "-u", "750", mode] + extra
+    with open(out, "wb") as fo:
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert open(out, "rb").read() == open(os.path.join(d, "expected_%s.lsam" % tag), "rb").read()

@@ -102,3 +102,13 @@ def test_two_rank_sharding_and_count_allreduce_over_gloo(tmp_path):
                         "--master-port", "29577", str(w), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_lsam_restatement_matches_reference_tool(golden_dir):
+    """tests/lsam.py (the checker for the driver's -lsam mode) against the real cc/fastq2lsam's output on the goldens."""
+    import os
+    import lsam
+    g = os.path.join(golden_dir, "g1")
+    for tag, seq in (("a", True), ("d", True), ("e", True), ("g", True), ("h", True), ("a.noseq", False)):
+        src = open(os.path.join(g, "expected_%s.fq" % tag.split(".")[0]), "rb").read()
+        assert lsam.fastq_to_lsam(src, seq) == open(os.path.join(g, "expected_%s.lsam" % tag), "rb").read(), tag

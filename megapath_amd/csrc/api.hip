@@ -540,43 +540,48 @@ extern "C" int mp_get_seeds(mp_ctx *c, mp_seedpos *out_seeds, uint64_t cap, uint
 // ------------------------------------------------------------------------------------------------ DP
 namespace {
 
-struct DpShape { int c, nw; };
+struct DpShape { int lpi, c, nw; };
 
 inline int pick_shape(uint32_t max_len, DpShape &s)
 {
-    // 32 lanes per instance pair; C columns per lane; 5 bits per cell, 3 cells per 16-bit half of a flag word
-    static const int cs[] = {3, 5, 6, 8, 10, 12};
-    for (int c : cs) if ((uint32_t)(32 * c) >= max_len) { s.c = c; s.nw = (c + 2) / 3; return MP_OK; }
+    // LPI lanes per instance pair, C read columns per lane; 5 bits per cell, 3 cells per 16-bit half of a flag word.
+    // Few lanes with many columns each amortise the per-row work (lane hand-over, window base, row bookkeeping) and
+    // shorten the pipeline fill of the anti-diagonal sweep; 32 lanes only where 16 would need too many registers.
+    static const int shapes[][2] = {{16, 5}, {16, 10}, {16, 12}, {32, 8}, {32, 10}, {32, 12}};
+    static const bool wide = getenv("MP_DP_WIDE") != nullptr;       // measurement aid: the 32-lane shape for <= 160 bases
+    if (wide && max_len <= 160) { s.lpi = 32; s.c = 5; s.nw = 2; return MP_OK; }
+    for (auto &sh : shapes) if ((uint32_t)(sh[0] * sh[1]) >= max_len) { s.lpi = sh[0]; s.c = sh[1]; s.nw = (sh[1] + 2) / 3; return MP_OK; }
     return MP_ERANGE;   // reads longer than 384 bases (the reference's DP limit is ~312)
 }
 
-template <int C>
+template <int LPI, int C>
 void launch_fill(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, uint32_t *flags, uint32_t flag_rows,
                  mp_fill_result *fill, bool count)
 {
-    const unsigned pairs = (n + 1) / 2, groups = MP_DP_BLOCK / MP_DP_LPI;
+    const unsigned pairs = (n + 1) / 2, groups = MP_DP_BLOCK / LPI;
     if (count)
-        hipLaunchKernelGGL((dp_fill_kernel<C, true>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+        hipLaunchKernelGGL((dp_fill_kernel<LPI, C, true>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                            tasks, n, cl, cr, flags, flag_rows, fill);
     else
-        hipLaunchKernelGGL((dp_fill_kernel<C, false>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+        hipLaunchKernelGGL((dp_fill_kernel<LPI, C, false>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                            tasks, n, cl, cr, flags, flag_rows, fill);
 }
-template <int C>
+template <int LPI, int C>
 void launch_trace(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, const uint32_t *flags, uint32_t flag_rows,
                   const mp_fill_result *fill, mp_dp_result *res, uint8_t *ops, uint32_t ops_stride)
 {
-    hipLaunchKernelGGL((dp_trace_kernel<C>), dim3(grid_for(n, 64)), dim3(64), 0, s, tasks, c->d_lens, n, cl, cr, flags, flag_rows, fill, res, ops, ops_stride);
+    hipLaunchKernelGGL((dp_trace_kernel<LPI, C>), dim3(grid_for(n, 64)), dim3(64), 0, s, tasks, c->d_lens, n, cl, cr, flags, flag_rows, fill, res, ops, ops_stride);
 }
 
-#define MP_DP_DISPATCH(FN, ...)                      \
-    switch (shape.c) {                               \
-        case 3: FN<3>(__VA_ARGS__); break;           \
-        case 5: FN<5>(__VA_ARGS__); break;           \
-        case 6: FN<6>(__VA_ARGS__); break;           \
-        case 8: FN<8>(__VA_ARGS__); break;           \
-        case 10: FN<10>(__VA_ARGS__); break;         \
-        default: FN<12>(__VA_ARGS__); break;         \
+#define MP_DP_DISPATCH(FN, ...)                                   \
+    switch (shape.lpi * 100 + shape.c) {                          \
+        case 1605: FN<16, 5>(__VA_ARGS__); break;                 \
+        case 3205: FN<32, 5>(__VA_ARGS__); break;                 \
+        case 1610: FN<16, 10>(__VA_ARGS__); break;                \
+        case 1612: FN<16, 12>(__VA_ARGS__); break;                \
+        case 3208: FN<32, 8>(__VA_ARGS__); break;                 \
+        case 3210: FN<32, 10>(__VA_ARGS__); break;                \
+        default: FN<32, 12>(__VA_ARGS__); break;                  \
     }
 
 // Runs fill + traceback for device-resident tasks, chunked so that the flag slab stays bounded.
@@ -588,8 +593,8 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
     if (pick_shape(c->max_len, shape)) return MP_ERANGE;
     if (max_win > MP_DP_MAX_WIN) return MP_ERANGE;
     hipStream_t s = c->stream;
-    const uint32_t flag_rows = (max_win + MP_DP_LPI + MP_DP_FLUSH - 1) / MP_DP_FLUSH * MP_DP_FLUSH;   // whole 8-step runs
-    const size_t per_pair = (size_t)flag_rows * MP_DP_LPI * shape.nw * 4;
+    const uint32_t flag_rows = (max_win + (uint32_t)shape.lpi + MP_DP_FLUSH - 1) / MP_DP_FLUSH * MP_DP_FLUSH;   // whole 8-step runs
+    const size_t per_pair = (size_t)flag_rows * (size_t)shape.lpi * shape.nw * 4;
     uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 2 * std::max<uint64_t>(512, (3ull << 30) / per_pair));   // <= 3 GiB of flags, even
     chunk &= ~1u;
     if (chunk < 2) chunk = 2;

@@ -50,7 +50,7 @@ typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 #define TBP_NE 4u
 #define TBP_NEO 8u
 #define TBP_NFO 16u
-#define MP_DP_LPI 32
+#define MP_DP_LPI_MAX 32       // lanes per instance pair: 16 (reads <= 192 bases) or 32
 #define MP_DP_NEG16 ((short)-16000)
 
 // One instruction each, opaque to the optimiser (it would otherwise turn min_u16(x,1) into an unpacked compare+select)
@@ -153,14 +153,13 @@ __device__ __forceinline__ v2s as_v2s(int v) { return __builtin_bit_cast(v2s, v)
 #define MP_DP_NW(C) (((C) + 2) / 3)
 #define MP_DP_FLUSH 8          // steps of flag words staged per lane before one contiguous global write
 
-template <int C, bool COUNT>
+template <int LPI, int C, bool COUNT>
 __global__ void __launch_bounds__(MP_DP_BLOCK)
 dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t W,
                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, int clip_left, int clip_right,
                uint32_t *__restrict__ flags, uint32_t flag_rows /* rows of 32 x NW words reserved per instance PAIR */,
                mp_fill_result *__restrict__ out)
 {
-    constexpr int LPI = MP_DP_LPI;
     constexpr int GROUPS = MP_DP_BLOCK / LPI;          // lane groups per block, two instances each
     constexpr int NW = MP_DP_NW(C);
     __shared__ uint32_t s_win[GROUPS][2][MP_DP_MAX_WIN / 16 + 1];
@@ -334,13 +333,12 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 }
 
 // ------------------------------------------------------------------------------------------------ traceback
-template <int C>
+template <int LPI, int C>
 __global__ void __launch_bounds__(64)
 dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, uint32_t n_tasks, int clip_left, int clip_right,
                 const uint32_t *__restrict__ flags, uint32_t flag_rows, const mp_fill_result *__restrict__ fill,
                 mp_dp_result *__restrict__ out, uint8_t *__restrict__ ops, uint32_t ops_stride)
 {
-    constexpr int LPI = MP_DP_LPI;
     constexpr int NW = MP_DP_NW(C);
     const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
     if (inst >= n_tasks) return;

@@ -1,0 +1,62 @@
+"""Turns the raw rocprofv3 output of scripts/collect_profiles.sh into the small files kept under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out_dir, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(out_dir, "summary")
+os.makedirs(dst, exist_ok=True)
+OURS = ("seed_kernel", "seed_overflow_kernel", "expand_hits_kernel", "locate_kernel", "merge_kernel", "pair_kernel", "dp_fill_kernel", "dp_trace_kernel",
+        "dp_ops_fix_kernel", "build_left_tasks", "build_right_tasks", "collect_pair_hits", "gather64_kernel", "prep_scan_kernel", "mark_done", "failed_flag",
+        "list_failed", "single_cand", "single_task", "mate_rescue_task", "occ_count_kernel", "occ_build_kernel", "text_build_kernel", "lkt_hist_kernel")
+
+stats = glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = list(csv.reader(open(stats[0])))
+    keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in OURS)]
+    with open(os.path.join(dst, "%s_kernel_stats_bench_1g.csv" % tag), "w", newline="") as f:
+        csv.writer(f).writerows(keep)
+line = [l for l in open(os.path.join(out_dir, "bench_under_rocprof.json")) if l.startswith("{")]
+if line:
+    open(os.path.join(dst, "%s_bench_under_rocprof.json" % tag), "w").write(line[-1])
+
+
+def counters(sub, name):
+    per = {}
+    for path in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r.get("Counter_Name") != name:
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            per.setdefault(k, []).append(float(r["Counter_Value"]))
+    return per
+
+
+fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
+bench = json.loads([l for l in open(os.path.join(out_dir, "bench_fetch.json")) if l.startswith("{")][-1])
+per_launch = {}
+for k in sorted(set(fetch) | set(write)):
+    per_launch[k] = {}
+    if k in fetch:
+        per_launch[k]["FETCH_SIZE_KiB_per_launch"] = sum(fetch[k]) / len(fetch[k])
+        per_launch[k]["launches"] = len(fetch[k])
+    if k in write:
+        per_launch[k]["WRITE_SIZE_KiB_per_launch"] = sum(write[k]) / len(write[k])
+seed_stage = ("seed_kernel", "seed_overflow_kernel", "expand_hits_kernel", "locate_kernel")
+# one bench step launches each seed-stage kernel once: sum of all their counter values over the 1-step run
+traffic = 1024.0 * sum(sum(fetch.get(k, [])) + sum(write.get(k, [])) for k in seed_stage)
+g = per_launch.get("gather64_kernel", {})
+doc = {
+    "source": "scripts/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-include-regex '<this repo kernels>' -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+    "workload": {"genome_mbp": bench["config"]["genome_mbp"], "pairs_per_step": bench["config"]["pairs_per_step_per_gpu"], "read_len": 150},
+    "units": "FETCH_SIZE / WRITE_SIZE are in KiB (x1024 = bytes); gather64_kernel requests exactly %d B per launch (calibration of the unit for random 64-B sector gathers)" % (1 << 33),
+    "per_kernel": per_launch,
+    "gather64_calibration_ratio": (g.get("FETCH_SIZE_KiB_per_launch", 0) * 1024.0 / float(1 << 33)) if g else None,
+    "seed_stage_hbm_bytes_per_launch": traffic,
+    "seed_stage_algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+}
+json.dump(doc, open(os.path.join(dst, "%s_pmc_seed_stage.json" % tag), "w"), indent=1)
+print(json.dumps({k: doc[k] for k in ("gather64_calibration_ratio", "seed_stage_hbm_bytes_per_launch", "seed_stage_algorithmic_bytes_per_launch")}))

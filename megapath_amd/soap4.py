@@ -4,8 +4,9 @@
                                  [-T threads] [-u maxInsert] [-v minInsert] -F|-P [-nc] [-top N] [-b]
 
 Flags follow parseInputArgs (reference soap4/IniParam.cpp:542-942); ini keys follow ParseIniFile (:242-438).
-stdout carries the interleaved annotated FASTQ (MegaPath mode); stderr a free-form log.  `-b` (BAM files) is not
-written by this build (SURVEY 8a row a15 is "next"); the flag is accepted and reported.
+stdout carries the interleaved annotated FASTQ (MegaPath mode); stderr a free-form log.  This Python mirror exists for
+tests and scripting; `-b` (BAM side files) and `-lsam` are implemented by the C++ executable bin/soap4-mi355x only --
+here `-b` is accepted and reported.
 """
 from __future__ import annotations
 
@@ -123,7 +124,7 @@ def main(argv=None) -> int:
         ini = os.path.join(os.path.dirname(os.path.abspath(sys.argv[0])), "soap4.ini")
     parse_ini(ini, p)
     if want_bam:
-        sys.stderr.write("[soap4-mi355x] -b: BAM output is not written by this build (annotated FASTQ only)\n")
+        sys.stderr.write("[soap4-mi355x] -b: the Python mirror writes no BAM files; use bin/soap4-mi355x (the default of bin/soap4)\n")
     t0 = time.time()
     index = H.Index(prefix, device)
     t1 = time.time()

@@ -350,7 +350,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
 
 // Items with more than MP_SEED_SLAB seeds (repeat-rich or heavily mutated reads): redone with a slab that can hold the
 // theoretical maximum of one seed per scan position.  Their rank queries were already counted by seed_kernel.
-#define MP_SEED_BIG 320
+#define MP_SEED_BIG 384
 __global__ void __launch_bounds__(64)
 seed_overflow_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t W, mp_dev_mmp P,
                      const uint32_t *__restrict__ overflow_rs, uint32_t n_over, mp_seed_rec *__restrict__ big_slabs)

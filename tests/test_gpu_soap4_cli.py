@@ -167,3 +167,82 @@ def test_cli_direct_lsam_equals_reference_pipe(golden_dir, tmp_path, tag, L, mod
         r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
     assert open(out, "rb").read() == open(os.path.join(d, "expected_%s.lsam" % tag), "rb").read()
+
+
+def _oracle_stdout(prefix, f1, f2, L, tmp_path, mode=1, nc=True):
+    lib = O.oracle()
+    ix = lib.mpo_index_open(prefix.encode())
+    p = O.default_params(L=L, mode=mode, nc=nc)
+    st = O.AlignStats()
+    out = str(tmp_path / "oracle_edge.fq")
+    assert lib.mpo_align_fastq(ix, C.byref(p), f1.encode(), f2.encode(), out.encode(), None, C.byref(st)) == 0
+    lib.mpo_index_close(ix)
+    return out
+
+
+def test_cli_edge_cases_empty_single_ragged_and_mismatched_inputs(golden_dir, tmp_path):
+    """Empty read files, a single pair, a batch boundary in the middle of the input, FASTA input, and files with
+    different numbers of records (the reference exits with 'number of sequences of pair-end files not matched')."""
+    d = os.path.join(golden_dir, "g1")
+    prefix = os.path.join(d, "ref.fa.index")
+    ini = os.path.join(ROOT, "tests", "soap4-nt2.ini")
+    base = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix]
+    tail = ["-o", str(tmp_path / "o"), "-C", ini, "-L", "151", "-T", "2", "-u", "750", "-F", "-nc"]
+    e1, e2 = tmp_path / "e_1.fq", tmp_path / "e_2.fq"
+    e1.write_bytes(b""); e2.write_bytes(b"")
+    r = subprocess.run(base + [str(e1), str(e2)] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == b"", r.stderr.decode()
+    src1 = open(os.path.join(d, "reads_a_1.fq"), "rb").read().split(b"\n")
+    src2 = open(os.path.join(d, "reads_a_2.fq"), "rb").read().split(b"\n")
+    for n_pairs, batch in ((1, None), (7, 3)):
+        f1, f2 = tmp_path / ("s%d_1.fq" % n_pairs), tmp_path / ("s%d_2.fq" % n_pairs)
+        f1.write_bytes(b"\n".join(src1[:4 * n_pairs]) + b"\n"); f2.write_bytes(b"\n".join(src2[:4 * n_pairs]) + b"\n")
+        env = dict(os.environ)
+        if batch:
+            env["MP_BATCH_PAIRS"] = str(batch)
+        r = subprocess.run(base + [str(f1), str(f2)] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+        got = tmp_path / "got_edge.fq"
+        got.write_bytes(r.stdout)
+        assert fastq_records(str(got)) == fastq_records(_oracle_stdout(prefix, str(f1), str(f2), 151, tmp_path))
+    # FASTA input (kseq reads both): no quality line in, empty quality line out
+    fa1, fa2 = tmp_path / "fa_1.fa", tmp_path / "fa_2.fa"
+    fa1.write_bytes(b"".join(b">" + src1[i][1:] + b"\n" + src1[i + 1] + b"\n" for i in range(0, 40, 4)))
+    fa2.write_bytes(b"".join(b">" + src2[i][1:] + b"\n" + src2[i + 1] + b"\n" for i in range(0, 40, 4)))
+    r = subprocess.run(base + [str(fa1), str(fa2)] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = r.stdout.split(b"\n")
+    assert len(lines) == 10 * 2 * 4 + 1 and all(lines[i + 3] == b"" for i in range(0, 80, 4))
+    # ragged: one file has a record more
+    g1 = tmp_path / "g_1.fq"
+    g1.write_bytes(b"\n".join(src1[:4 * 5]) + b"\n")
+    g2 = tmp_path / "g_2.fq"
+    g2.write_bytes(b"\n".join(src2[:4 * 4]) + b"\n")
+    r = subprocess.run(base + [str(g1), str(g2)] + tail, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"number of sequences of pair-end files not matched" in r.stderr
+
+
+def test_cli_longest_supported_reads(tmp_path):
+    """Reads of 330-384 bases (the 32-lane x 12-column DP shape, 444-row windows, 751-row rescue windows) against the
+    oracle; one base more than the kernels cover is refused with a message instead of computed wrongly."""
+    from megapath_amd import index_builder, synth
+    genome = synth.random_genome(300000, 91, n_seqs=2, repeat_frac=0.05)
+    prefix = str(tmp_path / "long.index")
+    index_builder.write_index_files(prefix, index_builder.build_index_arrays(genome, sa_interval=16))
+    names, r1, r2 = synth.simulate_pairs(genome, 300, 384, 92, sub=0.02, ins=0.002, dele=0.002, random_frac=0.05, broken_mate_frac=0.1,
+                                         noisy_mate_frac=0.2, noisy_sub=0.15, len_range=(330, 384), frag_mean=600, frag_sd=40, frag_min=400, frag_max=740)
+    f1, f2 = str(tmp_path / "l_1.fq"), str(tmp_path / "l_2.fq")
+    synth.write_fastq_pair(f1, f2, names, r1, r2)
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix, f1, f2, "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
+           "-T", "2", "-u", "750", "-F", "-nc"]
+    r = subprocess.run(cmd + ["-L", "385"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    got = tmp_path / "got_long.fq"
+    got.write_bytes(r.stdout)
+    assert fastq_records(str(got)) == fastq_records(_oracle_stdout(prefix, f1, f2, 385, tmp_path))
+    # 385-base reads: refused
+    f3, f4 = str(tmp_path / "x_1.fq"), str(tmp_path / "x_2.fq")
+    open(f3, "wb").write(b"@x/1\n" + b"ACGT" * 97 + b"\n+\n" + b"I" * 388 + b"\n")
+    open(f4, "wb").write(b"@x/2\n" + b"TGCA" * 97 + b"\n+\n" + b"I" * 388 + b"\n")
+    r = subprocess.run(cmd[:3] + [f3, f4] + cmd[5:] + ["-L", "389"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"mp_" in r.stderr

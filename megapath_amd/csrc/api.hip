@@ -48,6 +48,7 @@ struct mp_ctx {
     DevBuf<uint32_t> reads, lens, scan;
     const uint32_t *d_reads = nullptr, *d_lens = nullptr;   // either our buffers or caller-owned device memory
     uint32_t n_reads = 0, W = 0, max_len = 0;
+    size_t slab_budget = 0;          // bytes of traceback flags per DP launch (decided at the first DP call)
     bool seeded = false;
     // seeding
     DevBuf<mp_seed_rec> slabs, big_slabs;
@@ -566,6 +567,19 @@ void launch_fill(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32
         hipLaunchKernelGGL((dp_fill_kernel<LPI, C, false>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                            tasks, n, cl, cr, flags, flag_rows, fill);
 }
+// instances one "round" of resident blocks of the fill kernel covers on this device: launches sized in whole rounds
+// leave no partly filled last round (blocks of one launch take the same time, so they finish round by round)
+template <int LPI, int C>
+void fill_round(const mp_ctx *c, bool count, uint32_t *out)
+{
+    int per_cu = 0, n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_fill_kernel<LPI, C, true>, MP_DP_BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_fill_kernel<LPI, C, false>, MP_DP_BLOCK, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 1;
+    *out = (uint32_t)n_cu * (uint32_t)per_cu * (uint32_t)(MP_DP_BLOCK / LPI) * 2u;
+}
+
 template <int LPI, int C>
 void launch_trace(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, const uint32_t *flags, uint32_t flag_rows,
                   const mp_fill_result *fill, mp_dp_result *res, uint8_t *ops, uint32_t ops_stride)
@@ -595,9 +609,19 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
     hipStream_t s = c->stream;
     const uint32_t flag_rows = (max_win + (uint32_t)shape.lpi + MP_DP_FLUSH - 1) / MP_DP_FLUSH * MP_DP_FLUSH;   // whole 8-step runs
     const size_t per_pair = (size_t)flag_rows * (size_t)shape.lpi * shape.nw * 4;
-    uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 2 * std::max<uint64_t>(512, (3ull << 30) / per_pair));   // <= 3 GiB of flags, even
+    // traceback slab: a quarter of the free HBM, between 2 and 24 GiB (with a 260 GB index replica little is left; with a
+    // human-sized index the launches become long enough that their tails do not matter)
+    if (c->slab_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 8ull << 30;
+        c->slab_budget = std::min<size_t>(24ull << 30, std::max<size_t>(2ull << 30, (free_b + c->flags.cap) / 4));
+    }
+    uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 2 * std::max<uint64_t>(512, c->slab_budget / per_pair));   // even
     chunk &= ~1u;
     if (chunk < 2) chunk = 2;
+    uint32_t round = 0;
+    MP_DP_DISPATCH(fill_round, c, count, &round);
+    if (round >= 2 && chunk > round && chunk < n) chunk = chunk / round * round;      // whole rounds of resident blocks per launch
     if (c->flags.reserve(((size_t)chunk / 2 + 1) * per_pair) || c->fill.reserve(chunk + 2)) return MP_ENOMEM;
     float tf = 0, tt = 0;
     const size_t n_chunks = (n + chunk - 1) / chunk;

@@ -66,78 +66,102 @@ __device__ __forceinline__ v2s pk_xor(v2s a, v2s b) { return a ^ b; }
 // lane k receives lane k-1's value (wavefront shift right by one; the first lane of each 32-lane group is overridden by the caller)
 __device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
 
-// constants the cell update needs in registers (VOP3P operands)
-struct dp_consts { v2s open, ext, one, zero, neg3, k2, k4, k8, k16; };
+// Number representation inside dp_fill_kernel.  A cell value x of read column j is held as the unsigned 16-bit number
+//   x + MP_DP_BIAS - j
+// in its half of a VGPR.  (1) Unsigned and never near 0 or 2^16 (|x| < ~1500, j <= 384), so one 32-bit v_sub_u32 on the
+// whole register subtracts small constants from both halves without a borrow crossing them: the five adds of the
+// recurrences run at full rate instead of half rate.  (2) The column term cancels the +1 of a match along the diagonal:
+// diag - {0 match, 3 mismatch} is the diagonal candidate, with the penalty read straight off min_u16(base XOR read, 3)
+// because the base codes are 0, 3, 5, 6 (every pair of different codes XORs to >= 3; the pad codes 9, 10, 12, 15 too).
+// Within a column all values share the frame, so the equality tests behind the traceback bits are unaffected; across
+// columns (best-cell tracking) the column term is added back inside the one multiply-add that builds the row code.
+#define MP_DP_BIAS 2048
+#define MP_DP_SENT 8            // "minus infinity" for E of row 0 and F of column 0: consumed once, against real values
+
+// constants the cell update needs in registers (VOP3P / VOP2 operands), both halves equal
+struct dp_consts { v2s k1, k2, k3, k4, k16; };
+// weights of the five traceback bits inside a flag word, for the three cells sharing a 16-bit half
+struct dp_weights { v2s z, d, e, eo, fo; };
 
 // One DP cell of two instances in ONE asm statement (hipcc pads every separate asm with s_nop).
 //   in : Hup/Eup (row above), Hl/Fl (cell to the left), diag, base (window bases), rb (read bases), floorv, elig
-//   out: e, f, h for this cell; fw (flag accumulator); COUNT=false: rowcode = max over the row of (eligible H << 4 | 15-cc)
-//        so that the first maximum of the row wins; COUNT=true: exact per-cell first-maximum tracking with tie counts.
-// Decision bits are arithmetic: x != 0  <=>  min_u16(x, 1) (x taken as unsigned); differences are formed with v_xor_b32
-// (full rate on gfx950; v_pk_* and v_max run at half rate -- scripts/valu_rate.hip) and stored negated (see TBP_*).
+//   out: e, f, h for this cell; fw (flag accumulator); COUNT=false: rowcode = max over the row of
+//        ((eligible H + bias) << 4 | 15-cc) so that the first maximum of the row wins; COUNT=true: exact per-cell
+//        first-maximum tracking with tie counts (jadd returns the value to the column-free frame first).
+// Decision bits are arithmetic: x != 0  <=>  min_u16(x, 1); differences are formed with v_xor_b32 (full rate on gfx950;
+// v_pk_* and every min/max run at half rate -- scripts/valu_rate.hip) and stored negated (see TBP_*).
+// The update is done in place: Hup / Eup enter as the cell above and leave as this cell's H / E, Fl enters as the left
+// cell's F and leaves as this one's, dnext receives the old Hup (the next column's diagonal).
+#define MP_DP_CELL_CORE \
+        "v_sub_u32 %[eo], %[Hup], %[k3]\n\t"                      /* open a deletion: H - 3   (same column) */ \
+        "v_mov_b32 %[dn], %[Hup]\n\t" \
+        "v_sub_u32 %[Eup], %[Eup], %[k1]\n\t"                     /* extend it:       E - 1 */ \
+        "v_pk_max_u16 %[Eup], %[eo], %[Eup]\n\t"                  /* E */ \
+        "v_sub_u32 %[fo], %[Hl], %[k4]\n\t"                       /* open an insertion: H - 3, one column to the right: -4 in this frame */ \
+        "v_sub_u32 %[Fl], %[Fl], %[k2]\n\t"                       /* extend it:         F - 1                         : -2 */ \
+        "v_pk_max_u16 %[Fl], %[fo], %[Fl]\n\t"                    /* F */ \
+        "v_xor_b32 %[t1], %[base], %[rb]\n\t" \
+        "v_pk_min_u16 %[t1], %[t1], %[k3]\n\t"                    /* 0 match / 3 mismatch */ \
+        "v_sub_u32 %[dg], %[diag], %[t1]\n\t"                     /* +1 / -2 along the diagonal (the +1 is the column term) */ \
+        "v_pk_max_u16 %[t1], %[dg], %[Eup]\n\t" \
+        "v_pk_max_u16 %[t1], %[t1], %[Fl]\n\t"                    /* H before the left-clip floor */ \
+        "v_pk_max_u16 %[Hup], %[t1], %[floorv]\n\t"               /* H */ \
+        "v_xor_b32 %[bits], %[Hup], %[t1]\n\t" \
+        "v_pk_min_u16 %[bits], %[bits], %[k1]\n\t" \
+        "v_pk_mad_i16 %[fw], %[bits], %[wz], %[fw]\n\t"           /* Z */ \
+        "v_xor_b32 %[t1], %[Hup], %[dg]\n\t" \
+        "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
+        "v_pk_mad_i16 %[fw], %[t1], %[wd], %[fw]\n\t"             /* nD */ \
+        "v_xor_b32 %[t1], %[Hup], %[Eup]\n\t" \
+        "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
+        "v_pk_mad_i16 %[fw], %[t1], %[we], %[fw]\n\t"             /* nE */ \
+        "v_xor_b32 %[t1], %[Eup], %[eo]\n\t" \
+        "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
+        "v_pk_mad_i16 %[fw], %[t1], %[weo], %[fw]\n\t"            /* nEO */ \
+        "v_xor_b32 %[t1], %[Fl], %[fo]\n\t" \
+        "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
+        "v_pk_mad_i16 %[fw], %[t1], %[wfo], %[fw]\n\t"            /* nFO */ \
+        "v_pk_min_u16 %[t1], %[Hup], %[elig]\n\t"                 /* eligible H (true -1 in columns that cannot end an alignment) */
+
 template <bool COUNT>
-__device__ __forceinline__ void dp_cell(const dp_consts &K, v2s Hup, v2s Eup, v2s Hl, v2s Fl, v2s diag, v2s base, v2s rb, v2s floorv, v2s elig,
-                                        v2s gate, v2s shiftk, v2s colk, v2s &e, v2s &f, v2s &h, v2s &fw, v2s &best, v2s &bpos, v2s &pos, v2s &cnt,
-                                        v2s &rowcode)
+__device__ __forceinline__ void dp_cell(const dp_consts &K, const dp_weights &Wt, v2s &Hup, v2s &Eup, v2s Hl, v2s &Fl, v2s diag, v2s base, v2s rb,
+                                        v2s floorv, v2s elig, v2s gate, v2s colk, v2s jadd, v2s &dnext, v2s &fw, v2s &best, v2s &bpos,
+                                        v2s &pos, v2s &cnt, v2s &rowcode)
 {
     v2s eo, fo, dg, t1, bits;
-    asm("v_pk_add_i16 %[eo], %[Hup], %[kopen]\n\t"
-        "v_pk_add_i16 %[e], %[Eup], %[kext]\n\t"
-        "v_pk_max_i16 %[e], %[eo], %[e]\n\t"
-        "v_pk_add_i16 %[fo], %[Hl], %[kopen]\n\t"
-        "v_pk_add_i16 %[f], %[Fl], %[kext]\n\t"
-        "v_pk_max_i16 %[f], %[fo], %[f]\n\t"
-        "v_xor_b32 %[t1], %[base], %[rb]\n\t"
-        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
-        "v_pk_mad_i16 %[t1], %[t1], %[kneg3], %[kone]\n\t"          // +1 match / -2 mismatch
-        "v_pk_add_i16 %[dg], %[diag], %[t1]\n\t"
-        "v_pk_max_i16 %[t1], %[dg], %[e]\n\t"
-        "v_pk_max_i16 %[t1], %[t1], %[f]\n\t"                       // H before the left-clip floor
-        "v_pk_max_i16 %[h], %[t1], %[floorv]\n\t"                   // H
-        "v_xor_b32 %[bits], %[h], %[t1]\n\t"
-        "v_pk_min_u16 %[bits], %[bits], %[kone]\n\t"                // Z
-        "v_xor_b32 %[t1], %[h], %[dg]\n\t"
-        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
-        "v_pk_mad_i16 %[bits], %[t1], %[k2], %[bits]\n\t"           // nD
-        "v_xor_b32 %[t1], %[h], %[e]\n\t"
-        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
-        "v_pk_mad_i16 %[bits], %[t1], %[k4], %[bits]\n\t"           // nE
-        "v_xor_b32 %[t1], %[e], %[eo]\n\t"
-        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
-        "v_pk_mad_i16 %[bits], %[t1], %[k8], %[bits]\n\t"           // nEO
-        "v_xor_b32 %[t1], %[f], %[fo]\n\t"
-        "v_pk_min_u16 %[t1], %[t1], %[kone]\n\t"
-        "v_pk_mad_i16 %[bits], %[t1], %[k16], %[bits]\n\t"          // nFO
-        "v_pk_mad_i16 %[fw], %[bits], %[shiftk], %[fw]\n\t"
-        "v_pk_min_i16 %[t1], %[h], %[elig]"                         // eligible H (<= -1 in columns that cannot end an alignment)
-        : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [bits] "=&v"(bits), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h),
-          [fw] "+&v"(fw)
-        : [Hup] "v"(Hup), [Eup] "v"(Eup), [Hl] "v"(Hl), [Fl] "v"(Fl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
-          [elig] "v"(elig), [shiftk] "v"(shiftk), [kopen] "v"(K.open), [kext] "v"(K.ext), [kone] "v"(K.one),
-          [kneg3] "v"(K.neg3), [k2] "v"(K.k2), [k4] "v"(K.k4), [k8] "v"(K.k8), [k16] "v"(K.k16));
     if (!COUNT) {
-        // (H << 4) | (15 - cc): one max per cell keeps the row's best score and, among equals, its first column
-        asm("v_pk_mad_i16 %[t1], %[t1], %[k16], %[colk]\n\t"
-            "v_pk_max_i16 %[rowcode], %[rowcode], %[t1]"
-            : [t1] "+&v"(t1), [rowcode] "+&v"(rowcode) : [k16] "v"(K.k16), [colk] "v"(colk));
+        // ((H + bias) << 4) | (15 - cc): one max per cell keeps the row's best score and, among equals, its first column;
+        // colk = 16 j + 15 - cc puts the column term back
+        asm(MP_DP_CELL_CORE
+            "v_pk_mad_i16 %[t1], %[t1], %[k16], %[colk]\n\t"
+            "v_pk_max_u16 %[rowcode], %[rowcode], %[t1]"
+            : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [bits] "=&v"(bits), [dn] "=&v"(dnext), [Hup] "+&v"(Hup), [Eup] "+&v"(Eup),
+              [Fl] "+&v"(Fl), [fw] "+&v"(fw), [rowcode] "+&v"(rowcode)
+            : [Hl] "v"(Hl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv), [elig] "v"(elig), [k1] "v"(K.k1), [k2] "v"(K.k2),
+              [k3] "v"(K.k3), [k4] "v"(K.k4), [k16] "v"(K.k16), [colk] "v"(colk),
+              [wz] "v"(Wt.z), [wd] "v"(Wt.d), [we] "v"(Wt.e), [weo] "v"(Wt.eo), [wfo] "v"(Wt.fo));
     } else {
         v2s eq, ng;
-        asm("v_pk_min_i16 %[t1], %[t1], %[gate]\n\t"                    // rows past this instance's window: <= 0
-            "v_pk_sub_i16 %[bits], %[t1], %[best]\n\t"
-            "v_pk_max_i16 %[bits], %[bits], %[kzero]\n\t"
-            "v_pk_min_u16 %[bits], %[bits], %[kone]\n\t"                // gt: strictly better than the best so far
-            "v_pk_max_i16 %[best], %[best], %[t1]\n\t"
+        asm(MP_DP_CELL_CORE
+            "v_add_u32 %[t1], %[t1], %[jadd]\n\t"                     // H + bias, comparable across columns
+            "v_pk_min_u16 %[t1], %[t1], %[gate]\n\t"                  // rows past this instance's window: <= true 0
+            "v_pk_max_u16 %[bits], %[t1], %[best]\n\t"
+            "v_sub_u32 %[bits], %[bits], %[best]\n\t"
+            "v_pk_min_u16 %[bits], %[bits], %[k1]\n\t"                // gt: strictly better than the best so far
+            "v_pk_max_u16 %[best], %[best], %[t1]\n\t"
             "v_pk_sub_i16 %[dg], %[pos], %[bpos]\n\t"
             "v_pk_mad_i16 %[bpos], %[bits], %[dg], %[bpos]\n\t"
-            "v_pk_add_i16 %[pos], %[pos], %[kone]\n\t"
-            "v_pk_sub_i16 %[eq], %[best], %[t1]\n\t"                    // cnt = gt ? 1 : cnt + (eligible H == best)
-            "v_pk_min_u16 %[eq], %[eq], %[kone]\n\t"
-            "v_pk_sub_i16 %[eq], %[kone], %[eq]\n\t"
-            "v_pk_sub_i16 %[ng], %[kone], %[bits]\n\t"
+            "v_pk_add_i16 %[pos], %[pos], %[k1]\n\t"
+            "v_sub_u32 %[eq], %[best], %[t1]\n\t"                     // cnt = gt ? 1 : cnt + (eligible H == best)
+            "v_pk_min_u16 %[eq], %[eq], %[k1]\n\t"
+            "v_pk_sub_i16 %[eq], %[k1], %[eq]\n\t"
+            "v_pk_sub_i16 %[ng], %[k1], %[bits]\n\t"
             "v_pk_mad_i16 %[cnt], %[cnt], %[ng], %[eq]"
-            : [t1] "+&v"(t1), [bits] "=&v"(bits), [dg] "=&v"(dg), [eq] "=&v"(eq), [ng] "=&v"(ng), [best] "+&v"(best), [bpos] "+&v"(bpos),
-              [pos] "+&v"(pos), [cnt] "+&v"(cnt)
-            : [gate] "v"(gate), [kzero] "v"(K.zero), [kone] "v"(K.one));
+            : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [bits] "=&v"(bits), [dn] "=&v"(dnext), [Hup] "+&v"(Hup), [Eup] "+&v"(Eup),
+              [Fl] "+&v"(Fl), [fw] "+&v"(fw), [eq] "=&v"(eq), [ng] "=&v"(ng), [best] "+&v"(best), [bpos] "+&v"(bpos), [pos] "+&v"(pos), [cnt] "+&v"(cnt)
+            : [Hl] "v"(Hl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv), [elig] "v"(elig), [k1] "v"(K.k1), [k2] "v"(K.k2),
+              [k3] "v"(K.k3), [k4] "v"(K.k4), [gate] "v"(gate), [jadd] "v"(jadd),
+              [wz] "v"(Wt.z), [wd] "v"(Wt.d), [we] "v"(Wt.e), [weo] "v"(Wt.eo), [wfo] "v"(Wt.fo));
     }
 }
 
@@ -146,6 +170,8 @@ __device__ __forceinline__ v2s pk1(short a) { v2s r; r.x = a; r.y = a; return r;
 __device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ v2u nz(v2s x) { return __builtin_elementwise_min(__builtin_bit_cast(v2u, x), (v2u){1, 1}); }   // x >= 0: (x != 0)
+__device__ __forceinline__ v2s umax(v2s a, v2s b) { return __builtin_bit_cast(v2s, __builtin_elementwise_max(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b))); }
+__device__ __forceinline__ v2s umin(v2s a, v2s b) { return __builtin_bit_cast(v2s, __builtin_elementwise_min(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b))); }
 __device__ __forceinline__ int as_int(v2s v) { return __builtin_bit_cast(int, v); }
 __device__ __forceinline__ v2s as_v2s(int v) { return __builtin_bit_cast(v2s, v); }
 
@@ -196,44 +222,53 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     }
     // per-column constants and row-0 boundary, both instances packed
     v2s rb[C], Hup[C], Eup[C], floorv[C], elig[C];
+    constexpr int B = MP_DP_BIAS;
+    // base codes 0, 3, 5, 6 (XOR of two of them is 0 or >= 3), looked up in a nibble table
+#define MP_DP_CODE(b) ((int)((0x6530u >> (4u * (uint32_t)(b))) & 15u))
 #pragma unroll
     for (int cc = 0; cc < C; cc++) {
         const int j = k * C + cc + 1;
         short b2[2], h2[2], fl2[2], el2[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            int b = 4 + q;                              // never matches a window base (0..3)
+            int b = 9 + q;                              // pad: never matches a window base or a window pad
             if (j <= L[q]) {
                 const uint32_t *rd = reads + (uint64_t)rid[q] * W;
                 int p = strand[q] == 1 ? j - 1 : L[q] - j;
                 b = (int)((rd[p >> 4] >> (2 * (p & 15))) & 3u);
                 if (strand[q] != 1) b = 3 - b;
+                b = MP_DP_CODE(b);
             }
             b2[q] = (short)b;
-            h2[q] = (short)(j <= clipL[q] ? 0 : MP_DP_OPEN + (j - clipL[q] - 1) * MP_DP_EXT);   // CPU_DP.cpp:394-432
-            fl2[q] = (short)(j <= clipL[q] ? 0 : -32768);                                      // floor inside the left clip (:505-510)
+            h2[q] = (short)((j <= clipL[q] ? 0 : MP_DP_OPEN + (j - clipL[q] - 1) * MP_DP_EXT) + B - j);   // CPU_DP.cpp:394-432
+            fl2[q] = (short)(j <= clipL[q] ? B - j : 0);                                       // floor inside the left clip (:505-510)
             int mc = L[q] - clipR[q]; if (mc < 0) mc = 0;
-            el2[q] = (short)((j >= mc && j <= L[q]) ? 32767 : -1);                             // best-cell columns (:538-591)
+            el2[q] = (short)((j >= mc && j <= L[q]) ? -1 /* 0xFFFF */ : B - 1 - j);            // best-cell columns (:538-591)
         }
-        rb[cc] = pk(b2[0], b2[1]); Hup[cc] = pk(h2[0], h2[1]); Eup[cc] = pk1(MP_DP_NEG16);
+        rb[cc] = pk(b2[0], b2[1]); Hup[cc] = pk(h2[0], h2[1]); Eup[cc] = pk1(MP_DP_SENT);
         floorv[cc] = pk(fl2[0], fl2[1]); elig[cc] = pk(el2[0], el2[1]);
     }
     v2s diag_carry;
     {
         const int j0 = k * C;
-        diag_carry = pk((short)(j0 <= clipL[0] ? 0 : MP_DP_OPEN + (j0 - clipL[0] - 1) * MP_DP_EXT),
-                        (short)(j0 <= clipL[1] ? 0 : MP_DP_OPEN + (j0 - clipL[1] - 1) * MP_DP_EXT));
+        diag_carry = pk((short)((j0 <= clipL[0] ? 0 : MP_DP_OPEN + (j0 - clipL[0] - 1) * MP_DP_EXT) + B - j0),
+                        (short)((j0 <= clipL[1] ? 0 : MP_DP_OPEN + (j0 - clipL[1] - 1) * MP_DP_EXT) + B - j0));
     }
     __syncthreads();
 
     dp_consts K;
-    K.open = pk1(MP_DP_OPEN); K.ext = pk1(MP_DP_EXT); K.one = pk1(1); K.zero = pk1(0); K.neg3 = pk1(-3);
-    K.k2 = pk1(2); K.k4 = pk1(4); K.k8 = pk1(8); K.k16 = pk1(16);
-    const v2s kShift[3] = {pk1(1), pk1(32), pk1(1024)};
+    K.k1 = pk1(1); K.k2 = pk1(2); K.k3 = pk1(3); K.k4 = pk1(4); K.k16 = pk1(16);
+    dp_weights Wt[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        Wt[q].z = pk1((short)(TBP_Z << (5 * q))); Wt[q].d = pk1((short)(TBP_ND << (5 * q))); Wt[q].e = pk1((short)(TBP_NE << (5 * q)));
+        Wt[q].eo = pk1((short)(TBP_NEO << (5 * q))); Wt[q].fo = pk1((short)(TBP_NFO << (5 * q)));
+    }
     const v2s kZero = pk1(0);
-    v2s best = kZero, bpos = kZero;
+    // best so far: COUNT: score + bias; otherwise the row code ((score + bias) << 4 | 15 - cc) -- both start at score 0
+    v2s best = COUNT ? pk1((short)B) : pk1((short)(B << 4)), bpos = kZero;
     v2s cnt = kZero;
-    v2s outH = kZero, outF = pk1(MP_DP_NEG16);
+    v2s outH = pk1((short)B), outF = pk1(MP_DP_SENT);
     int outB = 0;
     // slab of one instance pair: [lane][step][word] -- the traceback walks a lane's steps, 8 of them per 64-byte line
     uint32_t *frow = flags + (uint64_t)pair * flag_rows * (LPI * NW) + (uint64_t)k * flag_rows * NW;
@@ -249,35 +284,37 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         int inB = wave_shr1(outB);
         // the first lane of a group handles row t: its window bases come from LDS, one word per 16 steps (uniform in t)
         if (((t - 1) & 15) == 0) { wq0 = s_win[g][0][(t - 1) >> 4]; wq1 = s_win[g][1][(t - 1) >> 4]; }
-        const int r0 = t <= m[0] ? (int)(wq0 & 3u) : 6, r1 = t <= m[1] ? (int)(wq1 & 3u) : 7;
+        const int r0 = t <= m[0] ? MP_DP_CODE(wq0 & 3u) : 12, r1 = t <= m[1] ? MP_DP_CODE(wq1 & 3u) : 15;   // pads match nothing
         wq0 >>= 2; wq1 >>= 2;
-        if (k == 0) { inHi = 0; inFi = as_int(pk1(MP_DP_NEG16)); inB = r0 | (r1 << 16); }   // column 0: H = 0, no insertion state
+        if (k == 0) { inHi = as_int(pk1((short)B)); inFi = as_int(pk1(MP_DP_SENT)); inB = r0 | (r1 << 16); }   // column 0: H = 0, no insertion state
         const int i = t - k;                       // row handled now
         if (i >= 1 && i <= mmax) {
             const v2s base = as_v2s(inB);
-            // rows past an instance's own window must not count: cap 32767 while i <= m, 0 afterwards (best starts at 0
-            // and only a strictly greater value replaces it)
-            const v2s g2 = vmax(vmin(kZero, mrow - pk1((short)i)), pk1(-1));            // 0 or -1
-            const v2s gatecap = g2 * pk1(32767) + pk1(32767);
-            const v2s gatecode = (g2 + pk1(1)) * pk1(32735);                            // large in range, 0 past the window
+            // rows past an instance's own window must not count: no cap while i <= m, afterwards score 0 at most (best
+            // starts at score 0 and only a strictly greater value replaces it)
+            const v2s g2 = vmax(vmin(kZero, mrow - pk1((short)i)), pk1(-1));            // 0 in range, -1 past the window
+            const v2s gatecap = pk1(-1) - g2 * pk1((short)(B + 1));                     // 0xFFFF in range, bias (score 0) past it
+            const v2s gatecode = (g2 + pk1(1)) * pk1(-1);                               // 0xFFFF in range, 0 past the window
             v2s Hl = as_v2s(inHi), Fl = as_v2s(inFi), diag = diag_carry;
             v2s pos = pk1((short)(i * 16));
-            v2s rowcode = pk1(-32768);
+            v2s rowcode = kZero;
             v2s fw[NW];
 #pragma unroll
             for (int w = 0; w < NW; w++) fw[w] = kZero;
 #pragma unroll
             for (int cc = 0; cc < C; cc++) {
-                v2s e, f, h;
-                dp_cell<COUNT>(K, Hup[cc], Eup[cc], Hl, Fl, diag, base, rb[cc], floorv[cc], elig[cc], gatecap, kShift[cc % 3], pk1((short)(15 - cc)),
-                               e, f, h, fw[cc / 3], best, bpos, pos, cnt, rowcode);
-                diag = Hup[cc];
-                Hup[cc] = h; Eup[cc] = e; Hl = h; Fl = f;
+                v2s dnext;
+                const int j = k * C + cc + 1;
+                dp_cell<COUNT>(K, Wt[cc % 3], Hup[cc], Eup[cc], Hl, Fl, diag, base, rb[cc], floorv[cc], elig[cc], gatecap,
+                               pk1((short)(16 * j + 15 - cc)), pk1((short)j), dnext, fw[cc / 3], best, bpos, pos, cnt, rowcode);
+                diag = dnext;
+                Hl = Hup[cc];
             }
             if (!COUNT) {
                 // once per row: does this row beat the best so far?  (strictly: code > best code with its column bits saturated)
-                const v2s rc = vmin(rowcode, gatecode);                        // rows past the instance's window never win
-                const v2s gt = __builtin_bit_cast(v2s, nz(vmax(rc - (best | pk1(15)), kZero)));
+                const v2s rc = umin(rowcode, gatecode);                        // rows past the instance's window never win
+                const v2s b15 = best | pk1(15);
+                const v2s gt = __builtin_bit_cast(v2s, nz(umax(rc, b15) - b15));
                 best += gt * (rc - best);
                 bpos += gt * (pk1((short)i) - bpos);
             }
@@ -305,10 +342,10 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         int b, brow, bcol;
         if (COUNT) {
             const int pos = q == 0 ? bpos.x : bpos.y;
-            b = q == 0 ? best.x : best.y; brow = pos >> 4; bcol = k * C + (pos & 15) + 1;
+            b = (int)(unsigned short)(q == 0 ? best.x : best.y) - MP_DP_BIAS; brow = pos >> 4; bcol = k * C + (pos & 15) + 1;
         } else {
-            const int code = q == 0 ? best.x : best.y;      // (score << 4) | (15 - cc)
-            b = code >> 4; brow = q == 0 ? bpos.x : bpos.y; bcol = k * C + (15 - (code & 15)) + 1;
+            const int code = (int)(unsigned short)(q == 0 ? best.x : best.y);      // ((score + bias) << 4) | (15 - cc)
+            b = (code >> 4) - MP_DP_BIAS; brow = q == 0 ? bpos.x : bpos.y; bcol = k * C + (15 - (code & 15)) + 1;
         }
         unsigned long long key = b >= cutoff[q] && b > 0 ? ((unsigned long long)(uint32_t)b << 32) | ((uint32_t)(0xFFFF - brow) << 16) | (uint32_t)(0xFFFF - bcol) : 0ull;
         unsigned long long kmax = key;

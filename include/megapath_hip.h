@@ -49,6 +49,8 @@ typedef struct {
     uint64_t cum_freq[5];
     uint32_t sa_interval, num_seq;
     uint64_t device_bytes;          /* HBM held by the index */
+    uint32_t prefilter_k;           /* 17 when the k-mer presence bitmap of the seeding kernel is resident (2 GiB), else 0 */
+    uint32_t reserved;
 } mp_index_info;
 int mp_index_get_info(const mp_index *ix, mp_index_info *out);
 const char *mp_index_seq_name(const mp_index *ix, uint32_t seq_id_1based);
@@ -69,6 +71,10 @@ int mp_index_fetch_text(const mp_index *ix, const uint64_t *pos, const uint32_t 
 int mp_index_occ(const mp_index *ix, const uint64_t *idx, const uint32_t *sym, uint64_t n, uint64_t *out);
 int mp_index_sa(const mp_index *ix, const uint64_t *idx, uint64_t n, uint64_t *out);
 int mp_index_lkt(const mp_index *ix, const uint32_t *key, uint64_t n, uint64_t *out_l, uint64_t *out_r);
+/* The seeding kernel's pre-filter (mp_index_info.prefilter_k = 17): out[i] = 1 when backward search can reach length 17
+ * with the 17-mer keys[i] (34 bits, first scanned base in the low bits as for mp_index_lkt), i.e. when the 13-mer table
+ * range of its low 26 bits survives the four further extension steps.  MP_EINVAL when the bitmap is not resident. */
+int mp_index_prefilter(const mp_index *ix, const uint64_t *keys, uint64_t n, uint8_t *out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Context and reads. */
@@ -102,9 +108,14 @@ typedef struct {              /* DeepDP_Space::SeedPos (SeedPool.h:52-57) */
 typedef struct {
     uint64_t n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos;   /* event counts for the roofline */
     float ms_seed, ms_locate, ms_merge;                        /* HIP-event kernel times of this call */
+    float reserved;
+    uint64_t n_prefilter;                                      /* 17-mer bitmap probes (0 when the pre-filter is off) */
 } mp_seed_stats;
 
 int mp_seed_batch(mp_ctx *ctx, const mp_mmp_params *params, mp_seed_stats *out_stats);
+/* Measurement aid: on = 0 makes the seeding kernel ignore the index's 17-mer pre-filter, i.e. issue every table look-up
+ * and rank query the reference algorithm issues (the event counts SURVEY 8d prices the stage with).  Same seeds either way. */
+int mp_ctx_set_prefilter(mp_ctx *ctx, int on);
 /* Copies the kept seeds of the last mp_seed_batch to the host: out_offsets has n_reads+1 entries; read r owns
  * out_seeds[out_offsets[r] .. out_offsets[r+1]), '+' strand seeds first then '-', each in ascending pos. */
 int mp_get_seeds(mp_ctx *ctx, mp_seedpos *out_seeds, uint64_t cap, uint64_t *out_offsets);

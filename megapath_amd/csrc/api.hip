@@ -49,6 +49,7 @@ struct mp_ctx {
     const uint32_t *d_reads = nullptr, *d_lens = nullptr;   // either our buffers or caller-owned device memory
     uint32_t n_reads = 0, W = 0, max_len = 0;
     size_t slab_budget = 0;          // bytes of traceback flags per DP launch (decided at the first DP call)
+    bool use_prefilter = true;       // mp_ctx_set_prefilter
     bool seeded = false;
     // seeding
     DevBuf<mp_seed_rec> slabs, big_slabs;
@@ -159,8 +160,25 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
     (void)hipFree(d_bwt); (void)hipFree(d_pac); (void)hipFree(d_cnt); (void)hipFree(d_run); (void)hipFree(d_tmp);
+    d_bwt = d_pac = d_cnt = d_run = d_tmp = nullptr;
+    {
+        // 17-mer pre-filter of the seeding kernel (kernels_index.hip): 2 GiB; worth it for genome-sized chunks when the
+        // HBM is not needed for more index replicas.  MP_KMER_FILTER=0 / 1 overrides the automatic choice.
+        const char *e = getenv("MP_KMER_FILTER");
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        bool on = n >= (1ull << 25) && free_b >= (12ull << 30);
+        if (e) on = atoi(e) != 0;
+        const size_t kb = (size_t)1 << 31;
+        if (on && n >= 17 && hipMalloc(&ix->d_kmer, kb) == hipSuccess) {
+            if (hipMemset(ix->d_kmer, 0, kb) != hipSuccess) return fail(MP_ENODEV);
+            hipLaunchKernelGGL(kmer17_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, (uint32_t *)ix->d_kmer);
+            if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
+            ix->device_bytes += kb;
+        }
+    }
     ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt;
-    ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text;
+    ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text; ix->d.kmer17 = (const uint32_t *)ix->d_kmer;
     ix->d.n = (uint32_t)h.n; ix->d.inv_sa0 = (uint32_t)h.inv_sa0; ix->d.sa_interval = h.sa_interval;
     ix->d.sa_shift = 0xFFFFFFFFu;
     for (uint32_t b = 0; b < 31; b++) if ((1u << b) == h.sa_interval) ix->d.sa_shift = b;
@@ -205,6 +223,7 @@ extern "C" int mp_index_close(mp_index *ix)
     if (ix->d_lkt) (void)hipFree(ix->d_lkt);
     if (ix->d_sa) (void)hipFree(ix->d_sa);
     if (ix->d_text) (void)hipFree(ix->d_text);
+    if (ix->d_kmer) (void)hipFree(ix->d_kmer);
     delete ix;
     return MP_OK;
 }
@@ -216,6 +235,7 @@ extern "C" int mp_index_get_info(const mp_index *ix, mp_index_info *out)
     for (int i = 0; i < 5; i++) out->cum_freq[i] = ix->cum[i];
     out->sa_interval = ix->sa_interval; out->num_seq = (uint32_t)ix->seq_names.size();
     out->device_bytes = ix->device_bytes;
+    out->prefilter_k = ix->d_kmer ? 17u : 0u; out->reserved = 0;
     return MP_OK;
 }
 
@@ -354,6 +374,20 @@ extern "C" int mp_index_lkt(const mp_index *ix, const uint32_t *key, uint64_t n,
     return MP_OK;
 }
 
+extern "C" int mp_index_prefilter(const mp_index *ix, const uint64_t *keys, uint64_t n, uint8_t *out)
+{
+    if (!ix || !keys || !out) return MP_EINVAL;
+    if (!ix->d_kmer) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    uint64_t *d_k = nullptr; uint8_t *d_o = nullptr;
+    HIPCHK(hipMalloc((void **)&d_k, n * 8 + 8)); HIPCHK(hipMalloc((void **)&d_o, n + 8));
+    HIPCHK(hipMemcpy(d_k, keys, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kmer17_query_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_kmer, d_k, n, d_o);
+    HIPCHK(hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_k); (void)hipFree(d_o);
+    return MP_OK;
+}
+
 extern "C" int mp_bench_gather64(const mp_index *ix, uint32_t lanes, uint32_t per_lane, uint32_t repeats, float *out_ms, uint64_t *out_bytes)
 {
     if (!ix || !out_ms || !out_bytes || lanes == 0 || per_lane == 0 || repeats == 0) return MP_EINVAL;
@@ -448,6 +482,8 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipSetDevice(c->ix->device));
     const uint32_t n_reads = c->n_reads, W = c->W, n_items = 2 * n_reads;
     const mp_dev_mmp P = to_dev(params);
+    mp_dev_index dix = c->ix->d;
+    if (!c->use_prefilter) dix.kmer17 = nullptr;
     hipStream_t s = c->stream;
     const uint32_t overflow_cap = n_items;
     if (c->scan.reserve((size_t)n_items * (W + 1) + 16) || c->slabs.reserve((size_t)n_items * MP_SEED_SLAB) || c->seeds_per_rs.reserve(n_items + 2) ||
@@ -462,7 +498,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
     const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * 8u);
     HIPCHK(hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(seed_kernel, dim3(blocks), dim3(256), 0, s, c->ix->d, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
+    hipLaunchKernelGGL(seed_kernel, dim3(blocks), dim3(256), 0, s, dix, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
                        c->hits_per_rs.p, c->overflow_rs.p, c->over_slot.p, overflow_cap, c->queue.p, c->ctr.p);
     HIPCHK(hipEventRecord(c->ev[1], s));
     mp_counters h{};
@@ -481,7 +517,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipEventRecord(c->ev[8], s));
     if (n_over) {
         if (c->big_slabs.reserve((size_t)n_over * MP_SEED_BIG)) return MP_ENOMEM;
-        hipLaunchKernelGGL(seed_overflow_kernel, dim3(grid_for(n_over, 64)), dim3(64), 0, s, c->ix->d, c->scan.p, c->d_lens, W, P, c->overflow_rs.p, n_over,
+        hipLaunchKernelGGL(seed_overflow_kernel, dim3(grid_for(n_over, 64)), dim3(64), 0, s, dix, c->scan.p, c->d_lens, W, P, c->overflow_rs.p, n_over,
                            c->big_slabs.p);
     }
     if (c->seeds.reserve((size_t)n_hits + 64) || c->hit_row.reserve((size_t)n_hits + 64) || c->hits.reserve((size_t)n_hits + 64) ||
@@ -501,7 +537,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipStreamSynchronize(s));
     mp_seed_stats st{};
     st.n_occ = h.n_occ; st.n_lkt = h.n_lkt; st.n_sa = h.n_sa; st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
-    st.n_seeds = h.n_seeds;
+    st.n_seeds = h.n_seeds; st.n_prefilter = h.n_kmer;
     float ms_over = 0;
     (void)hipEventElapsedTime(&st.ms_seed, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&ms_over, c->ev[8], c->ev[9]);     // items redone with the full-size slab belong to K1
@@ -510,6 +546,13 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     (void)hipEventElapsedTime(&st.ms_merge, c->ev[3], c->ev[4]);
     c->last_seed = st; c->n_hits_total = n_hits; c->seeded = true;
     if (out_stats) *out_stats = st;
+    return MP_OK;
+}
+
+extern "C" int mp_ctx_set_prefilter(mp_ctx *c, int on)
+{
+    if (!c) return MP_EINVAL;
+    c->use_prefilter = on != 0;
     return MP_OK;
 }
 

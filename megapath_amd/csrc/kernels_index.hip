@@ -85,3 +85,33 @@ __global__ void lkt_hist_kernel(const uint32_t *__restrict__ text, uint64_t n, u
     const uint32_t key = mp_rev2(lsb) >> 6;                                // base s in bits 25:24
     atomicAdd(&lkt[key], 1u);
 }
+
+// 17-mer presence bitmap (4^17 bits = 2 GiB), the seeding kernel's pre-filter.  A seed start whose first 17 scanned
+// bases form a 17-mer that the index cannot extend to is a seed shorter than seedMinLength (17 or more): it is never
+// reported and the scan restarts one base further whatever its exact length (CHECK_AND_ADD_RANGE,
+// DV-DPfunctions.cpp:2197-2219), so one bit probe replaces the LKT look-up and the ~3 rank-query pairs it would cost.
+// "Can be extended to" is what the reference's own procedure reaches: the 13-mer table is built over the text continued
+// with 12 'A's (LTConstruct.c:44-105), the four further bases are true backward-search steps; that is the set of
+// 17-base windows of (text + 12 'A') starting at 0 .. n-5.  Key: leftmost text base in the top bits, as for the LKT.
+__global__ void kmer17_build_kernel(const uint32_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ bitmap)
+{
+    const uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (n < 5 || p > n - 5) return;
+    const uint64_t q = p >> 4;
+    const uint32_t sh = 2 * (uint32_t)(p & 15);
+    const uint64_t lo = ((uint64_t)text[q + 1] << 32) | text[q];
+    uint64_t v = lo >> sh;                                         // bases p .. in LSB-first order
+    if (sh > 30) v |= (uint64_t)text[q + 2] << (64 - sh);          // cannot happen (sh <= 30 leaves 34 bits), kept for clarity
+    v &= (1ull << 34) - 1;
+    // reverse the order of the 17 two-bit groups: base p goes to bits 33:32
+    uint64_t r = __brevll(v);                                      // bit i -> 63 - i
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);   // restore the bit order inside each pair
+    const uint64_t key = r >> 30;                                  // the 34 significant bits
+    atomicOr(&bitmap[key >> 5], 1u << (uint32_t)(key & 31));
+}
+
+__global__ void kmer17_query_kernel(const uint32_t *__restrict__ bitmap, const uint64_t *__restrict__ keys, uint64_t n, uint8_t *__restrict__ out)
+{
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t < n) { const uint64_t k = keys[t] & ((1ull << 34) - 1); out[t] = (uint8_t)((bitmap[k >> 5] >> (uint32_t)(k & 31)) & 1u); }
+}

@@ -242,7 +242,7 @@ __device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp 
 // Runs one item to completion or for one trip.  Returns true when the item is finished.
 template <int SLAB>
 __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev_mmp &P, mp_mmp_state &s, mp_seed_rec *slab,
-                                            uint32_t &my_occ, uint32_t &my_lkt)
+                                            uint32_t &my_occ, uint32_t &my_lkt, uint32_t &my_kmer)
 {
     const uint32_t n = ix.n;
     bool finished = false;
@@ -253,16 +253,27 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
         } else {
             const uint32_t wq = (uint32_t)s.i >> 4, sh = 2 * ((uint32_t)s.i & 15);
             const uint64_t two = ((uint64_t)s.sc[wq + 1] << 32) | s.sc[wq];
-            const uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
-            const uint32_t nextl = key ? ix.lkt[key - 1] + 1 : 1;
-            const uint32_t nextr = ix.lkt[key];
-            my_lkt++;
-            s.i += MP_LKT_K - 1;
-            s.seed_len = MP_LKT_K - 1;
-            if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
-            else mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
-            ++s.i;
-            if (s.i >= s.len) finished = true;
+            bool futile = false;
+            if (ix.kmer17 && P.seed_min_length >= 17) {
+                // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe
+                const uint64_t k17 = (two >> sh) & ((1ull << 34) - 1);
+                futile = ((ix.kmer17[k17 >> 5] >> (uint32_t)(k17 & 31)) & 1u) == 0;
+                my_kmer++;
+            }
+            if (futile) {
+                ++s.i;                                        // a seed shorter than seed_min_length: nothing reported, restart one base on
+            } else {
+                const uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
+                const uint32_t nextl = key ? ix.lkt[key - 1] + 1 : 1;
+                const uint32_t nextr = ix.lkt[key];
+                my_lkt++;
+                s.i += MP_LKT_K - 1;
+                s.seed_len = MP_LKT_K - 1;
+                if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
+                else mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
+                ++s.i;
+                if (s.i >= s.len) finished = true;
+            }
         }
     }
     // ---- at most one backward extension
@@ -301,7 +312,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             uint32_t *__restrict__ overflow_rs, uint32_t *__restrict__ over_slot, uint32_t overflow_cap, unsigned int *queue, mp_counters *ctr)
 {
     const int lane = threadIdx.x & (MP_WAVE - 1);
-    uint32_t my_occ = 0, my_lkt = 0;
+    uint32_t my_occ = 0, my_lkt = 0, my_kmer = 0;
     mp_mmp_state s;
     bool have = false;
     // Work queue: one global counter, but a wavefront takes MP_SEED_CHUNK items per atomic into a private range and hands
@@ -330,7 +341,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
         if (!__any(have)) { if (drained && pool_next == pool_end) break; else continue; }   // nothing to do this trip
         if (have) {
             mp_seed_rec *slab = slabs + (uint64_t)s.rs * MP_SEED_SLAB;
-            if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, my_occ, my_lkt)) {
+            if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, my_occ, my_lkt, my_kmer)) {
                 seeds_per_rs[s.rs] = s.n_seeds;
                 hits_per_rs[s.rs] = s.n_hits;
                 if (s.n_seeds > MP_SEED_SLAB) {
@@ -341,10 +352,11 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             }
         }
     }
-    for (int o = MP_WAVE / 2; o > 0; o >>= 1) { my_occ += __shfl_down(my_occ, o); my_lkt += __shfl_down(my_lkt, o); }
+    for (int o = MP_WAVE / 2; o > 0; o >>= 1) { my_occ += __shfl_down(my_occ, o); my_lkt += __shfl_down(my_lkt, o); my_kmer += __shfl_down(my_kmer, o); }
     if (lane == 0) {
         if (my_occ) atomicAdd(&ctr->n_occ, (unsigned long long)my_occ);
         if (my_lkt) atomicAdd(&ctr->n_lkt, (unsigned long long)my_lkt);
+        if (my_kmer) atomicAdd(&ctr->n_kmer, (unsigned long long)my_kmer);
     }
 }
 
@@ -359,9 +371,9 @@ seed_overflow_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const u
     if (t >= n_over) return;
     mp_mmp_state s;
     mp_mmp_begin(s, scan, lens, W, overflow_rs[t], ix.n);
-    uint32_t a = 0, b = 0;
+    uint32_t a = 0, b = 0, c = 0;
     mp_seed_rec *slab = big_slabs + (uint64_t)t * MP_SEED_BIG;
-    while (!mp_mmp_trip<MP_SEED_BIG>(ix, P, s, slab, a, b)) {}
+    while (!mp_mmp_trip<MP_SEED_BIG>(ix, P, s, slab, a, b, c)) {}
 }
 
 // ------------------------------------------------------------------------------------------------ K2

@@ -25,6 +25,7 @@ struct mp_dev_index {          // passed by value to kernels
     const uint32_t *lkt;       // 4^13 inclusive right SA bounds
     const uint32_t *sa;        // SA[k*interval]; entry 0 unused (handled as -1, BWT.c:242)
     const uint32_t *text;      // 2-bit text, LSB-first, 16 bases per word
+    const uint32_t *kmer17;    // optional: one bit per 17-mer, set when backward search can reach length 17 with it (nullptr = off)
     uint32_t n;                // text length
     uint32_t inv_sa0;
     uint32_t cum[5];
@@ -37,7 +38,7 @@ struct mp_translate_row { uint64_t start; uint32_t chr; uint64_t corr; };
 struct mp_index {
     int device = 0;
     mp_dev_index d{};
-    void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr;
+    void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr, *d_kmer = nullptr;
     uint64_t device_bytes = 0;
     uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};
     uint32_t sa_interval = 0;
@@ -93,8 +94,8 @@ struct mp_dev_mmp {
     double reseed_rlt_ratio, short_seed_ratio;
 };
 
-struct mp_counters {           // device-side event counters (one cache line)
-    unsigned long long n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos, n_cand, overflow;
+struct mp_counters {           // device-side event counters
+    unsigned long long n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos, n_cand, overflow, n_kmer;
 };
 
 struct mp_hit_task { uint32_t seed_slot; uint32_t k; };                         // one SA row to locate

@@ -43,7 +43,7 @@ class SeedPos(C.Structure):
 class SeedStats(C.Structure):
     _fields_ = [("n_occ", C.c_uint64), ("n_lkt", C.c_uint64), ("n_sa", C.c_uint64), ("n_seeds", C.c_uint64),
                 ("n_hits", C.c_uint64), ("n_seedpos", C.c_uint64), ("ms_seed", C.c_float), ("ms_locate", C.c_float),
-                ("ms_merge", C.c_float)]
+                ("ms_merge", C.c_float), ("reserved", C.c_float), ("n_prefilter", C.c_uint64)]
 
 
 class DpTask(C.Structure):
@@ -91,12 +91,13 @@ class RescueStats(C.Structure):
 
 class IndexInfo(C.Structure):
     _fields_ = [("text_length", C.c_uint64), ("inverse_sa0", C.c_uint64), ("cum_freq", C.c_uint64 * 5),
-                ("sa_interval", C.c_uint32), ("num_seq", C.c_uint32), ("device_bytes", C.c_uint64)]
+                ("sa_interval", C.c_uint32), ("num_seq", C.c_uint32), ("device_bytes", C.c_uint64), ("prefilter_k", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
-           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_ctx_create", "mp_ctx_destroy",
-           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
+           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_prefilter", "mp_ctx_create", "mp_ctx_destroy",
+           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
 
 
@@ -132,6 +133,11 @@ def load_library():
     lib.mp_index_occ.argtypes = [vp, vp, vp, C.c_uint64, vp]
     lib.mp_index_sa.argtypes = [vp, vp, C.c_uint64, vp]
     lib.mp_index_lkt.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    lib.mp_index_prefilter.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.mp_index_chr_pos_segment.argtypes = [vp, C.c_uint64, u64p, u32p, u64p]
+    lib.mp_index_seq_info.argtypes = [vp, C.c_uint32, u64p, u64p, u64p]
+    lib.mp_index_fetch_text.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32]
+    lib.mp_ctx_set_prefilter.argtypes = [vp, C.c_int]
     lib.mp_ctx_create.argtypes = [vp, C.POINTER(vp)]
     lib.mp_ctx_destroy.argtypes = [vp]
     lib.mp_set_reads.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
@@ -249,6 +255,13 @@ class Index:
         _chk(load_library().mp_bench_gather64(self._h, lanes, per_lane, repeats, C.byref(ms), C.byref(nb)), "mp_bench_gather64")
         return ms.value, nb.value
 
+    def prefilter(self, keys):
+        """Bits of the seeding kernel's 17-mer pre-filter for 34-bit keys (first scanned base in the low bits)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(len(keys), dtype=np.uint8)
+        _chk(load_library().mp_index_prefilter(self._h, keys.ctypes.data, len(keys), out.ctypes.data), "mp_index_prefilter")
+        return out
+
     def lkt(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint32)
         l = np.zeros(len(keys), dtype=np.uint64)
@@ -285,6 +298,9 @@ class Context:
         st = SeedStats()
         _chk(load_library().mp_seed_batch(self._h, C.byref(params), C.byref(st)), "mp_seed_batch")
         return st
+
+    def set_prefilter(self, on: bool):
+        _chk(load_library().mp_ctx_set_prefilter(self._h, int(bool(on))), "mp_ctx_set_prefilter")
 
     def get_seeds(self):
         lib = load_library()

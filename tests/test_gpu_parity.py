@@ -71,6 +71,71 @@ def test_fm_primitives_every_index_at_text_tail_shapes(tmp_path, n_bases):
     lib.mpo_index_close(oix)
 
 
+def test_kmer_prefilter_bitmap_equals_table_plus_four_steps(g1_prefix, monkeypatch):
+    """The 17-mer pre-filter bit must say exactly what the reference procedure would find: 13-mer table range of the first
+    13 scanned bases, then four backward-search steps (DV-DPfunctions.cpp:2245-2262).  Checked for every 17-base window
+    of the text (incl. the windows that run into the table's 'A' padding at the text end) and for random 17-mers."""
+    monkeypatch.setenv("MP_KMER_FILTER", "1")
+    gix = H.Index(g1_prefix, 0)
+    assert gix.info.prefilter_k == 17
+    lib = O.oracle()
+    oix = lib.mpo_index_open(g1_prefix.encode())
+    n = gix.info.text_length
+    text = np.array([lib.mpo_text_base(oix, i) for i in range(n)] + [0] * 16, dtype=np.uint64)
+    starts = np.concatenate([np.arange(0, 3000), np.arange(n - 40, n)])            # windows start .. start+16, padded with 'A'
+    keys = np.zeros(len(starts), dtype=np.uint64)
+    for t in range(17):                                                            # leftmost text base in the top bits
+        keys |= text[starts + t] << np.uint64(2 * (16 - t))
+    rng = np.random.default_rng(5)
+    keys = np.concatenate([keys, rng.integers(0, 1 << 34, size=20000, dtype=np.uint64)])
+    got = gix.prefilter(keys)
+    # the procedure, through the device's own table / rank queries (themselves pinned against the reference)
+    cum = [int(gix.info.cum_freq[c]) for c in range(5)]
+    l, r = gix.lkt((keys & np.uint64((1 << 26) - 1)).astype(np.uint32))
+    l = l.astype(np.int64); r = r.astype(np.int64)
+    for step in range(4):
+        c = ((keys >> np.uint64(26 + 2 * step)) & np.uint64(3)).astype(np.uint32)
+        alive = l <= r
+        li = np.where(alive, l, 0).astype(np.uint64); ri = np.where(alive, r + 1, 0).astype(np.uint64)
+        cl = np.array([cum[int(x)] for x in c], dtype=np.int64)
+        nl = cl + gix.occ(li, c).astype(np.int64) + 1
+        nr = cl + gix.occ(ri, c).astype(np.int64)
+        l = np.where(alive, nl, 1); r = np.where(alive, nr, 0)
+    want = (l <= r).astype(np.uint8)
+    assert want[:3040].sum() >= 3030                      # text windows are present (those cut by the text end may not be)
+    assert np.array_equal(got, want)
+    gix.close()
+    lib.mpo_index_close(oix)
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_seeds_and_hits_identical_with_prefilter(g1_prefix, golden_dir, monkeypatch, tag):
+    """Same kept seeds and the same deep-DP hits with the 17-mer pre-filter on and off; fewer rank queries with it."""
+    monkeypatch.setenv("MP_KMER_FILTER", "1")
+    gix = H.Index(g1_prefix, 0)
+    d = os.path.join(golden_dir, "g1")
+    L = int(open(os.path.join(d, "expected_%s.L" % tag)).read())
+    seqs = read_fastq_pairs(os.path.join(d, "reads_%s_1.fq" % tag), os.path.join(d, "reads_%s_2.fq" % tag))
+    packed, lens, W = H.pack_reads(seqs, L)
+    out = {}
+    for on in (True, False):
+        ctx = H.Context(gix)
+        ctx.set_prefilter(on)
+        ctx.set_reads(packed, lens)
+        st = ctx.seed_batch(H.MmpParams.nt2())
+        arr, off = ctx.get_seeds()
+        seeds = [(arr[i].pos, arr[i].strand_read_id, arr[i].paired_seed_length) for i in range(int(off[-1]))]
+        hits, nh, _ = ctx.deep_dp_round(H.AlignParams(max(150, int(lens.max())), 750, 130, 130, H.MmpParams.nt2(), 1, 0))
+        rec = sorted((hits[i].pair_id, hits[i].left_is_mate, hits[i].algnmt_1, hits[i].algnmt_2, hits[i].score_1, hits[i].score_2,
+                      hits[i].start_1, hits[i].start_2, hits[i].count_1, hits[i].count_2) for i in range(nh))   # slot order is not fixed
+        out[on] = (seeds, list(off), rec, st.n_occ, st.n_lkt, st.n_prefilter)
+        ctx.close()
+    assert out[True][:3] == out[False][:3]
+    assert out[False][5] == 0 and out[True][5] > 0
+    assert out[True][3] < out[False][3] and out[True][4] < out[False][4]
+    gix.close()
+
+
 @pytest.mark.parametrize("tag,mmp", [("a", H.MmpParams.nt2()), ("b", H.MmpParams.human()), ("c", H.MmpParams.nt2())])
 def test_seed_stage_matches_oracle(gidx, oidx, golden_dir, tag, mmp):
     d = os.path.join(golden_dir, "g1")

@@ -37,7 +37,8 @@ def _build(tmp_path, genome):
                                                                                           broken_mate_frac=0.05, noisy_mate_frac=0.4, noisy_sub=0.2,
                                                                                           n_frac=0.001)),
 ])
-def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg):
+def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg, monkeypatch):
+    monkeypatch.setenv("MP_KMER_FILTER", "1")          # the in-process run uses the 17-mer pre-filter, the C++ run below does not
     genome = synth.random_genome(cfg["n_bases"], 501, n_seqs=cfg["n_seqs"], repeat_frac=0.12)
     prefix = _build(tmp_path, genome)
     names, r1, r2 = synth.simulate_pairs(genome, cfg["n_pairs"], cfg["read_len"], 502, **cfg["sim"])
@@ -69,7 +70,7 @@ def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg):
     import subprocess
     from conftest import ROOT
     cxx_out = tmp_path / "cxx.fq"
-    env = dict(os.environ, MP_BATCH_PAIRS="1300")
+    env = dict(os.environ, MP_BATCH_PAIRS="1300", MP_KMER_FILTER="0")
     env.pop("MP_SOAP4_PYTHON", None)
     with open(cxx_out, "wb") as fo:
         r = subprocess.run([os.path.join(ROOT, "bin", "soap4"), "pair", prefix, f1, f2, "-o", str(tmp_path / "o"), "-C",

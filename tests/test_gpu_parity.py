@@ -50,7 +50,8 @@ def test_fm_primitives_exhaustive_small(gidx, oidx):
 
 
 @pytest.mark.parametrize("n_bases", [256 * 9 + 200, 192 * 25, 4096 + 17])
-def test_fm_primitives_every_index_at_text_tail_shapes(tmp_path, n_bases):
+def test_fm_primitives_every_index_at_text_tail_shapes(tmp_path, n_bases, monkeypatch):
+    monkeypatch.setenv("MP_SA_DENSE", "1" if n_bases % 2 else "0")        # the denser SA table derived at load time, on for one shape
     """Text lengths that end inside the upper half of an explicit-occurrence interval, on a rank-block boundary and just
     past a power of two: every rank (all four symbols) and every SA value, device vs oracle, on builder-written files."""
     from megapath_amd import index_builder, synth
@@ -112,6 +113,7 @@ def test_kmer_prefilter_bitmap_equals_table_plus_four_steps(g1_prefix, monkeypat
 def test_seeds_and_hits_identical_with_prefilter(g1_prefix, golden_dir, monkeypatch, tag):
     """Same kept seeds and the same deep-DP hits with the 17-mer pre-filter on and off; fewer rank queries with it."""
     monkeypatch.setenv("MP_KMER_FILTER", "1")
+    monkeypatch.setenv("MP_SA_DENSE", "1")
     gix = H.Index(g1_prefix, 0)
     d = os.path.join(golden_dir, "g1")
     L = int(open(os.path.join(d, "expected_%s.L" % tag)).read())

@@ -13,7 +13,12 @@ OURS = ("seed_kernel", "seed_overflow_kernel", "expand_hits_kernel", "locate_ker
         "dp_ops_fix_kernel", "build_left_tasks", "build_right_tasks", "collect_pair_hits", "gather64_kernel", "prep_scan_kernel", "mark_done", "failed_flag",
         "list_failed", "single_cand", "single_task", "mate_rescue_task", "occ_count_kernel", "occ_build_kernel", "text_build_kernel", "lkt_hist_kernel")
 
-stats = glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True)
+def newest(pattern):
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+stats = newest(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"))
 if stats:
     rows = list(csv.reader(open(stats[0])))
     keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in OURS)]
@@ -26,7 +31,7 @@ if line:
 
 def counters(sub, name):
     per = {}
-    for path in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+    for path in newest(os.path.join(out_dir, sub, "**", "*counter_collection.csv")):
         for r in csv.DictReader(open(path)):
             if r.get("Counter_Name") != name:
                 continue
@@ -35,19 +40,22 @@ def counters(sub, name):
     return per
 
 
+seed_stage = ("seed_kernel", "seed_overflow_kernel", "expand_hits_kernel", "locate_kernel")
 fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
 bench = json.loads([l for l in open(os.path.join(out_dir, "bench_fetch.json")) if l.startswith("{")][-1])
 per_launch = {}
 for k in sorted(set(fetch) | set(write)):
     per_launch[k] = {}
     if k in fetch:
-        per_launch[k]["FETCH_SIZE_KiB_per_launch"] = sum(fetch[k]) / len(fetch[k])
+        per_launch[k]["FETCH_SIZE_KiB_per_launch"] = fetch[k][-1] if k in seed_stage else sum(fetch[k]) / len(fetch[k])
         per_launch[k]["launches"] = len(fetch[k])
     if k in write:
-        per_launch[k]["WRITE_SIZE_KiB_per_launch"] = sum(write[k]) / len(write[k])
-seed_stage = ("seed_kernel", "seed_overflow_kernel", "expand_hits_kernel", "locate_kernel")
-# one bench step launches each seed-stage kernel once: sum of all their counter values over the 1-step run
-traffic = 1024.0 * sum(sum(fetch.get(k, [])) + sum(write.get(k, [])) for k in seed_stage)
+        per_launch[k]["WRITE_SIZE_KiB_per_launch"] = write[k][-1] if k in seed_stage else sum(write[k]) / len(write[k])
+# one bench step launches each seed-stage kernel once; with the 17-mer pre-filter resident the run has an untimed step
+# before it that ignores the filter (reference event counts): the LAST launch of each kernel is the timed configuration,
+# the first the reference walk
+traffic = 1024.0 * sum((fetch.get(k, [0])[-1]) + (write.get(k, [0])[-1]) for k in seed_stage)
+traffic_ref = 1024.0 * sum((fetch.get(k, [0])[0]) + (write.get(k, [0])[0]) for k in seed_stage)
 g = per_launch.get("gather64_kernel", {})
 doc = {
     "source": "scripts/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-include-regex '<this repo kernels>' -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
@@ -56,6 +64,7 @@ doc = {
     "per_kernel": per_launch,
     "gather64_calibration_ratio": (g.get("FETCH_SIZE_KiB_per_launch", 0) * 1024.0 / float(1 << 33)) if g else None,
     "seed_stage_hbm_bytes_per_launch": traffic,
+    "seed_stage_hbm_bytes_per_launch_reference_walk": traffic_ref,
     "seed_stage_algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
 }
 json.dump(doc, open(os.path.join(dst, "%s_pmc_seed_stage.json" % tag), "w"), indent=1)

@@ -371,7 +371,7 @@ void die(int rc, const char *what) { if (rc) { fprintf(stderr, "[soap4-mi355x] %
 
 struct Stats {
     uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0;
-    double t_upload = 0, t_deep = 0, t_sort = 0, t_cigar = 0, t_emit_deep = 0, t_rescue = 0, t_emit_rest = 0;   // seconds (MP_TIMING=1 prints them)
+    double t_read = 0, t_upload = 0, t_deep = 0, t_sort = 0, t_cigar = 0, t_emit_deep = 0, t_rescue = 0, t_emit_rest = 0;   // seconds (MP_TIMING=1 prints them)
 };
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -441,7 +441,7 @@ struct PairText {
 
 // OutputBuffer::ready for the three hit lists of a batch: sorted by (positions, scores), exact duplicates dropped
 // (DV-DPfunctions.h:165-196; :853-866 for the single-end hits; ready(1) also drops failed rescues, which never get here)
-void prepare_lists(Batch &b)
+void prepare_lists(Batch &b, int threads)
 {
     if (b.lists_ready) return;
     auto &hits = b.hits;
@@ -452,16 +452,39 @@ void prepare_lists(Batch &b)
         if (x.score_1 != y.score_1) return x.score_1 < y.score_1;
         return x.score_2 < y.score_2;
     };
-    // the device emits the hits in candidate order, i.e. already grouped by pair: then only the few hits of each pair
-    // need ordering
-    if (std::is_sorted(hits.begin(), hits.end(), [](const mp_pair_hit &x, const mp_pair_hit &y) { return x.pair_id < y.pair_id; })) {
-        for (size_t i = 0; i < hits.size();) {
+    // the device hands the hits over in slot order (arbitrary between wavefronts): bucket them by pair with one counting
+    // pass, then order the few hits of each pair, slices of the list side by side
+    const uint32_t n_pairs = b.n_reads / 2;
+    {
+        std::vector<uint32_t> start((size_t)n_pairs + 2, 0u);
+        for (const mp_pair_hit &h : hits) start[(size_t)h.pair_id + 2]++;
+        for (size_t q = 2; q < start.size(); q++) start[q] += start[q - 1];          // start[q+1] = first slot of pair q
+        std::vector<mp_pair_hit> bucketed(hits.size());
+        for (const mp_pair_hit &h : hits) bucketed[start[(size_t)h.pair_id + 1]++] = h;
+        hits.swap(bucketed);
+    }
+    auto sort_groups = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi;) {
             size_t j = i + 1;
-            while (j < hits.size() && hits[j].pair_id == hits[i].pair_id) j++;
+            while (j < hi && hits[j].pair_id == hits[i].pair_id) j++;
             if (j - i > 1) std::sort(hits.begin() + (long)i, hits.begin() + (long)j, hit_less);
             i = j;
         }
-    } else std::sort(hits.begin(), hits.end(), hit_less);
+    };
+    {
+        const size_t nt = (size_t)std::max(1, std::min(threads, (int)(hits.size() / 65536) + 1));
+        std::vector<size_t> cut(nt + 1, hits.size());
+        cut[0] = 0;
+        for (size_t t = 1; t < nt; t++) {
+            size_t c = hits.size() * t / nt;
+            while (c < hits.size() && c > 0 && hits[c].pair_id == hits[c - 1].pair_id) c++;
+            cut[t] = std::max(c, cut[t - 1]);
+        }
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; t++) pool.emplace_back(sort_groups, cut[t], cut[t + 1]);
+        sort_groups(cut[0], cut[1]);
+        for (auto &th : pool) th.join();
+    }
     hits.erase(std::unique(hits.begin(), hits.end(), [](const mp_pair_hit &x, const mp_pair_hit &y) {
         return x.pair_id == y.pair_id && x.algnmt_1 == y.algnmt_1 && x.algnmt_2 == y.algnmt_2 && x.score_1 == y.score_1 && x.score_2 == y.score_2; }), hits.end());
     auto &rows = b.rows;
@@ -482,11 +505,22 @@ void prepare_lists(Batch &b)
         return x.pair == y.pair && x.a1 == y.a1 && x.a2 == y.a2 && x.s1 == y.s1 && x.s2 == y.s2; }), rows.end());
     for (const RescueRow &r : rows) b.done[r.pair] = 2;
     auto &singles = b.singles;
-    std::sort(singles.begin(), singles.end(), [](const mp_single_hit &x, const mp_single_hit &y) {
+    auto single_less = [](const mp_single_hit &x, const mp_single_hit &y) {
         if (x.read_id != y.read_id) return x.read_id < y.read_id;
         if (x.algnmt != y.algnmt) return x.algnmt < y.algnmt;
         return x.score < y.score;
-    });
+    };
+    // single-end hits arrive in task order, i.e. grouped by read: only each read's few hits need ordering
+    bool grouped = true;
+    for (size_t i = 1; i < singles.size() && grouped; i++) grouped = singles[i].read_id >= singles[i - 1].read_id;
+    if (!grouped) std::sort(singles.begin(), singles.end(), single_less);
+    else
+        for (size_t i = 0; i < singles.size();) {
+            size_t j = i + 1;
+            while (j < singles.size() && singles[j].read_id == singles[i].read_id) j++;
+            if (j - i > 1) std::sort(singles.begin() + (long)i, singles.begin() + (long)j, single_less);
+            i = j;
+        }
     singles.erase(std::unique(singles.begin(), singles.end(), [](const mp_single_hit &x, const mp_single_hit &y) {
         return x.read_id == y.read_id && x.algnmt == y.algnmt && x.score == y.score; }), singles.end());
     b.lists_ready = true;
@@ -539,7 +573,7 @@ void gpu_stage(mp_ctx *ctx, Params &p, Batch &b, bool &first, bool bam, int thre
     }
     st.t_rescue += now_s() - t0; t0 = now_s();
     if (bam) {
-        prepare_lists(b);
+        prepare_lists(b, threads);
         st.t_sort += now_s() - t0; t0 = now_s();
         std::vector<mp_dp_task> tasks;
         tasks.reserve(2 * b.hits.size());
@@ -594,7 +628,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
 {
     const uint32_t n_pairs = b.n_reads / 2;
     double t0 = now_s();
-    prepare_lists(b);
+    prepare_lists(b, threads);
     st.t_sort += now_s() - t0; t0 = now_s();
     st.pairs += n_pairs; st.dp += b.dp_instances;
     const auto &hits = b.hits;
@@ -867,7 +901,9 @@ int main(int argc, char **argv)
         for (;;) {
             Batch *b = free_q.pop();
             if (!b) break;
+            const double tr = now_s();
             const bool got = fill_batch(ra, rb, p, *b);
+            st.t_read += now_s() - tr;
             if (got) filled_q.push(b);
             if (!got || b->last) break;
         }
@@ -885,7 +921,9 @@ int main(int argc, char **argv)
     for (;;) {
         Batch *b = filled_q.pop();
         if (!b) break;
+        const double tb = now_s();
         gpu_stage(ctx, p, *b, first, bam != nullptr, threads, st);
+        if (getenv("MP_TIMING")) fprintf(stderr, "[Main] device stage of a batch of %u pairs: %.3f s\n", b->n_reads / 2, now_s() - tb);
         aligned_q.push(b);
     }
     aligned_q.close();
@@ -899,8 +937,8 @@ int main(int argc, char **argv)
             (unsigned long long)st.deep, (unsigned long long)st.rescued, (unsigned long long)st.unpaired, (unsigned long long)st.dp);
     fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped)\n", t_loop, st.pairs / std::max(t_loop, 1e-9));
     if (getenv("MP_TIMING"))
-        fprintf(stderr, "[Main] seconds: upload %.2f, deep-DP round %.2f, sort %.2f, BAM CIGARs %.2f, output of deep pairs %.2f, rescue round %.2f, output of the rest %.2f\n",
-                st.t_upload, st.t_deep, st.t_sort, st.t_cigar, st.t_emit_deep, st.t_rescue, st.t_emit_rest);
+        fprintf(stderr, "[Main] seconds: reading and packing %.2f (own threads), upload %.2f, deep-DP round %.2f, sort %.2f, BAM CIGARs %.2f, output of deep pairs %.2f, rescue round %.2f, output of the rest %.2f\n",
+                st.t_read, st.t_upload, st.t_deep, st.t_sort, st.t_cigar, st.t_emit_deep, st.t_rescue, st.t_emit_rest);
     mp_ctx_destroy(ctx);
     mp_index_close(ix);
     return 0;

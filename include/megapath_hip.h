@@ -71,6 +71,9 @@ int mp_index_fetch_text(const mp_index *ix, const uint64_t *pos, const uint32_t 
 int mp_index_occ(const mp_index *ix, const uint64_t *idx, const uint32_t *sym, uint64_t n, uint64_t *out);
 int mp_index_sa(const mp_index *ix, const uint64_t *idx, uint64_t n, uint64_t *out);
 int mp_index_lkt(const mp_index *ix, const uint32_t *key, uint64_t n, uint64_t *out_l, uint64_t *out_r);
+/* The resident 13-mer table (4^13 inclusive right SA bounds, LT.h:49-55) -- read from <prefix>.lkt or rebuilt on the device
+ * at load time; lets a caller write the .lkt file the reference needs without recomputing it on the host. */
+int mp_index_copy_lkt(const mp_index *ix, uint32_t *out);
 /* The seeding kernel's pre-filter (mp_index_info.prefilter_k = 17): out[i] = 1 when backward search can reach length 17
  * with the 17-mer keys[i] (34 bits, first scanned base in the low bits as for mp_index_lkt), i.e. when the 13-mer table
  * range of its low 26 bits survives the four further extension steps.  MP_EINVAL when the bitmap is not resident. */

@@ -68,6 +68,9 @@ struct mp_ctx {
     DevBuf<mp_fill_result> fill;
     DevBuf<mp_dp_result> res_l, res_r, res_tmp;
     DevBuf<uint8_t> flags, ops;
+    DevBuf<uint32_t> sel_flag, sel_idx;          // score-only pre-pass of the rescue DP batches
+    DevBuf<mp_dp_task> sel_tasks;
+    DevBuf<mp_dp_result> sel_res;
     DevBuf<mp_pair_hit> pair_hits;
     DevBuf<unsigned long long> n_pair_hits;
     uint64_t n_pair_hits_host = 0;
@@ -392,6 +395,14 @@ extern "C" int mp_index_lkt(const mp_index *ix, const uint32_t *key, uint64_t n,
     return MP_OK;
 }
 
+extern "C" int mp_index_copy_lkt(const mp_index *ix, uint32_t *out)
+{
+    if (!ix || !out || !ix->d_lkt) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemcpy(out, ix->d_lkt, (size_t)MP_LKT_ENTRIES * 4, hipMemcpyDeviceToHost));
+    return MP_OK;
+}
+
 extern "C" int mp_index_prefilter(const mp_index *ix, const uint64_t *keys, uint64_t n, uint8_t *out)
 {
     if (!ix || !keys || !out) return MP_EINVAL;
@@ -451,7 +462,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->seedpos.release(); c->hit_row.release(); c->seeds_per_rs.release(); c->hits_per_rs.release(); c->rs_base.release(); c->overflow_rs.release(); c->over_slot.release();
     c->queue.release(); c->n_pos.release(); c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
     c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
-    c->ops.release(); c->pair_hits.release(); c->n_pair_hits.release();
+    c->ops.release(); c->pair_hits.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
     if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
     c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
     c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release();
@@ -622,10 +633,10 @@ void launch_fill(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32
 {
     const unsigned pairs = (n + 1) / 2, groups = MP_DP_BLOCK / LPI;
     if (count)
-        hipLaunchKernelGGL((dp_fill_kernel<LPI, C, true>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+        hipLaunchKernelGGL((dp_fill_kernel<LPI, C, 1>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                            tasks, n, cl, cr, flags, flag_rows, fill);
     else
-        hipLaunchKernelGGL((dp_fill_kernel<LPI, C, false>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+        hipLaunchKernelGGL((dp_fill_kernel<LPI, C, 0>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                            tasks, n, cl, cr, flags, flag_rows, fill);
 }
 // instances one "round" of resident blocks of the fill kernel covers on this device: launches sized in whole rounds
@@ -635,10 +646,18 @@ void fill_round(const mp_ctx *c, bool count, uint32_t *out)
 {
     int per_cu = 0, n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_fill_kernel<LPI, C, true>, MP_DP_BLOCK, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_fill_kernel<LPI, C, false>, MP_DP_BLOCK, 0);
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_fill_kernel<LPI, C, 1>, MP_DP_BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_fill_kernel<LPI, C, 0>, MP_DP_BLOCK, 0);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     *out = (uint32_t)n_cu * (uint32_t)per_cu * (uint32_t)(MP_DP_BLOCK / LPI) * 2u;
+}
+
+template <int LPI, int C>
+void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, mp_fill_result *fill)
+{
+    const unsigned pairs = (n + 1) / 2, groups = MP_DP_BLOCK / LPI;
+    hipLaunchKernelGGL((dp_fill_kernel<LPI, C, 2>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                       tasks, n, cl, cr, (uint32_t *)nullptr, 0u, fill);
 }
 
 template <int LPI, int C>
@@ -709,6 +728,43 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
     }
     if (ms_fill) *ms_fill += tf;
     if (ms_trace) *ms_trace += tt;
+    return MP_OK;
+}
+
+// For batches where most instances cannot reach their cutoff (the rescue passes): one score-only pass over all of them
+// (no traceback bits, no slab, one launch), then fill + traceback of the few that can pass.  Same results as run_dp.
+int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,
+                    float *ms_fill, float *ms_trace, bool count)
+{
+    if (n == 0) return MP_OK;
+    DpShape shape;
+    if (pick_shape(c->max_len, shape)) return MP_ERANGE;
+    if (max_win > MP_DP_MAX_WIN) return MP_ERANGE;
+    hipStream_t s = c->stream;
+    if (c->fill.reserve(n + 2) || c->sel_flag.reserve(n + 2) || c->sel_idx.reserve(n + 2)) return MP_ENOMEM;
+    while (c->ev_pool.size() < 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    HIPCHK(hipEventRecord(c->ev_pool[0], s));
+    MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p);
+    HIPCHK(hipEventRecord(c->ev_pool[1], s));
+    hipLaunchKernelGGL(dp_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->fill.p, c->d_lens, n, c->sel_flag.p, d_res);
+    {
+        size_t tmp_bytes = 0;
+        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, c->sel_flag.p, c->sel_idx.p, (int)n, s);
+        if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+        (void)hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, c->sel_flag.p, c->sel_idx.p, (int)n, s);
+    }
+    uint32_t n_sel = 0;
+    HIPCHK(hipMemcpyAsync(&n_sel, c->sel_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float t_score = 0;
+    (void)hipEventElapsedTime(&t_score, c->ev_pool[0], c->ev_pool[1]);
+    if (ms_fill) *ms_fill += t_score;
+    if (n_sel == 0) return MP_OK;
+    if (c->sel_tasks.reserve(n_sel + 2) || c->sel_res.reserve(n_sel + 2)) return MP_ENOMEM;
+    hipLaunchKernelGGL(dp_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->sel_flag.p, c->sel_idx.p, n, c->sel_tasks.p);
+    int rc = run_dp(c, c->sel_tasks.p, n_sel, max_win, cl, cr, c->sel_res.p, nullptr, 0, ms_fill, ms_trace, count);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dp_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, c->sel_res.p, n, d_res);
     return MP_OK;
 }
 
@@ -882,15 +938,15 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
                            c->s_off.p, c->d_lens, c->ix->n, c->stasks.p);
         HIPCHK(hipEventRecord(t1, s));
         const uint32_t max_win = c->max_len + 60;
-        rc = run_dp(c, c->stasks.p, nst, max_win, ap->clip_left, ap->clip_right, c->sres.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
+        rc = run_dp_filtered(c, c->stasks.p, nst, max_win, ap->clip_left, ap->clip_right, c->sres.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         if (!skip_default_dp) {
             hipLaunchKernelGGL(mate_rescue_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->s_off.p, c->stasks.p, c->sres.p,
                                c->d_lens, c->ix->n, ap->insert_low, ap->insert_high, c->rtasks.p, c->rsrc.p);
             const uint32_t rwin = (uint32_t)(ap->insert_high - ap->insert_low) + c->max_len + 1;   // HalfEnd maxDNALength (DV-DPfunctions.cpp:1340)
             if (rwin > MP_DP_MAX_WIN) return MP_ERANGE;
-            rc = run_dp(c, c->rtasks.p, 4 * nf, rwin, ap->clip_left, ap->clip_right, c->rres.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace,
-                        ap->want_tie_counts != 0);
+            rc = run_dp_filtered(c, c->rtasks.p, 4 * nf, rwin, ap->clip_left, ap->clip_right, c->rres.p, &st.ms_dp_fill, &st.ms_dp_trace,
+                                 ap->want_tie_counts != 0);
             if (rc) return rc;
             st.n_rescue_tasks = 4ull * nf;
         }

@@ -123,13 +123,41 @@ struct dp_weights { v2s z, d, e, eo, fo; };
         "v_pk_mad_i16 %[fw], %[t1], %[wfo], %[fw]\n\t"            /* nFO */ \
         "v_pk_min_u16 %[t1], %[Hup], %[elig]\n\t"                 /* eligible H (true -1 in columns that cannot end an alignment) */
 
-template <bool COUNT>
+// the same recurrences without the traceback bits: a score-only pass decides cheaply which instances can pass their
+// cutoff at all (most rescue instances cannot); only those are run again with the bits
+#define MP_DP_CELL_SCORE \
+        "v_sub_u32 %[eo], %[Hup], %[k3]\n\t" \
+        "v_mov_b32 %[dn], %[Hup]\n\t" \
+        "v_sub_u32 %[Eup], %[Eup], %[k1]\n\t" \
+        "v_pk_max_u16 %[Eup], %[eo], %[Eup]\n\t" \
+        "v_sub_u32 %[fo], %[Hl], %[k4]\n\t" \
+        "v_sub_u32 %[Fl], %[Fl], %[k2]\n\t" \
+        "v_pk_max_u16 %[Fl], %[fo], %[Fl]\n\t" \
+        "v_xor_b32 %[t1], %[base], %[rb]\n\t" \
+        "v_pk_min_u16 %[t1], %[t1], %[k3]\n\t" \
+        "v_sub_u32 %[dg], %[diag], %[t1]\n\t" \
+        "v_pk_max_u16 %[t1], %[dg], %[Eup]\n\t" \
+        "v_pk_max_u16 %[t1], %[t1], %[Fl]\n\t" \
+        "v_pk_max_u16 %[Hup], %[t1], %[floorv]\n\t" \
+        "v_pk_min_u16 %[t1], %[Hup], %[elig]\n\t"
+
+// MODE 0: traceback bits + row code (text output); 1: traceback bits + exact first-maximum tracking with tie counts
+// (BAM output, mp_sgdp_batch); 2: scores only
+template <int MODE>
 __device__ __forceinline__ void dp_cell(const dp_consts &K, const dp_weights &Wt, v2s &Hup, v2s &Eup, v2s Hl, v2s &Fl, v2s diag, v2s base, v2s rb,
                                         v2s floorv, v2s elig, v2s gate, v2s colk, v2s jadd, v2s &dnext, v2s &fw, v2s &best, v2s &bpos,
                                         v2s &pos, v2s &cnt, v2s &rowcode)
 {
     v2s eo, fo, dg, t1, bits;
-    if (!COUNT) {
+    if (MODE == 2) {
+        asm(MP_DP_CELL_SCORE
+            "v_pk_mad_i16 %[t1], %[t1], %[k16], %[colk]\n\t"
+            "v_pk_max_u16 %[rowcode], %[rowcode], %[t1]"
+            : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [dn] "=&v"(dnext), [Hup] "+&v"(Hup), [Eup] "+&v"(Eup),
+              [Fl] "+&v"(Fl), [rowcode] "+&v"(rowcode)
+            : [Hl] "v"(Hl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv), [elig] "v"(elig), [k1] "v"(K.k1), [k2] "v"(K.k2),
+              [k3] "v"(K.k3), [k4] "v"(K.k4), [k16] "v"(K.k16), [colk] "v"(colk));
+    } else if (MODE == 0) {
         // ((H + bias) << 4) | (15 - cc): one max per cell keeps the row's best score and, among equals, its first column;
         // colk = 16 j + 15 - cc puts the column term back
         asm(MP_DP_CELL_CORE
@@ -179,7 +207,7 @@ __device__ __forceinline__ v2s as_v2s(int v) { return __builtin_bit_cast(v2s, v)
 #define MP_DP_NW(C) (((C) + 2) / 3)
 #define MP_DP_FLUSH 8          // steps of flag words staged per lane before one contiguous global write
 
-template <int LPI, int C, bool COUNT>
+template <int LPI, int C, int MODE>
 __global__ void __launch_bounds__(MP_DP_BLOCK)
 dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t W,
                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, int clip_left, int clip_right,
@@ -188,10 +216,11 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 {
     constexpr int GROUPS = MP_DP_BLOCK / LPI;          // lane groups per block, two instances each
     constexpr int NW = MP_DP_NW(C);
+    constexpr bool COUNT = MODE == 1, FLAGS = MODE != 2;
     __shared__ uint32_t s_win[GROUPS][2][MP_DP_MAX_WIN / 16 + 1];
     // per-lane staging of 8 steps of flag words (odd row stride: conflict-free ds_write_b32); a lane only ever reads its
     // own row, so no barrier is involved -- LDS is used as a transposing scratchpad
-    __shared__ uint32_t s_fl[GROUPS][LPI][MP_DP_FLUSH * NW + 1];
+    __shared__ uint32_t s_fl[FLAGS ? GROUPS : 1][FLAGS ? LPI : 1][MP_DP_FLUSH * NW + 1];
     const int g = threadIdx.x / LPI;
     const int k = threadIdx.x % LPI;
     const uint32_t pair = blockIdx.x * GROUPS + g;
@@ -305,7 +334,7 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             for (int cc = 0; cc < C; cc++) {
                 v2s dnext;
                 const int j = k * C + cc + 1;
-                dp_cell<COUNT>(K, Wt[cc % 3], Hup[cc], Eup[cc], Hl, Fl, diag, base, rb[cc], floorv[cc], elig[cc], gatecap,
+                dp_cell<MODE>(K, Wt[cc % 3], Hup[cc], Eup[cc], Hl, Fl, diag, base, rb[cc], floorv[cc], elig[cc], gatecap,
                                pk1((short)(16 * j + 15 - cc)), pk1((short)j), dnext, fw[cc / 3], best, bpos, pos, cnt, rowcode);
                 diag = dnext;
                 Hl = Hup[cc];
@@ -320,11 +349,13 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             }
             diag_carry = as_v2s(inHi);
             outH = Hl; outF = Fl;
+            if (FLAGS) {
 #pragma unroll
-            for (int w = 0; w < NW; w++) s_fl[g][k][((t - 1) & (MP_DP_FLUSH - 1)) * NW + w] = __builtin_bit_cast(uint32_t, fw[w]);
+                for (int w = 0; w < NW; w++) s_fl[g][k][((t - 1) & (MP_DP_FLUSH - 1)) * NW + w] = __builtin_bit_cast(uint32_t, fw[w]);
+            }
         }
         outB = inB;
-        if ((t & (MP_DP_FLUSH - 1)) == 0 || t == steps) {
+        if (FLAGS && ((t & (MP_DP_FLUSH - 1)) == 0 || t == steps)) {
             // flush this lane's last (up to) 8 steps as one contiguous run
             uint32_t *dst = frow + (uint64_t)((t - 1) & ~(MP_DP_FLUSH - 1)) * NW;
 #pragma unroll
@@ -441,6 +472,34 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
     }
     if (valid) { res.score = fr.score; res.hit_loc = (uint32_t)hit; res.n_ops = n; }
     out[inst] = res;
+}
+
+// ---- score-only pre-pass bookkeeping: which instances can pass, compaction of their tasks, scatter of their results
+__global__ void dp_select_kernel(const mp_dp_task *__restrict__ tasks, const mp_fill_result *__restrict__ fill, const uint32_t *__restrict__ lens,
+                                 uint32_t n, uint32_t *__restrict__ flag, mp_dp_result *__restrict__ res)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const mp_fill_result fr = fill[t];
+    const int cutoff = mp_dp_cutoff((int)lens[tasks[t].read_id]);
+    const bool pass = fr.score >= cutoff && fr.score > 0 && tasks[t].win_len != 0;
+    flag[t] = pass ? 1u : 0u;
+    mp_dp_result z; z.score = 0; z.hit_loc = 0; z.max_score_count = 0; z.n_ops = 0;
+    res[t] = z;                                          // what the traceback kernel writes for an instance below its cutoff
+}
+
+__global__ void dp_compact_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ idx,
+                                  uint32_t n, mp_dp_task *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && flag[t]) out[idx[t] - 1] = tasks[t];
+}
+
+__global__ void dp_scatter_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ idx, const mp_dp_result *__restrict__ sel,
+                                  uint32_t n, mp_dp_result *__restrict__ res)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && flag[t]) res[t] = sel[idx[t] - 1];
 }
 
 // 'X' marks a diagonal step; this pass turns it into 'M' / 'm' by comparing the bases (kept out of the traceback

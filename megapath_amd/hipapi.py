@@ -96,7 +96,7 @@ class IndexInfo(C.Structure):
 
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
-           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_prefilter", "mp_ctx_create", "mp_ctx_destroy",
+           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_ctx_create", "mp_ctx_destroy",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
 
@@ -134,6 +134,7 @@ def load_library():
     lib.mp_index_sa.argtypes = [vp, vp, C.c_uint64, vp]
     lib.mp_index_lkt.argtypes = [vp, vp, C.c_uint64, vp, vp]
     lib.mp_index_prefilter.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.mp_index_copy_lkt.argtypes = [vp, vp]
     lib.mp_index_chr_pos_segment.argtypes = [vp, C.c_uint64, u64p, u32p, u64p]
     lib.mp_index_seq_info.argtypes = [vp, C.c_uint32, u64p, u64p, u64p]
     lib.mp_index_fetch_text.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32]
@@ -254,6 +255,12 @@ class Index:
         ms, nb = C.c_float(), C.c_uint64()
         _chk(load_library().mp_bench_gather64(self._h, lanes, per_lane, repeats, C.byref(ms), C.byref(nb)), "mp_bench_gather64")
         return ms.value, nb.value
+
+    def lkt_table(self):
+        """The resident 13-mer table: 4^13 inclusive right SA bounds (uint32)."""
+        out = np.zeros(4 ** 13, dtype=np.uint32)
+        _chk(load_library().mp_index_copy_lkt(self._h, out.ctypes.data), "mp_index_copy_lkt")
+        return out
 
     def prefilter(self, keys):
         """Bits of the seeding kernel's 17-mer pre-filter for 34-bit keys (first scanned base in the low bits)."""

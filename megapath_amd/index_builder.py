@@ -8,7 +8,7 @@ frequencies, sampled SA, packed text.  The result can be handed to the HIP libra
 soap4 and this repo's loaders both read.
 
 Limits: ACGT only ('N' and other letters map to G/A as the read path does; runs of >= 10 non-ACGT letters are not
-removed as HSPParseFASTAToPacked does, HSP.c:486-527); text length < 2^31 - 2.
+removed as HSPParseFASTAToPacked does, HSP.c:486-527); text length < 3.03e9 (the 63-bit rank-pair key of the doubling).
 """
 from __future__ import annotations
 
@@ -22,11 +22,80 @@ def _device():
     return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
 
+_CH = 1 << 30          # this torch build mishandles several ops beyond INT_MAX elements: they are applied in slices
+
+
+def _slices(n):
+    return [(c, min(n, c + _CH)) for c in range(0, n, _CH)]
+
+
+def _gather(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    if idx.numel() < 2 ** 31 - 1:
+        return src[idx]
+    out = torch.empty(idx.numel(), dtype=src.dtype, device=src.device)
+    for c0, c1 in _slices(idx.numel()):
+        out[c0:c1] = src[idx[c0:c1]]
+    return out
+
+
+def _scatter(dst: torch.Tensor, idx: torch.Tensor, val: torch.Tensor) -> None:
+    for c0, c1 in _slices(idx.numel()):
+        dst[idx[c0:c1]] = val[c0:c1]
+
+
+def _cumsum(x: torch.Tensor) -> torch.Tensor:
+    if x.numel() < 2 ** 31 - 1:
+        return torch.cumsum(x, 0)
+    out = torch.empty_like(x)
+    carry = 0
+    for c0, c1 in _slices(x.numel()):
+        out[c0:c1] = torch.cumsum(x[c0:c1], 0) + carry
+        carry = int(out[c1 - 1].item())
+    return out
+
+
+def _nonzero(mask_fn, n, device) -> torch.Tensor:
+    """Indices where mask_fn(c0, c1) (a bool tensor for that slice) holds."""
+    parts = [torch.nonzero(mask_fn(c0, c1)).squeeze(1) + c0 for c0, c1 in _slices(n)]
+    return torch.cat(parts) if parts else torch.empty(0, dtype=torch.int64, device=device)
+
+
+def _argsort_big(key: torch.Tensor) -> torch.Tensor:
+    """argsort for more than INT_MAX elements (torch.sort's limit): the keys are cut into value ranges that are sorted
+    one by one -- ranges of the key are ranges of the order."""
+    n = key.numel()
+    if n < 2 ** 31 - 1:
+        return torch.argsort(key, stable=False)
+    parts = 8
+    while True:
+        kmax = max(int(key[c0:c1].max().item()) for c0, c1 in _slices(n)) + 1
+        step = (kmax + parts - 1) // parts
+        sizes = [0] * parts
+        for c0, c1 in _slices(n):
+            cnt = torch.bincount(torch.div(key[c0:c1], step, rounding_mode="floor"), minlength=parts).cpu().tolist()
+            sizes = [a + b for a, b in zip(sizes, cnt)]
+        if max(sizes) < 2 ** 31 - 1:
+            break
+        parts *= 2
+    order = torch.empty(n, dtype=torch.int64, device=key.device)
+    off = 0
+    for b in range(parts):
+        if sizes[b] == 0:
+            continue
+        lo, hi = b * step, (b + 1) * step
+        idx = _nonzero(lambda c0, c1: (key[c0:c1] >= lo) & (key[c0:c1] < hi), n, key.device)
+        sub = torch.argsort(key[idx], stable=False)
+        order[off:off + sizes[b]] = idx[sub]
+        off += sizes[b]
+        del idx, sub
+    return order
+
+
 def suffix_array(codes: torch.Tensor) -> torch.Tensor:
     """Suffix array of codes + '$' ('$' smallest), length n+1, int64, on codes.device.  Prefix doubling."""
     dev = codes.device
     n = codes.numel()
-    assert n + 2 < 2 ** 31
+    assert (n + 2) * (n + 2) < 2 ** 63 and n + 2 < 2 ** 32 - 16      # the (rank, next rank) key must fit 63 bits; index chunks are < 2^32
     K = 20                                              # 5^20 < 2^63: first pass ranks by 20-mers
     sym = torch.zeros(n + 1 + K, dtype=torch.int64, device=dev)
     sym[:n] = codes.to(torch.int64) + 1                 # '$' and everything past the end = 0
@@ -36,14 +105,14 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
     del sym
     h = K
     while True:
-        order = torch.argsort(key, stable=False)
-        sk = key[order]
+        order = _argsort_big(key)
+        sk = _gather(key, order)
         newgrp = torch.ones(n + 1, dtype=torch.int64, device=dev)
         newgrp[1:] = (sk[1:] != sk[:-1]).to(torch.int64)
-        rank_sorted = torch.cumsum(newgrp, 0) - 1
+        rank_sorted = _cumsum(newgrp) - 1
         del sk, newgrp
         rank = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        rank[order] = rank_sorted
+        _scatter(rank, order, rank_sorted)
         done = int(rank_sorted[-1].item()) == n
         del rank_sorted
         if done:
@@ -82,12 +151,11 @@ def build_index_arrays(seqs, sa_interval: int = 16, device=None):
     n = len(text)
     codes = torch.from_numpy(text).to(dev)
     sa = suffix_array(codes)                            # n+1 entries, sa[0] == n
-    inv_sa0 = int(torch.nonzero(sa == 0)[0].item())
-    # BWT with the '$' row removed (BWT.c:605)
-    prev = sa - 1
-    keep = prev >= 0
-    bwt = codes[prev[keep]].to(torch.uint8)
-    del prev, keep
+    inv_sa0 = int(_nonzero(lambda c0, c1: sa[c0:c1] == 0, n + 1, dev)[0].item())
+    # BWT with the '$' row removed (BWT.c:605): rows in order, the one whose suffix starts the text dropped
+    prev = torch.cat([sa[:inv_sa0], sa[inv_sa0 + 1:]]) - 1
+    bwt = _gather(codes, prev).to(torch.uint8)
+    del prev
     cnt = torch.bincount(codes.to(torch.int64), minlength=4).cpu().numpy()
     cum = np.zeros(5, dtype=np.uint64)
     cum[1:] = np.cumsum(cnt)
@@ -111,7 +179,7 @@ def build_index_arrays(seqs, sa_interval: int = 16, device=None):
                 names=names, starts=np.asarray(starts, dtype=np.uint64), lengths=np.asarray(lengths, dtype=np.uint64))
 
 
-def write_index_files(prefix: str, arrs, write_lkt: bool = False) -> None:
+def write_index_files(prefix: str, arrs, write_lkt: bool = False, lkt_table=None) -> None:
     """Write <prefix>.{bwt,fmv,sa,pac,ann,amb,tra} in the reference's formats so that the reference
     soap4, the oracle and mp_index_open can all load the index.  The 512 MiB .lkt is optional (every loader in this
     repo rebuilds it from .pac; the reference soap4 needs the file)."""
@@ -122,18 +190,27 @@ def write_index_files(prefix: str, arrs, write_lkt: bool = False) -> None:
     with open(prefix + ".bwt", "wb") as f:
         f.write(hdr.tobytes())
         f.write(np.asarray(arrs["bwt_words"], dtype=np.uint32).tobytes())
-    # explicit occurrences (BWTConstruct.c:1229-1233; read side BWT.c:783-797)
+    # explicit occurrences (BWTConstruct.c:1229-1233; read side BWT.c:783-797): symbol counts per 256-symbol interval from
+    # a per-byte table (4 symbols per byte), never materialising one element per base
     bw = np.asarray(arrs["bwt_words"], dtype=np.uint32)
-    syms = ((bw[:, None] >> (2 * (15 - np.arange(16, dtype=np.uint32)))) & 3).reshape(-1)[:n].astype(np.uint8)
     n_occ = (n + 255) // 256 + 1
-    occ = np.zeros((n_occ, 4), dtype=np.uint64)
     # the reference counts whole 256-symbol intervals after clearing the trailing code (BWTConstruct.c:312-314, 1036-1041):
     # the sample past the text end includes the zero padding as 'A's, and BWTOccValue subtracts them again when it
     # decodes backwards from that sample (reachable whenever n mod 256 > 128)
-    padded = np.concatenate([syms, np.zeros((n_occ - 1) * 256 - n, dtype=np.uint8)])
+    words = np.zeros((n_occ - 1) * 16, dtype=np.uint32)
+    words[: len(bw)] = bw
+    if n % 16:
+        words[n // 16] &= np.uint32(0xFFFFFFFF) << np.uint32(2 * (16 - n % 16))          # clear the trailing code (MSB-first symbols)
+    words[(n + 15) // 16:] = 0
+    by = words.view(np.uint8)
+    tab = np.zeros((256, 4), dtype=np.uint8)
+    for v in range(256):
+        for k in range(4):
+            tab[v, (v >> (2 * k)) & 3] += 1
+    occ = np.zeros((n_occ, 4), dtype=np.uint64)
     for c in range(4):
-        cs = np.concatenate([[0], np.cumsum(padded == c, dtype=np.uint64)])
-        occ[:, c] = cs[np.arange(n_occ, dtype=np.int64) * 256]
+        per_iv = tab[by, c].reshape(n_occ - 1, 64).sum(axis=1, dtype=np.uint64)
+        occ[1:, c] = np.cumsum(per_iv, dtype=np.uint64)
     n_major = (n_occ + 255) // 256
     major = occ[::256][:n_major].copy()
     rel = (occ - np.repeat(major, 256, axis=0)[:n_occ]).astype(np.uint32)
@@ -176,7 +253,12 @@ def write_index_files(prefix: str, arrs, write_lkt: bool = False) -> None:
             f.write("%d %d %d\n" % (int(s), i + 1, (int(s) - 1) % (1 << 64)))
         for s, l in zip(starts, lengths):
             f.write("%d %d\n" % (int(s), int(l)))
-    if write_lkt:
+    if lkt_table is not None:
+        # the 13-mer table as a loader already built it (mp_index_copy_lkt): inclusive right bounds, written as u64
+        with open(prefix + ".lkt", "wb") as f:
+            f.write(np.int32(13).tobytes())
+            f.write(np.asarray(lkt_table).astype(np.uint64).tobytes())
+    elif write_lkt:
         text = np.concatenate([((pac[:, None] >> (2 * (3 - np.arange(4, dtype=np.uint8)))) & 3).reshape(-1)[:n],
                                np.zeros(12, dtype=np.uint8)]).astype(np.uint64)
         key = np.zeros(n, dtype=np.uint64)

@@ -511,6 +511,8 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipSetDevice(c->ix->device));
     const uint32_t n_reads = c->n_reads, W = c->W, n_items = 2 * n_reads;
     const mp_dev_mmp P = to_dev(params);
+    uint32_t slab_limit = MP_SEED_SLAB;
+    if (const char *e = getenv("MP_SEED_SLAB_LIMIT")) { int v = atoi(e); if (v >= 1 && v < MP_SEED_SLAB) slab_limit = (uint32_t)v; }   // test knob
     mp_dev_index dix = c->ix->d;
     if (!c->use_prefilter) { dix.kmer17 = nullptr; dix.sa_dense = nullptr; }
     hipStream_t s = c->stream;
@@ -528,7 +530,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * 8u);
     HIPCHK(hipEventRecord(c->ev[0], s));
     hipLaunchKernelGGL(seed_kernel, dim3(blocks), dim3(256), 0, s, dix, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
-                       c->hits_per_rs.p, c->overflow_rs.p, c->over_slot.p, overflow_cap, c->queue.p, c->ctr.p);
+                       c->hits_per_rs.p, c->overflow_rs.p, c->over_slot.p, overflow_cap, c->queue.p, c->ctr.p, slab_limit);
     HIPCHK(hipEventRecord(c->ev[1], s));
     mp_counters h{};
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
@@ -554,7 +556,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipEventRecord(c->ev[9], s));
     HIPCHK(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(expand_hits_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, c->slabs.p, c->seeds_per_rs.p, c->rs_base.p, n_items,
-                       c->over_slot.p, c->big_slabs.p, c->seeds.p, c->hit_row.p, c->ctr.p);
+                       c->over_slot.p, c->big_slabs.p, c->seeds.p, c->hit_row.p, c->ctr.p, slab_limit);
     if (n_hits)
         hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, dix, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
                            c->ctr.p);

@@ -327,7 +327,8 @@ __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *sc
 __global__ void __launch_bounds__(256)
 seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t n_items, uint32_t W, mp_dev_mmp P,
             mp_seed_rec *__restrict__ slabs, uint32_t *__restrict__ seeds_per_rs, uint32_t *__restrict__ hits_per_rs,
-            uint32_t *__restrict__ overflow_rs, uint32_t *__restrict__ over_slot, uint32_t overflow_cap, unsigned int *queue, mp_counters *ctr)
+            uint32_t *__restrict__ overflow_rs, uint32_t *__restrict__ over_slot, uint32_t overflow_cap, unsigned int *queue, mp_counters *ctr,
+            uint32_t slab_limit /* <= MP_SEED_SLAB; smaller only to exercise the overflow path */)
 {
     const int lane = threadIdx.x & (MP_WAVE - 1);
     uint32_t my_occ = 0, my_lkt = 0, my_kmer = 0;
@@ -362,7 +363,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, my_occ, my_lkt, my_kmer)) {
                 seeds_per_rs[s.rs] = s.n_seeds;
                 hits_per_rs[s.rs] = s.n_hits;
-                if (s.n_seeds > MP_SEED_SLAB) {
+                if (s.n_seeds > slab_limit) {
                     uint32_t slot = (uint32_t)atomicAdd(&ctr->overflow, 1ull);
                     if (slot < overflow_cap) { overflow_rs[slot] = s.rs; over_slot[s.rs] = slot; }
                 }
@@ -400,7 +401,7 @@ seed_overflow_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const u
 __global__ void __launch_bounds__(256)
 expand_hits_kernel(const mp_seed_rec *__restrict__ slabs, const uint32_t *__restrict__ seeds_per_rs, const uint32_t *__restrict__ rs_base,
                    uint32_t n_items, const uint32_t *__restrict__ over_slot, const mp_seed_rec *__restrict__ big_slabs,
-                   mp_sa_seed *__restrict__ seeds_out /* one per hit */, uint32_t *__restrict__ hit_row, mp_counters *ctr)
+                   mp_sa_seed *__restrict__ seeds_out /* one per hit */, uint32_t *__restrict__ hit_row, mp_counters *ctr, uint32_t slab_limit)
 {
     const uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ns = rs < n_items ? seeds_per_rs[rs] : 0;
@@ -409,7 +410,7 @@ expand_hits_kernel(const mp_seed_rec *__restrict__ slabs, const uint32_t *__rest
     if ((threadIdx.x & (MP_WAVE - 1)) == 0 && tot) atomicAdd(&ctr->n_seeds, (unsigned long long)tot);
     if (ns == 0) return;
     const mp_seed_rec *src = slabs + (uint64_t)rs * MP_SEED_SLAB;
-    if (ns > MP_SEED_SLAB) src = big_slabs + (uint64_t)over_slot[rs] * MP_SEED_BIG;
+    if (ns > slab_limit) src = big_slabs + (uint64_t)over_slot[rs] * MP_SEED_BIG;
     uint32_t w = rs_base[rs];
     for (uint32_t j = 0; j < ns; j++) {
         const mp_seed_rec rec = src[j];

@@ -274,7 +274,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "seed_kernel+locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "random64_gather_ceiling_gbs": gather_gbs, "frac_of_gather_ceiling": achieved / gather_gbs,
-                         "algorithmic_bytes_per_pair": b_seed / (K * P), "launch_ms": (acc["seed"] + acc["locate"]) / K,
+                         "algorithmic_bytes_per_pair": b_seed / (K * P), "algorithmic_bytes_per_launch": b_seed / K,
+                         "launch_ms": (acc["seed"] + acc["locate"]) / K,
                          "executed_bytes_per_pair": b_exec / (K * P), "achieved_on_executed_bytes": b_exec / t_seed_s / 1e9 if t_seed_s > 0 else 0.0,
                          "prefilter_k": int(gix.info.prefilter_k)},
             "kernel_ms_per_step": kernel_ms,
@@ -292,7 +293,6 @@ def main():
             wl = pmc["workload"]
             if wl["genome_mbp"] == args.genome_mbp and wl["pairs_per_step"] == P and wl["read_len"] == args.read_len:
                 out["roofline"]["traffic"] = pmc["seed_stage_hbm_bytes_per_launch"]
-                out["roofline"]["algorithmic_bytes_per_launch"] = b_seed / K
         except Exception:  # noqa: BLE001
             pass
         cb = None

@@ -444,8 +444,17 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
         h.mult = (seedlen >= (uint32_t)P.good_seed_len || seedlen >= len / 2) ? (uint16_t)1 : (uint16_t)(s.sa_diff + 1);
         hits[t] = h;
     }
+    // one counter update per block: a single address takes only ~100 M atomics per second chip-wide, and a launch of
+    // 57 M hits has 890 k wavefronts
+    __shared__ uint32_t s_occ[256 / MP_WAVE];
     for (int o = MP_WAVE / 2; o > 0; o >>= 1) my_occ += __shfl_down(my_occ, o);
-    if ((threadIdx.x & (MP_WAVE - 1)) == 0 && my_occ) atomicAdd(&ctr->n_occ, (unsigned long long)my_occ);
+    if ((threadIdx.x & (MP_WAVE - 1)) == 0) s_occ[threadIdx.x / MP_WAVE] = my_occ;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 256 / MP_WAVE; w++) tot += s_occ[w];
+        if (tot) atomicAdd(&ctr->n_occ, (unsigned long long)tot);
+    }
     if (t == 0) { atomicAdd(&ctr->n_sa, (unsigned long long)n_tasks); atomicAdd(&ctr->n_hits, (unsigned long long)n_tasks); }
 }
 

@@ -255,7 +255,10 @@ def main():
         b_seed = K * (64 * ev["occ"] + 16 * ev["lkt"] + 8 * ev["sa"] + 0.25 * (2 * P * args.read_len) + 16 * ev["seedpos"])
         b_exec = 64 * acc["occ"] + 16 * acc["lkt"] + 8 * acc["sa"] + 0.25 * (2 * P * K * args.read_len) + 16 * acc["seedpos"] + 4 * acc["kmer"]
         t_seed_s = (acc["seed"] + acc["locate"]) / 1e3
-        achieved = b_seed / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
+        # `achieved` is priced with the events the kernels themselves issued and counted ("counters the kernel emits");
+        # the rate at which the reference algorithm's look-ups are delivered is reported next to it
+        achieved = b_exec / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
+        achieved_ref = b_seed / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
         kernel_ms = {k: acc[k] / K for k in ("seed", "locate", "merge", "pair", "fill", "trace", "rescue_tasks", "rescue_fill", "rescue_trace")}
         n_inst = 2 * acc["cand"] + acc["stasks"] + acc["rtasks"]
         cells = (2 * acc["cand"] + acc["stasks"]) * (args.read_len + 61) * args.read_len + acc["rtasks"] * (750 - args.read_len + args.read_len + 1) * args.read_len
@@ -274,9 +277,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "seed_kernel+locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "random64_gather_ceiling_gbs": gather_gbs, "frac_of_gather_ceiling": achieved / gather_gbs,
-                         "algorithmic_bytes_per_pair": b_seed / (K * P), "algorithmic_bytes_per_launch": b_seed / K,
+                         "algorithmic_bytes_per_pair": b_exec / (K * P), "algorithmic_bytes_per_launch": b_exec / K,
                          "launch_ms": (acc["seed"] + acc["locate"]) / K,
-                         "executed_bytes_per_pair": b_exec / (K * P), "achieved_on_executed_bytes": b_exec / t_seed_s / 1e9 if t_seed_s > 0 else 0.0,
+                         "reference_algorithm": {"bytes_per_pair": b_seed / (K * P), "bytes_per_launch": b_seed / K, "delivered_gbs": achieved_ref,
+                                                 "frac_of_peak": achieved_ref / HBM_PEAK_GBS,
+                                                 "note": "look-ups soap4 itself issues for this batch (one untimed step with the 17-mer pre-filter "
+                                                         "and the dense SA samples ignored); the timed kernels skip most of them"},
                          "prefilter_k": int(gix.info.prefilter_k)},
             "kernel_ms_per_step": kernel_ms,
             "dp": {"bound": "valu", "unit": "Gcells/s", "achieved": cells / ((acc["fill"] + acc["rescue_fill"]) / 1e3) / 1e9 if acc["fill"] else 0.0,

@@ -66,6 +66,7 @@ doc = {
     "seed_stage_hbm_bytes_per_launch": traffic,
     "seed_stage_hbm_bytes_per_launch_reference_walk": traffic_ref,
     "seed_stage_algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_pair"] * bench["config"]["pairs_per_step_per_gpu"],
+    "seed_stage_reference_algorithm_bytes_per_launch": bench["roofline"].get("reference_algorithm", {}).get("bytes_per_launch"),
 }
 json.dump(doc, open(os.path.join(dst, "%s_pmc_seed_stage.json" % tag), "w"), indent=1)
 print(json.dumps({k: doc[k] for k in ("gather64_calibration_ratio", "seed_stage_hbm_bytes_per_launch", "seed_stage_algorithmic_bytes_per_launch")}))

@@ -11,6 +11,7 @@
 #include "kernels_index.hip"
 #include "kernels_seed.hip"
 #include "kernels_dp.hip"
+#include "kernels_dp_band.hip"
 #include "kernels_rescue.hip"
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -71,6 +72,11 @@ struct mp_ctx {
     DevBuf<uint32_t> sel_flag, sel_idx;          // score-only pre-pass of the rescue DP batches
     DevBuf<mp_dp_task> sel_tasks;
     DevBuf<mp_dp_result> sel_res;
+    DevBuf<uint32_t> band_flag, band_idx;        // instances the band kernel left to the full kernels
+    DevBuf<mp_dp_task> band_tasks;
+    DevBuf<mp_dp_result> band_res;
+    DevBuf<mp_fill_result> band_fill;
+    uint64_t n_band = 0, n_band_full = 0;        // instances run through the band kernel / re-run by the full kernels
     DevBuf<mp_pair_hit> pair_hits;
     DevBuf<unsigned long long> n_pair_hits;
     uint64_t n_pair_hits_host = 0;
@@ -770,6 +776,82 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     return MP_OK;
 }
 
+// Deep-DP batches (windows = read + 2 x DP2_MARGIN) without tie counts or op strings: the band kernel decides every
+// instance whose best alignment provably stays inside the band (kernels_dp_band.hip), the rest go through the
+// score-only pre-pass and the full kernels.  Same results as run_dp.
+bool band_applicable(const mp_ctx *c, uint32_t max_win, int cl, int cr, bool count)
+{
+    static const bool off = getenv("MP_DP_BAND") && atoi(getenv("MP_DP_BAND")) == 0;
+    return !off && !count && c->max_len <= MP_BAND_MAXL && max_win <= MP_BAND_MAXL + MP_BAND_DMAX && cl >= MP_BAND_GB && cr >= MP_BAND_GB;
+}
+
+int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,
+                float *ms_fill, float *ms_trace)
+{
+    if (n == 0) return MP_OK;
+    hipStream_t s = c->stream;
+    const uint32_t ncols = c->max_len;
+    const size_t per_block = (size_t)ncols * MP_BAND_NW * 64 * 4;              // 64 instance pairs
+    if (c->slab_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 8ull << 30;
+        c->slab_budget = std::min<size_t>(24ull << 30, std::max<size_t>(2ull << 30, (free_b + c->flags.cap) / 4));
+    }
+    static uint32_t round_blocks = 0;
+    if (round_blocks == 0) {
+        int per_cu = 0, n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        round_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
+    }
+    const uint32_t n_blocks = (uint32_t)(((uint64_t)n + 127) / 128);
+    uint32_t chunk_blocks = (uint32_t)std::min<uint64_t>(n_blocks, std::max<uint64_t>(1, c->slab_budget / per_block));
+    if (chunk_blocks > round_blocks && chunk_blocks < n_blocks) chunk_blocks = chunk_blocks / round_blocks * round_blocks;
+    if (c->flags.reserve((size_t)chunk_blocks * per_block) || c->band_fill.reserve(n + 2) || c->band_flag.reserve(n + 2) || c->band_idx.reserve(n + 2))
+        return MP_ENOMEM;
+    const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
+    while (c->ev_pool.size() < 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    size_t ci = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks, ci++) {
+        const uint32_t off = b0 * 128u;
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>((uint64_t)chunk_blocks * 128u, n - off);
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci], s));
+        hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB>), dim3((cnt + 127) / 128), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                           d_tasks + off, cnt, cl, cr, (uint32_t *)c->flags.p, ncols, c->band_fill.p + off);
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
+        hipLaunchKernelGGL((dp_trace_kernel<16, 5, MP_BAND_W, MP_BAND_GB>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks + off, c->d_lens, cnt, cl, cr,
+                           (const uint32_t *)c->flags.p, ncols, c->band_fill.p + off, d_res + off, (uint8_t *)nullptr, 0u);
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
+    }
+    hipLaunchKernelGGL(dp_band_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_fill.p, n, c->band_flag.p);
+    {
+        size_t tmp_bytes = 0;
+        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, c->band_flag.p, c->band_idx.p, (int)n, s);
+        if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+        (void)hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, c->band_flag.p, c->band_idx.p, (int)n, s);
+    }
+    uint32_t n_sel = 0;
+    HIPCHK(hipMemcpyAsync(&n_sel, c->band_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t q = 0; q < n_chunks; q++) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, c->ev_pool[3 * q], c->ev_pool[3 * q + 1]);
+        (void)hipEventElapsedTime(&b, c->ev_pool[3 * q + 1], c->ev_pool[3 * q + 2]);
+        if (ms_fill) *ms_fill += a;
+        if (ms_trace) *ms_trace += b;
+    }
+    c->n_band += n; c->n_band_full += n_sel;
+    static const bool verbose = getenv("MP_DP_BAND_STATS") != nullptr;
+    if (verbose) fprintf(stderr, "[band] %u instances, %u left to the full kernels\n", n, n_sel);
+    if (n_sel == 0) return MP_OK;
+    if (c->band_tasks.reserve(n_sel + 2) || c->band_res.reserve(n_sel + 2)) return MP_ENOMEM;
+    hipLaunchKernelGGL(dp_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->band_flag.p, c->band_idx.p, n, c->band_tasks.p);
+    int rc = run_dp_filtered(c, c->band_tasks.p, n_sel, max_win, cl, cr, c->band_res.p, ms_fill, ms_trace, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dp_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_flag.p, c->band_idx.p, c->band_res.p, n, d_res);
+    return MP_OK;
+}
+
 }  // namespace
 
 extern "C" int mp_sgdp_batch(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int clip_left, int clip_right, mp_dp_result *out_results,
@@ -836,12 +918,15 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         if (c->tasks_l.reserve(nc) || c->tasks_r.reserve(nc) || c->res_l.reserve(nc) || c->res_r.reserve(nc) || c->pair_hits.reserve(nc)) return MP_ENOMEM;
         const uint32_t margin2 = 60;
         const uint32_t max_win = c->max_len + margin2;
+        const bool use_band = band_applicable(c, max_win, ap->clip_left, ap->clip_right, ap->want_tie_counts != 0);
         hipLaunchKernelGGL(build_left_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, c->tasks_l.p);
-        rc = run_dp(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
+        rc = use_band ? run_dp_band(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, &st.ms_dp_fill, &st.ms_dp_trace)
+                      : run_dp(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         hipLaunchKernelGGL(build_right_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, ap->insert_high,
                            c->tasks_l.p, c->res_l.p, c->tasks_r.p);
-        rc = run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
+        rc = use_band ? run_dp_band(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, &st.ms_dp_fill, &st.ms_dp_trace)
+                      : run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(c->n_pair_hits.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(collect_pair_hits_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,

@@ -401,7 +401,8 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 }
 
 // ------------------------------------------------------------------------------------------------ traceback
-template <int LPI, int C>
+// BW > 0: the slab was written by dp_band_kernel<BW, GB> (kernels_dp_band.hip): [block of 64 pairs][column][word][lane]
+template <int LPI, int C, int BW = 0, int GB = 0>
 __global__ void __launch_bounds__(64)
 dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, uint32_t n_tasks, int clip_left, int clip_right,
                 const uint32_t *__restrict__ flags, uint32_t flag_rows, const mp_fill_result *__restrict__ fill,
@@ -418,7 +419,9 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
     mp_dp_result res; res.score = 0; res.hit_loc = 0; res.max_score_count = 0; res.n_ops = 0;
     if (fr.score < cutoff || fr.score <= 0 || task.win_len == 0) { out[inst] = res; return; }
     res.max_score_count = fr.count;
-    const uint32_t *fpair = flags + (uint64_t)(inst >> 1) * flag_rows * (LPI * NW);
+    constexpr int NWB = (BW + 2) / 3;
+    const uint32_t *fpair = BW > 0 ? flags + (uint64_t)(inst >> 7) * flag_rows * (NWB * 64) + ((inst >> 1) & 63u)
+                                   : flags + (uint64_t)(inst >> 1) * flag_rows * (LPI * NW);
     const int half = (int)(inst & 1u) * 16;
     uint8_t *op = ops ? ops + (uint64_t)inst * ops_stride : nullptr;
     uint32_t n = 0;
@@ -427,6 +430,13 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
     auto cell = [&](int r, int c) -> uint32_t {
         if (c == 0) return TB_Z;
         if (r == 0) return c <= clipL ? TB_Z : 0u;
+        if (BW > 0) {
+            const int d = r - c + GB;
+            if (d < 0 || d >= BW) return 0u;          // never reached for an instance the band kernel qualified
+            const uint32_t w = fpair[((uint64_t)(c - 1) * NWB + (uint32_t)(d / 3)) * 64];
+            const uint32_t b = (w >> (half + 5 * (d % 3))) & 31u;
+            return (b & TBP_Z) | ((b ^ 30u) & 30u);
+        }
         const int lane = (c - 1) / C, cc = (c - 1) % C;
         const uint32_t w = fpair[((uint64_t)lane * flag_rows + (uint32_t)(r + lane - 1)) * NW + cc / 3];
         const uint32_t b = (w >> (half + 5 * (cc % 3))) & 31u;

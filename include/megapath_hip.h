@@ -180,6 +180,12 @@ typedef struct {
 /* Runs seeding (unless already done for this batch), pairing and both DP legs on the device.  The hits are kept in the
  * context until the next call; *out_n_hits receives their number. */
 int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n_hits, mp_round_stats *out_stats);
+/* Measurement / test aid.  The deep-DP legs of a text-mode round (no tie counts) run a banded fill kernel that decides
+ * every instance whose best alignment provably stays inside the band and leaves the rest to the full-table kernels; the
+ * results are identical either way.  on = 0 sends every instance through the full-table kernels.  The counters report
+ * how many instances went through the band kernel and how many of those were re-run, since the context was created. */
+int mp_ctx_set_dp_band(mp_ctx *ctx, int on);
+int mp_ctx_dp_band_stats(mp_ctx *ctx, uint64_t *out_n_band, uint64_t *out_n_full);
 int mp_get_pair_hits(mp_ctx *ctx, mp_pair_hit *out_hits, uint64_t cap);
 /* Same without a pageable copy: the hits land in a pinned buffer owned by the context (valid until the next call). */
 int mp_get_pair_hits_view(mp_ctx *ctx, const mp_pair_hit **out_hits, uint64_t *out_n);

@@ -51,6 +51,7 @@ struct mp_ctx {
     uint32_t n_reads = 0, W = 0, max_len = 0;
     size_t slab_budget = 0;          // bytes of traceback flags per DP launch (decided at the first DP call)
     bool use_prefilter = true;       // mp_ctx_set_prefilter
+    bool use_band = true;            // mp_ctx_set_dp_band
     bool seeded = false;
     // seeding
     DevBuf<mp_seed_rec> slabs, big_slabs;
@@ -593,6 +594,21 @@ extern "C" int mp_ctx_set_prefilter(mp_ctx *c, int on)
     return MP_OK;
 }
 
+extern "C" int mp_ctx_set_dp_band(mp_ctx *c, int on)
+{
+    if (!c) return MP_EINVAL;
+    c->use_band = on != 0;
+    return MP_OK;
+}
+
+extern "C" int mp_ctx_dp_band_stats(mp_ctx *c, uint64_t *out_n_band, uint64_t *out_n_full)
+{
+    if (!c) return MP_EINVAL;
+    if (out_n_band) *out_n_band = c->n_band;
+    if (out_n_full) *out_n_full = c->n_band_full;
+    return MP_OK;
+}
+
 extern "C" int mp_get_seeds(mp_ctx *c, mp_seedpos *out_seeds, uint64_t cap, uint64_t *out_offsets)
 {
     if (!c || !c->seeded || !out_offsets) return MP_EINVAL;
@@ -782,7 +798,7 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
 bool band_applicable(const mp_ctx *c, uint32_t max_win, int cl, int cr, bool count)
 {
     static const bool off = getenv("MP_DP_BAND") && atoi(getenv("MP_DP_BAND")) == 0;
-    return !off && !count && c->max_len <= MP_BAND_MAXL && max_win <= MP_BAND_MAXL + MP_BAND_DMAX && cl >= MP_BAND_GB && cr >= MP_BAND_GB;
+    return !off && c->use_band && !count && c->max_len <= MP_BAND_MAXL && max_win <= MP_BAND_MAXL + MP_BAND_DMAX && cl >= MP_BAND_GB && cr >= MP_BAND_GB;
 }
 
 int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,

@@ -17,7 +17,9 @@
 // Mapping: ONE LANE per instance pair (the two instances in the halves of packed 16-bit registers, as in dp_fill_kernel),
 // sweeping the read columns; the band's W cells of a column live in registers (H and F, in place), the vertical gap
 // state E is a running value.  No cross-lane traffic at all, ~31 VALU instructions per cell pair, 1 wave per SIMD.
-// Window base codes are staged in LDS as bytes ([instance][row][lane]: a wavefront reads 64 consecutive bytes).
+// Window base codes are staged in LDS, one byte per row and lane holding both instances' 4-bit codes ([row][lane]: a
+// wavefront reads 64 consecutive bytes); 16 KB per block keeps two waves per SIMD resident, which the dependent chain of
+// a single lane needs to fill the VALU.
 #pragma once
 
 #define MP_BAND_MAXL 160            // longest read the band kernel is instantiated for
@@ -74,7 +76,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     constexpr int NW = (W + 2) / 3;
     constexpr int R = MP_BAND_MAXL + W + 1;        // LDS rows: row i of the window sits at index i + GB
     constexpr int B = MP_DP_BIAS;
-    __shared__ uint8_t s_code[2][R][64];
+    __shared__ uint8_t s_code[R][64];                 // code of instance 0 | code of instance 1 << 4
     const int lane = threadIdx.x;
     const uint32_t pair = blockIdx.x * 64 + lane;
     int L[2], m[2], clipL[2], clipR[2], strand[2];
@@ -95,8 +97,8 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         fit[q] = live && L[q] >= 1 && L[q] <= MP_BAND_MAXL && m[q] >= 1 && m[q] - L[q] <= W - 1 - 2 * GB && m[q] + GB < R && clipL[q] >= GB;
         empty[q] = live && task.win_len == 0;          // nothing to align: decided, score 0 (as the full kernels report it)
         if (!fit[q]) { L[q] = 0; m[q] = 0; }
-        const uint8_t pad = q == 0 ? 12 : 15;
-        for (int r = 0; r < R; r++) s_code[q][r][lane] = pad;
+        if (q == 0)
+            for (int r = 0; r < R; r++) s_code[r][lane] = (uint8_t)(12 | (15 << 4));      // pads: match nothing
         for (int w = 0; w * 16 < m[q]; w++) {
             uint64_t p = task.win_start + 16ull * (uint64_t)w;
             uint32_t sh = 2 * (uint32_t)(p & 15);
@@ -104,7 +106,9 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             if (sh) two |= (uint64_t)text[(p >> 4) + 1] << 32;
             uint32_t bases = (uint32_t)(two >> sh);
             for (int x = 0; x < 16 && w * 16 + x < m[q]; x++) {
-                s_code[q][GB + 1 + w * 16 + x][lane] = (uint8_t)MP_DP_CODE(bases & 3u);
+                uint8_t &cell = s_code[GB + 1 + w * 16 + x][lane];
+                const uint32_t code = (uint32_t)MP_DP_CODE(bases & 3u);
+                cell = q == 0 ? (uint8_t)((cell & 0xF0u) | code) : (uint8_t)((cell & 0x0Fu) | (code << 4));
                 bases >>= 2;
             }
         }
@@ -153,11 +157,11 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         const v2s rb = pk(b2[0], b2[1]), floorv = pk(fl2[0], fl2[1]), thr = pk(th2[0], th2[1]);
         v2s Ec = sent, colcode = pk1(0), cnt = pk1(127);
         v2s fw = pk1(0);
-        const uint8_t *c0 = &s_code[0][j][lane], *c1 = &s_code[1][j][lane];
+        const uint8_t *c0 = &s_code[j][lane];
 #pragma unroll
         for (int d = 0; d < W; d++) {
-            v2s base;
-            base.x = (short)c0[d * 64]; base.y = (short)c1[d * 64];            // row j + d - GB of each window
+            const uint32_t cb = c0[d * 64];                                    // row j + d - GB of both windows
+            const v2s base = as_v2s((int)((cb | (cb << 12)) & 0x000F000Fu));
             v2s eo, fo, dg, t1, bits;
             const v2s Hc = d == 0 ? sent : H[d - 1];
             const v2s Hn = d + 1 < W ? H[d + 1] : sent;

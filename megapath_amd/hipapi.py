@@ -97,7 +97,7 @@ class IndexInfo(C.Structure):
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_ctx_create", "mp_ctx_destroy",
-           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
+           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
 
 
@@ -139,6 +139,8 @@ def load_library():
     lib.mp_index_seq_info.argtypes = [vp, C.c_uint32, u64p, u64p, u64p]
     lib.mp_index_fetch_text.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.mp_ctx_set_prefilter.argtypes = [vp, C.c_int]
+    lib.mp_ctx_set_dp_band.argtypes = [vp, C.c_int]
+    lib.mp_ctx_dp_band_stats.argtypes = [vp, u64p, u64p]
     lib.mp_ctx_create.argtypes = [vp, C.POINTER(vp)]
     lib.mp_ctx_destroy.argtypes = [vp]
     lib.mp_set_reads.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
@@ -308,6 +310,15 @@ class Context:
 
     def set_prefilter(self, on: bool):
         _chk(load_library().mp_ctx_set_prefilter(self._h, int(bool(on))), "mp_ctx_set_prefilter")
+
+    def set_dp_band(self, on: bool):
+        _chk(load_library().mp_ctx_set_dp_band(self._h, int(bool(on))), "mp_ctx_set_dp_band")
+
+    def dp_band_stats(self):
+        """(instances run through the band kernel, instances of those re-run by the full kernels)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _chk(load_library().mp_ctx_dp_band_stats(self._h, C.byref(a), C.byref(b)), "mp_ctx_dp_band_stats")
+        return int(a.value), int(b.value)
 
     def get_seeds(self):
         lib = load_library()

@@ -65,12 +65,16 @@ def _mutate(frag: np.ndarray, rng, sub: float, ins: float, dele: float) -> np.nd
 def simulate_pairs(seqs, n_pairs: int, read_len: int, seed: int, frag_mean: float = 350.0, frag_sd: float = 40.0,
                    frag_min: int = 200, frag_max: int = 600, sub: float = 0.01, ins: float = 0.0005,
                    dele: float = 0.0005, random_frac: float = 0.0, len_range=None, n_frac: float = 0.0,
-                   broken_mate_frac: float = 0.0, noisy_mate_frac: float = 0.0, noisy_sub: float = 0.2):
+                   broken_mate_frac: float = 0.0, noisy_mate_frac: float = 0.0, noisy_sub: float = 0.2,
+                   long_indel_frac: float = 0.0, long_indel_max: int = 24, junk_end_frac: float = 0.0, junk_end_max: int = 40):
     """Return (names, reads1, reads2) with reads as ASCII byte strings; FR orientation.
 
     `len_range=(lo,hi)` draws each mate's length uniformly (config C5); `random_frac` replaces whole
     pairs by random sequence; `broken_mate_frac` replaces one mate by random sequence; `noisy_mate_frac` gives one
-    mate extra substitutions at rate `noisy_sub` (too few exact seeds: only mate rescue can place it).
+    mate extra substitutions at rate `noisy_sub` (too few exact seeds: only mate rescue can place it);
+    `long_indel_frac` gives a mate one insertion or deletion of 2..`long_indel_max` bases (alignments far off the main
+    diagonal of their DP window); `junk_end_frac` replaces up to `junk_end_max` bases at one end of a mate by random
+    sequence (soft clips).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     lens = np.asarray([len(s[1]) for s in seqs], dtype=np.int64)
@@ -93,8 +97,30 @@ def simulate_pairs(seqs, n_pairs: int, read_len: int, seed: int, frag_mean: floa
             frag = _mutate(text[pos:pos + flen], rng, sub, ins, dele)
             if len(frag) < max(l1, l2):
                 frag = np.concatenate([frag, _BASES[rng.integers(0, 4, size=max(l1, l2) - len(frag))]])
+            if long_indel_frac > 0 and rng.random() < long_indel_frac and len(frag) > 2 * long_indel_max + 40:
+                k = int(rng.integers(2, long_indel_max + 1))
+                at = int(rng.integers(10, max(l1, l2) - 10)) if rng.random() < 0.5 else len(frag) - int(rng.integers(10, max(l1, l2) - 10))
+                at = min(max(at, 5), len(frag) - k - 5)
+                if rng.random() < 0.5:
+                    frag = np.concatenate([frag[:at], frag[at + k:]])                                   # deletion from the read
+                else:
+                    frag = np.concatenate([frag[:at], _BASES[rng.integers(0, 4, size=k)], frag[at:]])      # insertion
+                if len(frag) < max(l1, l2):
+                    frag = np.concatenate([frag, _BASES[rng.integers(0, 4, size=max(l1, l2) - len(frag))]])
             a = frag[:l1]
             b = _COMP[frag[len(frag) - l2:]][::-1]
+            if junk_end_frac > 0 and rng.random() < junk_end_frac:
+                k = int(rng.integers(3, junk_end_max + 1))
+                pick_a = rng.random() < 0.5
+                tgt = (a if pick_a else b).copy()
+                if rng.random() < 0.5:
+                    tgt[:k] = _BASES[rng.integers(0, 4, size=k)]
+                else:
+                    tgt[len(tgt) - k:] = _BASES[rng.integers(0, 4, size=k)]
+                if pick_a:
+                    a = tgt
+                else:
+                    b = tgt
             if rng.random() < 0.5:
                 a, b = b, a
             if broken_mate_frac > 0 and rng.random() < broken_mate_frac:

@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-RX="gather64_kernel|seed_kernel|seed_overflow_kernel|locate_kernel|expand_hits_kernel|dp_fill_kernel"
+RX="gather64_kernel|seed_kernel|seed_overflow_kernel|locate_kernel|expand_hits_kernel|dp_fill_kernel|dp_band_kernel"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$RX" --output-format csv -d $OUT/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/fetch.err

@@ -36,6 +36,11 @@ def _build(tmp_path, genome):
     dict(tag="noisy", n_bases=600000, n_seqs=40, n_pairs=3000, read_len=150, L=151, sim=dict(sub=0.02, ins=0.002, dele=0.002, random_frac=0.03,
                                                                                           broken_mate_frac=0.05, noisy_mate_frac=0.4, noisy_sub=0.2,
                                                                                           n_frac=0.001)),
+    # long indels and junk ends: alignments far off the window's main diagonal -- the banded DP kernel must hand exactly
+    # the right instances to the full-table kernels; mixed lengths <= 150 exercise both DP margins (25 / 30)
+    dict(tag="gappy", n_bases=700000, n_seqs=4, n_pairs=4000, read_len=150, L=151, sim=dict(sub=0.01, ins=0.002, dele=0.002, random_frac=0.02,
+                                                                                         broken_mate_frac=0.05, long_indel_frac=0.5, long_indel_max=26,
+                                                                                         junk_end_frac=0.3, junk_end_max=45, len_range=(90, 150))),
 ])
 def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg, monkeypatch):
     monkeypatch.setenv("MP_KMER_FILTER", "1")          # the in-process run uses the 17-mer pre-filter and the denser SA
@@ -142,4 +147,42 @@ def test_batch_scale_properties():
     b, _ = run(P // 3, P)
     assert np.array_equal(full, np.concatenate([a, b]))
     assert st.seed.n_occ > 0 and st.n_candidates >= P
+    gix.close()
+
+
+@pytest.mark.parametrize("clips,banded", [((130, 130), True), ((40, 13), True), ((13, 60), True), ((12, 130), False)])
+def test_banded_dp_kernel_changes_nothing(tmp_path, clips, banded):
+    """The deep-DP legs with the banded fill kernel (plus full-table fallback) against the full-table kernels alone, on
+    reads with long indels and junk ends: the same hit set (positions, scores, windows) in every field, for several
+    soft-clip limits -- below MP_BAND_GB the band path must not engage at all."""
+    genome = synth.random_genome(500000, 611, n_seqs=3, repeat_frac=0.1)
+    arrs = index_builder.build_index_arrays(genome, sa_interval=16)
+    gix = H.Index.from_arrays(0, **arrs)
+    names, r1, r2 = synth.simulate_pairs(genome, 3000, 150, 612, sub=0.01, ins=0.002, dele=0.002, random_frac=0.02, long_indel_frac=0.5,
+                                         long_indel_max=26, junk_end_frac=0.3, junk_end_max=45, len_range=(90, 150))
+    seqs = [x for pr in zip(r1, r2) for x in pr]
+    packed, lens, W = H.pack_reads(seqs, 151)
+
+    def run(band):
+        ctx = H.Context(gix)
+        ctx.set_reads(packed, lens)
+        ctx.set_dp_band(band)
+        ap = H.AlignParams(1, 750, clips[0], clips[1], H.MmpParams.nt2())
+        hits, nh, st = ctx.deep_dp_round(ap)
+        got = sorted((h.pair_id, h.left_is_mate, h.algnmt_1, h.algnmt_2, h.score_1, h.score_2, h.start_1, h.start_2, h.dplen_1, h.dplen_2)
+                     for h in hits[:nh])
+        stats = ctx.dp_band_stats()
+        ctx.close()
+        return got, stats, st
+    full, s_full, st_full = run(False)
+    band, s_band, st_band = run(True)
+    assert s_full == (0, 0)
+    assert len(full) > 1500
+    assert band == full
+    assert st_band.n_candidates == st_full.n_candidates
+    if banded:
+        assert s_band[0] == 2 * st_band.n_candidates      # both legs of every candidate went through the band kernel
+        assert 0 < s_band[1] < s_band[0] // 2            # some, not most, instances needed the full table
+    else:
+        assert s_band == (0, 0)
     gix.close()

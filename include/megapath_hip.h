@@ -180,7 +180,7 @@ typedef struct {
 /* Runs seeding (unless already done for this batch), pairing and both DP legs on the device.  The hits are kept in the
  * context until the next call; *out_n_hits receives their number. */
 int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n_hits, mp_round_stats *out_stats);
-/* Measurement / test aid.  The deep-DP legs of a text-mode round (no tie counts) run a banded fill kernel that decides
+/* Measurement / test aid.  The deep-DP legs of a round run a banded fill kernel that decides
  * every instance whose best alignment provably stays inside the band and leaves the rest to the full-table kernels; the
  * results are identical either way.  on = 0 sends every instance through the full-table kernels.  The counters report
  * how many instances went through the band kernel and how many of those were re-run, since the context was created. */

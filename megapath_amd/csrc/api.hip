@@ -792,17 +792,17 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     return MP_OK;
 }
 
-// Deep-DP batches (windows = read + 2 x DP2_MARGIN) without tie counts or op strings: the band kernel decides every
+// Deep-DP batches (windows = read + 2 x DP2_MARGIN) without op strings: the band kernel decides every
 // instance whose best alignment provably stays inside the band (kernels_dp_band.hip), the rest go through the
 // score-only pre-pass and the full kernels.  Same results as run_dp.
-bool band_applicable(const mp_ctx *c, uint32_t max_win, int cl, int cr, bool count)
+bool band_applicable(const mp_ctx *c, uint32_t max_win, int cl, int cr)
 {
     static const bool off = getenv("MP_DP_BAND") && atoi(getenv("MP_DP_BAND")) == 0;
-    return !off && c->use_band && !count && c->max_len <= MP_BAND_MAXL && max_win <= MP_BAND_MAXL + MP_BAND_DMAX && cl >= MP_BAND_GB && cr >= MP_BAND_GB;
+    return !off && c->use_band && c->max_len <= MP_BAND_MAXL && max_win <= MP_BAND_MAXL + MP_BAND_DMAX && cl >= MP_BAND_GB && cr >= MP_BAND_GB;
 }
 
 int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,
-                float *ms_fill, float *ms_trace)
+                float *ms_fill, float *ms_trace, bool count)
 {
     if (n == 0) return MP_OK;
     hipStream_t s = c->stream;
@@ -862,7 +862,7 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     if (n_sel == 0) return MP_OK;
     if (c->band_tasks.reserve(n_sel + 2) || c->band_res.reserve(n_sel + 2)) return MP_ENOMEM;
     hipLaunchKernelGGL(dp_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->band_flag.p, c->band_idx.p, n, c->band_tasks.p);
-    int rc = run_dp_filtered(c, c->band_tasks.p, n_sel, max_win, cl, cr, c->band_res.p, ms_fill, ms_trace, false);
+    int rc = run_dp_filtered(c, c->band_tasks.p, n_sel, max_win, cl, cr, c->band_res.p, ms_fill, ms_trace, count);
     if (rc) return rc;
     hipLaunchKernelGGL(dp_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_flag.p, c->band_idx.p, c->band_res.p, n, d_res);
     return MP_OK;
@@ -934,14 +934,14 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         if (c->tasks_l.reserve(nc) || c->tasks_r.reserve(nc) || c->res_l.reserve(nc) || c->res_r.reserve(nc) || c->pair_hits.reserve(nc)) return MP_ENOMEM;
         const uint32_t margin2 = 60;
         const uint32_t max_win = c->max_len + margin2;
-        const bool use_band = band_applicable(c, max_win, ap->clip_left, ap->clip_right, ap->want_tie_counts != 0);
+        const bool use_band = band_applicable(c, max_win, ap->clip_left, ap->clip_right);
         hipLaunchKernelGGL(build_left_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, c->tasks_l.p);
-        rc = use_band ? run_dp_band(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, &st.ms_dp_fill, &st.ms_dp_trace)
+        rc = use_band ? run_dp_band(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0)
                       : run_dp(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         hipLaunchKernelGGL(build_right_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, ap->insert_high,
                            c->tasks_l.p, c->res_l.p, c->tasks_r.p);
-        rc = use_band ? run_dp_band(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, &st.ms_dp_fill, &st.ms_dp_trace)
+        rc = use_band ? run_dp_band(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0)
                       : run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(c->n_pair_hits.p, 0, sizeof(unsigned long long), s));

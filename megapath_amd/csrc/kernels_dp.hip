@@ -434,8 +434,9 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
             const int d = r - c + GB;
             if (d < 0 || d >= BW) return 0u;          // never reached for an instance the band kernel qualified
             const uint32_t w = fpair[((uint64_t)(c - 1) * NWB + (uint32_t)(d / 3)) * 64];
-            const uint32_t b = (w >> (half + 5 * (d % 3))) & 31u;
-            return (b & TBP_Z) | ((b ^ 30u) & 30u);
+            // the band kernel shifts its bits in: first cell of a word highest, within a cell Z, nD, nE, nEO, nFO from the top
+            const uint32_t b = (w >> (half + 5 * (2 - d % 3))) & 31u;
+            return ((b >> 4) & 1u) | ((~b & 8u) >> 2) | (~b & 4u) | ((~b & 2u) << 2) | ((~b & 1u) << 4);
         }
         const int lane = (c - 1) / C, cc = (c - 1) % C;
         const uint32_t w = fpair[((uint64_t)lane * flag_rows + (uint32_t)(r + lane - 1)) * NW + cc / 3];

@@ -10,8 +10,8 @@
 //   as well (the rows below the cell are too few).  The band holds every cell with -GB <= delta <= W - 1 - GB, cells
 //   outside it are treated as minus infinity, so every banded value is a lower bound of the true one and exact whenever
 //   the best path to that cell stays inside.  If the banded best score S satisfies S >= L - GB then no path leaving the
-//   band can tie or beat it: the true best cell (first maximum by row, then column), every value on its optimal path and every
-//   tie the traceback bits record are identical to the full table's.  Instances that do not reach that score (or whose
+//   band can tie or beat it: the true best cell (first maximum by row, then column), the number of cells sharing its score,
+//   every value on its optimal path and every tie the traceback bits record are identical to the full table's.  Instances that do not reach that score (or whose
 //   shape does not fit the band) are marked and re-run by the full kernel -- see run_dp_band in api.hip.
 //
 // Mapping: ONE LANE per instance pair (the two instances in the halves of packed 16-bit registers, as in dp_fill_kernel),
@@ -48,23 +48,23 @@
         "v_pk_max_u16 %[Hd], %[t1], %[floorv]\n\t"                /* H */ \
         "v_xor_b32 %[bits], %[Hd], %[t1]\n\t" \
         "v_pk_min_u16 %[bits], %[bits], %[k1]\n\t" \
-        "v_pk_mad_i16 %[fw], %[bits], %[wz], %[fw]\n\t"           /* Z */ \
+        "v_pk_mad_u16 %[fw], %[fw], %[k2], %[bits]\n\t"           /* Z: the word is built by shifting the bits in */ \
         "v_xor_b32 %[t1], %[Hd], %[dg]\n\t" \
         "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
-        "v_pk_mad_i16 %[fw], %[t1], %[wd], %[fw]\n\t"             /* nD */ \
+        "v_pk_mad_u16 %[fw], %[fw], %[k2], %[t1]\n\t"             /* nD */ \
         "v_xor_b32 %[t1], %[Hd], %[Ec]\n\t" \
         "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
-        "v_pk_mad_i16 %[fw], %[t1], %[we], %[fw]\n\t"             /* nE */ \
+        "v_pk_mad_u16 %[fw], %[fw], %[k2], %[t1]\n\t"             /* nE */ \
         "v_xor_b32 %[t1], %[Ec], %[eo]\n\t" \
         "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
-        "v_pk_mad_i16 %[fw], %[t1], %[weo], %[fw]\n\t"            /* nEO */ \
+        "v_pk_mad_u16 %[fw], %[fw], %[k2], %[t1]\n\t"            /* nEO */ \
         "v_xor_b32 %[t1], %[Fd], %[fo]\n\t" \
         "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
-        "v_pk_mad_i16 %[fw], %[t1], %[wfo], %[fw]\n\t"            /* nFO */ \
-        "v_pk_sub_u16 %[t1], %[Hd], %[thr] clamp\n\t"             /* score above the qualifying threshold, 0 below it */ \
-        "v_pk_mad_u16 %[t1], %[t1], %[k128], %[cnt]\n\t"          /* (excess << 7) | (127 - d): first maximum of the column */ \
-        "v_pk_max_u16 %[colcode], %[colcode], %[t1]\n\t" \
-        "v_sub_u32 %[cnt], %[cnt], %[k1]"
+        "v_pk_mad_u16 %[fw], %[fw], %[k2], %[t1]\n\t"            /* nFO */ \
+        "v_pk_max_u16 %[colmax], %[colmax], %[Hd]"                /* the column's maximum; its row is looked for only when it matters */
+
+MP_PKOP2(pk_maxu, "v_pk_max_u16")
+__device__ __forceinline__ v2s pk_subsat(v2s a, v2s b) { v2s r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 template <int W, int GB>
 __global__ void __launch_bounds__(64)
@@ -74,38 +74,39 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
                mp_fill_result *__restrict__ out)
 {
     constexpr int NW = (W + 2) / 3;
+    static_assert(W % 3 == 0, "three cells per 16-bit half of a flag word");
     constexpr int R = MP_BAND_MAXL + W + 1;        // LDS rows: row i of the window sits at index i + GB
     constexpr int B = MP_DP_BIAS;
     __shared__ uint8_t s_code[R][64];                 // code of instance 0 | code of instance 1 << 4
     const int lane = threadIdx.x;
     const uint32_t pair = blockIdx.x * 64 + lane;
-    int L[2], m[2], clipL[2], clipR[2], strand[2];
-    uint32_t rid[2];
-    bool fit[2], empty[2];
+    // per-instance state, packed to keep the register budget for the band: L | m << 8 | forward << 16 | fit << 17 |
+    // empty << 18 | bad << 19
+    uint32_t info[2], rid[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const uint32_t inst = 2 * pair + q;
         mp_dp_task task; task.read_id = 0; task.strand = 1; task.win_start = 0; task.win_len = 0; task.reserved = 0;
         const bool live = inst < n_tasks;
         if (live) task = tasks[inst];
-        L[q] = live ? (int)lens[task.read_id] : 0;
-        m[q] = (int)task.win_len;
-        strand[q] = (int)task.strand; rid[q] = task.read_id;
-        clipL[q] = task.strand == 1 ? clip_left : clip_right;
-        clipR[q] = task.strand == 1 ? clip_right : clip_left;
+        int L = live ? (int)lens[task.read_id] : 0;
+        int m = (int)task.win_len;
+        rid[q] = task.read_id;
+        const int clipL = task.strand == 1 ? clip_left : clip_right;
         // the band covers this instance: read short enough, window surplus inside the band, rows <= 0 only under the left clip
-        fit[q] = live && L[q] >= 1 && L[q] <= MP_BAND_MAXL && m[q] >= 1 && m[q] - L[q] <= W - 1 - 2 * GB && m[q] + GB < R && clipL[q] >= GB;
-        empty[q] = live && task.win_len == 0;          // nothing to align: decided, score 0 (as the full kernels report it)
-        if (!fit[q]) { L[q] = 0; m[q] = 0; }
+        const bool fit = live && L >= 30 && L <= MP_BAND_MAXL && m >= 1 && m - L <= W - 1 - 2 * GB && m + GB < R && clipL >= GB;
+        const bool empty = live && task.win_len == 0;  // nothing to align: decided, score 0 (as the full kernels report it)
+        if (!fit) { L = 0; m = 0; }
+        info[q] = (uint32_t)L | ((uint32_t)m << 8) | (task.strand == 1 ? 1u << 16 : 0u) | (fit ? 1u << 17 : 0u) | (empty ? 1u << 18 : 0u);
         if (q == 0)
             for (int r = 0; r < R; r++) s_code[r][lane] = (uint8_t)(12 | (15 << 4));      // pads: match nothing
-        for (int w = 0; w * 16 < m[q]; w++) {
+        for (int w = 0; w * 16 < m; w++) {
             uint64_t p = task.win_start + 16ull * (uint64_t)w;
             uint32_t sh = 2 * (uint32_t)(p & 15);
             uint64_t two = (uint64_t)text[p >> 4];
             if (sh) two |= (uint64_t)text[(p >> 4) + 1] << 32;
             uint32_t bases = (uint32_t)(two >> sh);
-            for (int x = 0; x < 16 && w * 16 + x < m[q]; x++) {
+            for (int x = 0; x < 16 && w * 16 + x < m; x++) {
                 uint8_t &cell = s_code[GB + 1 + w * 16 + x][lane];
                 const uint32_t code = (uint32_t)MP_DP_CODE(bases & 3u);
                 cell = q == 0 ? (uint8_t)((cell & 0xF0u) | code) : (uint8_t)((cell & 0x0Fu) | (code << 4));
@@ -113,24 +114,19 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             }
         }
     }
-    int Lw = L[0] > L[1] ? L[0] : L[1];
+    int Lw = (int)max(info[0] & 255u, info[1] & 255u);
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(Lw, o); Lw = v > Lw ? v : Lw; }
     __syncthreads();
 
     dp_consts K;
     K.k1 = pk1(1); K.k2 = pk1(2); K.k3 = pk1(3); K.k4 = pk1(4); K.k16 = pk1(16);
-    const v2s k128 = pk1(128);
-    dp_weights Wt[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        Wt[q].z = pk1((short)(TBP_Z << (5 * q))); Wt[q].d = pk1((short)(TBP_ND << (5 * q))); Wt[q].e = pk1((short)(TBP_NE << (5 * q)));
-        Wt[q].eo = pk1((short)(TBP_NEO << (5 * q))); Wt[q].fo = pk1((short)(TBP_NFO << (5 * q)));
-    }
     v2s H[W], F[W];
 #pragma unroll
     for (int d = 0; d < W; d++) { H[d] = pk1((short)B); F[d] = pk1(MP_DP_SENT); }     // column 0: H = 0, no insertion state
     const v2s sent = pk1(MP_DP_SENT);
-    int bu[2] = {0, 0}, brow[2] = {0, 0}, bcol[2] = {0, 0};
+    // best so far: key = excess score << 16 | 0xFFFF - row (larger score, then smaller row; columns ascend), and
+    // column | ties << 8
+    uint32_t key[2] = {0, 0}, colties[2] = {0, 0};
     uint32_t rw[2] = {0, 0};                                  // 16 read bases of each instance
     uint32_t *fcol = flags + (uint64_t)blockIdx.x * ncols * (NW * 64) + lane;
 
@@ -139,28 +135,36 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             // read base of column j in alignment orientation (packRead, DV-DPfunctions.cpp:3009-3040)
-            const int p = strand[q] == 1 ? j - 1 : L[q] - j;
+            const int L = (int)(info[q] & 255u);
+            const bool fwd = (info[q] >> 16) & 1u;
+            const int clipL = fwd ? clip_left : clip_right, clipR = fwd ? clip_right : clip_left;
+            const int p = fwd ? j - 1 : L - j;
             int b = 9 + q;
-            if (j <= L[q]) {
+            if (j <= L) {
                 const uint32_t *rd = reads + (uint64_t)rid[q] * Wr;
-                if (j == 1 || (strand[q] == 1 ? (p & 15) == 0 : (p & 15) == 15)) rw[q] = rd[p >> 4];
+                if (j == 1 || (fwd ? (p & 15) == 0 : (p & 15) == 15)) rw[q] = rd[p >> 4];
                 b = (int)((rw[q] >> (2 * (p & 15))) & 3u);
-                if (strand[q] != 1) b = 3 - b;
+                if (!fwd) b = 3 - b;
                 b = MP_DP_CODE(b);
             }
             b2[q] = (short)b;
-            fl2[q] = (short)(j <= clipL[q] ? B - j : 0);
-            th2[q] = (short)(L[q] - GB - 1 + B - j);          // score L - GB - 1 in this column's frame
-            int mc = L[q] - clipR[q]; if (mc < 0) mc = 0;
-            el2[q] = (short)((j >= mc && j <= L[q]) ? -1 : 0);
+            fl2[q] = (short)(j <= clipL ? B - j : 0);
+            th2[q] = (short)(L - GB - 1 + B - j);             // score L - GB - 1 in this column's frame
+            int mc = L - clipR; if (mc < 0) mc = 0;
+            el2[q] = (short)((j >= mc && j <= L) ? -1 : 0);
         }
         const v2s rb = pk(b2[0], b2[1]), floorv = pk(fl2[0], fl2[1]), thr = pk(th2[0], th2[1]);
-        v2s Ec = sent, colcode = pk1(0), cnt = pk1(127);
+        v2s Ec = sent, colmax = pk1(0);
         v2s fw = pk1(0);
         const uint8_t *c0 = &s_code[j][lane];
+        constexpr int PF = 4;                                                   // LDS bytes are fetched this many cells ahead
+        uint32_t cbq[W + PF];
+#pragma unroll
+        for (int d = 0; d < PF; d++) cbq[d] = c0[d * 64];
 #pragma unroll
         for (int d = 0; d < W; d++) {
-            const uint32_t cb = c0[d * 64];                                    // row j + d - GB of both windows
+            if (d + PF < W) cbq[d + PF] = c0[(d + PF) * 64];
+            const uint32_t cb = cbq[d];                                         // row j + d - GB of both windows
             const v2s base = as_v2s((int)((cb | (cb << 12)) & 0x000F000Fu));
             v2s eo, fo, dg, t1, bits;
             const v2s Hc = d == 0 ? sent : H[d - 1];
@@ -168,21 +172,47 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             const v2s Fn = d + 1 < W ? F[d + 1] : sent;
             asm(MP_BAND_CELL
                 : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [bits] "=&v"(bits), [Hd] "+&v"(H[d]), [Ec] "+&v"(Ec),
-                  [Fd] "=&v"(F[d]), [fw] "+&v"(fw), [colcode] "+&v"(colcode), [cnt] "+&v"(cnt)
-                : [Hc] "v"(Hc), [Hn] "v"(Hn), [Fn] "v"(Fn), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv), [thr] "v"(thr),
-                  [k1] "v"(K.k1), [k2] "v"(K.k2), [k3] "v"(K.k3), [k4] "v"(K.k4), [k128] "v"(k128),
-                  [wz] "v"(Wt[d % 3].z), [wd] "v"(Wt[d % 3].d), [we] "v"(Wt[d % 3].e), [weo] "v"(Wt[d % 3].eo), [wfo] "v"(Wt[d % 3].fo));
+                  [Fd] "=&v"(F[d]), [fw] "+&v"(fw), [colmax] "+&v"(colmax)
+                : [Hc] "v"(Hc), [Hn] "v"(Hn), [Fn] "v"(Fn), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
+                  [k1] "v"(K.k1), [k2] "v"(K.k2), [k3] "v"(K.k3), [k4] "v"(K.k4));
             if (d % 3 == 2 || d == W - 1) {
                 fcol[(uint64_t)(j - 1) * (NW * 64) + (d / 3) * 64] = __builtin_bit_cast(uint32_t, fw);
                 fw = pk1(0);
             }
         }
-        // first maximum of this column against the best so far: larger score, then smaller row (columns ascend)
+        // Does this column hold an eligible value at or above the qualifying score?  Only the last GB or so columns of a
+        // read can; there the band is walked once more for the first row of the maximum and the number of its ties.
+        const v2s ex = pk_subsat(colmax, thr) & pk(el2[0], el2[1]);
+        if (__any(as_int(ex) != 0)) {
+            short lim2[2];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int code = (int)(unsigned short)(q == 0 ? colcode.x : colcode.y) & (int)(unsigned short)el2[q];
-            const int u = code >> 7, row = j + (127 - (code & 127)) - GB;
-            if (u > bu[q] || (u == bu[q] && u > 0 && row < brow[q])) { bu[q] = u; brow[q] = row; bcol[q] = j; }
+            for (int q = 0; q < 2; q++) {                      // rows past the window's end (d > m - j + GB) do not count
+                int lim = 127 - ((int)((info[q] >> 8) & 255u) - j + GB);
+                lim2[q] = (short)(lim < 0 ? 0 : (lim > 128 ? 128 : lim));
+            }
+            const v2s lim = pk(lim2[0], lim2[1]);
+            v2s cntv = pk1(127), first = pk1(0), neq = pk1(0);
+#pragma unroll
+            for (int d = 0; d < W; d++) {
+                // opaque packed ops: the optimiser would otherwise unpack this into per-half compares and selects
+                const v2s b = pk_minu((H[d] ^ colmax) | pk_subsat(lim, cntv), K.k1);   // 0: equals the maximum, inside the window
+                neq = as_v2s(as_int(neq) + as_int(b));
+                first = pk_maxu(first, pk_sub(b, K.k1) & cntv);
+                cntv = as_v2s(as_int(cntv) - as_int(K.k1));
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int u = (int)(unsigned short)(q == 0 ? ex.x : ex.y);
+                if (u == 0) continue;
+                const int ties = W - (int)(unsigned short)(q == 0 ? neq.x : neq.y);
+                const int row = j + (127 - (int)(unsigned short)(q == 0 ? first.x : first.y)) - GB;
+                if (ties == 0) { info[q] |= 1u << 19; continue; }      // the column's maximum sits on a pad row: leave it to the full table
+                const uint32_t k2 = ((uint32_t)u << 16) | (uint32_t)(0xFFFF - row);
+                const uint32_t told = (key[q] >> 16) == (uint32_t)u ? colties[q] >> 8 : 0u;
+                const uint32_t tnew = min(told + (uint32_t)ties, 0xFFFFu);
+                if (k2 > key[q]) { key[q] = k2; colties[q] = (uint32_t)j | (tnew << 8); }
+                else if ((key[q] >> 16) == (uint32_t)u) colties[q] = (colties[q] & 255u) | (tnew << 8);
+            }
         }
     }
 #pragma unroll
@@ -192,9 +222,13 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         mp_fill_result r;
         // score -1: "not decided by the band" -- below the qualifying score, outside the band's shape, or the first
         // maximum fell on a pad row past the window
-        const bool ok = fit[q] && bu[q] >= 1 && brow[q] >= 1 && brow[q] <= m[q];
-        r.score = ok ? bu[q] + L[q] - GB - 1 : (empty[q] ? 0 : -1);
-        r.row = ok ? (uint16_t)brow[q] : 0; r.col = ok ? (uint16_t)bcol[q] : 0; r.count = 0;
+        const int L = (int)(info[q] & 255u), m = (int)((info[q] >> 8) & 255u);
+        const int u = (int)(key[q] >> 16), row = 0xFFFF - (int)(key[q] & 0xFFFFu);
+        const uint32_t ties = colties[q] >> 8;
+        const bool ok = ((info[q] >> 17) & 1u) && !((info[q] >> 19) & 1u) && u >= 1 && row >= 1 && row <= m;
+        r.score = ok ? u + L - GB - 1 : (((info[q] >> 18) & 1u) ? 0 : -1);
+        r.row = ok ? (uint16_t)row : 0; r.col = ok ? (uint16_t)(colties[q] & 255u) : 0;
+        r.count = ok ? (ties > 255u ? 255u : ties) : 0u;       // num_sameScore, capped as in dp_fill_kernel
         out[inst] = r;
     }
 }

@@ -568,7 +568,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
         hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, dix, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
                            c->ctr.p);
     HIPCHK(hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, 128)), dim3(128), 0, s, c->hits.p, c->rs_base.p, n_reads, P, c->seedpos.p, c->n_pos.p,
+    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_BLOCK), 0, s, c->hits.p, c->rs_base.p, n_reads, P, c->seedpos.p, c->n_pos.p,
                        c->n_neg.p, c->ctr.p);
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
@@ -862,7 +862,8 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     if (n_sel == 0) return MP_OK;
     if (c->band_tasks.reserve(n_sel + 2) || c->band_res.reserve(n_sel + 2)) return MP_ENOMEM;
     hipLaunchKernelGGL(dp_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->band_flag.p, c->band_idx.p, n, c->band_tasks.p);
-    int rc = run_dp_filtered(c, c->band_tasks.p, n_sel, max_win, cl, cr, c->band_res.p, ms_fill, ms_trace, count);
+    // what the band leaves over are mostly real alignments with several differences: no score-only pre-pass for them
+    int rc = run_dp(c, c->band_tasks.p, n_sel, max_win, cl, cr, c->band_res.p, nullptr, 0, ms_fill, ms_trace, count);
     if (rc) return rc;
     hipLaunchKernelGGL(dp_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_flag.p, c->band_idx.p, c->band_res.p, n, d_res);
     return MP_OK;

@@ -502,17 +502,11 @@ __device__ void sort_hits(mp_seed_hit *a, int n)
     }
 }
 
-// Output: seedpos[read_base[r] .. ) holds the kept seeds of read r, '+' first; n_pos[r], n_neg[r] their counts.
-__global__ void __launch_bounds__(128)
-merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P,
-             mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
+// seed merging of one read (DV-DPfunctions.cpp:2470-2560): h[0..n) are its located seed hits, out receives the kept ones.
+// out may alias h: entry k of out is written only after hits 0..k have been consumed.
+__device__ __forceinline__ void merge_read(mp_seed_hit *h, int n, mp_seedpos *out, uint32_t r, const mp_dev_mmp &P,
+                                           uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint32_t base = rs_base[2 * r];
-    const int n = (int)(rs_base[2 * r + 2] - base);
-    mp_seed_hit *h = hits + base;
-    mp_seedpos *out = seedpos + base;
     sort_hits(h, n);
     uint32_t max_cov = 0;
     int n_kept = 0;
@@ -523,29 +517,27 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_bas
         int g0 = m;
         // group while next.offset <= first.offset + indelFuzz on the same strand (DV-DPfunctions.cpp:2514)
         while (m + 1 < n && h[m + 1].strand == strand && h[m + 1].offset <= pos + (uint64_t)P.indel_fuzz) m++;
-        // covered read length = union of [qo, qo+len) over the group: intervals taken in ascending (qo, end) order
-        uint32_t total = 0, cs = 0, ce = 0;
-        uint32_t prev_lo = 0, prev_hi = 0;
-        bool first = true;
-        for (int cnt = g0; cnt <= m; cnt++) {
-            // select the next interval in (qo, end) order without allocating: groups are tiny (<= 31 * few seeds)
-            uint32_t best_lo = 0xFFFFFFFFu, best_hi = 0xFFFFFFFFu;
-            int same = 0;
-            for (int q = g0; q <= m; q++) {
-                uint32_t lo = h[q].qo, hi = (uint32_t)h[q].length + h[q].qo;
-                bool after_prev = first || lo > prev_lo || (lo == prev_lo && hi > prev_hi);
-                if (!after_prev) continue;
-                if (lo < best_lo || (lo == best_lo && hi < best_hi)) { best_lo = lo; best_hi = hi; }
-            }
-            if (best_lo == 0xFFFFFFFFu) break;           // remaining intervals are duplicates of ones already taken
-            (void)same;
-            if (best_lo >= ce) { total += ce - cs; cs = best_lo; }
-            if (best_hi > ce) ce = best_hi;
-            prev_lo = best_lo; prev_hi = best_hi; first = false;
-        }
-        total += ce - cs;
-        for (int q = g0; q <= m; q++)
+        // covered read length = size of the union of [qo, qo+len) over the group (DV-DPfunctions.cpp:2518-2531 walks the
+        // intervals in (qo, end) order and adds up the merged runs): a bitmap over the read positions, linear in the
+        // group size -- repeat-rich reads have groups of hundreds of hits
+        uint64_t cov[MP_SEED_BIG / 64];
+#pragma unroll
+        for (int w = 0; w < MP_SEED_BIG / 64; w++) cov[w] = 0;
+        for (int q = g0; q <= m; q++) {
+            const int lo = (int)h[q].qo, hi = lo + (int)h[q].length;
             has_unique |= (int)h[q].mult <= P.uniq_threshold && (int)h[q].length >= P.seed_min_length;
+#pragma unroll
+            for (int w = 0; w < MP_SEED_BIG / 64; w++) {
+                int a = lo - 64 * w, e = hi - 64 * w;
+                a = a < 0 ? 0 : (a > 64 ? 64 : a);
+                e = e < 0 ? 0 : (e > 64 ? 64 : e);
+                const uint64_t below_e = e >= 64 ? ~0ull : ((1ull << e) - 1ull), below_a = a >= 64 ? ~0ull : ((1ull << a) - 1ull);
+                cov[w] |= below_e & ~below_a;
+            }
+        }
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < MP_SEED_BIG / 64; w++) total += (uint32_t)__popcll(cov[w]);
         if (max_cov < total) max_cov = total;
         if (has_unique || total >= (uint32_t)P.good_seed_len) {
             mp_seedpos sp;
@@ -567,6 +559,44 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_bas
     n_pos[r] = (uint32_t)np;
     n_neg[r] = (uint32_t)nn;
     if (w) atomicAdd(&ctr->n_seedpos, (unsigned long long)w);      // no-return atomic; rare enough after the early exits
+}
+
+
+// Output: seedpos[read_base[r] .. ) holds the kept seeds of read r, '+' first; n_pos[r], n_neg[r] their counts.
+// One lane per read, one wavefront per block.  The hits of a block's 64 reads are one contiguous range: it is staged in
+// LDS with coalesced loads, sorted and grouped there by the lanes (each inside its own sub-range; the kept seeds
+// overwrite hits already consumed -- both records are 16 bytes), and written back in one coalesced sweep.  Blocks
+// whose range does not fit work in global memory as before.
+#define MP_MERGE_BLOCK 64
+#define MP_MERGE_CAP 2560          // hits staged per block (40 KB)
+static_assert(sizeof(mp_seed_hit) == 16 && sizeof(mp_seedpos) == 16, "in-place merge");
+__global__ void __launch_bounds__(MP_MERGE_BLOCK)
+merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P,
+             mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
+{
+    __shared__ uint4 s_h[MP_MERGE_CAP];
+    const uint32_t r0 = blockIdx.x * MP_MERGE_BLOCK;
+    const uint32_t r1 = min(r0 + MP_MERGE_BLOCK, n_reads);
+    const uint32_t b0 = rs_base[2 * r0], T = rs_base[2 * r1] - b0;
+    const bool staged = T <= MP_MERGE_CAP;
+    if (staged) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(hits + b0);
+        for (uint32_t i = threadIdx.x; i < T; i += MP_MERGE_BLOCK) s_h[i] = src[i];
+        __syncthreads();
+    }
+    const uint32_t r = r0 + threadIdx.x;
+    if (r < n_reads) {
+        const uint32_t base = rs_base[2 * r];
+        const int n = (int)(rs_base[2 * r + 2] - base);
+        mp_seed_hit *h = staged ? reinterpret_cast<mp_seed_hit *>(s_h) + (base - b0) : hits + base;
+        mp_seedpos *out = staged ? reinterpret_cast<mp_seedpos *>(s_h) + (base - b0) : seedpos + base;
+        merge_read(h, n, out, r, P, n_pos, n_neg, ctr);
+    }
+    if (staged) {
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(seedpos + b0);
+        for (uint32_t i = threadIdx.x; i < T; i += MP_MERGE_BLOCK) dst[i] = s_h[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K4

@@ -226,6 +226,7 @@ def main():
     tstart = time.perf_counter()
     acc = dict(seed=0.0, locate=0.0, merge=0.0, pair=0.0, fill=0.0, trace=0.0, occ=0, lkt=0, sa=0, seedpos=0, kmer=0, cand=0, hits=0,
                rescue_fill=0.0, rescue_trace=0.0, rescue_tasks=0.0, failed=0, stasks=0, rtasks=0)
+    band0 = ctx.dp_band_stats()
     for _ in range(args.steps):
         hits, nh, st, rst = one_step()
         acc["rescue_fill"] += rst.ms_dp_fill; acc["rescue_trace"] += rst.ms_dp_trace; acc["rescue_tasks"] += rst.ms_tasks
@@ -244,6 +245,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    band1 = ctx.dp_band_stats()
     if rank == 0:
         K = args.steps
         total_pairs = world * K * P
@@ -286,7 +288,12 @@ def main():
                          "prefilter_k": int(gix.info.prefilter_k)},
             "kernel_ms_per_step": kernel_ms,
             "dp": {"bound": "valu", "unit": "Gcells/s", "achieved": cells / ((acc["fill"] + acc["rescue_fill"]) / 1e3) / 1e9 if acc["fill"] else 0.0,
-                   "instances_per_step": n_inst / K, "note": "integer max/add recurrences: VALU-bound, no MFMA, not an HBM roofline (SURVEY 8d)"},
+                   "instances_per_step": n_inst / K,
+                   "band_instances_per_step": (band1[0] - band0[0]) / K, "band_left_to_full_table_per_step": (band1[1] - band0[1]) / K,
+                   "note": "integer max/add recurrences: VALU-bound, no MFMA, not an HBM roofline (SURVEY 8d).  `achieved` counts the "
+                           "full-table cells of every instance (SURVEY 8d) over the DP fill time; the deep-DP legs run an exact banded "
+                           "kernel that computes 87 of a window's ~211 rows per column and hands the instances it cannot decide to "
+                           "the full-table kernels"},
             "events_per_pair": {"occ": ev["occ"] / P, "lkt": ev["lkt"] / P, "sa": ev["sa"] / P,
                                 "executed_occ": acc["occ"] / (K * P), "executed_lkt": acc["lkt"] / (K * P), "prefilter_probes": acc["kmer"] / (K * P),
                                 "candidates": acc["cand"] / (K * P), "pair_hits": acc["hits"] / (K * P),

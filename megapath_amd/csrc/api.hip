@@ -813,11 +813,15 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 8ull << 30;
         c->slab_budget = std::min<size_t>(24ull << 30, std::max<size_t>(2ull << 30, (free_b + c->flags.cap) / 4));
     }
-    static uint32_t round_blocks = 0;
+    const bool small = c->max_len <= 160;                       // the 160-base instance stages fewer window rows in LDS
+    static uint32_t round_cache[2] = {0, 0};
+    uint32_t &round_blocks = round_cache[small ? 0 : 1];
     if (round_blocks == 0) {
         int per_cu = 0, n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        hipError_t e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160>, 64, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL>, 64, 0);
+        if (e != hipSuccess || per_cu < 1) per_cu = 1;
         round_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
     }
     const uint32_t n_blocks = (uint32_t)(((uint64_t)n + 127) / 128);
@@ -832,8 +836,12 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
         const uint32_t off = b0 * 128u;
         const uint32_t cnt = (uint32_t)std::min<uint64_t>((uint64_t)chunk_blocks * 128u, n - off);
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci], s));
-        hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB>), dim3((cnt + 127) / 128), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                           d_tasks + off, cnt, cl, cr, (uint32_t *)c->flags.p, ncols, c->band_fill.p + off);
+        if (small)
+            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160>), dim3((cnt + 127) / 128), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                               d_tasks + off, cnt, cl, cr, (uint32_t *)c->flags.p, ncols, c->band_fill.p + off);
+        else
+            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL>), dim3((cnt + 127) / 128), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                               d_tasks + off, cnt, cl, cr, (uint32_t *)c->flags.p, ncols, c->band_fill.p + off);
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
         hipLaunchKernelGGL((dp_trace_kernel<16, 5, MP_BAND_W, MP_BAND_GB>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks + off, c->d_lens, cnt, cl, cr,
                            (const uint32_t *)c->flags.p, ncols, c->band_fill.p + off, d_res + off, (uint8_t *)nullptr, 0u);

@@ -22,7 +22,7 @@
 // a single lane needs to fill the VALU.
 #pragma once
 
-#define MP_BAND_MAXL 160            // longest read the band kernel is instantiated for
+#define MP_BAND_MAXL 256            // longest read the band kernel is instantiated for (a second instance for <= 160 needs less LDS)
 #define MP_BAND_DMAX 60             // 2 x DP2_MARGIN: widest window surplus of a deep-DP instance
 #define MP_BAND_GB 13               // guard diagonals either side; qualifies scores >= L - 13
 
@@ -66,7 +66,7 @@
 MP_PKOP2(pk_maxu, "v_pk_max_u16")
 __device__ __forceinline__ v2s pk_subsat(v2s a, v2s b) { v2s r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-template <int W, int GB>
+template <int W, int GB, int MAXL>
 __global__ void __launch_bounds__(64)
 dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, int clip_left, int clip_right,
@@ -75,13 +75,13 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 {
     constexpr int NW = (W + 2) / 3;
     static_assert(W % 3 == 0, "three cells per 16-bit half of a flag word");
-    constexpr int R = MP_BAND_MAXL + W + 1;        // LDS rows: row i of the window sits at index i + GB
+    constexpr int R = MAXL + W + 1;        // LDS rows: row i of the window sits at index i + GB
     constexpr int B = MP_DP_BIAS;
     __shared__ uint8_t s_code[R][64];                 // code of instance 0 | code of instance 1 << 4
     const int lane = threadIdx.x;
     const uint32_t pair = blockIdx.x * 64 + lane;
-    // per-instance state, packed to keep the register budget for the band: L | m << 8 | forward << 16 | fit << 17 |
-    // empty << 18 | bad << 19
+    // per-instance state, packed to keep the register budget for the band: L | m << 9 | forward << 18 | fit << 19 |
+    // empty << 20 | bad << 21
     uint32_t info[2], rid[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -94,10 +94,10 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         rid[q] = task.read_id;
         const int clipL = task.strand == 1 ? clip_left : clip_right;
         // the band covers this instance: read short enough, window surplus inside the band, rows <= 0 only under the left clip
-        const bool fit = live && L >= 30 && L <= MP_BAND_MAXL && m >= 1 && m - L <= W - 1 - 2 * GB && m + GB < R && clipL >= GB;
+        const bool fit = live && L >= 30 && L <= MAXL && m >= 1 && m - L <= W - 1 - 2 * GB && m + GB < R && clipL >= GB;
         const bool empty = live && task.win_len == 0;  // nothing to align: decided, score 0 (as the full kernels report it)
         if (!fit) { L = 0; m = 0; }
-        info[q] = (uint32_t)L | ((uint32_t)m << 8) | (task.strand == 1 ? 1u << 16 : 0u) | (fit ? 1u << 17 : 0u) | (empty ? 1u << 18 : 0u);
+        info[q] = (uint32_t)L | ((uint32_t)m << 9) | (task.strand == 1 ? 1u << 18 : 0u) | (fit ? 1u << 19 : 0u) | (empty ? 1u << 20 : 0u);
         if (q == 0)
             for (int r = 0; r < R; r++) s_code[r][lane] = (uint8_t)(12 | (15 << 4));      // pads: match nothing
         for (int w = 0; w * 16 < m; w++) {
@@ -114,7 +114,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             }
         }
     }
-    int Lw = (int)max(info[0] & 255u, info[1] & 255u);
+    int Lw = (int)max(info[0] & 511u, info[1] & 511u);
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(Lw, o); Lw = v > Lw ? v : Lw; }
     __syncthreads();
 
@@ -125,7 +125,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     for (int d = 0; d < W; d++) { H[d] = pk1((short)B); F[d] = pk1(MP_DP_SENT); }     // column 0: H = 0, no insertion state
     const v2s sent = pk1(MP_DP_SENT);
     // best so far: key = excess score << 16 | 0xFFFF - row (larger score, then smaller row; columns ascend), and
-    // column | ties << 8
+    // column | ties << 9
     uint32_t key[2] = {0, 0}, colties[2] = {0, 0};
     uint32_t rw[2] = {0, 0};                                  // 16 read bases of each instance
     uint32_t *fcol = flags + (uint64_t)blockIdx.x * ncols * (NW * 64) + lane;
@@ -135,8 +135,8 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             // read base of column j in alignment orientation (packRead, DV-DPfunctions.cpp:3009-3040)
-            const int L = (int)(info[q] & 255u);
-            const bool fwd = (info[q] >> 16) & 1u;
+            const int L = (int)(info[q] & 511u);
+            const bool fwd = (info[q] >> 18) & 1u;
             const int clipL = fwd ? clip_left : clip_right, clipR = fwd ? clip_right : clip_left;
             const int p = fwd ? j - 1 : L - j;
             int b = 9 + q;
@@ -187,7 +187,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             short lim2[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {                      // rows past the window's end (d > m - j + GB) do not count
-                int lim = 127 - ((int)((info[q] >> 8) & 255u) - j + GB);
+                int lim = 127 - ((int)((info[q] >> 9) & 511u) - j + GB);
                 lim2[q] = (short)(lim < 0 ? 0 : (lim > 128 ? 128 : lim));
             }
             const v2s lim = pk(lim2[0], lim2[1]);
@@ -206,12 +206,12 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
                 if (u == 0) continue;
                 const int ties = W - (int)(unsigned short)(q == 0 ? neq.x : neq.y);
                 const int row = j + (127 - (int)(unsigned short)(q == 0 ? first.x : first.y)) - GB;
-                if (ties == 0) { info[q] |= 1u << 19; continue; }      // the column's maximum sits on a pad row: leave it to the full table
+                if (ties == 0) { info[q] |= 1u << 21; continue; }      // the column's maximum sits on a pad row: leave it to the full table
                 const uint32_t k2 = ((uint32_t)u << 16) | (uint32_t)(0xFFFF - row);
-                const uint32_t told = (key[q] >> 16) == (uint32_t)u ? colties[q] >> 8 : 0u;
+                const uint32_t told = (key[q] >> 16) == (uint32_t)u ? colties[q] >> 9 : 0u;
                 const uint32_t tnew = min(told + (uint32_t)ties, 0xFFFFu);
-                if (k2 > key[q]) { key[q] = k2; colties[q] = (uint32_t)j | (tnew << 8); }
-                else if ((key[q] >> 16) == (uint32_t)u) colties[q] = (colties[q] & 255u) | (tnew << 8);
+                if (k2 > key[q]) { key[q] = k2; colties[q] = (uint32_t)j | (tnew << 9); }
+                else if ((key[q] >> 16) == (uint32_t)u) colties[q] = (colties[q] & 511u) | (tnew << 9);
             }
         }
     }
@@ -222,12 +222,12 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         mp_fill_result r;
         // score -1: "not decided by the band" -- below the qualifying score, outside the band's shape, or the first
         // maximum fell on a pad row past the window
-        const int L = (int)(info[q] & 255u), m = (int)((info[q] >> 8) & 255u);
+        const int L = (int)(info[q] & 511u), m = (int)((info[q] >> 9) & 511u);
         const int u = (int)(key[q] >> 16), row = 0xFFFF - (int)(key[q] & 0xFFFFu);
-        const uint32_t ties = colties[q] >> 8;
-        const bool ok = ((info[q] >> 17) & 1u) && !((info[q] >> 19) & 1u) && u >= 1 && row >= 1 && row <= m;
-        r.score = ok ? u + L - GB - 1 : (((info[q] >> 18) & 1u) ? 0 : -1);
-        r.row = ok ? (uint16_t)row : 0; r.col = ok ? (uint16_t)(colties[q] & 255u) : 0;
+        const uint32_t ties = colties[q] >> 9;
+        const bool ok = ((info[q] >> 19) & 1u) && !((info[q] >> 21) & 1u) && u >= 1 && row >= 1 && row <= m;
+        r.score = ok ? u + L - GB - 1 : (((info[q] >> 20) & 1u) ? 0 : -1);
+        r.row = ok ? (uint16_t)row : 0; r.col = ok ? (uint16_t)(colties[q] & 511u) : 0;
         r.count = ok ? (ties > 255u ? 255u : ties) : 0u;       // num_sameScore, capped as in dp_fill_kernel
         out[inst] = r;
     }

@@ -150,18 +150,20 @@ def test_batch_scale_properties():
     gix.close()
 
 
-@pytest.mark.parametrize("clips,banded", [((130, 130), True), ((40, 13), True), ((13, 60), True), ((12, 130), False)])
-def test_banded_dp_kernel_changes_nothing(tmp_path, clips, banded):
+@pytest.mark.parametrize("clips,banded,read_len", [((130, 130), True, 150), ((40, 13), True, 150), ((13, 60), True, 150), ((12, 130), False, 150),
+                                                  ((130, 130), True, 250), ((130, 130), False, 300)])
+def test_banded_dp_kernel_changes_nothing(tmp_path, clips, banded, read_len):
     """The deep-DP legs with the banded fill kernel (plus full-table fallback) against the full-table kernels alone, on
     reads with long indels and junk ends: the same hit set (positions, scores, windows) in every field, for several
-    soft-clip limits -- below MP_BAND_GB the band path must not engage at all."""
+    soft-clip limits -- below MP_BAND_GB, or with reads longer than MP_BAND_MAXL, the band path must not engage at all."""
     genome = synth.random_genome(500000, 611, n_seqs=3, repeat_frac=0.1)
     arrs = index_builder.build_index_arrays(genome, sa_interval=16)
     gix = H.Index.from_arrays(0, **arrs)
-    names, r1, r2 = synth.simulate_pairs(genome, 3000, 150, 612, sub=0.01, ins=0.002, dele=0.002, random_frac=0.02, long_indel_frac=0.5,
-                                         long_indel_max=26, junk_end_frac=0.3, junk_end_max=45, len_range=(90, 150))
+    names, r1, r2 = synth.simulate_pairs(genome, 3000, read_len, 612, sub=0.01, ins=0.002, dele=0.002, random_frac=0.02, long_indel_frac=0.5,
+                                         long_indel_max=26, junk_end_frac=0.3, junk_end_max=45, len_range=(read_len * 3 // 5, read_len),
+                                         frag_mean=read_len + 200, frag_max=read_len + 450)
     seqs = [x for pr in zip(r1, r2) for x in pr]
-    packed, lens, W = H.pack_reads(seqs, 151)
+    packed, lens, W = H.pack_reads(seqs, read_len + 1)
 
     def run(band):
         ctx = H.Context(gix)

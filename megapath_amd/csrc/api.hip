@@ -121,6 +121,9 @@ extern "C" int mp_device_check(int device, char *out_name, size_t name_cap)
 // Uploads the raw index arrays and builds the HBM layouts with streaming kernels (kernels_index.hip).
 static int upload_index(int device, mp_host_index &h, mp_index **out)
 {
+    // positions are 32-bit on the device; the topmost MP_SEED_BIG values stay free so that a seed projection that wrapped
+    // below zero (DV-DPfunctions.cpp:2489) can be told from a real position (merge_kernel)
+    if (h.n == 0 || h.n > 0xFFFFFFFFull - 2 * MP_SEED_BIG) return MP_ERANGE;
     HIPCHK(hipSetDevice(device));
     mp_index *ix = new (std::nothrow) mp_index();
     if (!ix) return MP_ENOMEM;
@@ -568,7 +571,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
         hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, dix, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
                            c->ctr.p);
     HIPCHK(hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_BLOCK), 0, s, c->hits.p, c->rs_base.p, n_reads, P, c->seedpos.p, c->n_pos.p,
+    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_BLOCK), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, c->seedpos.p, c->n_pos.p,
                        c->n_neg.p, c->ctr.p);
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));

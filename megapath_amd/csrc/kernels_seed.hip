@@ -459,73 +459,94 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
 }
 
 // ------------------------------------------------------------------------------------------------ K3
-__device__ __forceinline__ bool hit_less(const mp_seed_hit &a, const mp_seed_hit &b)
+// A located hit as one sortable word: strand | offset (32 bits: an index chunk holds < 2^32 bases) | qo | length | unique.
+// Sorting by the word sorts by (strand, offset) -- SeedAlign order (DV-DPfunctions.cpp:2144-2160); the order among equal
+// (strand, offset) does not matter to what follows (group start, union of intervals, any-unique).
+__device__ __forceinline__ uint64_t hit_key(const mp_seed_hit &h, const mp_dev_mmp &P)
 {
-    if (a.strand != b.strand) return a.strand < b.strand;
-    return a.offset < b.offset;
+    const uint64_t uniq = ((int)h.mult <= P.uniq_threshold && (int)h.length >= P.seed_min_length) ? 1ull : 0ull;
+    return ((uint64_t)h.strand << 52) | ((h.offset & 0xFFFFFFFFull) << 20) | ((uint64_t)(h.qo & 511u) << 11) | ((uint64_t)(h.length & 511u) << 2) | uniq;
 }
+#define MP_KEY_STRAND(k) ((uint32_t)((k) >> 52))
+// The projection seed position - query offset is done in unsigned 64-bit arithmetic and may wrap below zero exactly as
+// in the reference (DV-DPfunctions.cpp:2489).  Real positions are < text_len, so a 32-bit offset >= text_len can only be
+// the low word of such a wrapped value (text_len <= 2^32 - MP_SEED_BIG): it is sign-extended back.
+__device__ __forceinline__ uint64_t key_pos(uint64_t k, uint64_t text_len)
+{
+    const uint64_t o = (k >> 20) & 0xFFFFFFFFull;
+    return o >= text_len ? (o | 0xFFFFFFFF00000000ull) : o;
+}
+#define MP_KEY_QO(k) ((int)(((k) >> 11) & 511u))
+#define MP_KEY_LEN(k) ((int)(((k) >> 2) & 511u))
+#define MP_KEY_UNIQ(k) ((bool)((k) & 1u))
 
-__device__ void sort_hits(mp_seed_hit *a, int n)
+__device__ void sort_keys(uint64_t *a, int n)
 {
     if (n <= 24) {
         for (int i = 1; i < n; i++) {
-            mp_seed_hit t = a[i];
+            const uint64_t t = a[i];
             int j = i - 1;
-            while (j >= 0 && hit_less(t, a[j])) { a[j + 1] = a[j]; j--; }
+            while (j >= 0 && t < a[j]) { a[j + 1] = a[j]; j--; }
             a[j + 1] = t;
         }
         return;
     }
-    // heap sort for the rare large (repeat-rich) segments
+    // heap sort for the larger (repeat-rich) segments
     for (int start = n / 2 - 1; start >= 0; start--) {
         int root = start;
+        const uint64_t v = a[root];
         for (;;) {
             int child = 2 * root + 1;
             if (child >= n) break;
-            if (child + 1 < n && hit_less(a[child], a[child + 1])) child++;
-            if (!hit_less(a[root], a[child])) break;
-            mp_seed_hit t = a[root]; a[root] = a[child]; a[child] = t;
+            uint64_t cv = a[child];
+            if (child + 1 < n) { const uint64_t c2 = a[child + 1]; if (cv < c2) { cv = c2; child++; } }
+            if (!(v < cv)) break;
+            a[root] = cv;
             root = child;
         }
+        a[root] = v;
     }
     for (int end = n - 1; end > 0; end--) {
-        mp_seed_hit t = a[0]; a[0] = a[end]; a[end] = t;
+        const uint64_t v = a[end];
+        a[end] = a[0];
         int root = 0;
         for (;;) {
             int child = 2 * root + 1;
             if (child >= end) break;
-            if (child + 1 < end && hit_less(a[child], a[child + 1])) child++;
-            if (!hit_less(a[root], a[child])) break;
-            mp_seed_hit u = a[root]; a[root] = a[child]; a[child] = u;
+            uint64_t cv = a[child];
+            if (child + 1 < end) { const uint64_t c2 = a[child + 1]; if (cv < c2) { cv = c2; child++; } }
+            if (!(v < cv)) break;
+            a[root] = cv;
             root = child;
         }
+        a[root] = v;
     }
 }
 
-// seed merging of one read (DV-DPfunctions.cpp:2470-2560): h[0..n) are its located seed hits, out receives the kept ones.
-// out may alias h: entry k of out is written only after hits 0..k have been consumed.
-__device__ __forceinline__ void merge_read(mp_seed_hit *h, int n, mp_seedpos *out, uint32_t r, const mp_dev_mmp &P,
+// seed merging of one read (DV-DPfunctions.cpp:2470-2560): k[0..n) are the keys of its located seed hits, out receives
+// the kept seeds.
+__device__ __forceinline__ void merge_read(uint64_t *k, int n, mp_seedpos *__restrict__ out, uint32_t r, const mp_dev_mmp &P, uint64_t text_len,
                                            uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
-    sort_hits(h, n);
+    sort_keys(k, n);
     uint32_t max_cov = 0;
     int n_kept = 0;
     for (int m = 0; m < n; m++) {
-        const uint16_t strand = h[m].strand;
-        const uint64_t pos = h[m].offset;
+        const uint64_t first = k[m];
+        const uint64_t pos = key_pos(first, text_len);
+        const uint64_t group_end = pos + (uint64_t)P.indel_fuzz;
         bool has_unique = false;
-        int g0 = m;
-        // group while next.offset <= first.offset + indelFuzz on the same strand (DV-DPfunctions.cpp:2514)
-        while (m + 1 < n && h[m + 1].strand == strand && h[m + 1].offset <= pos + (uint64_t)P.indel_fuzz) m++;
         // covered read length = size of the union of [qo, qo+len) over the group (DV-DPfunctions.cpp:2518-2531 walks the
         // intervals in (qo, end) order and adds up the merged runs): a bitmap over the read positions, linear in the
-        // group size -- repeat-rich reads have groups of hundreds of hits
+        // group size -- repeat-rich reads have groups of hundreds of hits.  The group: while next.offset <= first.offset
+        // + indelFuzz on the same strand (:2514).
         uint64_t cov[MP_SEED_BIG / 64];
 #pragma unroll
         for (int w = 0; w < MP_SEED_BIG / 64; w++) cov[w] = 0;
-        for (int q = g0; q <= m; q++) {
-            const int lo = (int)h[q].qo, hi = lo + (int)h[q].length;
-            has_unique |= (int)h[q].mult <= P.uniq_threshold && (int)h[q].length >= P.seed_min_length;
+        uint64_t cur = first;
+        for (;;) {
+            const int lo = MP_KEY_QO(cur), hi = lo + MP_KEY_LEN(cur);
+            has_unique |= MP_KEY_UNIQ(cur);
 #pragma unroll
             for (int w = 0; w < MP_SEED_BIG / 64; w++) {
                 int a = lo - 64 * w, e = hi - 64 * w;
@@ -534,6 +555,10 @@ __device__ __forceinline__ void merge_read(mp_seed_hit *h, int n, mp_seedpos *ou
                 const uint64_t below_e = e >= 64 ? ~0ull : ((1ull << e) - 1ull), below_a = a >= 64 ? ~0ull : ((1ull << a) - 1ull);
                 cov[w] |= below_e & ~below_a;
             }
+            if (m + 1 >= n) break;
+            cur = k[m + 1];
+            if (MP_KEY_STRAND(cur) != MP_KEY_STRAND(first) || key_pos(cur, text_len) > group_end) break;
+            m++;
         }
         uint32_t total = 0;
 #pragma unroll
@@ -543,7 +568,7 @@ __device__ __forceinline__ void merge_read(mp_seed_hit *h, int n, mp_seedpos *ou
             mp_seedpos sp;
             sp.pos = pos;
             sp.paired_seed_length = total;
-            sp.strand_read_id = (r & ~1u) | ((uint32_t)strand << 31);
+            sp.strand_read_id = (r & ~1u) | (MP_KEY_STRAND(first) << 31);
             out[n_kept++] = sp;
         }
     }
@@ -561,42 +586,36 @@ __device__ __forceinline__ void merge_read(mp_seed_hit *h, int n, mp_seedpos *ou
     if (w) atomicAdd(&ctr->n_seedpos, (unsigned long long)w);      // no-return atomic; rare enough after the early exits
 }
 
-
 // Output: seedpos[read_base[r] .. ) holds the kept seeds of read r, '+' first; n_pos[r], n_neg[r] their counts.
-// One lane per read, one wavefront per block.  The hits of a block's 64 reads are one contiguous range: it is staged in
-// LDS with coalesced loads, sorted and grouped there by the lanes (each inside its own sub-range; the kept seeds
-// overwrite hits already consumed -- both records are 16 bytes), and written back in one coalesced sweep.  Blocks
-// whose range does not fit work in global memory as before.
+// One lane per read, one wavefront per block.  The hits of a block's 64 reads are one contiguous range: it is read with
+// coalesced loads, packed to 8-byte keys and staged in LDS, where the lanes sort and group their own sub-ranges.  A
+// block whose range does not fit packs and sorts in place in global memory.
 #define MP_MERGE_BLOCK 64
-#define MP_MERGE_CAP 2560          // hits staged per block (40 KB)
-static_assert(sizeof(mp_seed_hit) == 16 && sizeof(mp_seedpos) == 16, "in-place merge");
+#define MP_MERGE_CAP 4096          // keys staged per block (32 KB)
 __global__ void __launch_bounds__(MP_MERGE_BLOCK)
-merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P,
+merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P, uint64_t text_len,
              mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
-    __shared__ uint4 s_h[MP_MERGE_CAP];
+    __shared__ uint64_t s_key[MP_MERGE_CAP];
     const uint32_t r0 = blockIdx.x * MP_MERGE_BLOCK;
     const uint32_t r1 = min(r0 + MP_MERGE_BLOCK, n_reads);
     const uint32_t b0 = rs_base[2 * r0], T = rs_base[2 * r1] - b0;
     const bool staged = T <= MP_MERGE_CAP;
     if (staged) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(hits + b0);
-        for (uint32_t i = threadIdx.x; i < T; i += MP_MERGE_BLOCK) s_h[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < T; i += MP_MERGE_BLOCK) s_key[i] = hit_key(hits[b0 + i], P);
         __syncthreads();
     }
     const uint32_t r = r0 + threadIdx.x;
-    if (r < n_reads) {
-        const uint32_t base = rs_base[2 * r];
-        const int n = (int)(rs_base[2 * r + 2] - base);
-        mp_seed_hit *h = staged ? reinterpret_cast<mp_seed_hit *>(s_h) + (base - b0) : hits + base;
-        mp_seedpos *out = staged ? reinterpret_cast<mp_seedpos *>(s_h) + (base - b0) : seedpos + base;
-        merge_read(h, n, out, r, P, n_pos, n_neg, ctr);
+    if (r >= n_reads) return;
+    const uint32_t base = rs_base[2 * r];
+    const int n = (int)(rs_base[2 * r + 2] - base);
+    uint64_t *k = s_key + (base - b0);
+    if (!staged) {
+        // in place: key i overwrites bytes 8i..8i+7 of this read's own records, all of them already consumed
+        k = reinterpret_cast<uint64_t *>(hits + base);
+        for (int i = 0; i < n; i++) { const mp_seed_hit h = hits[base + i]; k[i] = hit_key(h, P); }
     }
-    if (staged) {
-        __syncthreads();
-        uint4 *dst = reinterpret_cast<uint4 *>(seedpos + b0);
-        for (uint32_t i = threadIdx.x; i < T; i += MP_MERGE_BLOCK) dst[i] = s_h[i];
-    }
+    merge_read(k, n, seedpos + base, r, P, text_len, n_pos, n_neg, ctr);
 }
 
 // ------------------------------------------------------------------------------------------------ K4

@@ -188,3 +188,51 @@ def test_banded_dp_kernel_changes_nothing(tmp_path, clips, banded, read_len):
     else:
         assert s_band == (0, 0)
     gix.close()
+
+
+def test_seed_projection_wrapping_below_zero(tmp_path):
+    """Reads whose first bases are junk and whose match starts within the first bases of the text: the seed projection
+    position - query offset wraps below zero in unsigned arithmetic, exactly as in the reference
+    (DV-DPfunctions.cpp:2489).  The device keeps positions in 32 bits and restores such values; the whole path must still
+    print what the oracle prints."""
+    genome = synth.random_genome(300000, 701, n_seqs=1)
+    prefix = _build(tmp_path, genome)
+    text = genome[0][1]
+    rng = np.random.Generator(np.random.PCG64(702))
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    names, r1, r2 = [], [], []
+    for p in range(120):
+        junk = int(rng.integers(5, 60))
+        start = int(rng.integers(0, 12))                       # match starts at text position 0..11
+        a = np.concatenate([bases[rng.integers(0, 4, size=junk)], text[start:start + 150 - junk]])
+        fl = int(rng.integers(300, 500))
+        b = np.asarray([comp[int(x)] for x in text[start + fl - 150:start + fl][::-1]], dtype=np.uint8)
+        if p % 2:
+            a, b = b, a
+        names.append("w%d" % (p + 1)); r1.append(a.tobytes()); r2.append(b.tobytes())
+    f1, f2 = str(tmp_path / "w_1.fq"), str(tmp_path / "w_2.fq")
+    synth.write_fastq_pair(f1, f2, names, r1, r2)
+    lib = O.oracle()
+    oix = lib.mpo_index_open(prefix.encode())
+    p = O.default_params(L=151)
+    st = O.AlignStats()
+    want_path = str(tmp_path / "oracle.fq")
+    assert lib.mpo_align_fastq(oix, C.byref(p), f1.encode(), f2.encode(), want_path.encode(), None, C.byref(st)) == 0
+    lib.mpo_index_close(oix)
+    gix = H.Index(prefix, 0)
+    # the wrapped projections must really occur in this batch
+    seqs = [x for pr in zip(r1, r2) for x in pr]
+    packed, lens, W = H.pack_reads(seqs, 151)
+    ctx = H.Context(gix)
+    ctx.set_reads(packed, lens)
+    ctx.seed_batch(H.MmpParams.nt2())
+    sp, off = ctx.get_seeds()
+    assert sum(1 for i in range(int(off[-1])) if sp[i].pos >= (1 << 63)) > 20
+    ctx.close()
+    buf = io.BytesIO()
+    pipeline.align_fastq(gix, pipeline.Soap4Params(max_read_length=151, insert_high=750), f1, f2, buf, batch_pairs=500)
+    gix.close()
+    got_path = tmp_path / "got.fq"
+    got_path.write_bytes(buf.getvalue())
+    assert fastq_records(str(got_path)) == fastq_records(want_path)

@@ -57,9 +57,14 @@ struct RescueRow { uint32_t pair; uint64_t a1, a2; int s1, s2; uint32_t src; };
 
 // One batch on its way through the three stages: reader threads fill the inputs, the GPU stage the hit lists, the output
 // stage prints.  The objects are recycled, so the strings keep their capacity.
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct RawRec { size_t h, hn, s, sn, q, qn; bool fasta; };
+
 struct Batch {
     // ---- stage 1: parsed and packed reads (2 per pair)
     std::vector<Rec> recs[2];               // per mate file, grown on demand
+    std::vector<RawRec> raw[2];             // where each record's lines sit in the reader's buffer (parse_file)
     std::vector<uint32_t> packed_m[2], lens_m[2];
     std::vector<uint32_t> packed, lens;     // interleaved 2q / 2q+1 as the device wants them
     uint32_t W = 0, n_reads = 0;
@@ -121,20 +126,26 @@ struct FqReader {
     std::vector<char> buf;
     size_t pos = 0, end = 0;
     bool eof = false;
-    bool open(const char *path) { f = gzopen(path, "rb"); if (f) gzbuffer(f, 1 << 20); buf.resize(1 << 22); return f != nullptr; }
-    // next line without its terminator; the pointer stays valid until the next call
-    bool line(const char *&p, size_t &n)
+    bool open(const char *path) { f = gzopen(path, "rb"); if (f) gzbuffer(f, 1 << 20); buf.resize(1 << 24); return f != nullptr; }
+    // Drops what earlier batches consumed.  Within a batch the buffer only grows, so offsets handed out by line() stay
+    // valid until the next begin_batch() (the buffer may be reallocated: use data() + offset, never a kept pointer).
+    void begin_batch()
+    {
+        if (pos) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
+    }
+    const char *data() const { return buf.data(); }
+    // next line without its terminator, as offset + length
+    bool line(size_t &off, size_t &n)
     {
         for (;;) {
-            char *nl = end > pos ? (char *)memchr(buf.data() + pos, '\n', end - pos) : nullptr;
-            if (nl) { p = buf.data() + pos; n = (size_t)(nl - p); pos = (size_t)(nl - buf.data()) + 1; break; }
-            if (eof) { if (pos >= end) return false; p = buf.data() + pos; n = end - pos; pos = end; break; }
-            memmove(buf.data(), buf.data() + pos, end - pos);
-            end -= pos; pos = 0;
-            if (end == buf.size()) buf.resize(buf.size() * 2);
-            const int got = gzread(f, buf.data() + end, (unsigned)std::min(buf.size() - end, (size_t)1 << 30));
+            const char *nl = end > pos ? (const char *)memchr(buf.data() + pos, '\n', end - pos) : nullptr;
+            if (nl) { off = pos; n = (size_t)(nl - buf.data()) - pos; pos = (size_t)(nl - buf.data()) + 1; break; }
+            if (eof) { if (pos >= end) return false; off = pos; n = end - pos; pos = end; break; }
+            if (end + (1u << 22) > buf.size()) buf.resize(buf.size() * 2);
+            const int got = gzread(f, buf.data() + end, (unsigned)std::min(buf.size() - end, (size_t)1 << 28));
             if (got <= 0) eof = true; else end += (size_t)got;
         }
+        const char *p = buf.data() + off;
         while (n && (p[n - 1] == '\r' || p[n - 1] == '\n')) n--;
         return true;
     }
@@ -145,59 +156,84 @@ struct FqReader {
 // (QueryParser.cpp:184-234): length capped to maxReadLength-1, N/other -> G/A through the character map, 2 bits per base
 // LSB-first, words contiguous per read.  The name loses a trailing /1 /2 (QueryParser.cpp:177); the comment is the rest
 // of the header line (kseq).  Returns the number of records read.
-size_t parse_file(FqReader &rd, const Params &p, Batch &out, int k, size_t max_pairs)
+// Two phases: one thread splits the text into records (memchr speed), then `threads` threads copy and pack them.
+size_t parse_file(FqReader &rd, const Params &p, Batch &out, int k, size_t max_pairs, int threads)
 {
     const uint32_t W = out.W;
     const size_t cap = (size_t)p.max_read_length - 1;
-    size_t q = 0;
-    const char *h, *sq, *pl, *ql; size_t hn, sn, pn, qn;
+    std::vector<RawRec> &raw = out.raw[k];
+    raw.clear();
+    const double t_begin = now_s();
+    rd.begin_batch();
+    while (raw.size() < max_pairs) {
+        RawRec r;
+        do { if (!rd.line(r.h, r.hn)) goto scanned; } while (r.hn == 0);
+        r.fasta = rd.data()[r.h] == '>';
+        if (!rd.line(r.s, r.sn)) break;
+        r.q = 0; r.qn = 0;
+        if (!r.fasta) {
+            size_t po, pn;
+            if (!rd.line(po, pn) || !rd.line(r.q, r.qn)) break;
+        }
+        raw.push_back(r);
+    }
+scanned:
+    const size_t n = raw.size();
+    const double t_scan = now_s();
     std::vector<Rec> &recs = out.recs[k];
     std::vector<uint32_t> &packed = out.packed_m[k], &lens = out.lens_m[k];
-    for (; q < max_pairs; q++) {
-        do { if (!rd.line(h, hn)) return q; } while (hn == 0);
-        if (q >= recs.size()) { const size_t grow = std::max<size_t>(4096, recs.size()); recs.resize(recs.size() + grow); }
-        if ((q + 1) * (size_t)W > packed.size()) { packed.resize(std::max<size_t>(4096 * (size_t)W, 2 * packed.size())); lens.resize(packed.size() / W); }
-        Rec &r = recs[q];
-        const bool fasta = h[0] == '>';
-        size_t cut = 1;
-        while (cut < hn && h[cut] != ' ' && h[cut] != '\t') cut++;
-        size_t nl = cut - 1;
-        if (nl > 2 && h[cut - 2] == '/' && h[cut - 1] >= '0' && h[cut - 1] <= '9') nl -= 2;
-        r.name.assign(h + 1, nl);
-        r.has_comment = !p.ignore_comments && cut + 1 < hn;
-        if (r.has_comment) r.comment.assign(h + cut + 1, hn - cut - 1); else r.comment.clear();
-        if (!rd.line(sq, sn)) return q;
-        const size_t keep = std::min(sn, cap);                                          // QueryParser.cpp:188
-        r.seq.resize(keep);
-        uint32_t *dst = packed.data() + q * (size_t)W;
-        for (uint32_t w = 0; w < W; w++) {
-            uint32_t v = 0;
-            const size_t lo = (size_t)w * 16, hi = std::min(keep, lo + 16);
-            for (size_t i = lo; i < hi; i++) {
-                const unsigned c = g_code[(unsigned char)sq[i]];
-                v |= c << (2 * (i - lo));
-                r.seq[i] = "ACGT"[c];
+    if (recs.size() < n) recs.resize(n);
+    if (packed.size() < n * (size_t)W) packed.resize(n * (size_t)W);
+    if (lens.size() < n) lens.resize(n);
+    const char *base = rd.data();
+    auto work = [&](size_t q0, size_t q1) {
+        for (size_t q = q0; q < q1; q++) {
+            const RawRec &rr = raw[q];
+            const char *h = base + rr.h, *sq = base + rr.s, *ql = base + rr.q;
+            const size_t hn = rr.hn, sn = rr.sn, qn = rr.qn;
+            Rec &r = recs[q];
+            size_t cut = 1;
+            while (cut < hn && h[cut] != ' ' && h[cut] != '\t') cut++;
+            size_t nl = cut - 1;
+            if (nl > 2 && h[cut - 2] == '/' && h[cut - 1] >= '0' && h[cut - 1] <= '9') nl -= 2;
+            r.name.assign(h + 1, nl);
+            r.has_comment = !p.ignore_comments && cut + 1 < hn;
+            if (r.has_comment) r.comment.assign(h + cut + 1, hn - cut - 1); else r.comment.clear();
+            const size_t keep = std::min(sn, cap);                                          // QueryParser.cpp:188
+            r.seq.resize(keep);
+            uint32_t *dst = packed.data() + q * (size_t)W;
+            for (uint32_t w = 0; w < W; w++) {
+                uint32_t v = 0;
+                const size_t lo = (size_t)w * 16, hi = std::min(keep, lo + 16);
+                for (size_t i = lo; i < hi; i++) {
+                    const unsigned c = g_code[(unsigned char)sq[i]];
+                    v |= c << (2 * (i - lo));
+                    r.seq[i] = "ACGT"[c];
+                }
+                dst[w] = v;
             }
-            dst[w] = v;
+            lens[q] = (uint32_t)keep;
+            if (rr.fasta) r.qual.clear(); else r.qual.assign(ql, std::min(qn, keep));
         }
-        lens[q] = (uint32_t)keep;
-        if (fasta) r.qual.clear();
-        else {
-            if (!rd.line(pl, pn) || !rd.line(ql, qn)) return q;
-            r.qual.assign(ql, std::min(qn, keep));
-        }
-    }
-    return q;
+    };
+    const int T = std::max(1, std::min(threads, (int)(n / 4096) + 1));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(work, n * (size_t)t / T, n * (size_t)(t + 1) / T);
+    work(0, n / (size_t)T);
+    for (auto &th : pool) th.join();
+    if (k == 0 && getenv("MP_TIMING")) fprintf(stderr, "[Main] reader: %zu records split in %.3f s, copied and packed in %.3f s by %d threads\n", n, t_scan - t_begin, now_s() - t_scan, T);
+    return n;
 }
 
 // reads the next batch: the two files are parsed side by side
-bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out)
+bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out, int threads)
 {
     const size_t bp = p.batch_pairs;
     out.W = (uint32_t)(p.max_read_length + 15) / 16;
     size_t nb = 0;
-    std::thread second([&]() { nb = parse_file(b, p, out, 1, bp); });
-    const size_t na = parse_file(a, p, out, 0, bp);
+    const int per_file = std::max(1, threads / 4);          // the output stage of the previous batch runs at the same time
+    std::thread second([&]() { nb = parse_file(b, p, out, 1, bp, per_file); });
+    const size_t na = parse_file(a, p, out, 0, bp, per_file);
     second.join();
     if (na != nb) { fprintf(stderr, "Error: number of sequences of pair-end files not matched.\n"); exit(1); }
     out.n_reads = (uint32_t)(2 * na);
@@ -373,7 +409,6 @@ struct Stats {
     uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0;
     double t_read = 0, t_upload = 0, t_deep = 0, t_sort = 0, t_cigar = 0, t_emit_deep = 0, t_rescue = 0, t_emit_rest = 0;   // seconds (MP_TIMING=1 prints them)
 };
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // -b only: the special CIGAR of each listed DP instance.  The hits name their instance (read, strand, window); the same
 // kernels run it again with the op strings switched on (mp_sgdp_batch), in bounded chunks.
@@ -902,7 +937,7 @@ int main(int argc, char **argv)
             Batch *b = free_q.pop();
             if (!b) break;
             const double tr = now_s();
-            const bool got = fill_batch(ra, rb, p, *b);
+            const bool got = fill_batch(ra, rb, p, *b, threads);
             st.t_read += now_s() - tr;
             if (got) filled_q.push(b);
             if (!got || b->last) break;
@@ -918,10 +953,16 @@ int main(int argc, char **argv)
         }
     });
     bool first = true;
+    int n_batches = 0;
+    double t_steady = 0; uint64_t pairs_before_steady = 0, pairs_seen = 0;
     for (;;) {
         Batch *b = filled_q.pop();
         if (!b) break;
         const double tb = now_s();
+        // the three recycled batch objects are first-touched (page faults, hipMalloc of the device buffers) during the
+        // first three batches: MP_TIMING also reports the rate from the fourth batch on
+        if (++n_batches == 4) { t_steady = tb; pairs_before_steady = pairs_seen; }
+        pairs_seen += b->n_reads / 2;
         gpu_stage(ctx, p, *b, first, bam != nullptr, threads, st);
         if (getenv("MP_TIMING")) fprintf(stderr, "[Main] device stage of a batch of %u pairs: %.3f s\n", b->n_reads / 2, now_s() - tb);
         aligned_q.push(b);
@@ -936,6 +977,9 @@ int main(int argc, char **argv)
     fprintf(stderr, "[Main] %llu pairs: %llu aligned by deep DP, %llu by mate rescue, %llu unpaired; %llu DP instances\n", (unsigned long long)st.pairs,
             (unsigned long long)st.deep, (unsigned long long)st.rescued, (unsigned long long)st.unpaired, (unsigned long long)st.dp);
     fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped)\n", t_loop, st.pairs / std::max(t_loop, 1e-9));
+    if (getenv("MP_TIMING") && t_steady > 0)
+        fprintf(stderr, "[Main] from the fourth batch on: %.0f pairs/s (%llu pairs in %.2f s)\n", (double)(pairs_seen - pairs_before_steady) / std::max(t_start + t_loop - t_steady, 1e-9),
+                (unsigned long long)(pairs_seen - pairs_before_steady), t_start + t_loop - t_steady);
     if (getenv("MP_TIMING"))
         fprintf(stderr, "[Main] seconds: reading and packing %.2f (own threads), upload %.2f, deep-DP round %.2f, sort %.2f, BAM CIGARs %.2f, output of deep pairs %.2f, rescue round %.2f, output of the rest %.2f\n",
                 st.t_read, st.t_upload, st.t_deep, st.t_sort, st.t_cigar, st.t_emit_deep, st.t_rescue, st.t_emit_rest);

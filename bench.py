@@ -306,6 +306,9 @@ def main():
             wl = pmc["workload"]
             if wl["genome_mbp"] == args.genome_mbp and wl["pairs_per_step"] == P and wl["read_len"] == args.read_len:
                 out["roofline"]["traffic"] = pmc["seed_stage_hbm_bytes_per_launch"]
+                # VALU occupancy of the DP kernels from the committed SQ-counter pass of this command (profiles/r01_pmc_dp_valu.json)
+                valu = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dp_valu.json")))["per_kernel"]
+                out["dp"]["valu_busy_frac"] = {k.replace("void ", ""): round(v["valu_busy_frac"], 3) for k, v in valu.items()}
         except Exception:  # noqa: BLE001
             pass
         cb = None

@@ -810,20 +810,30 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     if (n == 0) return MP_OK;
     hipStream_t s = c->stream;
     const uint32_t ncols = c->max_len;
-    const size_t per_block = (size_t)ncols * MP_BAND_NW * 64 * 4;              // 64 instance pairs
+    // Two passes when the soft-clip limits allow it (rows <= 0 of the second pass's band reach column 2 GB + 1): scores of
+    // the whole band first, then the traceback bits only around the best cell's diagonal -- 87 x 15 + 27 x 33 instead
+    // of 87 x 33 instructions per column.  MP_DP_BAND=1 keeps the single pass.
+    static const bool one_pass_env = getenv("MP_DP_BAND") && atoi(getenv("MP_DP_BAND")) == 1;
+    const bool two_pass = !one_pass_env && cl >= 2 * MP_BAND_GB + 1 && cr >= 2 * MP_BAND_GB + 1;
+    const int nw = two_pass ? MP_BAND_NW2 : MP_BAND_NW;
+    const size_t per_block = (size_t)ncols * nw * 64 * 4;                      // 64 instance pairs
     if (c->slab_budget == 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 8ull << 30;
         c->slab_budget = std::min<size_t>(24ull << 30, std::max<size_t>(2ull << 30, (free_b + c->flags.cap) / 4));
     }
-    const bool small = c->max_len <= 160;                       // the 160-base instance stages fewer window rows in LDS
-    static uint32_t round_cache[2] = {0, 0};
-    uint32_t &round_blocks = round_cache[small ? 0 : 1];
+    const bool small = c->max_len <= 160;                       // the 160-base instances stage fewer window rows in LDS
+    // blocks one round of the slab-writing kernel holds on the device
+    static uint32_t round_cache[4] = {0, 0, 0, 0};
+    uint32_t &round_blocks = round_cache[(small ? 0 : 1) + (two_pass ? 2 : 0)];
     if (round_blocks == 0) {
         int per_cu = 0, n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
-        hipError_t e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160>, 64, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL>, 64, 0);
+        hipError_t e;
+        if (two_pass) e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W2, MP_BAND_GB, 160, 2>, 64, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W2, MP_BAND_GB, MP_BAND_MAXL, 2>, 64, 0);
+        else e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 0>, 64, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 0>, 64, 0);
         if (e != hipSuccess || per_cu < 1) per_cu = 1;
         round_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
     }
@@ -833,21 +843,48 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     if (c->flags.reserve((size_t)chunk_blocks * per_block) || c->band_fill.reserve(n + 2) || c->band_flag.reserve(n + 2) || c->band_idx.reserve(n + 2))
         return MP_ENOMEM;
     const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
-    while (c->ev_pool.size() < 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    while (c->ev_pool.size() < 3 * n_chunks + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    const size_t ev_a = 3 * n_chunks, ev_b = 3 * n_chunks + 1;
+    uint32_t *slab = (uint32_t *)c->flags.p;
+    const mp_fill_result *none = nullptr;
+    if (two_pass) {
+        HIPCHK(hipEventRecord(c->ev_pool[ev_a], s));
+        if (small)
+            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 1>), dim3(n_blocks), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                               d_tasks, n, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p);
+        else
+            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 1>), dim3(n_blocks), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                               d_tasks, n, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p);
+        HIPCHK(hipEventRecord(c->ev_pool[ev_b], s));
+    }
     size_t ci = 0;
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks, ci++) {
         const uint32_t off = b0 * 128u;
         const uint32_t cnt = (uint32_t)std::min<uint64_t>((uint64_t)chunk_blocks * 128u, n - off);
+        const dim3 grid((cnt + 127) / 128), block(64);
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci], s));
-        if (small)
-            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160>), dim3((cnt + 127) / 128), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                               d_tasks + off, cnt, cl, cr, (uint32_t *)c->flags.p, ncols, c->band_fill.p + off);
-        else
-            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL>), dim3((cnt + 127) / 128), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                               d_tasks + off, cnt, cl, cr, (uint32_t *)c->flags.p, ncols, c->band_fill.p + off);
+        if (two_pass) {
+            if (small)
+                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W2, MP_BAND_GB, 160, 2>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                   d_tasks + off, cnt, cl, cr, slab, ncols, (const mp_fill_result *)(c->band_fill.p + off), (mp_fill_result *)nullptr);
+            else
+                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W2, MP_BAND_GB, MP_BAND_MAXL, 2>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                   d_tasks + off, cnt, cl, cr, slab, ncols, (const mp_fill_result *)(c->band_fill.p + off), (mp_fill_result *)nullptr);
+        } else {
+            if (small)
+                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 0>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                   d_tasks + off, cnt, cl, cr, slab, ncols, none, c->band_fill.p + off);
+            else
+                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 0>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                   d_tasks + off, cnt, cl, cr, slab, ncols, none, c->band_fill.p + off);
+        }
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
-        hipLaunchKernelGGL((dp_trace_kernel<16, 5, MP_BAND_W, MP_BAND_GB>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks + off, c->d_lens, cnt, cl, cr,
-                           (const uint32_t *)c->flags.p, ncols, c->band_fill.p + off, d_res + off, (uint8_t *)nullptr, 0u);
+        if (two_pass)
+            hipLaunchKernelGGL((dp_trace_kernel<16, 5, MP_BAND_W2, MP_BAND_GB, true>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks + off, c->d_lens, cnt, cl, cr,
+                               (const uint32_t *)slab, ncols, c->band_fill.p + off, d_res + off, (uint8_t *)nullptr, 0u);
+        else
+            hipLaunchKernelGGL((dp_trace_kernel<16, 5, MP_BAND_W, MP_BAND_GB, false>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks + off, c->d_lens, cnt, cl, cr,
+                               (const uint32_t *)slab, ncols, c->band_fill.p + off, d_res + off, (uint8_t *)nullptr, 0u);
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
     }
     hipLaunchKernelGGL(dp_band_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_fill.p, n, c->band_flag.p);
@@ -867,6 +904,7 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
         if (ms_fill) *ms_fill += a;
         if (ms_trace) *ms_trace += b;
     }
+    if (two_pass && ms_fill) { float a = 0; (void)hipEventElapsedTime(&a, c->ev_pool[ev_a], c->ev_pool[ev_b]); *ms_fill += a; }
     c->n_band += n; c->n_band_full += n_sel;
     static const bool verbose = getenv("MP_DP_BAND_STATS") != nullptr;
     if (verbose) fprintf(stderr, "[band] %u instances, %u left to the full kernels\n", n, n_sel);

@@ -402,7 +402,8 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 
 // ------------------------------------------------------------------------------------------------ traceback
 // BW > 0: the slab was written by dp_band_kernel<BW, GB> (kernels_dp_band.hip): [block of 64 pairs][column][word][lane]
-template <int LPI, int C, int BW = 0, int GB = 0>
+// CENTER: the band is the one of dp_band_kernel's second pass, centred on the diagonal of the best cell
+template <int LPI, int C, int BW = 0, int GB = 0, bool CENTER = false>
 __global__ void __launch_bounds__(64)
 dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, uint32_t n_tasks, int clip_left, int clip_right,
                 const uint32_t *__restrict__ flags, uint32_t flag_rows, const mp_fill_result *__restrict__ fill,
@@ -431,7 +432,7 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
         if (c == 0) return TB_Z;
         if (r == 0) return c <= clipL ? TB_Z : 0u;
         if (BW > 0) {
-            const int d = r - c + GB;
+            const int d = r - c + GB - (CENTER ? (int)fr.row - (int)fr.col : 0);
             if (d < 0 || d >= BW) return 0u;          // never reached for an instance the band kernel qualified
             const uint32_t w = fpair[((uint64_t)(c - 1) * NWB + (uint32_t)(d / 3)) * 64];
             // the band kernel shifts its bits in: first cell of a word highest, within a cell Z, nD, nE, nEO, nFO from the top

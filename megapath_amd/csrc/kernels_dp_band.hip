@@ -29,11 +29,14 @@
 // cells of the band in one column, words of traceback bits per column (3 cells per 16-bit half)
 #define MP_BAND_W (MP_BAND_DMAX + 2 * MP_BAND_GB + 1)
 #define MP_BAND_NW ((MP_BAND_W + 2) / 3)
+// second pass of the two-pass scheme: diagonals of the best cell +- MP_BAND_GB
+#define MP_BAND_W2 (2 * MP_BAND_GB + 1)
+#define MP_BAND_NW2 ((MP_BAND_W2 + 2) / 3)
 
 // One band cell of two instances.  Hd enters as H of (row-1, col-1) [same d, previous column] and leaves as H of this
 // cell; Hn / Fn are the previous column's H / F one row down (d + 1): the horizontal neighbour; Hc / Ec the cell above
 // in this column.  Frame arithmetic as in MP_DP_CELL_CORE (values are x + BIAS - column).
-#define MP_BAND_CELL \
+#define MP_BAND_CORE \
         "v_sub_u32 %[eo], %[Hc], %[k3]\n\t" \
         "v_sub_u32 %[Ec], %[Ec], %[k1]\n\t" \
         "v_pk_max_u16 %[Ec], %[eo], %[Ec]\n\t"                    /* E */ \
@@ -45,7 +48,8 @@
         "v_sub_u32 %[dg], %[Hd], %[t1]\n\t" \
         "v_pk_max_u16 %[t1], %[dg], %[Ec]\n\t" \
         "v_pk_max_u16 %[t1], %[t1], %[Fd]\n\t" \
-        "v_pk_max_u16 %[Hd], %[t1], %[floorv]\n\t"                /* H */ \
+        "v_pk_max_u16 %[Hd], %[t1], %[floorv]\n\t"                /* H */
+#define MP_BAND_BITS \
         "v_xor_b32 %[bits], %[Hd], %[t1]\n\t" \
         "v_pk_min_u16 %[bits], %[bits], %[k1]\n\t" \
         "v_pk_mad_u16 %[fw], %[fw], %[k2], %[bits]\n\t"           /* Z: the word is built by shifting the bits in */ \
@@ -60,18 +64,27 @@
         "v_pk_mad_u16 %[fw], %[fw], %[k2], %[t1]\n\t"            /* nEO */ \
         "v_xor_b32 %[t1], %[Fd], %[fo]\n\t" \
         "v_pk_min_u16 %[t1], %[t1], %[k1]\n\t" \
-        "v_pk_mad_u16 %[fw], %[fw], %[k2], %[t1]\n\t"            /* nFO */ \
-        "v_pk_max_u16 %[colmax], %[colmax], %[Hd]"                /* the column's maximum; its row is looked for only when it matters */
+        "v_pk_mad_u16 %[fw], %[fw], %[k2], %[t1]\n\t"            /* nFO */
+// the column's maximum; its row is looked for only when it matters
+#define MP_BAND_COLMAX "v_pk_max_u16 %[colmax], %[colmax], %[Hd]"
+#define MP_BAND_NOP ""
 
 MP_PKOP2(pk_maxu, "v_pk_max_u16")
 __device__ __forceinline__ v2s pk_subsat(v2s a, v2s b) { v2s r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-template <int W, int GB, int MAXL>
+// MODE 0: one pass -- band of W = MP_BAND_W diagonals fixed to the window, traceback bits and best cell.
+// MODE 1: the same band, scores only (best cell, ties): first pass of the two-pass scheme.
+// MODE 2: second pass of the two-pass scheme, traceback bits only, over the W = 2 GB + 1 diagonals around the diagonal of
+//         the best cell found by the first pass (`center`).  An instance the first pass qualified scored >= L - 13: its
+//         gaps cost at most 13 in total, i.e. at most 11 gap bases, so every optimal path into the best cell -- and every
+//         tied alternative the bits have to record -- stays within 11 diagonals of it.  Rows <= 0 can now appear up to
+//         column 2 GB + 1, which must lie under the left clip (run_dp_band checks the limit).
+template <int W, int GB, int MAXL, int MODE>
 __global__ void __launch_bounds__(64)
 dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, int clip_left, int clip_right,
                uint32_t *__restrict__ flags, uint32_t ncols /* columns of NW x 64 words reserved per block */,
-               mp_fill_result *__restrict__ out)
+               const mp_fill_result *__restrict__ center, mp_fill_result *__restrict__ out)
 {
     constexpr int NW = (W + 2) / 3;
     static_assert(W % 3 == 0, "three cells per 16-bit half of a flag word");
@@ -83,6 +96,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     // per-instance state, packed to keep the register budget for the band: L | m << 9 | forward << 18 | fit << 19 |
     // empty << 20 | bad << 21
     uint32_t info[2], rid[2];
+    int rbase[2];                                   // row of band cell d in column j: j + d + rbase
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const uint32_t inst = 2 * pair + q;
@@ -94,7 +108,14 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         rid[q] = task.read_id;
         const int clipL = task.strand == 1 ? clip_left : clip_right;
         // the band covers this instance: read short enough, window surplus inside the band, rows <= 0 only under the left clip
-        const bool fit = live && L >= 30 && L <= MAXL && m >= 1 && m - L <= W - 1 - 2 * GB && m + GB < R && clipL >= GB;
+        bool fit;
+        rbase[q] = -GB;
+        if (MODE == 2) {
+            const mp_fill_result ctr = live ? center[inst] : mp_fill_result{0, 0, 0, 0};
+            fit = live && ctr.score > 0 && L <= MAXL && m >= 1 && clipL >= 2 * GB + 1;
+            rbase[q] = (int)ctr.row - (int)ctr.col - GB;
+        } else
+            fit = live && L >= 30 && L <= MAXL && m >= 1 && m - L <= W - 1 - 2 * GB && m + GB < R && clipL >= GB;
         const bool empty = live && task.win_len == 0;  // nothing to align: decided, score 0 (as the full kernels report it)
         if (!fit) { L = 0; m = 0; }
         info[q] = (uint32_t)L | ((uint32_t)m << 9) | (task.strand == 1 ? 1u << 18 : 0u) | (fit ? 1u << 19 : 0u) | (empty ? 1u << 20 : 0u);
@@ -107,10 +128,12 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             if (sh) two |= (uint64_t)text[(p >> 4) + 1] << 32;
             uint32_t bases = (uint32_t)(two >> sh);
             for (int x = 0; x < 16 && w * 16 + x < m; x++) {
-                uint8_t &cell = s_code[GB + 1 + w * 16 + x][lane];
+                const int at = w * 16 + x + 1 - rbase[q];               // window row i sits at index i - rbase
                 const uint32_t code = (uint32_t)MP_DP_CODE(bases & 3u);
-                cell = q == 0 ? (uint8_t)((cell & 0xF0u) | code) : (uint8_t)((cell & 0x0Fu) | (code << 4));
                 bases >>= 2;
+                if (at < 0 || at >= R) continue;
+                uint8_t &cell = s_code[at][lane];
+                cell = q == 0 ? (uint8_t)((cell & 0xF0u) | code) : (uint8_t)((cell & 0x0Fu) | (code << 4));
             }
         }
     }
@@ -170,12 +193,24 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             const v2s Hc = d == 0 ? sent : H[d - 1];
             const v2s Hn = d + 1 < W ? H[d + 1] : sent;
             const v2s Fn = d + 1 < W ? F[d + 1] : sent;
-            asm(MP_BAND_CELL
-                : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [bits] "=&v"(bits), [Hd] "+&v"(H[d]), [Ec] "+&v"(Ec),
-                  [Fd] "=&v"(F[d]), [fw] "+&v"(fw), [colmax] "+&v"(colmax)
-                : [Hc] "v"(Hc), [Hn] "v"(Hn), [Fn] "v"(Fn), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
-                  [k1] "v"(K.k1), [k2] "v"(K.k2), [k3] "v"(K.k3), [k4] "v"(K.k4));
-            if (d % 3 == 2 || d == W - 1) {
+            if (MODE == 1)
+                asm(MP_BAND_CORE MP_BAND_COLMAX
+                    : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [Hd] "+&v"(H[d]), [Ec] "+&v"(Ec), [Fd] "=&v"(F[d]), [colmax] "+&v"(colmax)
+                    : [Hc] "v"(Hc), [Hn] "v"(Hn), [Fn] "v"(Fn), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
+                      [k1] "v"(K.k1), [k2] "v"(K.k2), [k3] "v"(K.k3), [k4] "v"(K.k4));
+            else if (MODE == 2)
+                asm(MP_BAND_CORE MP_BAND_BITS MP_BAND_NOP
+                    : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [bits] "=&v"(bits), [Hd] "+&v"(H[d]), [Ec] "+&v"(Ec),
+                      [Fd] "=&v"(F[d]), [fw] "+&v"(fw)
+                    : [Hc] "v"(Hc), [Hn] "v"(Hn), [Fn] "v"(Fn), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
+                      [k1] "v"(K.k1), [k2] "v"(K.k2), [k3] "v"(K.k3), [k4] "v"(K.k4));
+            else
+                asm(MP_BAND_CORE MP_BAND_BITS MP_BAND_COLMAX
+                    : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [bits] "=&v"(bits), [Hd] "+&v"(H[d]), [Ec] "+&v"(Ec),
+                      [Fd] "=&v"(F[d]), [fw] "+&v"(fw), [colmax] "+&v"(colmax)
+                    : [Hc] "v"(Hc), [Hn] "v"(Hn), [Fn] "v"(Fn), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
+                      [k1] "v"(K.k1), [k2] "v"(K.k2), [k3] "v"(K.k3), [k4] "v"(K.k4));
+            if (MODE != 1 && (d % 3 == 2 || d == W - 1)) {
                 fcol[(uint64_t)(j - 1) * (NW * 64) + (d / 3) * 64] = __builtin_bit_cast(uint32_t, fw);
                 fw = pk1(0);
             }
@@ -183,7 +218,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         // Does this column hold an eligible value at or above the qualifying score?  Only the last GB or so columns of a
         // read can; there the band is walked once more for the first row of the maximum and the number of its ties.
         const v2s ex = pk_subsat(colmax, thr) & pk(el2[0], el2[1]);
-        if (__any(as_int(ex) != 0)) {
+        if (MODE != 2 && __any(as_int(ex) != 0)) {
             short lim2[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {                      // rows past the window's end (d > m - j + GB) do not count
@@ -218,7 +253,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const uint32_t inst = 2 * pair + q;
-        if (inst >= n_tasks) continue;
+        if (MODE == 2 || inst >= n_tasks) continue;
         mp_fill_result r;
         // score -1: "not decided by the band" -- below the qualifying score, outside the band's shape, or the first
         // maximum fell on a pad row past the window

@@ -176,7 +176,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             int mc = L - clipR; if (mc < 0) mc = 0;
             el2[q] = (short)((j >= mc && j <= L) ? -1 : 0);
         }
-        const v2s rb = pk(b2[0], b2[1]), floorv = pk(fl2[0], fl2[1]), thr = pk(th2[0], th2[1]);
+        const v2s rb = pk((short)(b2[0] << 12), b2[1]), floorv = pk(fl2[0], fl2[1]), thr = pk(th2[0], th2[1]);
         v2s Ec = sent, colmax = pk1(0);
         v2s fw = pk1(0);
         const uint8_t *c0 = &s_code[j][lane];
@@ -188,7 +188,9 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         for (int d = 0; d < W; d++) {
             if (d + PF < W) cbq[d + PF] = c0[(d + PF) * 64];
             const uint32_t cb = cbq[d];                                         // row j + d - GB of both windows
-            const v2s base = as_v2s((int)((cb | (cb << 12)) & 0x000F000Fu));
+            // one shift separates the two codes: instance 0's lands in bits 12-15 of the low half, instance 1's in bits 0-3 of
+            // the high half (the read codes of the column are laid out the same way, so XOR / min_u16(.,3) still work)
+            const v2s base = as_v2s((int)(cb << 12));
             v2s eo, fo, dg, t1, bits;
             const v2s Hc = d == 0 ? sent : H[d - 1];
             const v2s Hn = d + 1 < W ? H[d + 1] : sent;

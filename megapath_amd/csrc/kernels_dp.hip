@@ -138,8 +138,7 @@ struct dp_weights { v2s z, d, e, eo, fo; };
         "v_sub_u32 %[dg], %[diag], %[t1]\n\t" \
         "v_pk_max_u16 %[t1], %[dg], %[Eup]\n\t" \
         "v_pk_max_u16 %[t1], %[t1], %[Fl]\n\t" \
-        "v_pk_max_u16 %[Hup], %[t1], %[floorv]\n\t" \
-        "v_pk_min_u16 %[t1], %[Hup], %[elig]\n\t"
+        "v_pk_max_u16 %[Hup], %[t1], %[floorv]\n\t"
 
 // MODE 0: traceback bits + row code (text output); 1: traceback bits + exact first-maximum tracking with tie counts
 // (BAM output, mp_sgdp_batch); 2: scores only
@@ -150,13 +149,15 @@ __device__ __forceinline__ void dp_cell(const dp_consts &K, const dp_weights &Wt
 {
     v2s eo, fo, dg, t1, bits;
     if (MODE == 2) {
+        // score-only filter: `rowcode` is this COLUMN's running maximum of H over all rows (one frame per column).  Rows past
+        // the window and columns that cannot end an alignment are included: the filter may over-estimate (the instance is
+        // then filled in full and decided exactly), it must never under-estimate.
         asm(MP_DP_CELL_SCORE
-            "v_pk_mad_i16 %[t1], %[t1], %[k16], %[colk]\n\t"
-            "v_pk_max_u16 %[rowcode], %[rowcode], %[t1]"
+            "v_pk_max_u16 %[rowcode], %[rowcode], %[Hup]"
             : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [dn] "=&v"(dnext), [Hup] "+&v"(Hup), [Eup] "+&v"(Eup),
               [Fl] "+&v"(Fl), [rowcode] "+&v"(rowcode)
-            : [Hl] "v"(Hl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv), [elig] "v"(elig), [k1] "v"(K.k1), [k2] "v"(K.k2),
-              [k3] "v"(K.k3), [k4] "v"(K.k4), [k16] "v"(K.k16), [colk] "v"(colk));
+            : [Hl] "v"(Hl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv), [k1] "v"(K.k1), [k2] "v"(K.k2),
+              [k3] "v"(K.k3), [k4] "v"(K.k4));
     } else if (MODE == 0) {
         // ((H + bias) << 4) | (15 - cc): one max per cell keeps the row's best score and, among equals, its first column;
         // colk = 16 j + 15 - cc puts the column term back
@@ -297,6 +298,9 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     // best so far: COUNT: score + bias; otherwise the row code ((score + bias) << 4 | 15 - cc) -- both start at score 0
     v2s best = COUNT ? pk1((short)B) : pk1((short)(B << 4)), bpos = kZero;
     v2s cnt = kZero;
+    v2s colmax[MODE == 2 ? C : 1];                     // score-only pass: running maximum of every column
+#pragma unroll
+    for (int cc = 0; cc < (MODE == 2 ? C : 1); cc++) colmax[cc] = kZero;
     v2s outH = pk1((short)B), outF = pk1(MP_DP_SENT);
     int outB = 0;
     // slab of one instance pair: [lane][step][word] -- the traceback walks a lane's steps, 8 of them per 64-byte line
@@ -335,11 +339,11 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
                 v2s dnext;
                 const int j = k * C + cc + 1;
                 dp_cell<MODE>(K, Wt[cc % 3], Hup[cc], Eup[cc], Hl, Fl, diag, base, rb[cc], floorv[cc], elig[cc], gatecap,
-                               pk1((short)(16 * j + 15 - cc)), pk1((short)j), dnext, fw[cc / 3], best, bpos, pos, cnt, rowcode);
+                               pk1((short)(16 * j + 15 - cc)), pk1((short)j), dnext, fw[cc / 3], best, bpos, pos, cnt, MODE == 2 ? colmax[cc] : rowcode);
                 diag = dnext;
                 Hl = Hup[cc];
             }
-            if (!COUNT) {
+            if (MODE == 0) {
                 // once per row: does this row beat the best so far?  (strictly: code > best code with its column bits saturated)
                 const v2s rc = umin(rowcode, gatecode);                        // rows past the instance's window never win
                 const v2s b15 = best | pk1(15);
@@ -371,7 +375,14 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         int b, brow, bcol;
-        if (COUNT) {
+        if (MODE == 2) {
+            b = 0; brow = 0; bcol = 0;
+#pragma unroll
+            for (int cc = 0; cc < C; cc++) {             // back to the column-free frame
+                const int v = (int)(unsigned short)(q == 0 ? colmax[cc].x : colmax[cc].y) + (k * C + cc + 1) - MP_DP_BIAS;
+                b = v > b ? v : b;
+            }
+        } else if (COUNT) {
             const int pos = q == 0 ? bpos.x : bpos.y;
             b = (int)(unsigned short)(q == 0 ? best.x : best.y) - MP_DP_BIAS; brow = pos >> 4; bcol = k * C + (pos & 15) + 1;
         } else {

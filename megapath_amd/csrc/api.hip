@@ -197,17 +197,24 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
     for (uint32_t b = 0; b < 31; b++) if ((1u << b) == h.sa_interval) ix->d.sa_shift = b;
     for (int i = 0; i < 5; i++) ix->d.cum[i] = (uint32_t)h.cum[i];
     {
-        // denser SA samples (every 4th row instead of every 16th: locate walks 1.5 LF steps on average instead of 7.5),
-        // n bytes, derived here from the file's samples; same automatic rule and override as the pre-filter
-        // (MP_SA_DENSE=0 / 1)
-        const char *e = getenv("MP_SA_DENSE");
+        // denser SA samples, derived here from the file's: the whole suffix array (4n bytes, locate needs no LF step)
+        // when that leaves >= 16 GiB free, else every 2nd or every 4th row (1.5 LF steps on average instead of 7.5 with
+        // the file's interval 16); same automatic rule and override as the pre-filter (MP_SA_DENSE=0 / 1;
+        // MP_SA_DENSE_SPACING=1|2|4 forces a spacing)
+        const char *e = getenv("MP_SA_DENSE"), *sp = getenv("MP_SA_DENSE_SPACING");
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        bool on = n >= (1ull << 25) && free_b >= (12ull << 30) && h.sa_interval > MP_SA_DENSE;
-        if (e) on = atoi(e) != 0 && h.sa_interval > MP_SA_DENSE;
-        const uint32_t rows = (uint32_t)(n / MP_SA_DENSE + 1);
-        if (on && hipMalloc(&ix->d_sa_dense, (size_t)rows * 4) == hipSuccess) {
-            hipLaunchKernelGGL(sa_dense_build_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, 0, ix->d, rows, (uint32_t *)ix->d_sa_dense);
+        bool on = n >= (1ull << 25) && free_b >= n + (12ull << 30);
+        if (e) on = atoi(e) != 0;
+        uint32_t shift = free_b >= 4 * n + (16ull << 30) ? 0u : free_b >= 2 * n + (14ull << 30) ? 1u : 2u;
+        if (e && atoi(e) != 0 && !sp && n < (1ull << 25)) shift = 0;                  // forced on for a small text: the whole array
+        if (sp) shift = atoi(sp) <= 1 ? 0u : atoi(sp) == 2 ? 1u : 2u;
+        if (h.sa_interval <= (1u << shift)) on = false;
+        const uint64_t rows64 = (n >> shift) + 1;
+        if (on && rows64 < 0xFFFFFFFFull && hipMalloc(&ix->d_sa_dense, (size_t)rows64 * 4) == hipSuccess) {
+            const uint32_t rows = (uint32_t)rows64;
+            ix->d.sa_dense_shift = shift;
+            hipLaunchKernelGGL(sa_dense_build_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, 0, ix->d, rows, shift, (uint32_t *)ix->d_sa_dense);
             if (hipDeviceSynchronize() != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
             ix->d.sa_dense = (const uint32_t *)ix->d_sa_dense;
             ix->device_bytes += (size_t)rows * 4;

@@ -79,17 +79,18 @@ __global__ void occ_query_kernel(mp_dev_index ix, const uint64_t *idx, const uin
     if (t < n) out[t] = mp_occ(ix, (uint32_t)idx[t], sym[t]);
 }
 
-// SA samples every MP_SA_DENSE rows (optional table sa_dense, derived at load time from the file's samples): since
-// SA[LF(i)] = SA[i] - 1 the walk may stop at any sampled row
-#define MP_SA_DENSE 4
+// Denser SA samples than the file's (optional table sa_dense, derived at load time from the file's samples): since
+// SA[LF(i)] = SA[i] - 1 the walk may stop at any sampled row.  With HBM to spare the table is the whole suffix array
+// (shift 0: no LF step at all), else every 2nd or 4th row.
 __device__ __forceinline__ uint64_t mp_sa_value(const mp_dev_index &ix, uint32_t idx, uint32_t *steps_out)
 {
     uint32_t steps = 0, q;
     if (ix.sa_dense) {
-        while (idx & (MP_SA_DENSE - 1)) { idx = mp_lf(ix, idx); steps++; }
+        const uint32_t mask = (1u << ix.sa_dense_shift) - 1u;
+        while (idx & mask) { idx = mp_lf(ix, idx); steps++; }
         *steps_out = steps;
-        q = idx / MP_SA_DENSE;
-        return (q == 0 ? ~0ull : (uint64_t)ix.sa_dense[q]) + steps;
+        q = idx >> ix.sa_dense_shift;
+        return (idx == 0 ? ~0ull : (uint64_t)ix.sa_dense[q]) + steps;
     }
     if (ix.sa_shift != 0xFFFFFFFFu) {             // power-of-two sampling: mask and shift instead of integer division
         const uint32_t mask = ix.sa_interval - 1;
@@ -105,13 +106,13 @@ __device__ __forceinline__ uint64_t mp_sa_value(const mp_dev_index &ix, uint32_t
     return base + steps;
 }
 
-// fills sa_dense[k] = SA[MP_SA_DENSE * k] by the ordinary walk to the file's samples (ix.sa_dense must be null here)
-__global__ void sa_dense_build_kernel(mp_dev_index ix, uint32_t n_rows, uint32_t *__restrict__ out)
+// fills sa_dense[k] = SA[k << shift] by the ordinary walk to the file's samples (ix.sa_dense must be null here)
+__global__ void sa_dense_build_kernel(mp_dev_index ix, uint32_t n_rows, uint32_t shift, uint32_t *__restrict__ out)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (k >= n_rows) return;
     uint32_t steps;
-    out[k] = (uint32_t)mp_sa_value(ix, k * MP_SA_DENSE, &steps);
+    out[k] = (uint32_t)mp_sa_value(ix, (uint32_t)(k << shift), &steps);
 }
 
 __global__ void sa_query_kernel(mp_dev_index ix, const uint64_t *idx, uint64_t n, uint64_t *out)

@@ -26,7 +26,8 @@ struct mp_dev_index {          // passed by value to kernels
     const uint32_t *sa;        // SA[k*interval]; entry 0 unused (handled as -1, BWT.c:242)
     const uint32_t *text;      // 2-bit text, LSB-first, 16 bases per word
     const uint32_t *kmer17;    // optional: one bit per 17-mer, set when backward search can reach length 17 with it (nullptr = off)
-    const uint32_t *sa_dense;  // optional: SA[4k], filled on the device from the interval-16 samples (nullptr = off)
+    const uint32_t *sa_dense;  // optional: SA[k << sa_dense_shift], filled on the device from the file's samples (nullptr = off)
+    uint32_t sa_dense_shift;   // 0: the whole suffix array, 1: every 2nd row, 2: every 4th
     uint32_t n;                // text length
     uint32_t inv_sa0;
     uint32_t cum[5];

@@ -78,6 +78,11 @@ int mp_index_copy_lkt(const mp_index *ix, uint32_t *out);
  * with the 17-mer keys[i] (34 bits, first scanned base in the low bits as for mp_index_lkt), i.e. when the 13-mer table
  * range of its low 26 bits survives the four further extension steps.  MP_EINVAL when the bitmap is not resident. */
 int mp_index_prefilter(const mp_index *ix, const uint64_t *keys, uint64_t n, uint8_t *out);
+/* Test aid.  When the index carries the 16-mer look-up table (17 GB, built next to the pre-filter when HBM allows; the
+ * seeding kernel then reads the SA range of a seed start's first 16 bases directly): compares the table with the index's
+ * own procedure -- 13-mer table plus three backward-search steps -- for the 16-mer at every text position and for
+ * n_random arbitrary keys.  MP_EINVAL when the table is not resident. */
+int mp_index_check_lkt16(mp_index *index, uint64_t n_random, uint64_t *out_checked, uint64_t *out_mismatches);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Context and reads. */

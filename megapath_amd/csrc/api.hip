@@ -190,7 +190,39 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
             ix->device_bytes += kb;
         }
     }
-    ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt;
+    if (ix->d_kmer) {
+        // 16-mer look-up table behind the pre-filter (kernels_index.hip): 17 GB, three backward-search steps less per seed
+        // start; automatic when that leaves >= 16 GiB free, MP_LKT16=0 / 1 overrides
+        const char *e = getenv("MP_LKT16");
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const size_t entries = (size_t)1 << 32, bytes = entries * 4;
+        bool on = n >= (1ull << 25) && free_b >= bytes + (16ull << 30);
+        if (e) on = atoi(e) != 0;
+        if (on && hipMalloc(&ix->d_lkt16, bytes) == hipSuccess) {
+            uint32_t *t16 = (uint32_t *)ix->d_lkt16;
+            if (hipMemset(t16, 0, bytes) != hipSuccess) return fail(MP_ENODEV);
+            hipLaunchKernelGGL(lkt16_hist_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, t16);
+            // inclusive prefix sum over 2^32 entries: four scans of 2^30 (the library takes int counts), then the carries
+            const size_t part = (size_t)1 << 30;
+            size_t tb = 0;
+            (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, t16, t16, (int)part, 0);
+            void *tmp16 = nullptr;
+            if (hipMalloc(&tmp16, tb + 256) != hipSuccess) return fail(MP_ENOMEM);
+            uint32_t carry = 0;
+            for (int c = 0; c < 4; c++) {
+                (void)hipcub::DeviceScan::InclusiveSum(tmp16, tb, t16 + c * part, t16 + c * part, (int)part, 0);
+                if (carry) hipLaunchKernelGGL(add_offset_kernel, dim3(grid_for(part, 256)), dim3(256), 0, 0, t16 + c * part, (uint64_t)part, carry);
+                uint32_t last = 0;
+                if (hipMemcpy(&last, t16 + (c + 1) * part - 1, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(tmp16); return fail(MP_ENODEV); }
+                carry = last;
+            }
+            (void)hipFree(tmp16);
+            if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
+            ix->device_bytes += bytes;
+        }
+    }
+    ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt; ix->d.lkt16 = (const uint32_t *)ix->d_lkt16;
     ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text; ix->d.kmer17 = (const uint32_t *)ix->d_kmer;
     ix->d.n = (uint32_t)h.n; ix->d.inv_sa0 = (uint32_t)h.inv_sa0; ix->d.sa_interval = h.sa_interval;
     ix->d.sa_shift = 0xFFFFFFFFu;
@@ -261,6 +293,7 @@ extern "C" int mp_index_close(mp_index *ix)
     if (ix->d_sa) (void)hipFree(ix->d_sa);
     if (ix->d_text) (void)hipFree(ix->d_text);
     if (ix->d_kmer) (void)hipFree(ix->d_kmer);
+    if (ix->d_lkt16) (void)hipFree(ix->d_lkt16);
     if (ix->d_sa_dense) (void)hipFree(ix->d_sa_dense);
     delete ix;
     return MP_OK;
@@ -434,6 +467,23 @@ extern "C" int mp_index_prefilter(const mp_index *ix, const uint64_t *keys, uint
     return MP_OK;
 }
 
+extern "C" int mp_index_check_lkt16(mp_index *ix, uint64_t n_random, uint64_t *out_checked, uint64_t *out_mismatches)
+{
+    if (!ix || !out_checked || !out_mismatches) return MP_EINVAL;
+    if (!ix->d_lkt16) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
+    HIPCHK(hipMalloc((void **)&d_out, 16));
+    HIPCHK(hipMemset(d_out, 0, 16));
+    const uint64_t n_text = ix->n >= 4 ? ix->n - 3 : 0;
+    hipLaunchKernelGGL(lkt16_check_kernel, dim3(grid_for(n_text + n_random, 256)), dim3(256), 0, 0, ix->d, n_text, n_random, d_out);
+    hipError_t e = hipMemcpy(h_out, d_out, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return MP_ENODEV;
+    *out_checked = h_out[0]; *out_mismatches = h_out[1];
+    return MP_OK;
+}
+
 extern "C" int mp_bench_gather64(const mp_index *ix, uint32_t lanes, uint32_t per_lane, uint32_t repeats, float *out_ms, uint64_t *out_bytes)
 {
     if (!ix || !out_ms || !out_bytes || lanes == 0 || per_lane == 0 || repeats == 0) return MP_EINVAL;
@@ -531,7 +581,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     uint32_t slab_limit = MP_SEED_SLAB;
     if (const char *e = getenv("MP_SEED_SLAB_LIMIT")) { int v = atoi(e); if (v >= 1 && v < MP_SEED_SLAB) slab_limit = (uint32_t)v; }   // test knob
     mp_dev_index dix = c->ix->d;
-    if (!c->use_prefilter) { dix.kmer17 = nullptr; dix.sa_dense = nullptr; }
+    if (!c->use_prefilter) { dix.kmer17 = nullptr; dix.sa_dense = nullptr; dix.lkt16 = nullptr; }
     hipStream_t s = c->stream;
     const uint32_t overflow_cap = n_items;
     if (c->scan.reserve((size_t)n_items * (W + 1) + 16) || c->slabs.reserve((size_t)n_items * MP_SEED_SLAB) || c->seeds_per_rs.reserve(n_items + 2) ||

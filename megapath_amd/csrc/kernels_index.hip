@@ -86,6 +86,30 @@ __global__ void lkt_hist_kernel(const uint32_t *__restrict__ text, uint64_t n, u
     atomicAdd(&lkt[key], 1u);
 }
 
+// A second look-up table over 16-mers (4^16 x 4 B = 17 GB), used by the seeding kernel behind the 17-mer pre-filter: when
+// the next 17 scanned bases are known to be reachable, the SA range of the first 16 can be read directly instead of the
+// 13-mer table plus three backward-search steps (none of the skipped steps is observable: all are below seedMinLength).
+// Same construction as the 13-mer table (LTConstruct.c:44-105): every suffix counts with the text continued by 'A's, then
+// an inclusive prefix sum -- so the row numbering is that of the suffix array.  The last three suffixes have fewer than
+// four real bases: the reference's procedure (13-mer window starting three bases further) never reaches them, they sit
+// in buckets whose 13 rightmost bases are all 'A', and the seeding kernel keeps the 13-mer path for those keys.
+__global__ void lkt16_hist_kernel(const uint32_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ lkt16)
+{
+    const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint64_t q = s >> 4;
+    const uint32_t sh = 2 * (uint32_t)(s & 15);
+    const uint64_t two = ((uint64_t)text[q + 1] << 32) | text[q];
+    const uint32_t lsb = (uint32_t)(two >> sh);                            // base s in bits 1:0 ('A' beyond n: zero padded)
+    atomicAdd(&lkt16[mp_rev2(lsb)], 1u);                                   // base s in bits 31:30
+}
+
+__global__ void add_offset_kernel(uint32_t *__restrict__ a, uint64_t n, uint32_t off)
+{
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t < n) a[t] += off;
+}
+
 // 17-mer presence bitmap (4^17 bits = 2 GiB), the seeding kernel's pre-filter.  A seed start whose first 17 scanned
 // bases form a 17-mer that the index cannot extend to is a seed shorter than seedMinLength (17 or more): it is never
 // reported and the scan restarts one base further whatever its exact length (CHECK_AND_ADD_RANGE,

@@ -220,6 +220,39 @@ __device__ __forceinline__ void mp_occ_pair(const mp_dev_index &ix, uint32_t k1,
     o2 = bsum;
 }
 
+// Test aid: for the 16-mer starting at every text position s <= n - 4 (and for `n_random` arbitrary keys) compares the
+// 16-mer table's range with what the index's own procedure yields: 13-mer table, then three backward-search steps.
+__global__ void lkt16_check_kernel(mp_dev_index ix, uint64_t n_text, uint64_t n_random, unsigned long long *__restrict__ out /* [checked, mismatches] */)
+{
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n_text + n_random) return;
+    uint32_t key16;                                            // scan order: rightmost base in bits 1:0
+    if (t < n_text) {
+        const uint64_t q = t >> 4;
+        const uint32_t sh = 2 * (uint32_t)(t & 15);
+        const uint64_t two = ((uint64_t)ix.text[q + 1] << 32) | ix.text[q];
+        const uint32_t lsb = (uint32_t)(two >> sh);            // text order, base t in bits 1:0
+        const uint32_t r = __brev(lsb);
+        key16 = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+    } else {
+        uint64_t x = (t - n_text + 1) * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        key16 = (uint32_t)x;
+    }
+    if ((key16 & (MP_LKT_ENTRIES - 1)) == 0) return;           // keys the seeding kernel leaves to the 13-mer path
+    const uint32_t key13 = key16 & (MP_LKT_ENTRIES - 1);
+    uint32_t l = key13 ? ix.lkt[key13 - 1] + 1 : 1, r = ix.lkt[key13];
+    for (int step = 0; step < 3 && l <= r; step++) {
+        const uint32_t c = (key16 >> (26 + 2 * step)) & 3u;
+        uint32_t o1, o2;
+        mp_occ_pair(ix, l, r + 1, c, o1, o2);
+        l = ix.cum[c] + o1 + 1; r = ix.cum[c] + o2;
+    }
+    const uint32_t tl = ix.lkt16[key16 - 1] + 1, tr = ix.lkt16[key16];
+    const bool same = l <= r ? (tl == l && tr == r) : tl > tr;
+    atomicAdd(&out[0], 1ull);
+    if (!same) atomicAdd(&out[1], 1ull);
+}
+
 // State of one (read, strand) backward search -- the variables of mmp<0>/mmp<2> (DV-DPfunctions.cpp:2224-2377)
 struct mp_mmp_state {
     const uint32_t *sc;     // scan-order bases of this item
@@ -279,8 +312,21 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
                 futile = ((ix.kmer17[k17 >> 5] >> (uint32_t)(k17 & 31)) & 1u) == 0;
                 my_kmer++;
             }
+            const uint32_t key16 = (uint32_t)(two >> sh);
             if (futile) {
                 ++s.i;                                        // a seed shorter than seed_min_length: nothing reported, restart one base on
+            } else if (ix.lkt16 && ix.kmer17 && P.seed_min_length >= 17 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
+                // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
+                // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
+                // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
+                const uint32_t nextl = ix.lkt16[key16 - 1] + 1, nextr = ix.lkt16[key16];
+                my_lkt++;
+                s.i += 15;
+                s.seed_len = 15;
+                if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
+                else mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
+                ++s.i;
+                if (s.i >= s.len) finished = true;
             } else {
                 const uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
                 const uint32_t nextl = key ? ix.lkt[key - 1] + 1 : 1;

@@ -109,10 +109,33 @@ def test_kmer_prefilter_bitmap_equals_table_plus_four_steps(g1_prefix, monkeypat
     lib.mpo_index_close(oix)
 
 
+@pytest.mark.parametrize("n_bases", [600000, 192 * 25 + 3, 4096 + 17])
+def test_lkt16_table_equals_table_plus_three_steps(tmp_path, n_bases, monkeypatch):
+    """The 16-mer look-up table the seeding kernel reads behind the pre-filter must hold, for every key the kernel uses it
+    for, the SA range the index's own procedure reaches: 13-mer table, then three backward-search steps.  Checked on the
+    device for the 16-mer at every text position (incl. those running into the 'A' padding at the text end, and a text
+    ending in a poly-A run) and for random keys."""
+    from megapath_amd import index_builder, synth
+    monkeypatch.setenv("MP_KMER_FILTER", "1")
+    monkeypatch.setenv("MP_LKT16", "1")
+    genome = synth.random_genome(n_bases, 91, n_seqs=2)
+    if n_bases < 10000:                                   # a poly-A tail: the buckets the kernel leaves to the 13-mer path
+        name, arr = genome[-1]
+        arr = arr.copy(); arr[-20:] = ord("A")
+        genome[-1] = (name, arr)
+    gix = H.Index.from_arrays(0, **index_builder.build_index_arrays(genome, sa_interval=16))
+    checked, bad = gix.check_lkt16(500000)
+    assert bad == 0
+    assert checked > n_bases - 200 + 400000
+    gix.close()
+
+
 @pytest.mark.parametrize("tag", ["a", "c"])
 def test_seeds_and_hits_identical_with_prefilter(g1_prefix, golden_dir, monkeypatch, tag):
-    """Same kept seeds and the same deep-DP hits with the 17-mer pre-filter on and off; fewer rank queries with it."""
+    """Same kept seeds and the same deep-DP hits with the 17-mer pre-filter (and the 16-mer table behind it) on and off;
+    fewer rank queries with it."""
     monkeypatch.setenv("MP_KMER_FILTER", "1")
+    monkeypatch.setenv("MP_LKT16", "1")
     monkeypatch.setenv("MP_SA_DENSE", "1")
     gix = H.Index(g1_prefix, 0)
     d = os.path.join(golden_dir, "g1")

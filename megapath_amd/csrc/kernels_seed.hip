@@ -527,9 +527,13 @@ __device__ __forceinline__ uint64_t key_pos(uint64_t k, uint64_t text_len)
 #define MP_KEY_LEN(k) ((int)(((k) >> 2) & 511u))
 #define MP_KEY_UNIQ(k) ((bool)((k) & 1u))
 
+#define MP_MERGE_BLOCK 64
+#define MP_MERGE_CAP 4096          // keys staged per block (32 KB)
+#define MP_MERGE_SMALL 32          // up to here a lane sorts its own read
+#define MP_MERGE_COOP 512          // up to here the wavefront sorts a read together (scratch: 4 KB)
 __device__ void sort_keys(uint64_t *a, int n)
 {
-    if (n <= 24) {
+    if (n <= MP_MERGE_SMALL) {
         for (int i = 1; i < n; i++) {
             const uint64_t t = a[i];
             int j = i - 1;
@@ -570,12 +574,11 @@ __device__ void sort_keys(uint64_t *a, int n)
     }
 }
 
-// seed merging of one read (DV-DPfunctions.cpp:2470-2560): k[0..n) are the keys of its located seed hits, out receives
-// the kept seeds.
+// seed merging of one read (DV-DPfunctions.cpp:2470-2560): k[0..n) are the SORTED keys of its located seed hits, out
+// receives the kept seeds.
 __device__ __forceinline__ void merge_read(uint64_t *k, int n, mp_seedpos *__restrict__ out, uint32_t r, const mp_dev_mmp &P, uint64_t text_len,
                                            uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
-    sort_keys(k, n);
     uint32_t max_cov = 0;
     int n_kept = 0;
     for (int m = 0; m < n; m++) {
@@ -635,33 +638,65 @@ __device__ __forceinline__ void merge_read(uint64_t *k, int n, mp_seedpos *__res
 
 // Output: seedpos[read_base[r] .. ) holds the kept seeds of read r, '+' first; n_pos[r], n_neg[r] their counts.
 // One lane per read, one wavefront per block.  The hits of a block's 64 reads are one contiguous range: it is read with
-// coalesced loads, packed to 8-byte keys and staged in LDS, where the lanes sort and group their own sub-ranges.  A
-// block whose range does not fit packs and sorts in place in global memory.
-#define MP_MERGE_BLOCK 64
-#define MP_MERGE_CAP 4096          // keys staged per block (32 KB)
+// coalesced loads, packed to 8-byte keys and staged in LDS.  Sorting: a wavefront waits for its largest read (nine in ten
+// wavefronts hold a read with more than 64 hits, while the median read has 20), so reads with more than MP_MERGE_SMALL
+// keys are sorted one after the other by all 64 lanes together (bitonic network in an LDS scratch area), the others by
+// their own lane (insertion sort).  The grouping pass is linear and runs one lane per read.  A block whose range does not
+// fit in LDS packs and sorts in place in global memory, lane by lane.
 __global__ void __launch_bounds__(MP_MERGE_BLOCK)
 merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P, uint64_t text_len,
              mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
     __shared__ uint64_t s_key[MP_MERGE_CAP];
+    __shared__ uint64_t s_tmp[MP_MERGE_COOP];
     const uint32_t r0 = blockIdx.x * MP_MERGE_BLOCK;
     const uint32_t r1 = min(r0 + MP_MERGE_BLOCK, n_reads);
     const uint32_t b0 = rs_base[2 * r0], T = rs_base[2 * r1] - b0;
     const bool staged = T <= MP_MERGE_CAP;
-    if (staged) {
-        for (uint32_t i = threadIdx.x; i < T; i += MP_MERGE_BLOCK) s_key[i] = hit_key(hits[b0 + i], P);
+    const int lane = threadIdx.x;
+    const uint32_t r = r0 + threadIdx.x;
+    const bool live = r < n_reads;
+    const uint32_t base = live ? rs_base[2 * r] : b0;
+    const int n = live ? (int)(rs_base[2 * r + 2] - base) : 0;
+    if (!staged) {
+        if (!live) return;
+        // in place: key i overwrites bytes 8i..8i+7 of this read's own records, all of them already consumed
+        uint64_t *k = reinterpret_cast<uint64_t *>(hits + base);
+        for (int i = 0; i < n; i++) { const mp_seed_hit h = hits[base + i]; k[i] = hit_key(h, P); }
+        sort_keys(k, n);
+        merge_read(k, n, seedpos + base, r, P, text_len, n_pos, n_neg, ctr);
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < T; i += MP_MERGE_BLOCK) s_key[i] = hit_key(hits[b0 + i], P);
+    __syncthreads();
+    uint64_t *k = s_key + (base - b0);
+    // ---- reads of medium size, one at a time, by the whole wavefront
+    const bool coop = n > MP_MERGE_SMALL && n <= MP_MERGE_COOP;
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int ns = __shfl(n, src);
+        const uint32_t os = __shfl(base - b0, src);
+        int Pw = 64;
+        while (Pw < ns) Pw <<= 1;
+        for (int i = lane; i < Pw; i += 64) s_tmp[i] = i < ns ? s_key[os + i] : ~0ull;
+        __syncthreads();
+        for (int kk = 2; kk <= Pw; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < Pw / 2; t += 64) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const uint64_t a = s_tmp[i], b = s_tmp[l];
+                    if ((a > b) == ((i & kk) == 0)) { s_tmp[i] = b; s_tmp[l] = a; }
+                }
+                __syncthreads();
+            }
+        for (int i = lane; i < ns; i += 64) s_key[os + i] = s_tmp[i];
         __syncthreads();
     }
-    const uint32_t r = r0 + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint32_t base = rs_base[2 * r];
-    const int n = (int)(rs_base[2 * r + 2] - base);
-    uint64_t *k = s_key + (base - b0);
-    if (!staged) {
-        // in place: key i overwrites bytes 8i..8i+7 of this read's own records, all of them already consumed
-        k = reinterpret_cast<uint64_t *>(hits + base);
-        for (int i = 0; i < n; i++) { const mp_seed_hit h = hits[base + i]; k[i] = hit_key(h, P); }
-    }
+    if (!live) return;
+    if (!coop) sort_keys(k, n);                    // small reads (insertion sort) and the rare very large one (heap sort)
     merge_read(k, n, seedpos + base, r, P, text_len, n_pos, n_neg, ctr);
 }
 

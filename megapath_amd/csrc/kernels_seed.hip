@@ -529,8 +529,8 @@ __device__ __forceinline__ uint64_t key_pos(uint64_t k, uint64_t text_len)
 
 #define MP_MERGE_BLOCK 64
 #define MP_MERGE_CAP 4096          // keys staged per block (32 KB)
-#define MP_MERGE_SMALL 32          // up to here a lane sorts its own read
-#define MP_MERGE_COOP 512          // up to here the wavefront sorts a read together (scratch: 4 KB)
+#define MP_MERGE_SMALL 32          // insertion sort up to here when a lane sorts on its own (blocks that do not fit in LDS)
+#define MP_MERGE_COOP 512          // up to here the wavefront sorts a read together, eight keys per lane
 __device__ void sort_keys(uint64_t *a, int n)
 {
     if (n <= MP_MERGE_SMALL) {
@@ -576,7 +576,7 @@ __device__ void sort_keys(uint64_t *a, int n)
 
 // seed merging of one read (DV-DPfunctions.cpp:2470-2560): k[0..n) are the SORTED keys of its located seed hits, out
 // receives the kept seeds.
-__device__ __forceinline__ void merge_read(uint64_t *k, int n, mp_seedpos *__restrict__ out, uint32_t r, const mp_dev_mmp &P, uint64_t text_len,
+__device__ __forceinline__ void merge_read(uint64_t *k, int n, mp_seedpos *__restrict__ out, uint32_t r, const mp_dev_mmp &P, uint64_t text_len, int cov_words,
                                            uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
     uint32_t max_cov = 0;
@@ -599,6 +599,7 @@ __device__ __forceinline__ void merge_read(uint64_t *k, int n, mp_seedpos *__res
             has_unique |= MP_KEY_UNIQ(cur);
 #pragma unroll
             for (int w = 0; w < MP_SEED_BIG / 64; w++) {
+                if (w >= cov_words) break;                 // reads of this batch are no longer than 64 cov_words bases
                 int a = lo - 64 * w, e = hi - 64 * w;
                 a = a < 0 ? 0 : (a > 64 ? 64 : a);
                 e = e < 0 ? 0 : (e > 64 ? 64 : e);
@@ -636,19 +637,64 @@ __device__ __forceinline__ void merge_read(uint64_t *k, int n, mp_seedpos *__res
     if (w) atomicAdd(&ctr->n_seedpos, (unsigned long long)w);      // no-return atomic; rare enough after the early exits
 }
 
+// Bitonic sort of 64 K keys held K per lane (element i lives in lane i & 63, register i >> 6): partners less than 64
+// apart are exchanged with a wavefront shuffle, the others are register pairs of the same lane.  No LDS, no barrier.
+template <int K>
+__device__ __forceinline__ void wave_bitonic(uint64_t (&key)[K], int lane)
+{
+#pragma unroll
+    for (int kk = 2; kk <= 64 * K; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int jr = j >> 6;
+#pragma unroll
+                for (int rg = 0; rg < K; rg++) {
+                    if (rg & jr) continue;
+                    const bool up = ((rg * 64) & kk) == 0;            // kk >= 128 here: the direction bit is a register bit
+                    const uint64_t a = key[rg], b = key[rg | jr];
+                    const bool sw = (a > b) == up;
+                    key[rg] = sw ? b : a; key[rg | jr] = sw ? a : b;
+                }
+            } else {
+#pragma unroll
+                for (int rg = 0; rg < K; rg++) {
+                    const uint64_t a = key[rg];
+                    const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)a, j), phi = (uint32_t)__shfl_xor((int)(uint32_t)(a >> 32), j);
+                    const uint64_t b = ((uint64_t)phi << 32) | plo;
+                    const bool lower = (lane & j) == 0;
+                    const bool up = (((rg * 64) | lane) & kk) == 0;
+                    const bool keep_min = lower == up;
+                    key[rg] = keep_min ? (a < b ? a : b) : (a > b ? a : b);
+                }
+            }
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void wave_sort_read(uint64_t *k, int n, int lane)
+{
+    uint64_t key[K];
+#pragma unroll
+    for (int rg = 0; rg < K; rg++) { const int i = rg * 64 + lane; key[rg] = i < n ? k[i] : ~0ull; }
+    wave_bitonic<K>(key, lane);
+#pragma unroll
+    for (int rg = 0; rg < K; rg++) { const int i = rg * 64 + lane; if (i < n) k[i] = key[rg]; }
+}
+
 // Output: seedpos[read_base[r] .. ) holds the kept seeds of read r, '+' first; n_pos[r], n_neg[r] their counts.
 // One lane per read, one wavefront per block.  The hits of a block's 64 reads are one contiguous range: it is read with
-// coalesced loads, packed to 8-byte keys and staged in LDS.  Sorting: a wavefront waits for its largest read (nine in ten
-// wavefronts hold a read with more than 64 hits, while the median read has 20), so reads with more than MP_MERGE_SMALL
-// keys are sorted one after the other by all 64 lanes together (bitonic network in an LDS scratch area), the others by
-// their own lane (insertion sort).  The grouping pass is linear and runs one lane per read.  A block whose range does not
+// coalesced loads, packed to 8-byte keys and staged in LDS.  Sorting: a lane-per-read sort makes the wavefront wait for
+// its largest read (nine in ten wavefronts hold a read with more than 64 hits, while the median read has 20), so the
+// reads are sorted one after the other by all 64 lanes together: a bitonic network over registers and wavefront
+// shuffles, 1 to 8 keys per lane.  The grouping pass is linear and runs one lane per read.  A block whose range does not
 // fit in LDS packs and sorts in place in global memory, lane by lane.
 __global__ void __launch_bounds__(MP_MERGE_BLOCK)
-merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P, uint64_t text_len,
+merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P, uint64_t text_len, int cov_words,
              mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
     __shared__ uint64_t s_key[MP_MERGE_CAP];
-    __shared__ uint64_t s_tmp[MP_MERGE_COOP];
     const uint32_t r0 = blockIdx.x * MP_MERGE_BLOCK;
     const uint32_t r1 = min(r0 + MP_MERGE_BLOCK, n_reads);
     const uint32_t b0 = rs_base[2 * r0], T = rs_base[2 * r1] - b0;
@@ -664,40 +710,36 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_bas
         uint64_t *k = reinterpret_cast<uint64_t *>(hits + base);
         for (int i = 0; i < n; i++) { const mp_seed_hit h = hits[base + i]; k[i] = hit_key(h, P); }
         sort_keys(k, n);
-        merge_read(k, n, seedpos + base, r, P, text_len, n_pos, n_neg, ctr);
+        merge_read(k, n, seedpos + base, r, P, text_len, cov_words, n_pos, n_neg, ctr);
         return;
     }
-    for (uint32_t i = threadIdx.x; i < T; i += MP_MERGE_BLOCK) s_key[i] = hit_key(hits[b0 + i], P);
+    // four independent 16-byte loads in flight per lane
+    for (uint32_t i0 = 0; i0 < T; i0 += 4 * MP_MERGE_BLOCK) {
+        mp_seed_hit h4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_BLOCK + threadIdx.x; if (i < T) h4[u] = hits[b0 + i]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_BLOCK + threadIdx.x; if (i < T) s_key[i] = hit_key(h4[u], P); }
+    }
     __syncthreads();
     uint64_t *k = s_key + (base - b0);
-    // ---- reads of medium size, one at a time, by the whole wavefront
-    const bool coop = n > MP_MERGE_SMALL && n <= MP_MERGE_COOP;
+    // ---- every read with more than one key, one at a time, by the whole wavefront
+    const bool coop = n > 1 && n <= MP_MERGE_COOP;
     unsigned long long todo = __ballot(coop);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int ns = __shfl(n, src);
-        const uint32_t os = __shfl(base - b0, src);
-        int Pw = 64;
-        while (Pw < ns) Pw <<= 1;
-        for (int i = lane; i < Pw; i += 64) s_tmp[i] = i < ns ? s_key[os + i] : ~0ull;
-        __syncthreads();
-        for (int kk = 2; kk <= Pw; kk <<= 1)
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int t = lane; t < Pw / 2; t += 64) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const int l = i | j;
-                    const uint64_t a = s_tmp[i], b = s_tmp[l];
-                    if ((a > b) == ((i & kk) == 0)) { s_tmp[i] = b; s_tmp[l] = a; }
-                }
-                __syncthreads();
-            }
-        for (int i = lane; i < ns; i += 64) s_key[os + i] = s_tmp[i];
-        __syncthreads();
+        uint64_t *ks = s_key + __shfl(base - b0, src);
+        if (ns <= 64) wave_sort_read<1>(ks, ns, lane);
+        else if (ns <= 128) wave_sort_read<2>(ks, ns, lane);
+        else if (ns <= 256) wave_sort_read<4>(ks, ns, lane);
+        else wave_sort_read<8>(ks, ns, lane);
     }
+    __syncthreads();
     if (!live) return;
     if (!coop) sort_keys(k, n);                    // small reads (insertion sort) and the rare very large one (heap sort)
-    merge_read(k, n, seedpos + base, r, P, text_len, n_pos, n_neg, ctr);
+    merge_read(k, n, seedpos + base, r, P, text_len, cov_words, n_pos, n_neg, ctr);
 }
 
 // ------------------------------------------------------------------------------------------------ K4

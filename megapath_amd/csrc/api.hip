@@ -74,6 +74,7 @@ struct mp_ctx {
     DevBuf<mp_dp_task> sel_tasks;
     DevBuf<mp_dp_result> sel_res;
     DevBuf<uint32_t> band_flag, band_idx;        // instances the band kernel left to the full kernels
+    DevBuf<uint32_t> near_flag, near_idx, near_list, far_flag, far_idx, far_list;   // classes of the second band pass
     DevBuf<mp_dp_task> band_tasks;
     DevBuf<mp_dp_result> band_res;
     DevBuf<mp_fill_result> band_fill;
@@ -861,6 +862,50 @@ bool band_applicable(const mp_ctx *c, uint32_t max_win, int cl, int cr)
     return !off && c->use_band && c->max_len <= MP_BAND_MAXL && max_win <= MP_BAND_MAXL + MP_BAND_DMAX && cl >= MP_BAND_GB && cr >= MP_BAND_GB;
 }
 
+// second pass of the two-pass band scheme over the instances of one class (`list`, n_c of them) + their traceback
+template <int W2, int G2>
+int band_second_pass(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *list, uint32_t n_c, int cl, int cr, mp_dp_result *d_res, float *ms_fill,
+                     float *ms_trace)
+{
+    if (n_c == 0) return MP_OK;
+    hipStream_t s = c->stream;
+    const uint32_t ncols = c->max_len;
+    const bool small = c->max_len <= 160;
+    const size_t per_block = (size_t)ncols * ((W2 + 2) / 3) * 64 * 4;
+    const uint32_t n_blocks = (uint32_t)(((uint64_t)n_c + 127) / 128);
+    const uint32_t chunk_blocks = (uint32_t)std::min<uint64_t>(n_blocks, std::max<uint64_t>(1, c->slab_budget / per_block));
+    if (c->flags.reserve((size_t)chunk_blocks * per_block)) return MP_ENOMEM;
+    const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
+    while (c->ev_pool.size() < 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    uint32_t *slab = (uint32_t *)c->flags.p;
+    size_t ci = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks, ci++) {
+        const uint32_t off = b0 * 128u;
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>((uint64_t)chunk_blocks * 128u, n_c - off);
+        const dim3 grid((cnt + 127) / 128), block(64);
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci], s));
+        if (small)
+            hipLaunchKernelGGL((dp_band_kernel<W2, G2, 160, 2>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, cnt, cl, cr, slab, ncols,
+                               (const mp_fill_result *)c->band_fill.p, (mp_fill_result *)nullptr, list + off);
+        else
+            hipLaunchKernelGGL((dp_band_kernel<W2, G2, MP_BAND_MAXL, 2>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, cnt, cl, cr, slab,
+                               ncols, (const mp_fill_result *)c->band_fill.p, (mp_fill_result *)nullptr, list + off);
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
+        hipLaunchKernelGGL((dp_trace_kernel<16, 5, W2, G2, true>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks, c->d_lens, cnt, cl, cr, (const uint32_t *)slab,
+                           ncols, (const mp_fill_result *)c->band_fill.p, d_res, (uint8_t *)nullptr, 0u, list + off);
+        HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t q = 0; q < n_chunks; q++) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, c->ev_pool[3 * q], c->ev_pool[3 * q + 1]);
+        (void)hipEventElapsedTime(&b, c->ev_pool[3 * q + 1], c->ev_pool[3 * q + 2]);
+        if (ms_fill) *ms_fill += a;
+        if (ms_trace) *ms_trace += b;
+    }
+    return MP_OK;
+}
+
 int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,
                 float *ms_fill, float *ms_trace, bool count)
 {
@@ -872,96 +917,98 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     // of 87 x 33 instructions per column.  MP_DP_BAND=1 keeps the single pass.
     static const bool one_pass_env = getenv("MP_DP_BAND") && atoi(getenv("MP_DP_BAND")) == 1;
     const bool two_pass = !one_pass_env && cl >= 2 * MP_BAND_GB + 1 && cr >= 2 * MP_BAND_GB + 1;
-    const int nw = two_pass ? MP_BAND_NW2 : MP_BAND_NW;
-    const size_t per_block = (size_t)ncols * nw * 64 * 4;                      // 64 instance pairs
     if (c->slab_budget == 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 8ull << 30;
         c->slab_budget = std::min<size_t>(24ull << 30, std::max<size_t>(2ull << 30, (free_b + c->flags.cap) / 4));
     }
     const bool small = c->max_len <= 160;                       // the 160-base instances stage fewer window rows in LDS
-    // blocks one round of the slab-writing kernel holds on the device
-    static uint32_t round_cache[4] = {0, 0, 0, 0};
-    uint32_t &round_blocks = round_cache[(small ? 0 : 1) + (two_pass ? 2 : 0)];
-    if (round_blocks == 0) {
-        int per_cu = 0, n_cu = 256;
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
-        hipError_t e;
-        if (two_pass) e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W2, MP_BAND_GB, 160, 2>, 64, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W2, MP_BAND_GB, MP_BAND_MAXL, 2>, 64, 0);
-        else e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 0>, 64, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 0>, 64, 0);
-        if (e != hipSuccess || per_cu < 1) per_cu = 1;
-        round_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
-    }
     const uint32_t n_blocks = (uint32_t)(((uint64_t)n + 127) / 128);
-    uint32_t chunk_blocks = (uint32_t)std::min<uint64_t>(n_blocks, std::max<uint64_t>(1, c->slab_budget / per_block));
-    if (chunk_blocks > round_blocks && chunk_blocks < n_blocks) chunk_blocks = chunk_blocks / round_blocks * round_blocks;
-    if (c->flags.reserve((size_t)chunk_blocks * per_block) || c->band_fill.reserve(n + 2) || c->band_flag.reserve(n + 2) || c->band_idx.reserve(n + 2))
-        return MP_ENOMEM;
-    const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
-    while (c->ev_pool.size() < 3 * n_chunks + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
-    const size_t ev_a = 3 * n_chunks, ev_b = 3 * n_chunks + 1;
-    uint32_t *slab = (uint32_t *)c->flags.p;
+    if (c->band_fill.reserve(n + 2) || c->band_flag.reserve(n + 2) || c->band_idx.reserve(n + 2)) return MP_ENOMEM;
+    while (c->ev_pool.size() < 4) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
     const mp_fill_result *none = nullptr;
+    uint32_t n_sel = 0;
+    auto scan = [&](uint32_t *flag, uint32_t *idx) -> int {
+        size_t tmp_bytes = 0;
+        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, flag, idx, (int)n, s);
+        if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+        (void)hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, flag, idx, (int)n, s);
+        return MP_OK;
+    };
     if (two_pass) {
-        HIPCHK(hipEventRecord(c->ev_pool[ev_a], s));
+        if (c->near_flag.reserve(n + 2) || c->near_idx.reserve(n + 2) || c->far_flag.reserve(n + 2) || c->far_idx.reserve(n + 2)) return MP_ENOMEM;
+        HIPCHK(hipEventRecord(c->ev_pool[0], s));
         if (small)
             hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 1>), dim3(n_blocks), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                                d_tasks, n, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p);
         else
             hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 1>), dim3(n_blocks), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                                d_tasks, n, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p);
-        HIPCHK(hipEventRecord(c->ev_pool[ev_b], s));
-    }
-    size_t ci = 0;
-    for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks, ci++) {
-        const uint32_t off = b0 * 128u;
-        const uint32_t cnt = (uint32_t)std::min<uint64_t>((uint64_t)chunk_blocks * 128u, n - off);
-        const dim3 grid((cnt + 127) / 128), block(64);
-        HIPCHK(hipEventRecord(c->ev_pool[3 * ci], s));
-        if (two_pass) {
-            if (small)
-                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W2, MP_BAND_GB, 160, 2>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                   d_tasks + off, cnt, cl, cr, slab, ncols, (const mp_fill_result *)(c->band_fill.p + off), (mp_fill_result *)nullptr);
-            else
-                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W2, MP_BAND_GB, MP_BAND_MAXL, 2>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                   d_tasks + off, cnt, cl, cr, slab, ncols, (const mp_fill_result *)(c->band_fill.p + off), (mp_fill_result *)nullptr);
-        } else {
+        HIPCHK(hipEventRecord(c->ev_pool[1], s));
+        // classes by distance from the best cell's diagonal; perfect matches and instances below their cutoff are finished here
+        hipLaunchKernelGGL(dp_band_classify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, (const mp_fill_result *)c->band_fill.p, n,
+                           c->near_flag.p, c->far_flag.p, c->band_flag.p, d_res);
+        int rc = scan(c->near_flag.p, c->near_idx.p); if (rc) return rc;
+        rc = scan(c->far_flag.p, c->far_idx.p); if (rc) return rc;
+        rc = scan(c->band_flag.p, c->band_idx.p); if (rc) return rc;
+        uint32_t n_near = 0, n_far = 0;
+        HIPCHK(hipMemcpyAsync(&n_near, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&n_far, c->far_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&n_sel, c->band_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        { float a = 0; (void)hipEventElapsedTime(&a, c->ev_pool[0], c->ev_pool[1]); if (ms_fill) *ms_fill += a; }
+        if (c->near_list.reserve(n_near + 130) || c->far_list.reserve(n_far + 130)) return MP_ENOMEM;
+        if (n_near) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->near_list.p);
+        if (n_far) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->far_list.p);
+        rc = band_second_pass<MP_BAND_W1, MP_BAND_GB1>(c, d_tasks, c->near_list.p, n_near, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
+        rc = band_second_pass<MP_BAND_W2, MP_BAND_GB>(c, d_tasks, c->far_list.p, n_far, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
+    } else {
+        const size_t per_block = (size_t)ncols * MP_BAND_NW * 64 * 4;              // 64 instance pairs
+        static uint32_t round_cache[2] = {0, 0};
+        uint32_t &round_blocks = round_cache[small ? 0 : 1];
+        if (round_blocks == 0) {
+            int per_cu = 0, n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
+            hipError_t e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 0>, 64, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 0>, 64, 0);
+            if (e != hipSuccess || per_cu < 1) per_cu = 1;
+            round_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
+        }
+        uint32_t chunk_blocks = (uint32_t)std::min<uint64_t>(n_blocks, std::max<uint64_t>(1, c->slab_budget / per_block));
+        if (chunk_blocks > round_blocks && chunk_blocks < n_blocks) chunk_blocks = chunk_blocks / round_blocks * round_blocks;
+        if (c->flags.reserve((size_t)chunk_blocks * per_block)) return MP_ENOMEM;
+        const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
+        while (c->ev_pool.size() < 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+        uint32_t *slab = (uint32_t *)c->flags.p;
+        size_t ci = 0;
+        for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks, ci++) {
+            const uint32_t off = b0 * 128u;
+            const uint32_t cnt = (uint32_t)std::min<uint64_t>((uint64_t)chunk_blocks * 128u, n - off);
+            const dim3 grid((cnt + 127) / 128), block(64);
+            HIPCHK(hipEventRecord(c->ev_pool[3 * ci], s));
             if (small)
                 hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 0>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                                    d_tasks + off, cnt, cl, cr, slab, ncols, none, c->band_fill.p + off);
             else
                 hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 0>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                                    d_tasks + off, cnt, cl, cr, slab, ncols, none, c->band_fill.p + off);
-        }
-        HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
-        if (two_pass)
-            hipLaunchKernelGGL((dp_trace_kernel<16, 5, MP_BAND_W2, MP_BAND_GB, true>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks + off, c->d_lens, cnt, cl, cr,
-                               (const uint32_t *)slab, ncols, c->band_fill.p + off, d_res + off, (uint8_t *)nullptr, 0u);
-        else
+            HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
             hipLaunchKernelGGL((dp_trace_kernel<16, 5, MP_BAND_W, MP_BAND_GB, false>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks + off, c->d_lens, cnt, cl, cr,
                                (const uint32_t *)slab, ncols, c->band_fill.p + off, d_res + off, (uint8_t *)nullptr, 0u);
-        HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
+            HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
+        }
+        hipLaunchKernelGGL(dp_band_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_fill.p, n, c->band_flag.p);
+        int rc = scan(c->band_flag.p, c->band_idx.p); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(&n_sel, c->band_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (size_t q = 0; q < n_chunks; q++) {
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, c->ev_pool[3 * q], c->ev_pool[3 * q + 1]);
+            (void)hipEventElapsedTime(&b, c->ev_pool[3 * q + 1], c->ev_pool[3 * q + 2]);
+            if (ms_fill) *ms_fill += a;
+            if (ms_trace) *ms_trace += b;
+        }
     }
-    hipLaunchKernelGGL(dp_band_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_fill.p, n, c->band_flag.p);
-    {
-        size_t tmp_bytes = 0;
-        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, c->band_flag.p, c->band_idx.p, (int)n, s);
-        if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
-        (void)hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, c->band_flag.p, c->band_idx.p, (int)n, s);
-    }
-    uint32_t n_sel = 0;
-    HIPCHK(hipMemcpyAsync(&n_sel, c->band_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    for (size_t q = 0; q < n_chunks; q++) {
-        float a = 0, b = 0;
-        (void)hipEventElapsedTime(&a, c->ev_pool[3 * q], c->ev_pool[3 * q + 1]);
-        (void)hipEventElapsedTime(&b, c->ev_pool[3 * q + 1], c->ev_pool[3 * q + 2]);
-        if (ms_fill) *ms_fill += a;
-        if (ms_trace) *ms_trace += b;
-    }
-    if (two_pass && ms_fill) { float a = 0; (void)hipEventElapsedTime(&a, c->ev_pool[ev_a], c->ev_pool[ev_b]); *ms_fill += a; }
     c->n_band += n; c->n_band_full += n_sel;
     static const bool verbose = getenv("MP_DP_BAND_STATS") != nullptr;
     if (verbose) fprintf(stderr, "[band] %u instances, %u left to the full kernels\n", n, n_sel);

@@ -418,11 +418,13 @@ template <int LPI, int C, int BW = 0, int GB = 0, bool CENTER = false>
 __global__ void __launch_bounds__(64)
 dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, uint32_t n_tasks, int clip_left, int clip_right,
                 const uint32_t *__restrict__ flags, uint32_t flag_rows, const mp_fill_result *__restrict__ fill,
-                mp_dp_result *__restrict__ out, uint8_t *__restrict__ ops, uint32_t ops_stride)
+                mp_dp_result *__restrict__ out, uint8_t *__restrict__ ops, uint32_t ops_stride, const uint32_t *__restrict__ list = nullptr)
 {
     constexpr int NW = MP_DP_NW(C);
-    const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
-    if (inst >= n_tasks) return;
+    // `slot` is the position in the launch (and in the slab); with a list, slot s stands for instance list[s]
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_tasks) return;
+    const uint32_t inst = list ? list[slot] : slot;
     const mp_dp_task task = tasks[inst];
     const mp_fill_result fr = fill[inst];
     const int L = (int)lens[task.read_id];
@@ -432,9 +434,9 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
     if (fr.score < cutoff || fr.score <= 0 || task.win_len == 0) { out[inst] = res; return; }
     res.max_score_count = fr.count;
     constexpr int NWB = (BW + 2) / 3;
-    const uint32_t *fpair = BW > 0 ? flags + (uint64_t)(inst >> 7) * flag_rows * (NWB * 64) + ((inst >> 1) & 63u)
-                                   : flags + (uint64_t)(inst >> 1) * flag_rows * (LPI * NW);
-    const int half = (int)(inst & 1u) * 16;
+    const uint32_t *fpair = BW > 0 ? flags + (uint64_t)(slot >> 7) * flag_rows * (NWB * 64) + ((slot >> 1) & 63u)
+                                   : flags + (uint64_t)(slot >> 1) * flag_rows * (LPI * NW);
+    const int half = (int)(slot & 1u) * 16;
     uint8_t *op = ops ? ops + (uint64_t)inst * ops_stride : nullptr;
     uint32_t n = 0;
     auto emit = [&](uint8_t ch, int rep) { for (int q = 0; q < rep; q++) { if (op && n < ops_stride) op[n] = ch; n++; } };

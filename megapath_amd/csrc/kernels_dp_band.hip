@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64)
 dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, int clip_left, int clip_right,
                uint32_t *__restrict__ flags, uint32_t ncols /* columns of NW x 64 words reserved per block */,
-               const mp_fill_result *__restrict__ center, mp_fill_result *__restrict__ out)
+               const mp_fill_result *__restrict__ center, mp_fill_result *__restrict__ out, const uint32_t *__restrict__ list = nullptr)
 {
     constexpr int NW = (W + 2) / 3;
     static_assert(W % 3 == 0, "three cells per 16-bit half of a flag word");
@@ -99,9 +99,10 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     int rbase[2];                                   // row of band cell d in column j: j + d + rbase
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const uint32_t inst = 2 * pair + q;
+        const uint32_t slot = 2 * pair + q;                 // position in the launch; with a list, slot s stands for instance list[s]
         mp_dp_task task; task.read_id = 0; task.strand = 1; task.win_start = 0; task.win_len = 0; task.reserved = 0;
-        const bool live = inst < n_tasks;
+        const bool live = slot < n_tasks;
+        const uint32_t inst = live && list ? list[slot] : slot;
         if (live) task = tasks[inst];
         int L = live ? (int)lens[task.read_id] : 0;
         int m = (int)task.win_len;
@@ -275,4 +276,40 @@ __global__ void dp_band_select_kernel(const mp_fill_result *__restrict__ fill, u
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) flag[t] = fill[t].score < 0 ? 1u : 0u;
+}
+
+// Classes of the instances after the first pass of the two-pass scheme, by how far the best alignment can stray from the
+// best cell's diagonal.  score == L: every base matches, the path is the diagonal itself and the result is written here
+// (what dp_trace_kernel would find: L diagonal steps, hit_loc = row - L).  score >= L - MP_BAND_NEAR: gaps cost at most
+// MP_BAND_NEAR, one gap of at most MP_BAND_NEAR - 2 bases: second pass over 2 MP_BAND_GB1 + 1 diagonals.  Otherwise the
+// full second pass (2 MP_BAND_GB + 1 diagonals).  Undecided instances (score < 0) go to the full-table kernels.
+#define MP_BAND_NEAR 5
+#define MP_BAND_GB1 4
+#define MP_BAND_W1 (2 * MP_BAND_GB1 + 1)
+#define MP_BAND_NW1 ((MP_BAND_W1 + 2) / 3)
+__global__ void dp_band_classify_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, const mp_fill_result *__restrict__ fill,
+                                        uint32_t n, uint32_t *__restrict__ flag_near, uint32_t *__restrict__ flag_far, uint32_t *__restrict__ flag_full,
+                                        mp_dp_result *__restrict__ res)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const mp_fill_result fr = fill[t];
+    const int L = (int)lens[tasks[t].read_id];
+    uint32_t fn = 0, ff = 0, fu = 0;
+    mp_dp_result z; z.score = 0; z.hit_loc = 0; z.max_score_count = 0; z.n_ops = 0;
+    if (fr.score < 0) fu = 1;
+    else if (fr.score == 0 || fr.score < mp_dp_cutoff(L)) res[t] = z;              // nothing to align / below the cutoff
+    else if (fr.score == L && fr.col == L && fr.row >= L) {
+        z.score = L; z.hit_loc = (uint32_t)(fr.row - L); z.max_score_count = fr.count; z.n_ops = (uint32_t)L;
+        res[t] = z;
+    } else if (fr.score >= L - MP_BAND_NEAR) fn = 1;
+    else ff = 1;
+    flag_near[t] = fn; flag_far[t] = ff; flag_full[t] = fu;
+}
+
+// list[idx[t] - 1] = t for the flagged entries (idx = inclusive prefix sum of flag)
+__global__ void dp_band_list_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ list)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && flag[t]) list[idx[t] - 1] = t;
 }

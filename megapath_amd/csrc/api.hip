@@ -75,6 +75,7 @@ struct mp_ctx {
     DevBuf<mp_dp_result> sel_res;
     DevBuf<uint32_t> band_flag, band_idx;        // instances the band kernel left to the full kernels
     DevBuf<uint32_t> near_flag, near_idx, near_list, far_flag, far_idx, far_list;   // classes of the second band pass
+    DevBuf<uint32_t> rest_flag, rest_idx, rest_list;                                // instances without an exact diagonal: first band pass
     DevBuf<mp_dp_task> band_tasks;
     DevBuf<mp_dp_result> band_res;
     DevBuf<mp_fill_result> band_fill;
@@ -937,13 +938,26 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     };
     if (two_pass) {
         if (c->near_flag.reserve(n + 2) || c->near_idx.reserve(n + 2) || c->far_flag.reserve(n + 2) || c->far_idx.reserve(n + 2)) return MP_ENOMEM;
+        if (c->rest_flag.reserve(n + 2) || c->rest_idx.reserve(n + 2)) return MP_ENOMEM;
         HIPCHK(hipEventRecord(c->ev_pool[0], s));
-        if (small)
-            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 1>), dim3(n_blocks), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                               d_tasks, n, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p);
-        else
-            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 1>), dim3(n_blocks), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                               d_tasks, n, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p);
+        // exact diagonals first: those instances need no table at all
+        hipLaunchKernelGGL(dp_perfect_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->band_fill.p,
+                           c->rest_flag.p);
+        { int rc0 = scan(c->rest_flag.p, c->rest_idx.p); if (rc0) return rc0; }
+        uint32_t n_rest = 0;
+        HIPCHK(hipMemcpyAsync(&n_rest, c->rest_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (c->rest_list.reserve(n_rest + 130)) return MP_ENOMEM;
+        if (n_rest) {
+            hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->rest_flag.p, c->rest_idx.p, n, c->rest_list.p);
+            const dim3 g1((n_rest + 127) / 128);
+            if (small)
+                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                   d_tasks, n_rest, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->rest_list.p);
+            else
+                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                   d_tasks, n_rest, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->rest_list.p);
+        }
         HIPCHK(hipEventRecord(c->ev_pool[1], s));
         // classes by distance from the best cell's diagonal; perfect matches and instances below their cutoff are finished here
         hipLaunchKernelGGL(dp_band_classify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, (const mp_fill_result *)c->band_fill.p, n,

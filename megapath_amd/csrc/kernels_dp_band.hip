@@ -255,8 +255,9 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     }
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const uint32_t inst = 2 * pair + q;
-        if (MODE == 2 || inst >= n_tasks) continue;
+        const uint32_t slot = 2 * pair + q;
+        if (MODE == 2 || slot >= n_tasks) continue;
+        const uint32_t inst = list ? list[slot] : slot;
         mp_fill_result r;
         // score -1: "not decided by the band" -- below the qualifying score, outside the band's shape, or the first
         // maximum fell on a pad row past the window
@@ -268,6 +269,83 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         r.row = ok ? (uint16_t)row : 0; r.col = ok ? (uint16_t)(colties[q] & 511u) : 0;
         r.count = ok ? (ties > 255u ? 255u : ties) : 0u;       // num_sameScore, capped as in dp_fill_kernel
         out[inst] = r;
+    }
+}
+
+// Before any table is filled: does the read match the window exactly on some diagonal?  Then the best cell is known
+// without DP -- score L is the largest score there is, the first maximum is the exact diagonal with the smallest row, its
+// ties are the other exact diagonals -- and the instance skips the first band pass (dp_band_classify_kernel finishes it).
+// One lane per instance: the read in alignment orientation as packed words, XORed against the text at each of the
+// m - L + 1 shifts with an early exit at the first differing word (61 shifts x ~10 instructions against ~200 000 for the
+// band).  rest[t] = 1 for the instances that still need the first pass.
+#define MP_BAND_RW (MP_BAND_MAXL / 16)
+#define MP_BAND_SHIFT_WORDS ((MP_BAND_DMAX + 15) / 16 + 1)      // word offsets a shift of 0 .. MP_BAND_DMAX bases can have
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+dp_perfect_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
+                  const mp_dp_task *__restrict__ tasks, uint32_t n, mp_fill_result *__restrict__ fill, uint32_t *__restrict__ rest)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const mp_dp_task task = tasks[t];
+    const int L = (int)lens[task.read_id], m = (int)task.win_len;
+    rest[t] = 1u;
+    if (L < 30 || L > MP_BAND_MAXL || m < L || m - L > MP_BAND_DMAX) return;
+    const uint32_t *rd = reads + (uint64_t)task.read_id * Wr;
+    const int nw = (L + 15) / 16;
+    // the read in alignment orientation, LSB-first words.  Reverse strand: reverse the 2-bit groups of every word, take the
+    // words in reverse order, complement, and shift out the 16 nw - L pad bases that the reversal brought to the front.
+    uint32_t a[MP_BAND_RW + 1];
+#pragma unroll
+    for (int w = 0; w <= MP_BAND_RW; w++) a[w] = 0;
+    if (task.strand == 1) {
+#pragma unroll
+        for (int w = 0; w < MP_BAND_RW; w++) if (w < nw) a[w] = rd[w];
+    } else {
+        uint32_t z[MP_BAND_RW + 1];
+#pragma unroll
+        for (int w = 0; w <= MP_BAND_RW; w++) {
+            z[w] = 0;
+            if (w < nw) { const uint32_t r = __brev(rd[nw - 1 - w]); z[w] = ~(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u)); }
+        }
+        const uint32_t s2 = 2u * (uint32_t)(16 * nw - L);
+#pragma unroll
+        for (int w = 0; w < MP_BAND_RW; w++) a[w] = (uint32_t)((((uint64_t)z[w + 1] << 32) | z[w]) >> s2);
+    }
+    const uint32_t tail = (L & 15) ? ((1u << (2 * (L & 15))) - 1u) : 0xFFFFFFFFu;
+    __shared__ uint32_t s_a[MP_BAND_RW][64];           // the oriented read of every lane: only the rare full comparison walks it
+#pragma unroll
+    for (int w = 0; w < MP_BAND_RW; w++) { if (w == nw - 1) a[w] &= tail; if (w >= nw) a[w] = 0; s_a[w][threadIdx.x] = a[w]; }
+    const uint32_t a0 = a[0];
+    // first words of the window at every shift, loaded once: shift d is word offset (s0 + d) >> 4 and bit offset
+    // 2 ((s0 + d) & 15) from word q0.  Only a shift whose first word agrees (about one wrong shift in 10^9) is compared in full.
+    const uint64_t q0 = task.win_start >> 4;
+    const int s0 = (int)(task.win_start & 15);
+    uint32_t tw[MP_BAND_SHIFT_WORDS + 2];
+#pragma unroll
+    for (int w = 0; w < MP_BAND_SHIFT_WORDS + 2; w++) tw[w] = text[q0 + w];
+    const uint32_t m0 = nw == 1 ? tail : 0xFFFFFFFFu;
+    int first = -1, exact = 0;
+    for (int d = 0; d <= m - L; d++) {
+        const int wo = (s0 + d) >> 4;
+        const uint32_t sh = 2u * (uint32_t)((s0 + d) & 15);
+        uint32_t lo = tw[0], hi = tw[1];
+#pragma unroll
+        for (int w = 1; w <= MP_BAND_SHIFT_WORDS; w++) if (wo == w) { lo = tw[w]; hi = tw[w + 1]; }
+        if ((((uint32_t)((((uint64_t)hi << 32) | lo) >> sh) ^ a0) & m0) != 0) continue;
+        bool same = true;
+        for (int w = 1; w < nw && same; w++) {
+            const uint64_t two = ((uint64_t)text[q0 + wo + w + 1] << 32) | text[q0 + wo + w];
+            uint32_t x = (uint32_t)(two >> sh) ^ s_a[w][threadIdx.x];
+            if (w == nw - 1) x &= tail;
+            same = x == 0;
+        }
+        if (same) { if (first < 0) first = d; exact++; }
+    }
+    if (first >= 0) {
+        mp_fill_result r;
+        r.score = L; r.row = (uint16_t)(first + L); r.col = (uint16_t)L; r.count = exact > 255 ? 255u : (uint32_t)exact;
+        fill[t] = r;
+        rest[t] = 0u;
     }
 }
 

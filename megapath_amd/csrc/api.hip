@@ -75,7 +75,7 @@ struct mp_ctx {
     DevBuf<mp_dp_result> sel_res;
     DevBuf<uint32_t> band_flag, band_idx;        // instances the band kernel left to the full kernels
     DevBuf<uint32_t> near_flag, near_idx, near_list, far_flag, far_idx, far_list;   // classes of the second band pass
-    DevBuf<uint32_t> rest_flag, rest_idx, rest_list;                                // instances without an exact diagonal: first band pass
+    DevBuf<uint32_t> pre_cls, narrow_list, wide_list;                               // dp_prefilter_kernel's classes: first band pass over 27 / 87 diagonals
     DevBuf<mp_dp_task> band_tasks;
     DevBuf<mp_dp_result> band_res;
     DevBuf<mp_fill_result> band_fill;
@@ -938,26 +938,43 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     };
     if (two_pass) {
         if (c->near_flag.reserve(n + 2) || c->near_idx.reserve(n + 2) || c->far_flag.reserve(n + 2) || c->far_idx.reserve(n + 2)) return MP_ENOMEM;
-        if (c->rest_flag.reserve(n + 2) || c->rest_idx.reserve(n + 2)) return MP_ENOMEM;
+        if (c->pre_cls.reserve(n + 2)) return MP_ENOMEM;
         HIPCHK(hipEventRecord(c->ev_pool[0], s));
-        // exact diagonals first: those instances need no table at all
-        hipLaunchKernelGGL(dp_perfect_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->band_fill.p,
-                           c->rest_flag.p);
-        { int rc0 = scan(c->rest_flag.p, c->rest_idx.p); if (rc0) return rc0; }
-        uint32_t n_rest = 0;
-        HIPCHK(hipMemcpyAsync(&n_rest, c->rest_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        // block-match pre-filter: finished (exact diagonal), narrow first pass, whole band, or no qualifying alignment at all
+        hipLaunchKernelGGL(dp_prefilter_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->band_fill.p,
+                           c->pre_cls.p);
+        hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_NARROW, c->near_flag.p);
+        hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_WIDE, c->far_flag.p);
+        { int rc0 = scan(c->near_flag.p, c->near_idx.p); if (rc0) return rc0; rc0 = scan(c->far_flag.p, c->far_idx.p); if (rc0) return rc0; }
+        uint32_t n_narrow = 0, n_wide = 0;
+        HIPCHK(hipMemcpyAsync(&n_narrow, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&n_wide, c->far_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (c->rest_list.reserve(n_rest + 130)) return MP_ENOMEM;
-        if (n_rest) {
-            hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->rest_flag.p, c->rest_idx.p, n, c->rest_list.p);
-            const dim3 g1((n_rest + 127) / 128);
+        if (c->narrow_list.reserve(n_narrow + 130) || c->wide_list.reserve(n_wide + 130)) return MP_ENOMEM;
+        if (n_narrow) {
+            hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->narrow_list.p);
+            const dim3 g1((n_narrow + 127) / 128);
+            if (small)
+                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W2, MP_BAND_GB, 160, 3>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                   d_tasks, n_narrow, cl, cr, (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p,
+                                   (const uint32_t *)c->narrow_list.p);
+            else
+                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W2, MP_BAND_GB, MP_BAND_MAXL, 3>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                   d_tasks, n_narrow, cl, cr, (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p,
+                                   (const uint32_t *)c->narrow_list.p);
+        }
+        if (n_wide) {
+            hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->wide_list.p);
+            const dim3 g1((n_wide + 127) / 128);
             if (small)
                 hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                   d_tasks, n_rest, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->rest_list.p);
+                                   d_tasks, n_wide, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->wide_list.p);
             else
                 hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                   d_tasks, n_rest, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->rest_list.p);
+                                   d_tasks, n_wide, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->wide_list.p);
         }
+        static const bool verbose2 = getenv("MP_DP_BAND_STATS") != nullptr;
+        if (verbose2) fprintf(stderr, "[band] pre-filter: %u narrow, %u whole band, of %u\n", n_narrow, n_wide, n);
         HIPCHK(hipEventRecord(c->ev_pool[1], s));
         // classes by distance from the best cell's diagonal; perfect matches and instances below their cutoff are finished here
         hipLaunchKernelGGL(dp_band_classify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, (const mp_fill_result *)c->band_fill.p, n,

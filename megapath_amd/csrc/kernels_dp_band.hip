@@ -74,6 +74,8 @@ __device__ __forceinline__ v2s pk_subsat(v2s a, v2s b) { v2s r; asm("v_pk_sub_u1
 
 // MODE 0: one pass -- band of W = MP_BAND_W diagonals fixed to the window, traceback bits and best cell.
 // MODE 1: the same band, scores only (best cell, ties): first pass of the two-pass scheme.
+// MODE 3: as MODE 1, over the W = 2 GB + 1 diagonals around a centre found by dp_prefilter_kernel (instances for which it
+//         proved that every alignment of qualifying score lies within them).
 // MODE 2: second pass of the two-pass scheme, traceback bits only, over the W = 2 GB + 1 diagonals around the diagonal of
 //         the best cell found by the first pass (`center`).  An instance the first pass qualified scored >= L - 13: its
 //         gaps cost at most 13 in total, i.e. at most 11 gap bases, so every optimal path into the best cell -- and every
@@ -114,6 +116,11 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         if (MODE == 2) {
             const mp_fill_result ctr = live ? center[inst] : mp_fill_result{0, 0, 0, 0};
             fit = live && ctr.score > 0 && L <= MAXL && m >= 1 && clipL >= 2 * GB + 1;
+            rbase[q] = (int)ctr.row - (int)ctr.col - GB;
+        } else if (MODE == 3) {
+            // first pass over 2 GB + 1 diagonals around the centre dp_prefilter_kernel found (row - col of `center`)
+            const mp_fill_result ctr = live ? center[inst] : mp_fill_result{0, 0, 0, 0};
+            fit = live && L >= 30 && L <= MAXL && m >= 1 && clipL >= 2 * GB + 1;
             rbase[q] = (int)ctr.row - (int)ctr.col - GB;
         } else
             fit = live && L >= 30 && L <= MAXL && m >= 1 && m - L <= W - 1 - 2 * GB && m + GB < R && clipL >= GB;
@@ -196,7 +203,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             const v2s Hc = d == 0 ? sent : H[d - 1];
             const v2s Hn = d + 1 < W ? H[d + 1] : sent;
             const v2s Fn = d + 1 < W ? F[d + 1] : sent;
-            if (MODE == 1)
+            if (MODE == 1 || MODE == 3)
                 asm(MP_BAND_CORE MP_BAND_COLMAX
                     : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [Hd] "+&v"(H[d]), [Ec] "+&v"(Ec), [Fd] "=&v"(F[d]), [colmax] "+&v"(colmax)
                     : [Hc] "v"(Hc), [Hn] "v"(Hn), [Fn] "v"(Fn), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
@@ -213,7 +220,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
                       [Fd] "=&v"(F[d]), [fw] "+&v"(fw), [colmax] "+&v"(colmax)
                     : [Hc] "v"(Hc), [Hn] "v"(Hn), [Fn] "v"(Fn), [base] "v"(base), [rb] "v"(rb), [floorv] "v"(floorv),
                       [k1] "v"(K.k1), [k2] "v"(K.k2), [k3] "v"(K.k3), [k4] "v"(K.k4));
-            if (MODE != 1 && (d % 3 == 2 || d == W - 1)) {
+            if ((MODE == 0 || MODE == 2) && (d % 3 == 2 || d == W - 1)) {
                 fcol[(uint64_t)(j - 1) * (NW * 64) + (d / 3) * 64] = __builtin_bit_cast(uint32_t, fw);
                 fw = pk1(0);
             }
@@ -225,7 +232,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             short lim2[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {                      // rows past the window's end (d > m - j + GB) do not count
-                int lim = 127 - ((int)((info[q] >> 9) & 511u) - j + GB);
+                int lim = 127 - ((int)((info[q] >> 9) & 511u) - j - rbase[q]);
                 lim2[q] = (short)(lim < 0 ? 0 : (lim > 128 ? 128 : lim));
             }
             const v2s lim = pk(lim2[0], lim2[1]);
@@ -243,7 +250,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
                 const int u = (int)(unsigned short)(q == 0 ? ex.x : ex.y);
                 if (u == 0) continue;
                 const int ties = W - (int)(unsigned short)(q == 0 ? neq.x : neq.y);
-                const int row = j + (127 - (int)(unsigned short)(q == 0 ? first.x : first.y)) - GB;
+                const int row = j + (127 - (int)(unsigned short)(q == 0 ? first.x : first.y)) + rbase[q];
                 if (ties == 0) { info[q] |= 1u << 21; continue; }      // the column's maximum sits on a pad row: leave it to the full table
                 const uint32_t k2 = ((uint32_t)u << 16) | (uint32_t)(0xFFFF - row);
                 const uint32_t told = (key[q] >> 16) == (uint32_t)u ? colties[q] >> 9 : 0u;
@@ -272,81 +279,135 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     }
 }
 
-// Before any table is filled: does the read match the window exactly on some diagonal?  Then the best cell is known
-// without DP -- score L is the largest score there is, the first maximum is the exact diagonal with the smallest row, its
-// ties are the other exact diagonals -- and the instance skips the first band pass (dp_band_classify_kernel finishes it).
-// One lane per instance: the read in alignment orientation as packed words, XORed against the text at each of the
-// m - L + 1 shifts with an early exit at the first differing word (61 shifts x ~10 instructions against ~200 000 for the
-// band).  rest[t] = 1 for the instances that still need the first pass.
+// Before any table is filled, one lane per instance looks at exact matches of read blocks in the window.
+//
+// An alignment that qualifies for the band (score S >= L - 13, kernels above) loses at most 13 against a perfect match.
+// A mismatch costs 3 of that (a column without its +1, and -2), a gap at least 3, so it has at most 4 of them and its
+// matches -- at least S of them -- come in at most 5 exact runs: one run has R = ceil((L - 13) / 5) bases or more, and a
+// run of 2b - 1 bases contains a whole read block [kb, kb + b).  So with b = (R + 1) / 2 every qualifying alignment
+// shows up as a block of the read that equals the window on the run's diagonal, and all its cells lie within 11
+// diagonals of that one (its gaps have at most 11 bases in all).  The kernel tests every block against every diagonal
+// -13 .. (m - L) + 13 (rows outside the window do not count) and classifies:
+//   no block matches anywhere            -> no qualifying alignment exists: straight to the full-table kernels (score -1);
+//   matching diagonals span <= 4         -> every qualifying alignment lies within 13 diagonals of their centre: the
+//                                           first band pass runs over 27 diagonals instead of 87 (MODE 3); if the read
+//                                           equals the window on one of those diagonals the instance is finished here
+//                                           (score L, smallest exact row, ties = exact diagonals);
+//   otherwise (repeats inside the window) -> the first pass over the whole band.
+// Blocks shorter than MP_PRE_MINB bases would match by chance too often: such (short) reads take the whole band.
 #define MP_BAND_RW (MP_BAND_MAXL / 16)
-#define MP_BAND_SHIFT_WORDS ((MP_BAND_DMAX + 15) / 16 + 1)      // word offsets a shift of 0 .. MP_BAND_DMAX bases can have
+#define MP_BAND_TW ((MP_BAND_MAXL + MP_BAND_DMAX) / 16 + 2)
+#define MP_PRE_MINB 8
+#define MP_PRE_NONE 3u
+#define MP_PRE_WIDE 2u
+#define MP_PRE_NARROW 1u
+#define MP_PRE_DONE 0u
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
-dp_perfect_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
-                  const mp_dp_task *__restrict__ tasks, uint32_t n, mp_fill_result *__restrict__ fill, uint32_t *__restrict__ rest)
+dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
+                    const mp_dp_task *__restrict__ tasks, uint32_t n, mp_fill_result *__restrict__ fill, uint32_t *__restrict__ cls)
 {
+    __shared__ uint32_t s_a[MP_BAND_RW + 1][64];        // the read in alignment orientation, LSB-first words
+    __shared__ uint32_t s_t[MP_BAND_TW + 1][64];        // the window, word 0 starts at its first base
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    const int lane = threadIdx.x;
     const mp_dp_task task = tasks[t];
     const int L = (int)lens[task.read_id], m = (int)task.win_len;
-    rest[t] = 1u;
-    if (L < 30 || L > MP_BAND_MAXL || m < L || m - L > MP_BAND_DMAX) return;
+    mp_fill_result r; r.score = -1; r.row = 0; r.col = 0; r.count = 0;
+    cls[t] = MP_PRE_WIDE;
+    if (L < 30 || L > MP_BAND_MAXL || m < 1 || m - L > MP_BAND_DMAX) { fill[t] = r; return; }      // the first pass decides what to do with it
+    const int R = (L - MP_BAND_GB + 4) / 5, b = min(16, (R + 1) / 2);
+    if (b < MP_PRE_MINB) { fill[t] = r; return; }
     const uint32_t *rd = reads + (uint64_t)task.read_id * Wr;
     const int nw = (L + 15) / 16;
-    // the read in alignment orientation, LSB-first words.  Reverse strand: reverse the 2-bit groups of every word, take the
-    // words in reverse order, complement, and shift out the 16 nw - L pad bases that the reversal brought to the front.
-    uint32_t a[MP_BAND_RW + 1];
+    // ---- oriented read.  Reverse strand: reverse the 2-bit groups of every word, take the words in reverse order,
+    // complement, and shift out the 16 nw - L pad bases that the reversal brought to the front.
+    {
+        uint32_t a[MP_BAND_RW + 1];
 #pragma unroll
-    for (int w = 0; w <= MP_BAND_RW; w++) a[w] = 0;
-    if (task.strand == 1) {
+        for (int w = 0; w <= MP_BAND_RW; w++) a[w] = 0;
+        if (task.strand == 1) {
 #pragma unroll
-        for (int w = 0; w < MP_BAND_RW; w++) if (w < nw) a[w] = rd[w];
-    } else {
-        uint32_t z[MP_BAND_RW + 1];
+            for (int w = 0; w < MP_BAND_RW; w++) if (w < nw) a[w] = rd[w];
+        } else {
+            uint32_t z[MP_BAND_RW + 1];
 #pragma unroll
-        for (int w = 0; w <= MP_BAND_RW; w++) {
-            z[w] = 0;
-            if (w < nw) { const uint32_t r = __brev(rd[nw - 1 - w]); z[w] = ~(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u)); }
+            for (int w = 0; w <= MP_BAND_RW; w++) {
+                z[w] = 0;
+                if (w < nw) { const uint32_t x = __brev(rd[nw - 1 - w]); z[w] = ~(((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u)); }
+            }
+            const uint32_t s2 = 2u * (uint32_t)(16 * nw - L);
+#pragma unroll
+            for (int w = 0; w < MP_BAND_RW; w++) a[w] = (uint32_t)((((uint64_t)z[w + 1] << 32) | z[w]) >> s2);
         }
-        const uint32_t s2 = 2u * (uint32_t)(16 * nw - L);
+        const uint32_t tail = (L & 15) ? ((1u << (2 * (L & 15))) - 1u) : 0xFFFFFFFFu;
 #pragma unroll
-        for (int w = 0; w < MP_BAND_RW; w++) a[w] = (uint32_t)((((uint64_t)z[w + 1] << 32) | z[w]) >> s2);
+        for (int w = 0; w <= MP_BAND_RW; w++) { if (w == nw - 1) a[w] &= tail; if (w >= nw) a[w] = 0; s_a[w][lane] = a[w]; }
     }
-    const uint32_t tail = (L & 15) ? ((1u << (2 * (L & 15))) - 1u) : 0xFFFFFFFFu;
-    __shared__ uint32_t s_a[MP_BAND_RW][64];           // the oriented read of every lane: only the rare full comparison walks it
-#pragma unroll
-    for (int w = 0; w < MP_BAND_RW; w++) { if (w == nw - 1) a[w] &= tail; if (w >= nw) a[w] = 0; s_a[w][threadIdx.x] = a[w]; }
-    const uint32_t a0 = a[0];
-    // first words of the window at every shift, loaded once: shift d is word offset (s0 + d) >> 4 and bit offset
-    // 2 ((s0 + d) & 15) from word q0.  Only a shift whose first word agrees (about one wrong shift in 10^9) is compared in full.
-    const uint64_t q0 = task.win_start >> 4;
-    const int s0 = (int)(task.win_start & 15);
-    uint32_t tw[MP_BAND_SHIFT_WORDS + 2];
-#pragma unroll
-    for (int w = 0; w < MP_BAND_SHIFT_WORDS + 2; w++) tw[w] = text[q0 + w];
-    const uint32_t m0 = nw == 1 ? tail : 0xFFFFFFFFu;
+    // ---- window words, aligned to the window's first base
+    {
+        const uint64_t q0 = task.win_start >> 4;
+        const uint32_t sh = 2u * (uint32_t)(task.win_start & 15);
+        const int tw = (m + 15) / 16;
+        for (int w = 0; w <= MP_BAND_TW; w++) {
+            uint32_t v = 0;
+            if (w < tw) { const uint64_t two = ((uint64_t)text[q0 + w + 1] << 32) | text[q0 + w]; v = (uint32_t)(two >> sh); }
+            s_t[w][lane] = v;
+        }
+    }
+    // b bases starting at base `at` of a word array in LDS (b <= 16)
+    const uint32_t bmask = b == 16 ? 0xFFFFFFFFu : ((1u << (2 * b)) - 1u);
+    auto bases_a = [&](int at) -> uint32_t {
+        const uint64_t two = ((uint64_t)s_a[(at >> 4) + 1][lane] << 32) | s_a[at >> 4][lane];
+        return (uint32_t)(two >> (2 * (at & 15))) & bmask;
+    };
+    auto bases_t = [&](int at) -> uint32_t {
+        const uint64_t two = ((uint64_t)s_t[(at >> 4) + 1][lane] << 32) | s_t[at >> 4][lane];
+        return (uint32_t)(two >> (2 * (at & 15))) & bmask;
+    };
+    // ---- every block against every diagonal: window row (0-based) of read base u on diagonal dl is u + dl
+    const int nb = L / b;
+    int dlo = 1 << 20, dhi = -(1 << 20);
+    for (int k = 0; k < nb; k++) {
+        const uint32_t vb = bases_a(k * b);
+        int lo = -MP_BAND_GB, hi = m - L + MP_BAND_GB;
+        if (lo < -k * b) lo = -k * b;                           // the block's rows stay inside the window
+        if (hi > m - k * b - b) hi = m - k * b - b;
+        for (int dl = lo; dl <= hi; dl++)
+            if (bases_t(k * b + dl) == vb) { dlo = dl < dlo ? dl : dlo; dhi = dl > dhi ? dl : dhi; }
+    }
+    if (dhi < dlo) { cls[t] = MP_PRE_NONE; fill[t] = r; return; }
+    if (dhi - dlo > 4) { fill[t] = r; return; }                 // wide
+    const int centre = (dlo + dhi) >> 1;                        // floor: dlo + 2 >= centre >= dhi - 2
+    // ---- exact diagonals among the matching ones
     int first = -1, exact = 0;
-    for (int d = 0; d <= m - L; d++) {
-        const int wo = (s0 + d) >> 4;
-        const uint32_t sh = 2u * (uint32_t)((s0 + d) & 15);
-        uint32_t lo = tw[0], hi = tw[1];
-#pragma unroll
-        for (int w = 1; w <= MP_BAND_SHIFT_WORDS; w++) if (wo == w) { lo = tw[w]; hi = tw[w + 1]; }
-        if ((((uint32_t)((((uint64_t)hi << 32) | lo) >> sh) ^ a0) & m0) != 0) continue;
+    const uint32_t tail = (L & 15) ? ((1u << (2 * (L & 15))) - 1u) : 0xFFFFFFFFu;
+    for (int dl = max(dlo, 0); dl <= min(dhi, m - L); dl++) {
         bool same = true;
-        for (int w = 1; w < nw && same; w++) {
-            const uint64_t two = ((uint64_t)text[q0 + wo + w + 1] << 32) | text[q0 + wo + w];
-            uint32_t x = (uint32_t)(two >> sh) ^ s_a[w][threadIdx.x];
+        for (int w = 0; w < nw && same; w++) {
+            const int at = 16 * w + dl;
+            const uint64_t two = ((uint64_t)s_t[(at >> 4) + 1][lane] << 32) | s_t[at >> 4][lane];
+            uint32_t x = (uint32_t)(two >> (2 * (at & 15))) ^ s_a[w][lane];
             if (w == nw - 1) x &= tail;
             same = x == 0;
         }
-        if (same) { if (first < 0) first = d; exact++; }
+        if (same) { if (first < 0) first = dl; exact++; }
     }
     if (first >= 0) {
-        mp_fill_result r;
         r.score = L; r.row = (uint16_t)(first + L); r.col = (uint16_t)L; r.count = exact > 255 ? 255u : (uint32_t)exact;
-        fill[t] = r;
-        rest[t] = 0u;
+        cls[t] = MP_PRE_DONE;
+    } else {
+        r.score = -2; r.row = (uint16_t)(centre + 256); r.col = 256; r.count = 0;      // row - col = centre, read by the MODE 3 pass
+        cls[t] = MP_PRE_NARROW;
     }
+    fill[t] = r;
+}
+
+// flag[t] = (cls[t] == which)
+__global__ void dp_class_flag_kernel(const uint32_t *__restrict__ cls, uint32_t n, uint32_t which, uint32_t *__restrict__ flag)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) flag[t] = cls[t] == which ? 1u : 0u;
 }
 
 // tasks the band did not decide (score -1) are selected for the full kernels; decided ones are traced from the band slab

@@ -963,7 +963,9 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
                                    d_tasks, n_narrow, cl, cr, (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p,
                                    (const uint32_t *)c->narrow_list.p);
         }
-        if (n_wide) {
+        // a handful of whole-band instances is not worth a launch of its own: they stay undecided (the pre-filter left
+        // score -1) and go to the full-table kernels with the rest
+        if (n_wide >= 1024) {
             hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->wide_list.p);
             const dim3 g1((n_wide + 127) / 128);
             if (small)

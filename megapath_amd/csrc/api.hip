@@ -741,6 +741,13 @@ void fill_round(const mp_ctx *c, bool count, uint32_t *out)
 template <int LPI, int C>
 void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, mp_fill_result *fill)
 {
+    if (LPI * C <= 160) {
+        // the leaner filter kernel for reads of up to 160 bases: 8 lanes x 20 columns per instance pair (kernels_dp.hip)
+        const unsigned pairs8 = (n + 1) / 2, groups8 = MP_DP_BLOCK / 8;
+        hipLaunchKernelGGL((dp_score_kernel<8, 20>), dim3(grid_for(pairs8, groups8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                           tasks, n, fill);
+        return;
+    }
     const unsigned pairs = (n + 1) / 2, groups = MP_DP_BLOCK / LPI;
     hipLaunchKernelGGL((dp_fill_kernel<LPI, C, 2>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                        tasks, n, cl, cr, (uint32_t *)nullptr, 0u, fill);

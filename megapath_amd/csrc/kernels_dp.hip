@@ -413,6 +413,137 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 
 // ------------------------------------------------------------------------------------------------ traceback
 // BW > 0: the slab was written by dp_band_kernel<BW, GB> (kernels_dp_band.hip): [block of 64 pairs][column][word][lane]
+// ------------------------------------------------------------------------------------------------ score-only filter
+// dp_score_kernel<LPI, C>: the pre-pass of run_dp_filtered for reads of up to LPI x C bases.  It answers one question --
+// can this instance reach its cutoff? -- and may err on the high side only (an instance it lets through is filled in full
+// and decided exactly).  That freedom buys a leaner kernel than dp_fill_kernel<.., 2>:
+//  * cell values are held relative to the ROW (x + MP_DP_BIAS - i) instead of the column: the same cancellation of the
+//    match bonus along the diagonal, but now every cell of a row shares the frame, so the left-clip floor is one
+//    register per row and the maximum is one running register -- no per-column arrays, which lets a lane own 20 columns
+//    (8 lanes per instance pair) at five waves per SIMD and halves the per-row work per cell;
+//  * the floor is applied in every column and row 0 is all zeros (as if the whole read could be clipped on the left),
+//    rows past the shorter window of a pair and columns that cannot end an alignment are not excluded: all of these can
+//    only raise scores.
+#define MP_DP_SCORE_CELL \
+        "v_sub_u32 %[eo], %[Hup], %[k4]\n\t"                      /* open a deletion: H - 3, one row down: -4 in this frame */ \
+        "v_mov_b32 %[dn], %[Hup]\n\t" \
+        "v_sub_u32 %[Eup], %[Eup], %[k2]\n\t"                     /* extend it:       E - 1                : -2 */ \
+        "v_pk_max_u16 %[Eup], %[eo], %[Eup]\n\t" \
+        "v_sub_u32 %[fo], %[Hl], %[k3]\n\t"                       /* open an insertion: H - 3 (same row) */ \
+        "v_sub_u32 %[Fl], %[Fl], %[k1]\n\t" \
+        "v_pk_max_u16 %[Fl], %[fo], %[Fl]\n\t" \
+        "v_xor_b32 %[t1], %[base], %[rb]\n\t" \
+        "v_pk_min_u16 %[t1], %[t1], %[k3]\n\t" \
+        "v_sub_u32 %[dg], %[diag], %[t1]\n\t"                     /* the row term swallows the +1 of a match */ \
+        "v_pk_max_u16 %[t1], %[dg], %[Eup]\n\t" \
+        "v_pk_max_u16 %[t1], %[t1], %[Fl]\n\t" \
+        "v_pk_max_u16 %[Hup], %[t1], %[floorr]\n\t" \
+        "v_pk_max_u16 %[rowmax], %[rowmax], %[Hup]"
+
+template <int LPI, int C>
+__global__ void __launch_bounds__(MP_DP_BLOCK)
+dp_score_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t W,
+                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, mp_fill_result *__restrict__ out)
+{
+    constexpr int GROUPS = MP_DP_BLOCK / LPI;
+    constexpr int B = MP_DP_BIAS;
+    __shared__ uint32_t s_win[GROUPS][2][MP_DP_MAX_WIN / 16 + 1];
+    const int g = threadIdx.x / LPI;
+    const int k = threadIdx.x % LPI;
+    const uint32_t pair = blockIdx.x * GROUPS + g;
+    int L[2], m[2], strand[2];
+    uint32_t rid[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t inst = 2 * pair + q;
+        mp_dp_task task; task.read_id = 0; task.strand = 1; task.win_start = 0; task.win_len = 0; task.reserved = 0;
+        const bool live = inst < n_tasks;
+        if (live) task = tasks[inst];
+        L[q] = live ? (int)lens[task.read_id] : 0;
+        m[q] = (int)task.win_len;
+        if (m[q] > MP_DP_MAX_WIN) m[q] = MP_DP_MAX_WIN;
+        if (L[q] > LPI * C) m[q] = 0;                  // host guarantees the template covers the longest read
+        strand[q] = (int)task.strand; rid[q] = task.read_id;
+        for (int w = k; w * 16 < m[q]; w += LPI) {
+            uint64_t p = task.win_start + 16ull * (uint64_t)w;
+            uint32_t sh = 2 * (uint32_t)(p & 15);
+            uint64_t two = (uint64_t)text[p >> 4];
+            if (sh) two |= (uint64_t)text[(p >> 4) + 1] << 32;
+            s_win[g][q][w] = (uint32_t)(two >> sh);
+        }
+    }
+    v2s rb[C], Hup[C], Eup[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+        const int j = k * C + cc + 1;
+        short b2[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            int b = 9 + q;
+            if (j <= L[q]) {
+                const uint32_t *rd = reads + (uint64_t)rid[q] * W;
+                int p = strand[q] == 1 ? j - 1 : L[q] - j;
+                b = (int)((rd[p >> 4] >> (2 * (p & 15))) & 3u);
+                if (strand[q] != 1) b = 3 - b;
+                b = MP_DP_CODE(b);
+            }
+            b2[q] = (short)b;
+        }
+        rb[cc] = pk(b2[0], b2[1]); Hup[cc] = pk1((short)B); Eup[cc] = pk1(MP_DP_SENT);
+    }
+    v2s diag_carry = pk1((short)B);
+    __syncthreads();
+    const v2s k1 = pk1(1), k2 = pk1(2), k3 = pk1(3), k4 = pk1(4);
+    v2s best = pk1((short)B);                          // score 0
+    v2s outH = pk1((short)B), outF = pk1(MP_DP_SENT);
+    int outB = 0;
+    const int mmax = m[0] > m[1] ? m[0] : m[1];
+    int steps = mmax > 0 ? mmax + LPI - 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(steps, o); steps = v > steps ? v : steps; }
+    uint32_t wq0 = 0, wq1 = 0;
+    for (int t = 1; t <= steps; t++) {
+        int inHi = wave_shr1(as_int(outH));
+        int inFi = wave_shr1(as_int(outF));
+        int inB = wave_shr1(outB);
+        if (((t - 1) & 15) == 0) { wq0 = s_win[g][0][(t - 1) >> 4]; wq1 = s_win[g][1][(t - 1) >> 4]; }
+        const int r0 = t <= m[0] ? MP_DP_CODE(wq0 & 3u) : 12, r1 = t <= m[1] ? MP_DP_CODE(wq1 & 3u) : 15;   // pads match nothing
+        wq0 >>= 2; wq1 >>= 2;
+        const int i = t - k;                           // row handled now
+        if (k == 0) { inHi = as_int(pk1((short)(B - i))); inFi = as_int(pk1(MP_DP_SENT)); inB = r0 | (r1 << 16); }   // column 0: H = 0
+        if (i >= 1 && i <= mmax) {
+            const v2s base = as_v2s(inB);
+            const v2s floorr = pk1((short)(B - i));    // score 0 in this row's frame
+            v2s Hl = as_v2s(inHi), Fl = as_v2s(inFi), diag = diag_carry, rowmax = pk1(0);
+#pragma unroll
+            for (int cc = 0; cc < C; cc++) {
+                v2s eo, fo, dg, t1, dnext;
+                asm(MP_DP_SCORE_CELL
+                    : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [dn] "=&v"(dnext), [Hup] "+&v"(Hup[cc]), [Eup] "+&v"(Eup[cc]),
+                      [Fl] "+&v"(Fl), [rowmax] "+&v"(rowmax)
+                    : [Hl] "v"(Hl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb[cc]), [floorr] "v"(floorr), [k1] "v"(k1), [k2] "v"(k2),
+                      [k3] "v"(k3), [k4] "v"(k4));
+                diag = dnext;
+                Hl = Hup[cc];
+            }
+            best = umax(best, rowmax + pk1((short)i));     // back to the row-free frame
+            diag_carry = as_v2s(inHi);
+            outH = Hl; outF = Fl;
+        }
+        outB = inB;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        int b = (int)(unsigned short)(q == 0 ? best.x : best.y) - B;
+        for (int o = LPI / 2; o > 0; o >>= 1) { const int v = __shfl_xor(b, o, LPI); b = v > b ? v : b; }
+        const uint32_t inst = 2 * pair + q;
+        if (inst < n_tasks && k == 0) {
+            mp_fill_result r;
+            r.score = b; r.row = 0; r.col = 0; r.count = 0;
+            out[inst] = r;
+        }
+    }
+}
+
 // CENTER: the band is the one of dp_band_kernel's second pass, centred on the diagonal of the best cell
 template <int LPI, int C, int BW = 0, int GB = 0, bool CENTER = false>
 __global__ void __launch_bounds__(64)

@@ -76,6 +76,7 @@ struct mp_ctx {
     DevBuf<uint32_t> band_flag, band_idx;        // instances the band kernel left to the full kernels
     DevBuf<uint32_t> near_flag, near_idx, near_list, far_flag, far_idx, far_list;   // classes of the second band pass
     DevBuf<uint32_t> pre_cls, narrow_list, wide_list;                               // dp_prefilter_kernel's classes: first band pass over 27 / 87 diagonals
+    DevBuf<uint32_t> vfar_flag, vfar_idx, vfar_list, und_list[2];                   // second tier; instances still undecided after a tier
     DevBuf<mp_dp_task> band_tasks;
     DevBuf<mp_dp_result> band_res;
     DevBuf<mp_fill_result> band_fill;
@@ -914,15 +915,102 @@ int band_second_pass(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *list,
     return MP_OK;
 }
 
+// One tier of the two-pass band scheme over the instances `in_list` (nullptr: all n_in instances of d_tasks):
+// block-match pre-filter with budget GBUD, first pass over 2 GBUD + 1 diagonals for the instances it confines (TIER 1 also
+// over the whole band for the ones it cannot), classification, second pass by class with traceback.  Results of decided
+// instances land in d_res; the undecided ones are listed in und_out (*n_und of them).
+template <int GBUD, int MINB, bool TIER1>
+int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uint32_t n_in, int cl, int cr, mp_dp_result *d_res, float *ms_fill,
+              float *ms_trace, DevBuf<uint32_t> &und_out, uint32_t *n_und)
+{
+    *n_und = 0;
+    if (n_in == 0) return MP_OK;
+    hipStream_t s = c->stream;
+    const bool small = c->max_len <= 160;
+    const mp_fill_result *none = nullptr;
+    const uint32_t n = n_in;
+    if (c->pre_cls.reserve(n + 2) || c->near_flag.reserve(n + 2) || c->near_idx.reserve(n + 2) || c->far_flag.reserve(n + 2) || c->far_idx.reserve(n + 2) ||
+        c->vfar_flag.reserve(n + 2) || c->vfar_idx.reserve(n + 2) || c->band_flag.reserve(n + 2) || c->band_idx.reserve(n + 2))
+        return MP_ENOMEM;
+    while (c->ev_pool.size() < 4) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    auto scan = [&](uint32_t *flag, uint32_t *idx) -> int {
+        size_t tmp_bytes = 0;
+        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, flag, idx, (int)n, s);
+        if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+        (void)hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, flag, idx, (int)n, s);
+        return MP_OK;
+    };
+    HIPCHK(hipEventRecord(c->ev_pool[0], s));
+    // block-match pre-filter: finished (exact diagonal), narrow first pass, whole band, or no qualifying alignment at all
+    hipLaunchKernelGGL((dp_prefilter_kernel<GBUD, MINB>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n,
+                       c->band_fill.p, c->pre_cls.p, in_list);
+    hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_NARROW, c->near_flag.p);
+    hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_WIDE, c->far_flag.p);
+    { int rc0 = scan(c->near_flag.p, c->near_idx.p); if (rc0) return rc0; rc0 = scan(c->far_flag.p, c->far_idx.p); if (rc0) return rc0; }
+    uint32_t n_narrow = 0, n_wide = 0;
+    HIPCHK(hipMemcpyAsync(&n_narrow, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&n_wide, c->far_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->narrow_list.reserve(n_narrow + 130) || c->wide_list.reserve(n_wide + 130)) return MP_ENOMEM;
+    if (n_narrow) {
+        hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->narrow_list.p, in_list);
+        const dim3 g1((n_narrow + 127) / 128);
+        if (small)
+            hipLaunchKernelGGL((dp_band_kernel<2 * GBUD + 1, GBUD, 160, 3>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_narrow, cl, cr,
+                               (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p, (const uint32_t *)c->narrow_list.p);
+        else
+            hipLaunchKernelGGL((dp_band_kernel<2 * GBUD + 1, GBUD, MP_BAND_MAXL, 3>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_narrow,
+                               cl, cr, (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p, (const uint32_t *)c->narrow_list.p);
+    }
+    // whole-band instances (repeats inside the window, reads too short for the block test): first tier only, and only when
+    // they are worth a launch of their own -- otherwise they stay undecided (the pre-filter left score -1)
+    if (TIER1 && n_wide >= 1024) {
+        hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->wide_list.p, in_list);
+        const dim3 g1((n_wide + 127) / 128);
+        if (small)
+            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                               d_tasks, n_wide, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->wide_list.p);
+        else
+            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                               d_tasks, n_wide, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->wide_list.p);
+    }
+    static const bool verbose2 = getenv("MP_DP_BAND_STATS") != nullptr;
+    if (verbose2) fprintf(stderr, "[band] tier %d pre-filter: %u narrow, %u whole band, of %u\n", TIER1 ? 1 : 2, n_narrow, n_wide, n);
+    HIPCHK(hipEventRecord(c->ev_pool[1], s));
+    // classes by distance from the best cell's diagonal; perfect matches and instances below their cutoff are finished here
+    hipLaunchKernelGGL(dp_band_classify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, (const mp_fill_result *)c->band_fill.p, n,
+                       c->near_flag.p, c->far_flag.p, c->band_flag.p, d_res, in_list, TIER1 ? (uint32_t *)nullptr : c->vfar_flag.p);
+    int rc = scan(c->near_flag.p, c->near_idx.p); if (rc) return rc;
+    rc = scan(c->far_flag.p, c->far_idx.p); if (rc) return rc;
+    rc = scan(c->band_flag.p, c->band_idx.p); if (rc) return rc;
+    if (!TIER1) { rc = scan(c->vfar_flag.p, c->vfar_idx.p); if (rc) return rc; }
+    uint32_t n_near = 0, n_far = 0, n_vfar = 0, n_sel = 0;
+    HIPCHK(hipMemcpyAsync(&n_near, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&n_far, c->far_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&n_sel, c->band_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    if (!TIER1) HIPCHK(hipMemcpyAsync(&n_vfar, c->vfar_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    { float a = 0; (void)hipEventElapsedTime(&a, c->ev_pool[0], c->ev_pool[1]); if (ms_fill) *ms_fill += a; }
+    if (c->near_list.reserve(n_near + 130) || c->far_list.reserve(n_far + 130) || c->vfar_list.reserve(n_vfar + 130) || und_out.reserve(n_sel + 130)) return MP_ENOMEM;
+    if (n_near) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->near_list.p, in_list);
+    if (n_far) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->far_list.p, in_list);
+    if (n_vfar) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->vfar_flag.p, c->vfar_idx.p, n, c->vfar_list.p, in_list);
+    if (n_sel) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_flag.p, c->band_idx.p, n, und_out.p, in_list);
+    rc = band_second_pass<MP_BAND_W1, MP_BAND_GB1>(c, d_tasks, c->near_list.p, n_near, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
+    rc = band_second_pass<MP_BAND_W2, MP_BAND_GB>(c, d_tasks, c->far_list.p, n_far, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
+    rc = band_second_pass<MP_BAND_W3, MP_BAND_GB3>(c, d_tasks, c->vfar_list.p, n_vfar, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
+    *n_und = n_sel;
+    return MP_OK;
+}
+
 int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,
                 float *ms_fill, float *ms_trace, bool count)
 {
     if (n == 0) return MP_OK;
     hipStream_t s = c->stream;
     const uint32_t ncols = c->max_len;
-    // Two passes when the soft-clip limits allow it (rows <= 0 of the second pass's band reach column 2 GB + 1): scores of
-    // the whole band first, then the traceback bits only around the best cell's diagonal -- 87 x 15 + 27 x 33 instead
-    // of 87 x 33 instructions per column.  MP_DP_BAND=1 keeps the single pass.
+    // Two passes when the soft-clip limits allow it (rows <= 0 of a centred band reach column 2 GB + 1): scores first, then
+    // the traceback bits only around the best cell's diagonal.  MP_DP_BAND=1 keeps the single pass over the whole band.
     static const bool one_pass_env = getenv("MP_DP_BAND") && atoi(getenv("MP_DP_BAND")) == 1;
     const bool two_pass = !one_pass_env && cl >= 2 * MP_BAND_GB + 1 && cr >= 2 * MP_BAND_GB + 1;
     if (c->slab_budget == 0) {
@@ -933,75 +1021,20 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     const bool small = c->max_len <= 160;                       // the 160-base instances stage fewer window rows in LDS
     const uint32_t n_blocks = (uint32_t)(((uint64_t)n + 127) / 128);
     if (c->band_fill.reserve(n + 2) || c->band_flag.reserve(n + 2) || c->band_idx.reserve(n + 2)) return MP_ENOMEM;
-    while (c->ev_pool.size() < 4) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
     const mp_fill_result *none = nullptr;
     uint32_t n_sel = 0;
-    auto scan = [&](uint32_t *flag, uint32_t *idx) -> int {
-        size_t tmp_bytes = 0;
-        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, flag, idx, (int)n, s);
-        if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
-        (void)hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, flag, idx, (int)n, s);
-        return MP_OK;
-    };
+    const uint32_t *und = nullptr;                               // instances left to the full-table kernels
     if (two_pass) {
-        if (c->near_flag.reserve(n + 2) || c->near_idx.reserve(n + 2) || c->far_flag.reserve(n + 2) || c->far_idx.reserve(n + 2)) return MP_ENOMEM;
-        if (c->pre_cls.reserve(n + 2)) return MP_ENOMEM;
-        HIPCHK(hipEventRecord(c->ev_pool[0], s));
-        // block-match pre-filter: finished (exact diagonal), narrow first pass, whole band, or no qualifying alignment at all
-        hipLaunchKernelGGL(dp_prefilter_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->band_fill.p,
-                           c->pre_cls.p);
-        hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_NARROW, c->near_flag.p);
-        hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_WIDE, c->far_flag.p);
-        { int rc0 = scan(c->near_flag.p, c->near_idx.p); if (rc0) return rc0; rc0 = scan(c->far_flag.p, c->far_idx.p); if (rc0) return rc0; }
-        uint32_t n_narrow = 0, n_wide = 0;
-        HIPCHK(hipMemcpyAsync(&n_narrow, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(&n_wide, c->far_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (c->narrow_list.reserve(n_narrow + 130) || c->wide_list.reserve(n_wide + 130)) return MP_ENOMEM;
-        if (n_narrow) {
-            hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->narrow_list.p);
-            const dim3 g1((n_narrow + 127) / 128);
-            if (small)
-                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W2, MP_BAND_GB, 160, 3>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                   d_tasks, n_narrow, cl, cr, (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p,
-                                   (const uint32_t *)c->narrow_list.p);
-            else
-                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W2, MP_BAND_GB, MP_BAND_MAXL, 3>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                   d_tasks, n_narrow, cl, cr, (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p,
-                                   (const uint32_t *)c->narrow_list.p);
+        int rc = band_tier<MP_BAND_GB, MP_PRE_MINB, true>(c, d_tasks, nullptr, n, cl, cr, d_res, ms_fill, ms_trace, c->und_list[0], &n_sel);
+        if (rc) return rc;
+        und = c->und_list[0].p;
+        // second tier: alignments that lose up to 25 (scores down to L - 25) over 51 diagonals, for what the first left over
+        if (n_sel >= 1024 && cl >= 2 * MP_BAND_GB3 + 1 && cr >= 2 * MP_BAND_GB3 + 1) {
+            uint32_t n2 = 0;
+            rc = band_tier<MP_BAND_GB3, 7, false>(c, d_tasks, c->und_list[0].p, n_sel, cl, cr, d_res, ms_fill, ms_trace, c->und_list[1], &n2);
+            if (rc) return rc;
+            n_sel = n2; und = c->und_list[1].p;
         }
-        // a handful of whole-band instances is not worth a launch of its own: they stay undecided (the pre-filter left
-        // score -1) and go to the full-table kernels with the rest
-        if (n_wide >= 1024) {
-            hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->wide_list.p);
-            const dim3 g1((n_wide + 127) / 128);
-            if (small)
-                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                   d_tasks, n_wide, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->wide_list.p);
-            else
-                hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                   d_tasks, n_wide, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->wide_list.p);
-        }
-        static const bool verbose2 = getenv("MP_DP_BAND_STATS") != nullptr;
-        if (verbose2) fprintf(stderr, "[band] pre-filter: %u narrow, %u whole band, of %u\n", n_narrow, n_wide, n);
-        HIPCHK(hipEventRecord(c->ev_pool[1], s));
-        // classes by distance from the best cell's diagonal; perfect matches and instances below their cutoff are finished here
-        hipLaunchKernelGGL(dp_band_classify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, (const mp_fill_result *)c->band_fill.p, n,
-                           c->near_flag.p, c->far_flag.p, c->band_flag.p, d_res);
-        int rc = scan(c->near_flag.p, c->near_idx.p); if (rc) return rc;
-        rc = scan(c->far_flag.p, c->far_idx.p); if (rc) return rc;
-        rc = scan(c->band_flag.p, c->band_idx.p); if (rc) return rc;
-        uint32_t n_near = 0, n_far = 0;
-        HIPCHK(hipMemcpyAsync(&n_near, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(&n_far, c->far_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(&n_sel, c->band_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        { float a = 0; (void)hipEventElapsedTime(&a, c->ev_pool[0], c->ev_pool[1]); if (ms_fill) *ms_fill += a; }
-        if (c->near_list.reserve(n_near + 130) || c->far_list.reserve(n_far + 130)) return MP_ENOMEM;
-        if (n_near) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->near_list.p);
-        if (n_far) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->far_list.p);
-        rc = band_second_pass<MP_BAND_W1, MP_BAND_GB1>(c, d_tasks, c->near_list.p, n_near, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
-        rc = band_second_pass<MP_BAND_W2, MP_BAND_GB>(c, d_tasks, c->far_list.p, n_far, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
     } else {
         const size_t per_block = (size_t)ncols * MP_BAND_NW * 64 * 4;              // 64 instance pairs
         static uint32_t round_cache[2] = {0, 0};
@@ -1038,7 +1071,12 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
             HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
         }
         hipLaunchKernelGGL(dp_band_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_fill.p, n, c->band_flag.p);
-        int rc = scan(c->band_flag.p, c->band_idx.p); if (rc) return rc;
+        {
+            size_t tmp_bytes = 0;
+            (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, c->band_flag.p, c->band_idx.p, (int)n, s);
+            if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+            (void)hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, c->band_flag.p, c->band_idx.p, (int)n, s);
+        }
         HIPCHK(hipMemcpyAsync(&n_sel, c->band_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         for (size_t q = 0; q < n_chunks; q++) {
@@ -1048,17 +1086,21 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
             if (ms_fill) *ms_fill += a;
             if (ms_trace) *ms_trace += b;
         }
+        if (c->und_list[0].reserve(n_sel + 130)) return MP_ENOMEM;
+        if (n_sel) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_flag.p, c->band_idx.p, n, c->und_list[0].p,
+                                      (const uint32_t *)nullptr);
+        und = c->und_list[0].p;
     }
     c->n_band += n; c->n_band_full += n_sel;
     static const bool verbose = getenv("MP_DP_BAND_STATS") != nullptr;
     if (verbose) fprintf(stderr, "[band] %u instances, %u left to the full kernels\n", n, n_sel);
     if (n_sel == 0) return MP_OK;
     if (c->band_tasks.reserve(n_sel + 2) || c->band_res.reserve(n_sel + 2)) return MP_ENOMEM;
-    hipLaunchKernelGGL(dp_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->band_flag.p, c->band_idx.p, n, c->band_tasks.p);
+    hipLaunchKernelGGL(dp_gather_tasks_kernel, dim3(grid_for(n_sel, 256)), dim3(256), 0, s, d_tasks, und, n_sel, c->band_tasks.p);
     // what the band leaves over are mostly real alignments with several differences: no score-only pre-pass for them
     int rc = run_dp(c, c->band_tasks.p, n_sel, max_win, cl, cr, c->band_res.p, nullptr, 0, ms_fill, ms_trace, count);
     if (rc) return rc;
-    hipLaunchKernelGGL(dp_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_flag.p, c->band_idx.p, c->band_res.p, n, d_res);
+    hipLaunchKernelGGL(dp_scatter_list_kernel, dim3(grid_for(n_sel, 256)), dim3(256), 0, s, (const mp_dp_result *)c->band_res.p, und, n_sel, d_res);
     return MP_OK;
 }
 

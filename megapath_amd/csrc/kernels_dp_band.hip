@@ -32,6 +32,9 @@
 // second pass of the two-pass scheme: diagonals of the best cell +- MP_BAND_GB
 #define MP_BAND_W2 (2 * MP_BAND_GB + 1)
 #define MP_BAND_NW2 ((MP_BAND_W2 + 2) / 3)
+// second tier: instances the first tier left undecided, alignments that lose up to 25
+#define MP_BAND_GB3 25
+#define MP_BAND_W3 (2 * MP_BAND_GB3 + 1)
 
 // One band cell of two instances.  Hd enters as H of (row-1, col-1) [same d, previous column] and leaves as H of this
 // cell; Hn / Fn are the previous column's H / F one row down (d + 1): the horizontal neighbour; Hc / Ec the cell above
@@ -302,22 +305,29 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #define MP_PRE_WIDE 2u
 #define MP_PRE_NARROW 1u
 #define MP_PRE_DONE 0u
+// GBUD: what a qualifying alignment may lose against a perfect match (13: the first tier; 25: the second tier, run on the
+// instances the first tier left undecided, with band kernels of 51 diagonals).  With a list, slot s stands for instance
+// list[s]; cls is indexed by slot, fill by instance.
+template <int GBUD, int MINB>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
-                    const mp_dp_task *__restrict__ tasks, uint32_t n, mp_fill_result *__restrict__ fill, uint32_t *__restrict__ cls)
+                    const mp_dp_task *__restrict__ tasks, uint32_t n, mp_fill_result *__restrict__ fill, uint32_t *__restrict__ cls,
+                    const uint32_t *__restrict__ list = nullptr)
 {
     __shared__ uint32_t s_a[MP_BAND_RW + 1][64];        // the read in alignment orientation, LSB-first words
     __shared__ uint32_t s_t[MP_BAND_TW + 1][64];        // the window, word 0 starts at its first base
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t t = list ? list[slot] : slot;
     const int lane = threadIdx.x;
     const mp_dp_task task = tasks[t];
     const int L = (int)lens[task.read_id], m = (int)task.win_len;
     mp_fill_result r; r.score = -1; r.row = 0; r.col = 0; r.count = 0;
-    cls[t] = MP_PRE_WIDE;
+    cls[slot] = MP_PRE_WIDE;
     if (L < 30 || L > MP_BAND_MAXL || m < 1 || m - L > MP_BAND_DMAX) { fill[t] = r; return; }      // the first pass decides what to do with it
-    const int R = (L - MP_BAND_GB + 4) / 5, b = min(16, (R + 1) / 2);
-    if (b < MP_PRE_MINB) { fill[t] = r; return; }
+    constexpr int RUNS = GBUD / 3 + 1;               // at most GBUD / 3 mismatches and gaps
+    const int R = (L - GBUD + RUNS - 1) / RUNS, b = min(16, (R + 1) / 2);
+    if (b < MINB) { fill[t] = r; return; }
     const uint32_t *rd = reads + (uint64_t)task.read_id * Wr;
     const int nw = (L + 15) / 16;
     // ---- oriented read.  Reverse strand: reverse the 2-bit groups of every word, take the words in reverse order,
@@ -370,13 +380,13 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
     int dlo = 1 << 20, dhi = -(1 << 20);
     for (int k = 0; k < nb; k++) {
         const uint32_t vb = bases_a(k * b);
-        int lo = -MP_BAND_GB, hi = m - L + MP_BAND_GB;
+        int lo = -GBUD, hi = m - L + GBUD;
         if (lo < -k * b) lo = -k * b;                           // the block's rows stay inside the window
         if (hi > m - k * b - b) hi = m - k * b - b;
         for (int dl = lo; dl <= hi; dl++)
             if (bases_t(k * b + dl) == vb) { dlo = dl < dlo ? dl : dlo; dhi = dl > dhi ? dl : dhi; }
     }
-    if (dhi < dlo) { cls[t] = MP_PRE_NONE; fill[t] = r; return; }
+    if (dhi < dlo) { cls[slot] = MP_PRE_NONE; fill[t] = r; return; }
     if (dhi - dlo > 4) { fill[t] = r; return; }                 // wide
     const int centre = (dlo + dhi) >> 1;                        // floor: dlo + 2 >= centre >= dhi - 2
     // ---- exact diagonals among the matching ones
@@ -395,10 +405,10 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
     }
     if (first >= 0) {
         r.score = L; r.row = (uint16_t)(first + L); r.col = (uint16_t)L; r.count = exact > 255 ? 255u : (uint32_t)exact;
-        cls[t] = MP_PRE_DONE;
+        cls[slot] = MP_PRE_DONE;
     } else {
         r.score = -2; r.row = (uint16_t)(centre + 256); r.col = 256; r.count = 0;      // row - col = centre, read by the MODE 3 pass
-        cls[t] = MP_PRE_NARROW;
+        cls[slot] = MP_PRE_NARROW;
     }
     fill[t] = r;
 }
@@ -428,13 +438,17 @@ __global__ void dp_band_select_kernel(const mp_fill_result *__restrict__ fill, u
 #define MP_BAND_NW1 ((MP_BAND_W1 + 2) / 3)
 __global__ void dp_band_classify_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, const mp_fill_result *__restrict__ fill,
                                         uint32_t n, uint32_t *__restrict__ flag_near, uint32_t *__restrict__ flag_far, uint32_t *__restrict__ flag_full,
-                                        mp_dp_result *__restrict__ res)
+                                        mp_dp_result *__restrict__ res, const uint32_t *__restrict__ list = nullptr,
+                                        uint32_t *__restrict__ flag_vfar = nullptr)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+    // flags are indexed by slot; with a list, slot s stands for instance list[s].  The second tier (scores down to L - 25)
+    // has a third class, `flag_vfar`: scores below L - MP_BAND_GB, second pass over 51 diagonals.
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t t = list ? list[slot] : slot;
     const mp_fill_result fr = fill[t];
     const int L = (int)lens[tasks[t].read_id];
-    uint32_t fn = 0, ff = 0, fu = 0;
+    uint32_t fn = 0, ff = 0, fu = 0, fv = 0;
     mp_dp_result z; z.score = 0; z.hit_loc = 0; z.max_score_count = 0; z.n_ops = 0;
     if (fr.score < 0) fu = 1;
     else if (fr.score == 0 || fr.score < mp_dp_cutoff(L)) res[t] = z;              // nothing to align / below the cutoff
@@ -442,13 +456,28 @@ __global__ void dp_band_classify_kernel(const mp_dp_task *__restrict__ tasks, co
         z.score = L; z.hit_loc = (uint32_t)(fr.row - L); z.max_score_count = fr.count; z.n_ops = (uint32_t)L;
         res[t] = z;
     } else if (fr.score >= L - MP_BAND_NEAR) fn = 1;
-    else ff = 1;
-    flag_near[t] = fn; flag_far[t] = ff; flag_full[t] = fu;
+    else if (fr.score >= L - MP_BAND_GB || !flag_vfar) ff = 1;
+    else fv = 1;
+    flag_near[slot] = fn; flag_far[slot] = ff; flag_full[slot] = fu;
+    if (flag_vfar) flag_vfar[slot] = fv;
 }
 
 // list[idx[t] - 1] = t for the flagged entries (idx = inclusive prefix sum of flag)
-__global__ void dp_band_list_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ list)
+__global__ void dp_band_list_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ list,
+                                    const uint32_t *__restrict__ src = nullptr)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n && flag[t]) list[idx[t] - 1] = t;
+    if (t < n && flag[t]) list[idx[t] - 1] = src ? src[t] : t;
+}
+
+// tasks / results of the instances of a list, for the full-table kernels
+__global__ void dp_gather_tasks_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ list, uint32_t n, mp_dp_task *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = tasks[list[t]];
+}
+__global__ void dp_scatter_list_kernel(const mp_dp_result *__restrict__ sel, const uint32_t *__restrict__ list, uint32_t n, mp_dp_result *__restrict__ res)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) res[list[t]] = sel[t];
 }

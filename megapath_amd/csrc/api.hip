@@ -873,9 +873,10 @@ bool band_applicable(const mp_ctx *c, uint32_t max_win, int cl, int cr)
 
 // second pass of the two-pass band scheme over the instances of one class (`list`, n_c of them) + their traceback
 template <int W2, int G2>
-int band_second_pass(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *list, uint32_t n_c, int cl, int cr, mp_dp_result *d_res, float *ms_fill,
-                     float *ms_trace)
+int band_second_pass(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *list, uint32_t n_c, int cl, int cr, mp_dp_result *d_res, size_t *ev_cursor)
 {
+    // no host synchronisation here: the event triples (start, after fill, after traceback) are taken from *ev_cursor on
+    // and read by the caller once the stream has drained
     if (n_c == 0) return MP_OK;
     hipStream_t s = c->stream;
     const uint32_t ncols = c->max_len;
@@ -885,9 +886,10 @@ int band_second_pass(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *list,
     const uint32_t chunk_blocks = (uint32_t)std::min<uint64_t>(n_blocks, std::max<uint64_t>(1, c->slab_budget / per_block));
     if (c->flags.reserve((size_t)chunk_blocks * per_block)) return MP_ENOMEM;
     const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
-    while (c->ev_pool.size() < 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    while (c->ev_pool.size() < *ev_cursor + 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
     uint32_t *slab = (uint32_t *)c->flags.p;
-    size_t ci = 0;
+    size_t ci = *ev_cursor / 3;
+    *ev_cursor += 3 * n_chunks;
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks, ci++) {
         const uint32_t off = b0 * 128u;
         const uint32_t cnt = (uint32_t)std::min<uint64_t>((uint64_t)chunk_blocks * 128u, n_c - off);
@@ -903,14 +905,6 @@ int band_second_pass(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *list,
         hipLaunchKernelGGL((dp_trace_kernel<16, 5, W2, G2, true>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks, c->d_lens, cnt, cl, cr, (const uint32_t *)slab,
                            ncols, (const mp_fill_result *)c->band_fill.p, d_res, (uint8_t *)nullptr, 0u, list + off);
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
-    }
-    HIPCHK(hipStreamSynchronize(s));
-    for (size_t q = 0; q < n_chunks; q++) {
-        float a = 0, b = 0;
-        (void)hipEventElapsedTime(&a, c->ev_pool[3 * q], c->ev_pool[3 * q + 1]);
-        (void)hipEventElapsedTime(&b, c->ev_pool[3 * q + 1], c->ev_pool[3 * q + 2]);
-        if (ms_fill) *ms_fill += a;
-        if (ms_trace) *ms_trace += b;
     }
     return MP_OK;
 }
@@ -996,9 +990,29 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     if (n_far) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->far_list.p, in_list);
     if (n_vfar) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->vfar_flag.p, c->vfar_idx.p, n, c->vfar_list.p, in_list);
     if (n_sel) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_flag.p, c->band_idx.p, n, und_out.p, in_list);
-    rc = band_second_pass<MP_BAND_W1, MP_BAND_GB1>(c, d_tasks, c->near_list.p, n_near, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
-    rc = band_second_pass<MP_BAND_W2, MP_BAND_GB>(c, d_tasks, c->far_list.p, n_far, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
-    rc = band_second_pass<MP_BAND_W3, MP_BAND_GB3>(c, d_tasks, c->vfar_list.p, n_vfar, cl, cr, d_res, ms_fill, ms_trace); if (rc) return rc;
+    // the three second passes share the slab and run back to back in stream order; their timings are read after one sync.
+    // The slab is sized for the largest of them first: growing it between unsynchronised launches would free memory in use.
+    {
+        auto slab_bytes = [&](uint32_t n_c, int w) -> size_t {
+            const size_t per_block = (size_t)c->max_len * ((w + 2) / 3) * 64 * 4;
+            const uint64_t blocks = ((uint64_t)n_c + 127) / 128;
+            return (size_t)std::min<uint64_t>(blocks, std::max<uint64_t>(1, c->slab_budget / per_block)) * per_block;
+        };
+        const size_t need = std::max(slab_bytes(n_near, MP_BAND_W1), std::max(slab_bytes(n_far, MP_BAND_W2), slab_bytes(n_vfar, MP_BAND_W3)));
+        if (c->flags.reserve(need)) return MP_ENOMEM;
+    }
+    size_t ev_cursor = 6;                              // a multiple of 3 past the events used above
+    rc = band_second_pass<MP_BAND_W1, MP_BAND_GB1>(c, d_tasks, c->near_list.p, n_near, cl, cr, d_res, &ev_cursor); if (rc) return rc;
+    rc = band_second_pass<MP_BAND_W2, MP_BAND_GB>(c, d_tasks, c->far_list.p, n_far, cl, cr, d_res, &ev_cursor); if (rc) return rc;
+    rc = band_second_pass<MP_BAND_W3, MP_BAND_GB3>(c, d_tasks, c->vfar_list.p, n_vfar, cl, cr, d_res, &ev_cursor); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t q = 2; q < ev_cursor / 3; q++) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, c->ev_pool[3 * q], c->ev_pool[3 * q + 1]);
+        (void)hipEventElapsedTime(&b, c->ev_pool[3 * q + 1], c->ev_pool[3 * q + 2]);
+        if (ms_fill) *ms_fill += a;
+        if (ms_trace) *ms_trace += b;
+    }
     *n_und = n_sel;
     return MP_OK;
 }

@@ -238,3 +238,43 @@ def test_seed_projection_wrapping_below_zero(tmp_path):
     got_path = tmp_path / "got.fq"
     got_path.write_bytes(buf.getvalue())
     assert fastq_records(str(got_path)) == fastq_records(want_path)
+
+
+@pytest.mark.parametrize("rnd", [0, 1, 2, 3])
+def test_banded_dp_on_tandem_repeats(rnd, monkeypatch):
+    """Genomes with tandem repeats (several copies of a unit inside one DP window: the first-maximum rule has to pick among
+    equal alignments, the block pre-filter sees matches on several diagonals), random error profiles and read lengths:
+    band kernels vs full-table kernels, without and with tie counts (scripts/band_stress.py runs many more rounds)."""
+    monkeypatch.setenv("MP_KMER_FILTER", "1")
+    monkeypatch.setenv("MP_LKT16", "1")
+    rng = np.random.Generator(np.random.PCG64(9000 + rnd))
+    genome = []
+    for name, arr in synth.random_genome(300000, 100 + rnd, n_seqs=3, repeat_frac=0.15):
+        arr = arr.copy()
+        for _ in range(300):
+            u = int(rng.integers(7, 46)); k = int(rng.integers(2, 6)); p = int(rng.integers(0, len(arr) - u * (k + 1)))
+            for c in range(1, k + 1):
+                arr[p + c * u:p + (c + 1) * u] = arr[p:p + u]
+        genome.append((name, arr))
+    read_len = [150, 100, 200, 250][rnd]
+    sim = dict(sub=[0.01, 0.04, 0.003, 0.02][rnd], ins=0.002, dele=0.002, random_frac=0.02, broken_mate_frac=0.05, long_indel_frac=[0.2, 0.0, 0.5, 0.2][rnd],
+               long_indel_max=[15, 6, 26, 15][rnd], junk_end_frac=0.3, junk_end_max=45, len_range=(read_len * 3 // 5, read_len), frag_mean=read_len + 200,
+               frag_max=read_len + 450)
+    names, r1, r2 = synth.simulate_pairs(genome, 2500, read_len, 500 + rnd, **sim)
+    gix = H.Index.from_arrays(0, **index_builder.build_index_arrays(genome, sa_interval=16))
+    packed, lens, W = H.pack_reads([x for pr in zip(r1, r2) for x in pr], read_len + 1)
+    res = {}
+    for band in (False, True):
+        for counts in (0, 1):
+            ctx = H.Context(gix)
+            ctx.set_reads(packed, lens)
+            ctx.set_dp_band(band)
+            hits, nh, st = ctx.deep_dp_round(H.AlignParams(1, 750, 130, 130, H.MmpParams.nt2(), counts, 0))
+            rows = sorted((h.pair_id, h.left_is_mate, h.algnmt_1, h.algnmt_2, h.score_1, h.score_2, h.start_1, h.start_2, h.dplen_1, h.dplen_2,
+                           h.count_1, h.count_2) for h in hits[:nh])
+            res[(band, counts)] = rows if counts else [r[:10] for r in rows]     # the text-mode full-table kernel produces no tie counts
+            ctx.close()
+    gix.close()
+    assert len(res[(True, 1)]) > 1000
+    assert res[(True, 0)] == res[(False, 0)]
+    assert res[(True, 1)] == res[(False, 1)]

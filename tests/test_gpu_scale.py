@@ -41,12 +41,27 @@ def _build(tmp_path, genome):
     dict(tag="gappy", n_bases=700000, n_seqs=4, n_pairs=4000, read_len=150, L=151, sim=dict(sub=0.01, ins=0.002, dele=0.002, random_frac=0.02,
                                                                                          broken_mate_frac=0.05, long_indel_frac=0.5, long_indel_max=26,
                                                                                          junk_end_frac=0.3, junk_end_max=45, len_range=(90, 150))),
+    dict(tag="tandem", n_bases=400000, n_seqs=3, n_pairs=3000, read_len=150, L=151, tandem=500,
+         sim=dict(sub=0.01, ins=0.002, dele=0.002, random_frac=0.02, broken_mate_frac=0.05, long_indel_frac=0.2, long_indel_max=15)),
 ])
 def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg, monkeypatch):
     monkeypatch.setenv("MP_KMER_FILTER", "1")          # the in-process run uses the 17-mer pre-filter and the denser SA
     monkeypatch.setenv("MP_LKT16", "1")                # ... and the 16-mer look-up table behind the pre-filter
     monkeypatch.setenv("MP_SA_DENSE", "1")             # samples, the C++ run below neither
     genome = synth.random_genome(cfg["n_bases"], 501, n_seqs=cfg["n_seqs"], repeat_frac=0.12)
+    if cfg.get("tandem"):
+        # tandem repeats: several copies of a 7..45-base unit inside one DP window (ties among equal alignments: first
+        # maximum by row then column, traceback priorities, num_sameScore in the BAM records)
+        rng = np.random.Generator(np.random.PCG64(77))
+        g2 = []
+        for name, arr in genome:
+            arr = arr.copy()
+            for _ in range(cfg["tandem"]):
+                u = int(rng.integers(7, 46)); k = int(rng.integers(2, 6)); p = int(rng.integers(0, len(arr) - u * (k + 1)))
+                for c in range(1, k + 1):
+                    arr[p + c * u:p + (c + 1) * u] = arr[p:p + u]
+            g2.append((name, arr))
+        genome = g2
     prefix = _build(tmp_path, genome)
     names, r1, r2 = synth.simulate_pairs(genome, cfg["n_pairs"], cfg["read_len"], 502, **cfg["sim"])
     f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")

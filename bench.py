@@ -291,9 +291,10 @@ def main():
                    "instances_per_step": n_inst / K,
                    "band_instances_per_step": (band1[0] - band0[0]) / K, "band_left_to_full_table_per_step": (band1[1] - band0[1]) / K,
                    "note": "integer max/add recurrences: VALU-bound, no MFMA, not an HBM roofline (SURVEY 8d).  `achieved` counts the "
-                           "full-table cells of every instance (SURVEY 8d) over the DP fill time; the deep-DP legs run an exact banded "
-                           "kernel that computes 87 of a window's ~211 rows per column and hands the instances it cannot decide to "
-                           "the full-table kernels"},
+                           "full-table cells of every instance (SURVEY 8d) over the DP fill time; the deep-DP legs run exact banded kernels (a "
+                           "block-match pre-filter confines each alignment to 27 of its window's ~211 diagonals, perfect matches need no "
+                           "table) and hand the instances they cannot decide to the full-table kernels; the rescue batches go through a "
+                           "score-only filter first"},
             "events_per_pair": {"occ": ev["occ"] / P, "lkt": ev["lkt"] / P, "sa": ev["sa"] / P,
                                 "executed_occ": acc["occ"] / (K * P), "executed_lkt": acc["lkt"] / (K * P), "prefilter_probes": acc["kmer"] / (K * P),
                                 "candidates": acc["cand"] / (K * P), "pair_hits": acc["hits"] / (K * P),

@@ -11,15 +11,27 @@
 //   outside it are treated as minus infinity, so every banded value is a lower bound of the true one and exact whenever
 //   the best path to that cell stays inside.  If the banded best score S satisfies S >= L - GB then no path leaving the
 //   band can tie or beat it: the true best cell (first maximum by row, then column), the number of cells sharing its score,
-//   every value on its optimal path and every tie the traceback bits record are identical to the full table's.  Instances that do not reach that score (or whose
-//   shape does not fit the band) are marked and re-run by the full kernel -- see run_dp_band in api.hip.
+//   every value on its optimal path and every tie the traceback bits record are identical to the full table's.
+//   Instances that do not reach that score (or whose shape does not fit the band) are marked undecided and re-run by the
+//   full-table kernels.
 //
 // Mapping: ONE LANE per instance pair (the two instances in the halves of packed 16-bit registers, as in dp_fill_kernel),
 // sweeping the read columns; the band's W cells of a column live in registers (H and F, in place), the vertical gap
-// state E is a running value.  No cross-lane traffic at all, ~31 VALU instructions per cell pair, 1 wave per SIMD.
-// Window base codes are staged in LDS, one byte per row and lane holding both instances' 4-bit codes ([row][lane]: a
-// wavefront reads 64 consecutive bytes); 16 KB per block keeps two waves per SIMD resident, which the dependent chain of
-// a single lane needs to fill the VALU.
+// state E is a running value.  No cross-lane traffic at all, 15 (scores) to 32 (scores + traceback bits) VALU
+// instructions per cell pair.  Window base codes are staged in LDS, one byte per row and lane holding both instances'
+// 4-bit codes ([row][lane]: a wavefront reads 64 consecutive bytes), so that two waves per SIMD stay resident.
+//
+// How run_dp_band (api.hip) uses the kernels, every step exact (DESIGN.md section 4 has the arguments):
+//   dp_prefilter_kernel     exact matches of read blocks in the window confine every qualifying alignment to a few
+//                           diagonals (or show that there is none); perfect matches are finished without a table;
+//   dp_band_kernel MODE 3/1 first pass: best cell and ties, over 27 diagonals around the matching ones (MODE 3) or the
+//                           whole band (MODE 1: repeats inside the window, reads too short for the block test);
+//   dp_band_classify_kernel by the score: how far the alignment can stray from the best cell's diagonal;
+//   dp_band_kernel MODE 2   second pass: traceback bits over 9 / 27 / 51 diagonals around the best cell, then
+//                           dp_trace_kernel;
+//   second tier             the same once more, with a budget of 25 instead of 13, for what is still undecided;
+//   MODE 0                  single pass over the whole band with bits, when a soft-clip limit is too small for the
+//                           centred bands (their rows <= 0 must lie under the left clip).
 #pragma once
 
 #define MP_BAND_MAXL 256            // longest read the band kernel is instantiated for (a second instance for <= 160 needs less LDS)

@@ -206,8 +206,9 @@ def main():
         # a new batch arrives: forget the seeds of the previous one, then run the whole path on the device:
         # deep-DP round (seed, locate, merge, pair, both DP legs) and the rescue passes of the pairs it left unaligned
         ctx.set_reads_device(packed.data_ptr(), W, lens_i.data_ptr(), 2 * P, args.read_len, keep=(packed, lens_i))
-        hits, nh, st = ctx.deep_dp_round(params)
-        _, _, rst = ctx.rescue_round(params, False, fetch=False)
+        _, nh, st = ctx.deep_dp_round(params, fetch=False)             # the hits start travelling to the host ...
+        _, _, rst = ctx.rescue_round(params, False, fetch=False)       # ... while the rescue passes run
+        hits, nh = ctx.pair_hits_view()                                # the step ends when they have arrived
         return hits, nh, st, rst
 
     for _ in range(args.warmup):

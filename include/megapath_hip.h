@@ -192,7 +192,9 @@ int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n
 int mp_ctx_set_dp_band(mp_ctx *ctx, int on);
 int mp_ctx_dp_band_stats(mp_ctx *ctx, uint64_t *out_n_band, uint64_t *out_n_full);
 int mp_get_pair_hits(mp_ctx *ctx, mp_pair_hit *out_hits, uint64_t cap);
-/* Same without a pageable copy: the hits land in a pinned buffer owned by the context (valid until the next call). */
+/* Same without a pageable copy: the hits land in a pinned buffer owned by the context (valid until the next round).  The
+ * transfer is started by mp_deep_dp_round itself on a copy stream; this call waits for it, so a mp_rescue_round issued in
+ * between overlaps with it. */
 int mp_get_pair_hits_view(mp_ctx *ctx, const mp_pair_hit **out_hits, uint64_t *out_n);
 
 /* ---------------------------------------------------------------------------------------------------------------

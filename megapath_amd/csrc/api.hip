@@ -43,6 +43,9 @@ inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + bl
 struct mp_ctx {
     mp_index *ix = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // device-to-host copy of the pair hits, overlapping whatever runs next on `stream`
+    hipEvent_t ev_hits_ready = nullptr, ev_hits_copied = nullptr;
+    bool hits_copy_started = false;
     hipEvent_t ev[10] = {};
     std::vector<hipEvent_t> ev_pool;       // per-chunk DP timing without per-chunk host syncs
     // reads
@@ -515,6 +518,9 @@ extern "C" int mp_ctx_create(mp_index *ix, mp_ctx **out)
     if (!c) return MP_ENOMEM;
     c->ix = ix;
     HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipStreamCreate(&c->copy_stream));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_hits_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_hits_copied, hipEventDisableTiming));
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
     if (c->ctr.reserve(1) || c->n_pair_hits.reserve(1)) { mp_ctx_destroy(c); return MP_ENOMEM; }
     *out = c;
@@ -525,6 +531,9 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
 {
     if (!c) return MP_OK;
     (void)hipSetDevice(c->ix->device);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->ev_hits_ready) (void)hipEventDestroy(c->ev_hits_ready);
+    if (c->ev_hits_copied) (void)hipEventDestroy(c->ev_hits_copied);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1147,8 +1156,11 @@ extern "C" int mp_sgdp_batch(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int
 }
 
 // ------------------------------------------------------------------------------------------------ deep-DP round
+static int start_hits_copy(mp_ctx *c);
+
 extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *out_n_hits, mp_round_stats *out_stats)
 {
+    if (c && c->hits_copy_started) { (void)hipEventSynchronize(c->ev_hits_copied); c->hits_copy_started = false; }   // the previous round's hits are still travelling
     if (!c || !ap || !c->d_reads || c->n_reads == 0) return MP_EINVAL;
     HIPCHK(hipSetDevice(c->ix->device));
     hipStream_t s = c->stream;
@@ -1209,7 +1221,9 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     if (out_n_hits) *out_n_hits = c->n_pair_hits_host;
     if (out_stats) *out_stats = st;
-    return MP_OK;
+    // the hits start their way to the host now (mp_get_pair_hits_view waits for them): a rescue round called in between
+    // runs while they travel
+    return start_hits_copy(c);
 }
 
 extern "C" int mp_get_pair_hits(mp_ctx *c, mp_pair_hit *out_hits, uint64_t cap)
@@ -1221,21 +1235,48 @@ extern "C" int mp_get_pair_hits(mp_ctx *c, mp_pair_hit *out_hits, uint64_t cap)
     return MP_OK;
 }
 
+// pinned staging buffer for n hits
+static int reserve_pinned_hits(mp_ctx *c, size_t n)
+{
+    if (n <= c->h_pair_hits_cap) return MP_OK;
+    if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
+    c->h_pair_hits = nullptr; c->h_pair_hits_cap = 0;
+    const size_t want = n + n / 4 + 1024;
+    if (hipHostMalloc((void **)&c->h_pair_hits, want * sizeof(mp_pair_hit), hipHostMallocDefault) != hipSuccess) return MP_ENOMEM;
+    c->h_pair_hits_cap = want;
+    return MP_OK;
+}
+
+// Starts the device-to-host copy of the round's hits on the copy stream, behind everything queued on the compute stream so
+// far: whatever the caller runs next (the rescue round) overlaps with the transfer.
+static int start_hits_copy(mp_ctx *c)
+{
+    c->hits_copy_started = false;
+    const size_t n = c->n_pair_hits_host;
+    if (n == 0) return MP_OK;
+    int rc = reserve_pinned_hits(c, n);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_hits_ready, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_hits_ready, 0));
+    HIPCHK(hipMemcpyAsync(c->h_pair_hits, c->pair_hits.p, n * sizeof(mp_pair_hit), hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(hipEventRecord(c->ev_hits_copied, c->copy_stream));
+    c->hits_copy_started = true;
+    return MP_OK;
+}
+
 extern "C" int mp_get_pair_hits_view(mp_ctx *c, const mp_pair_hit **out_hits, uint64_t *out_n)
 {
     if (!c || !out_hits || !out_n) return MP_EINVAL;
     HIPCHK(hipSetDevice(c->ix->device));
     const size_t n = c->n_pair_hits_host;
-    if (n > c->h_pair_hits_cap) {
-        if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
-        c->h_pair_hits = nullptr; c->h_pair_hits_cap = 0;
-        const size_t want = n + n / 4 + 1024;
-        if (hipHostMalloc((void **)&c->h_pair_hits, want * sizeof(mp_pair_hit), hipHostMallocDefault) != hipSuccess) return MP_ENOMEM;
-        c->h_pair_hits_cap = want;
-    }
     if (n) {
-        HIPCHK(hipMemcpyAsync(c->h_pair_hits, c->pair_hits.p, n * sizeof(mp_pair_hit), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->hits_copy_started) HIPCHK(hipEventSynchronize(c->ev_hits_copied));      // started by mp_deep_dp_round
+        else {
+            int rc = reserve_pinned_hits(c, n);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(c->h_pair_hits, c->pair_hits.p, n * sizeof(mp_pair_hit), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
     }
     *out_hits = c->h_pair_hits; *out_n = n;
     return MP_OK;

@@ -366,12 +366,18 @@ class Context:
         _chk(lib.mp_get_rescue_hits(self._h, resc, n.value, C.byref(n)), "mp_get_rescue_hits")
         return (singles, ns), (resc, n.value), st
 
-    def deep_dp_round(self, params: AlignParams):
+    def deep_dp_round(self, params: AlignParams, fetch: bool = True):
         nh = C.c_uint64()
         st = RoundStats()
         _chk(load_library().mp_deep_dp_round(self._h, C.byref(params), C.byref(nh), C.byref(st)), "mp_deep_dp_round")
-        # view of the context's pinned staging buffer: one DMA, no pageable copy, valid until the next round
+        if not fetch:                      # the hits are on their way to the host; pair_hits_view() waits for them
+            return None, nh.value, st
+        return self.pair_hits_view() + (st,)
+
+    def pair_hits_view(self):
+        """(hits, n): view of the context's pinned staging buffer -- one DMA started by the round itself, no pageable copy;
+        valid until the next round."""
         ptr, n = C.c_void_p(), C.c_uint64()
         _chk(load_library().mp_get_pair_hits_view(self._h, C.byref(ptr), C.byref(n)), "mp_get_pair_hits_view")
         hits = (PairHit * max(n.value, 1)).from_address(ptr.value) if n.value else (PairHit * 1)()
-        return hits, nh.value, st
+        return hits, n.value

@@ -79,6 +79,7 @@ struct mp_ctx {
     DevBuf<uint32_t> band_flag, band_idx;        // instances the band kernel left to the full kernels
     DevBuf<uint32_t> near_flag, near_idx, near_list, far_flag, far_idx, far_list;   // classes of the second band pass
     DevBuf<uint32_t> pre_cls, narrow_list, wide_list;                               // dp_prefilter_kernel's classes: first band pass over 27 / 87 diagonals
+    DevBuf<uint32_t> mid_flag, mid_idx, mid_list;                                   // scores L-9 .. L-6: second pass over 15 diagonals
     DevBuf<uint32_t> vfar_flag, vfar_idx, vfar_list, und_list[2];                   // second tier; instances still undecided after a tier
     DevBuf<mp_dp_task> band_tasks;
     DevBuf<mp_dp_result> band_res;
@@ -933,7 +934,8 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     const mp_fill_result *none = nullptr;
     const uint32_t n = n_in;
     if (c->pre_cls.reserve(n + 2) || c->near_flag.reserve(n + 2) || c->near_idx.reserve(n + 2) || c->far_flag.reserve(n + 2) || c->far_idx.reserve(n + 2) ||
-        c->vfar_flag.reserve(n + 2) || c->vfar_idx.reserve(n + 2) || c->band_flag.reserve(n + 2) || c->band_idx.reserve(n + 2))
+        c->vfar_flag.reserve(n + 2) || c->vfar_idx.reserve(n + 2) || c->mid_flag.reserve(n + 2) || c->mid_idx.reserve(n + 2) ||
+        c->band_flag.reserve(n + 2) || c->band_idx.reserve(n + 2))
         return MP_ENOMEM;
     while (c->ev_pool.size() < 4) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
     auto scan = [&](uint32_t *flag, uint32_t *idx) -> int {
@@ -982,22 +984,26 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     HIPCHK(hipEventRecord(c->ev_pool[1], s));
     // classes by distance from the best cell's diagonal; perfect matches and instances below their cutoff are finished here
     hipLaunchKernelGGL(dp_band_classify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, (const mp_fill_result *)c->band_fill.p, n,
-                       c->near_flag.p, c->far_flag.p, c->band_flag.p, d_res, in_list, TIER1 ? (uint32_t *)nullptr : c->vfar_flag.p);
+                       c->near_flag.p, c->far_flag.p, c->band_flag.p, d_res, in_list, TIER1 ? (uint32_t *)nullptr : c->vfar_flag.p, c->mid_flag.p);
     int rc = scan(c->near_flag.p, c->near_idx.p); if (rc) return rc;
     rc = scan(c->far_flag.p, c->far_idx.p); if (rc) return rc;
     rc = scan(c->band_flag.p, c->band_idx.p); if (rc) return rc;
+    rc = scan(c->mid_flag.p, c->mid_idx.p); if (rc) return rc;
     if (!TIER1) { rc = scan(c->vfar_flag.p, c->vfar_idx.p); if (rc) return rc; }
-    uint32_t n_near = 0, n_far = 0, n_vfar = 0, n_sel = 0;
+    uint32_t n_near = 0, n_far = 0, n_vfar = 0, n_mid = 0, n_sel = 0;
     HIPCHK(hipMemcpyAsync(&n_near, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&n_far, c->far_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&n_sel, c->band_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&n_mid, c->mid_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     if (!TIER1) HIPCHK(hipMemcpyAsync(&n_vfar, c->vfar_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     { float a = 0; (void)hipEventElapsedTime(&a, c->ev_pool[0], c->ev_pool[1]); if (ms_fill) *ms_fill += a; }
-    if (c->near_list.reserve(n_near + 130) || c->far_list.reserve(n_far + 130) || c->vfar_list.reserve(n_vfar + 130) || und_out.reserve(n_sel + 130)) return MP_ENOMEM;
+    if (c->near_list.reserve(n_near + 130) || c->far_list.reserve(n_far + 130) || c->vfar_list.reserve(n_vfar + 130) || c->mid_list.reserve(n_mid + 130) ||
+        und_out.reserve(n_sel + 130)) return MP_ENOMEM;
     if (n_near) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->near_list.p, in_list);
     if (n_far) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->far_list.p, in_list);
     if (n_vfar) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->vfar_flag.p, c->vfar_idx.p, n, c->vfar_list.p, in_list);
+    if (n_mid) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->mid_flag.p, c->mid_idx.p, n, c->mid_list.p, in_list);
     if (n_sel) hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_flag.p, c->band_idx.p, n, und_out.p, in_list);
     // the three second passes share the slab and run back to back in stream order; their timings are read after one sync.
     // The slab is sized for the largest of them first: growing it between unsynchronised launches would free memory in use.
@@ -1007,11 +1013,13 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
             const uint64_t blocks = ((uint64_t)n_c + 127) / 128;
             return (size_t)std::min<uint64_t>(blocks, std::max<uint64_t>(1, c->slab_budget / per_block)) * per_block;
         };
-        const size_t need = std::max(slab_bytes(n_near, MP_BAND_W1), std::max(slab_bytes(n_far, MP_BAND_W2), slab_bytes(n_vfar, MP_BAND_W3)));
+        const size_t need = std::max(std::max(slab_bytes(n_near, MP_BAND_W1), slab_bytes(n_mid, MP_BAND_WM)),
+                                     std::max(slab_bytes(n_far, MP_BAND_W2), slab_bytes(n_vfar, MP_BAND_W3)));
         if (c->flags.reserve(need)) return MP_ENOMEM;
     }
     size_t ev_cursor = 6;                              // a multiple of 3 past the events used above
     rc = band_second_pass<MP_BAND_W1, MP_BAND_GB1>(c, d_tasks, c->near_list.p, n_near, cl, cr, d_res, &ev_cursor); if (rc) return rc;
+    rc = band_second_pass<MP_BAND_WM, MP_BAND_GBM>(c, d_tasks, c->mid_list.p, n_mid, cl, cr, d_res, &ev_cursor); if (rc) return rc;
     rc = band_second_pass<MP_BAND_W2, MP_BAND_GB>(c, d_tasks, c->far_list.p, n_far, cl, cr, d_res, &ev_cursor); if (rc) return rc;
     rc = band_second_pass<MP_BAND_W3, MP_BAND_GB3>(c, d_tasks, c->vfar_list.p, n_vfar, cl, cr, d_res, &ev_cursor); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s));

@@ -448,10 +448,14 @@ __global__ void dp_band_select_kernel(const mp_fill_result *__restrict__ fill, u
 #define MP_BAND_GB1 4
 #define MP_BAND_W1 (2 * MP_BAND_GB1 + 1)
 #define MP_BAND_NW1 ((MP_BAND_W1 + 2) / 3)
+// in between: score >= L - MP_BAND_MID, gaps of at most MP_BAND_MID - 2 bases in all: 2 MP_BAND_GBM + 1 diagonals
+#define MP_BAND_MID 9
+#define MP_BAND_GBM 7
+#define MP_BAND_WM (2 * MP_BAND_GBM + 1)
 __global__ void dp_band_classify_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, const mp_fill_result *__restrict__ fill,
                                         uint32_t n, uint32_t *__restrict__ flag_near, uint32_t *__restrict__ flag_far, uint32_t *__restrict__ flag_full,
                                         mp_dp_result *__restrict__ res, const uint32_t *__restrict__ list = nullptr,
-                                        uint32_t *__restrict__ flag_vfar = nullptr)
+                                        uint32_t *__restrict__ flag_vfar = nullptr, uint32_t *__restrict__ flag_mid = nullptr)
 {
     // flags are indexed by slot; with a list, slot s stands for instance list[s].  The second tier (scores down to L - 25)
     // has a third class, `flag_vfar`: scores below L - MP_BAND_GB, second pass over 51 diagonals.
@@ -460,7 +464,7 @@ __global__ void dp_band_classify_kernel(const mp_dp_task *__restrict__ tasks, co
     const uint32_t t = list ? list[slot] : slot;
     const mp_fill_result fr = fill[t];
     const int L = (int)lens[tasks[t].read_id];
-    uint32_t fn = 0, ff = 0, fu = 0, fv = 0;
+    uint32_t fn = 0, ff = 0, fu = 0, fv = 0, fm = 0;
     mp_dp_result z; z.score = 0; z.hit_loc = 0; z.max_score_count = 0; z.n_ops = 0;
     if (fr.score < 0) fu = 1;
     else if (fr.score == 0 || fr.score < mp_dp_cutoff(L)) res[t] = z;              // nothing to align / below the cutoff
@@ -468,10 +472,12 @@ __global__ void dp_band_classify_kernel(const mp_dp_task *__restrict__ tasks, co
         z.score = L; z.hit_loc = (uint32_t)(fr.row - L); z.max_score_count = fr.count; z.n_ops = (uint32_t)L;
         res[t] = z;
     } else if (fr.score >= L - MP_BAND_NEAR) fn = 1;
+    else if (flag_mid && fr.score >= L - MP_BAND_MID) fm = 1;
     else if (fr.score >= L - MP_BAND_GB || !flag_vfar) ff = 1;
     else fv = 1;
     flag_near[slot] = fn; flag_far[slot] = ff; flag_full[slot] = fu;
     if (flag_vfar) flag_vfar[slot] = fv;
+    if (flag_mid) flag_mid[slot] = fm;
 }
 
 // list[idx[t] - 1] = t for the flagged entries (idx = inclusive prefix sum of flag)

@@ -261,7 +261,10 @@ struct mp_mmp_state {
     uint32_t l, r, last_l, last_r, last_seed_len;
     uint32_t cur_w, cur_word;
     uint32_t n_seeds, n_hits;
+    uint32_t upos;          // text position of the match when its SA range was a single row and it was extended by text
+    bool uvalid;            // comparison (mp_mmp_trip): the record then carries the position instead of the row
 };
+#define MP_SEED_LOCATED 0xFFFFFFFFu     // mp_seed_rec::sa_diff / mp_sa_seed::sa_diff: sa_l is a text position, one hit
 
 template <int SLAB>
 __device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp &P, uint32_t n, int x, mp_seed_rec *slab)
@@ -277,9 +280,11 @@ __device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp 
             s.l = s.last_l; s.r = s.last_r; s.seed_len = (int)s.last_seed_len;
         }
         const uint32_t sa_diff = (s.r - s.l) < (uint32_t)P.sa_size_threshold ? (s.r - s.l) : (uint32_t)P.sa_size_threshold;
+        const bool located = s.uvalid && diff == 0;        // extended by text comparison and not re-seeded: the position is known
         if (s.n_seeds < (uint32_t)SLAB) {
             mp_seed_rec rec;
-            rec.sa_l = s.l; rec.query_offset = (uint16_t)(x & 1023); rec.seed_len = (uint16_t)s.seed_len; rec.sa_diff = sa_diff;
+            rec.sa_l = located ? s.upos : s.l; rec.query_offset = (uint16_t)(x & 1023); rec.seed_len = (uint16_t)s.seed_len;
+            rec.sa_diff = located ? MP_SEED_LOCATED : sa_diff;
             slab[s.n_seeds] = rec;
         }
         s.n_seeds++;
@@ -289,6 +294,7 @@ __device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp 
     s.i -= s.seed_len < P.seed_min_length ? s.seed_len : P.seed_min_length;
     s.l = 0; s.r = n; s.seed_len = 0;
     s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
+    s.uvalid = false;
 }
 
 // Runs one item to completion or for one trip.  Returns true when the item is finished.
@@ -341,6 +347,46 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
             }
         }
     }
+    // ---- a match whose SA range is a single row is extended by comparing the read with the text itself: the next base of
+    // the backward search is the text base in front of the match, 16 of them per word instead of one rank block each.  The
+    // rows the search would pass through are never needed: the range cannot shrink any more (so the re-seed bookkeeping
+    // stands still) and the seed is reported by its text position (MP_SEED_LOCATED).  Needs the whole suffix array.
+    if (!finished && s.seed_len > 0 && s.l == s.r && ix.sa_dense && ix.sa_dense_shift == 0 && s.l != 0) {
+        const uint32_t pos = s.uvalid ? s.upos : ix.sa_dense[s.l];
+        const int avail = min(s.len - s.i, (int)min(pos, (uint32_t)1 << 20));    // scan bases left / text bases in front of the match
+        int matched = 0;
+        bool stop = false;
+        while (matched < avail && !stop) {
+            const int si = s.i + matched;
+            const uint32_t swq = (uint32_t)si >> 4, ssh = 2 * ((uint32_t)si & 15);
+            const uint32_t scan16 = (uint32_t)((((uint64_t)s.sc[swq + 1] << 32) | s.sc[swq]) >> ssh);     // scan base si in bits 1:0
+            const uint32_t pend = pos - (uint32_t)matched - 1;                    // text base that must equal it
+            int nn = avail - matched; if (nn > 16) nn = 16;
+            uint32_t trev;
+            if (pend >= 15) {
+                const uint32_t p0 = pend - 15;
+                const uint32_t t16 = (uint32_t)((((uint64_t)ix.text[(p0 >> 4) + 1] << 32) | ix.text[p0 >> 4]) >> (2 * (p0 & 15)));
+                const uint32_t r = __brev(t16);
+                trev = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);      // text base pend in bits 1:0, pend - 1 in 3:2, ...
+            } else {
+                trev = 0;
+                for (int u = 0; u < nn; u++) { const uint32_t pp = pend - (uint32_t)u; trev |= ((ix.text[pp >> 4] >> (2 * (pp & 15))) & 3u) << (2 * u); }
+            }
+            const uint32_t x = scan16 ^ trev;
+            int same = x ? (__ffs((int)x) - 1) >> 1 : 16;
+            if (same >= nn) same = nn; else stop = true;
+            matched += same;
+        }
+        s.upos = pos - (uint32_t)matched; s.uvalid = true;
+        s.seed_len += matched; s.i += matched;
+        if (s.i >= s.len) finished = true;
+        else {
+            // the base at s.i does not extend the match (or the text starts here): what the failing rank query reports
+            mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
+            ++s.i;
+            if (s.i >= s.len) finished = true;
+        }
+    } else
     // ---- at most one backward extension
     if (!finished && s.seed_len > 0) {
         const uint32_t wq = (uint32_t)s.i >> 4;
@@ -368,7 +414,7 @@ __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *sc
     s.sc = scan + (uint64_t)rs * (W + 1);
     s.rs = rs; s.len = (int)lens[rs >> 1]; s.strand = (int)(rs & 1);
     s.i = 0; s.seed_len = 0; s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
-    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0;
+    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.upos = 0; s.uvalid = false;
 }
 
 __global__ void __launch_bounds__(256)
@@ -463,6 +509,7 @@ expand_hits_kernel(const mp_seed_rec *__restrict__ slabs, const uint32_t *__rest
         const mp_seed_rec rec = src[j];
         mp_sa_seed s;
         s.read_strand = rs; s.sa_l = rec.sa_l; s.query_offset = rec.query_offset; s.seed_len = rec.seed_len; s.sa_diff = rec.sa_diff;
+        if (rec.sa_diff == MP_SEED_LOCATED) { seeds_out[w] = s; hit_row[w] = rec.sa_l; w++; continue; }      // sa_l is the text position
         for (uint32_t k = 0; k <= rec.sa_diff; k++) { seeds_out[w] = s; hit_row[w] = rec.sa_l + k; w++; }
     }
 }
@@ -477,8 +524,9 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
         const mp_sa_seed s = seeds[t];
         const uint32_t read = s.read_strand >> 1, strand = s.read_strand & 1;
         const uint32_t len = lens[read];
-        uint32_t steps;
-        const uint64_t sav = mp_sa_value(ix, hit_row[t], &steps);
+        uint32_t steps = 0;
+        const bool located = s.sa_diff == MP_SEED_LOCATED;          // the seeding kernel already knows the text position
+        const uint64_t sav = located ? (uint64_t)hit_row[t] : mp_sa_value(ix, hit_row[t], &steps);
         my_occ = steps;
         const uint32_t off = s.query_offset, seedlen = s.seed_len;
         // unsigned 64-bit arithmetic: the projection may wrap exactly as in the reference (DV-DPfunctions.cpp:2489)
@@ -488,7 +536,7 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
         h.length = (uint16_t)seedlen;
         h.qo = (uint16_t)off;
         h.strand = (uint16_t)strand;
-        h.mult = (seedlen >= (uint32_t)P.good_seed_len || seedlen >= len / 2) ? (uint16_t)1 : (uint16_t)(s.sa_diff + 1);
+        h.mult = (seedlen >= (uint32_t)P.good_seed_len || seedlen >= len / 2 || located) ? (uint16_t)1 : (uint16_t)(s.sa_diff + 1);
         hits[t] = h;
     }
     // one counter update per block: a single address takes only ~100 M atomics per second chip-wide, and a launch of

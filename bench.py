@@ -235,7 +235,7 @@ def main():
         acc["seed"] += st.seed.ms_seed; acc["locate"] += st.seed.ms_locate; acc["merge"] += st.seed.ms_merge
         acc["pair"] += st.ms_pair; acc["fill"] += st.ms_dp_fill; acc["trace"] += st.ms_dp_trace
         acc["occ"] += st.seed.n_occ; acc["lkt"] += st.seed.n_lkt; acc["sa"] += st.seed.n_sa; acc["seedpos"] += st.seed.n_seedpos
-        acc["kmer"] += st.seed.n_prefilter
+        acc["kmer"] += st.seed.n_prefilter; acc["blk"] = acc.get("blk", 0) + st.seed.n_occ_loaded
         acc["cand"] += st.n_candidates; acc["hits"] += st.n_pair_hits
     torch.cuda.synchronize()
     if world > 1:
@@ -258,8 +258,10 @@ def main():
         b_seed = K * (64 * ev["occ"] + 16 * ev["lkt"] + 8 * ev["sa"] + 0.25 * (2 * P * args.read_len) + 16 * ev["seedpos"])
         b_exec = 64 * acc["occ"] + 16 * acc["lkt"] + 8 * acc["sa"] + 0.25 * (2 * P * K * args.read_len) + 16 * acc["seedpos"] + 4 * acc["kmer"]
         t_seed_s = (acc["seed"] + acc["locate"]) / 1e3
-        # `achieved` is priced with the events the kernels themselves issued and counted ("counters the kernel emits");
-        # the rate at which the reference algorithm's look-ups are delivered is reported next to it
+        # `achieved` is priced with the events the kernels themselves performed and counted ("counters the kernel emits",
+        # N_occ = 2 per backward-extension step performed -- whether the step loaded rank blocks or was taken by the 16-mer table or by
+        # comparing with the text; starts the 17-mer pre-filter rejects perform no steps).  The rank blocks actually loaded are in
+        # events_per_pair.rank_blocks_loaded; the rate at which the reference algorithm's look-ups are delivered is reported next to it
         achieved = b_exec / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
         achieved_ref = b_seed / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
         kernel_ms = {k: acc[k] / K for k in ("seed", "locate", "merge", "pair", "fill", "trace", "rescue_tasks", "rescue_fill", "rescue_trace")}
@@ -297,7 +299,8 @@ def main():
                            "table) and hand the instances they cannot decide to the full-table kernels; the rescue batches go through a "
                            "score-only filter first"},
             "events_per_pair": {"occ": ev["occ"] / P, "lkt": ev["lkt"] / P, "sa": ev["sa"] / P,
-                                "executed_occ": acc["occ"] / (K * P), "executed_lkt": acc["lkt"] / (K * P), "prefilter_probes": acc["kmer"] / (K * P),
+                                "executed_occ": acc["occ"] / (K * P), "rank_blocks_loaded": acc.get("blk", 0) / (K * P), "executed_lkt": acc["lkt"] / (K * P),
+                                "prefilter_probes": acc["kmer"] / (K * P),
                                 "candidates": acc["cand"] / (K * P), "pair_hits": acc["hits"] / (K * P),
                                 "failed_pairs": acc["failed"] / (K * P), "single_dp_tasks": acc["stasks"] / (K * P), "rescue_dp_tasks": acc["rtasks"] / (K * P)},
         }

@@ -118,6 +118,9 @@ typedef struct {
     float ms_seed, ms_locate, ms_merge;                        /* HIP-event kernel times of this call */
     float reserved;
     uint64_t n_prefilter;                                      /* 17-mer bitmap probes (0 when the pre-filter is off) */
+    uint64_t n_occ_loaded;     /* rank queries that loaded a rank block.  n_occ counts, as SURVEY 8d defines it, 2 per backward-
+                                * extension step (+1 per LF step of locate) whichever way the step was carried out: steps taken by
+                                * the 16-mer table or by comparing with the text load no rank block */
 } mp_seed_stats;
 
 int mp_seed_batch(mp_ctx *ctx, const mp_mmp_params *params, mp_seed_stats *out_stats);

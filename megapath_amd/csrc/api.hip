@@ -648,7 +648,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipStreamSynchronize(s));
     mp_seed_stats st{};
     st.n_occ = h.n_occ; st.n_lkt = h.n_lkt; st.n_sa = h.n_sa; st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
-    st.n_seeds = h.n_seeds; st.n_prefilter = h.n_kmer;
+    st.n_seeds = h.n_seeds; st.n_prefilter = h.n_kmer; st.n_occ_loaded = h.n_occ_loaded;
     float ms_over = 0;
     (void)hipEventElapsedTime(&st.ms_seed, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&ms_over, c->ev[8], c->ev[9]);     // items redone with the full-size slab belong to K1

@@ -300,7 +300,7 @@ __device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp 
 // Runs one item to completion or for one trip.  Returns true when the item is finished.
 template <int SLAB>
 __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev_mmp &P, mp_mmp_state &s, mp_seed_rec *slab,
-                                            uint32_t &my_occ, uint32_t &my_lkt, uint32_t &my_kmer)
+                                            uint32_t &my_occ, uint32_t &my_lkt, uint32_t &my_kmer, uint32_t &my_blk)
 {
     const uint32_t n = ix.n;
     bool finished = false;
@@ -327,6 +327,7 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
                 // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
                 const uint32_t nextl = ix.lkt16[key16 - 1] + 1, nextr = ix.lkt16[key16];
                 my_lkt++;
+                my_occ += 6;                                  // the three extension steps the table stands for (2 rank queries each)
                 s.i += 15;
                 s.seed_len = 15;
                 if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
@@ -379,6 +380,8 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
         }
         s.upos = pos - (uint32_t)matched; s.uvalid = true;
         s.seed_len += matched; s.i += matched;
+        // SURVEY 8d counts 2 rank queries per backward-extension step, however the step is carried out (n_occ); none was issued
+        my_occ += 2u * (uint32_t)(matched + (s.i < s.len ? 1 : 0));
         if (s.i >= s.len) finished = true;
         else {
             // the base at s.i does not extend the match (or the text starts here): what the failing rank query reports
@@ -394,7 +397,7 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
         const uint32_t c = (s.cur_word >> (2 * ((uint32_t)s.i & 15))) & 3u;
         uint32_t o1, o2;
         mp_occ_pair(ix, s.l, s.r + 1, c, o1, o2);
-        my_occ += 2;
+        my_occ += 2; my_blk += 2;
         const uint32_t nextl = ix.cum[c] + o1 + 1, nextr = ix.cum[c] + o2;
         if (nextl <= nextr) {
             if (s.seed_len >= P.seed_min_length && nextr - nextl < s.r - s.l) { s.last_r = s.r; s.last_l = s.l; s.last_seed_len = (uint32_t)s.seed_len; }
@@ -424,7 +427,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             uint32_t slab_limit /* <= MP_SEED_SLAB; smaller only to exercise the overflow path */)
 {
     const int lane = threadIdx.x & (MP_WAVE - 1);
-    uint32_t my_occ = 0, my_lkt = 0, my_kmer = 0;
+    uint32_t my_occ = 0, my_lkt = 0, my_kmer = 0, my_blk = 0;
     mp_mmp_state s;
     bool have = false;
     // Work queue: one global counter, but a wavefront takes MP_SEED_CHUNK items per atomic into a private range and hands
@@ -453,7 +456,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
         if (!__any(have)) { if (drained && pool_next == pool_end) break; else continue; }   // nothing to do this trip
         if (have) {
             mp_seed_rec *slab = slabs + (uint64_t)s.rs * MP_SEED_SLAB;
-            if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, my_occ, my_lkt, my_kmer)) {
+            if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, my_occ, my_lkt, my_kmer, my_blk)) {
                 seeds_per_rs[s.rs] = s.n_seeds;
                 hits_per_rs[s.rs] = s.n_hits;
                 if (s.n_seeds > slab_limit) {
@@ -464,11 +467,12 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             }
         }
     }
-    for (int o = MP_WAVE / 2; o > 0; o >>= 1) { my_occ += __shfl_down(my_occ, o); my_lkt += __shfl_down(my_lkt, o); my_kmer += __shfl_down(my_kmer, o); }
+    for (int o = MP_WAVE / 2; o > 0; o >>= 1) { my_occ += __shfl_down(my_occ, o); my_lkt += __shfl_down(my_lkt, o); my_kmer += __shfl_down(my_kmer, o); my_blk += __shfl_down(my_blk, o); }
     if (lane == 0) {
         if (my_occ) atomicAdd(&ctr->n_occ, (unsigned long long)my_occ);
         if (my_lkt) atomicAdd(&ctr->n_lkt, (unsigned long long)my_lkt);
         if (my_kmer) atomicAdd(&ctr->n_kmer, (unsigned long long)my_kmer);
+        if (my_blk) atomicAdd(&ctr->n_occ_loaded, (unsigned long long)my_blk);
     }
 }
 
@@ -483,9 +487,9 @@ seed_overflow_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const u
     if (t >= n_over) return;
     mp_mmp_state s;
     mp_mmp_begin(s, scan, lens, W, overflow_rs[t], ix.n);
-    uint32_t a = 0, b = 0, c = 0;
+    uint32_t a = 0, b = 0, c = 0, d = 0;
     mp_seed_rec *slab = big_slabs + (uint64_t)t * MP_SEED_BIG;
-    while (!mp_mmp_trip<MP_SEED_BIG>(ix, P, s, slab, a, b, c)) {}
+    while (!mp_mmp_trip<MP_SEED_BIG>(ix, P, s, slab, a, b, c, d)) {}
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -548,7 +552,7 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
         for (int w = 0; w < 256 / MP_WAVE; w++) tot += s_occ[w];
-        if (tot) atomicAdd(&ctr->n_occ, (unsigned long long)tot);
+        if (tot) { atomicAdd(&ctr->n_occ, (unsigned long long)tot); atomicAdd(&ctr->n_occ_loaded, (unsigned long long)tot); }
     }
     if (t == 0) { atomicAdd(&ctr->n_sa, (unsigned long long)n_tasks); atomicAdd(&ctr->n_hits, (unsigned long long)n_tasks); }
 }

@@ -98,7 +98,7 @@ struct mp_dev_mmp {
 };
 
 struct mp_counters {           // device-side event counters
-    unsigned long long n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos, n_cand, overflow, n_kmer;
+    unsigned long long n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos, n_cand, overflow, n_kmer, n_occ_loaded;
 };
 
 struct mp_hit_task { uint32_t seed_slot; uint32_t k; };                         // one SA row to locate

@@ -43,7 +43,7 @@ class SeedPos(C.Structure):
 class SeedStats(C.Structure):
     _fields_ = [("n_occ", C.c_uint64), ("n_lkt", C.c_uint64), ("n_sa", C.c_uint64), ("n_seeds", C.c_uint64),
                 ("n_hits", C.c_uint64), ("n_seedpos", C.c_uint64), ("ms_seed", C.c_float), ("ms_locate", C.c_float),
-                ("ms_merge", C.c_float), ("reserved", C.c_float), ("n_prefilter", C.c_uint64)]
+                ("ms_merge", C.c_float), ("reserved", C.c_float), ("n_prefilter", C.c_uint64), ("n_occ_loaded", C.c_uint64)]
 
 
 class DpTask(C.Structure):

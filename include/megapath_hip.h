@@ -78,6 +78,10 @@ int mp_index_copy_lkt(const mp_index *ix, uint32_t *out);
  * with the 17-mer keys[i] (34 bits, first scanned base in the low bits as for mp_index_lkt), i.e. when the 13-mer table
  * range of its low 26 bits survives the four further extension steps.  MP_EINVAL when the bitmap is not resident. */
 int mp_index_prefilter(const mp_index *ix, const uint64_t *keys, uint64_t n, uint8_t *out);
+/* Test aid.  When the index carries the per-15-mer arrangement of the pre-filter bits (8.6 GB, one load answers three
+ * consecutive probe positions): out[i] = the three answers for 17-mer key i (bit 0: as first, bit 1: as second, bit 2: as
+ * third position of a group); each must equal mp_index_prefilter's bit.  MP_EINVAL when the table is not resident. */
+int mp_index_prefilter3(mp_index *index, const uint64_t *keys, uint64_t n, uint8_t *out);
 /* Test aid.  When the index carries the 16-mer look-up table (17 GB, built next to the pre-filter when HBM allows; the
  * seeding kernel then reads the SA range of a seed start's first 16 bases directly): compares the table with the index's
  * own procedure -- 13-mer table plus three backward-search steps -- for the 16-mer at every text position and for

@@ -198,6 +198,22 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
         }
     }
     if (ix->d_kmer) {
+        // the pre-filter's bits once more, per 15-mer (kernels_index.hip): 8.6 GB, one load per three probed positions;
+        // automatic when that leaves >= 16 GiB free, MP_KMER15=0 / 1 overrides
+        const char *e = getenv("MP_KMER15");
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const size_t bytes = ((size_t)1 << 30) * 8;
+        bool on = n >= (1ull << 25) && free_b >= bytes + (16ull << 30);
+        if (e) on = atoi(e) != 0;
+        if (on && n >= 17 && hipMalloc(&ix->d_kmer15, bytes) == hipSuccess) {
+            if (hipMemset(ix->d_kmer15, 0, bytes) != hipSuccess) return fail(MP_ENODEV);
+            hipLaunchKernelGGL(kmer15x3_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, (unsigned long long *)ix->d_kmer15);
+            if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
+            ix->device_bytes += bytes;
+        }
+    }
+    if (ix->d_kmer) {
         // 16-mer look-up table behind the pre-filter (kernels_index.hip): 17 GB, three backward-search steps less per seed
         // start; automatic when that leaves >= 16 GiB free, MP_LKT16=0 / 1 overrides
         const char *e = getenv("MP_LKT16");
@@ -230,7 +246,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
         }
     }
     ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt; ix->d.lkt16 = (const uint32_t *)ix->d_lkt16;
-    ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text; ix->d.kmer17 = (const uint32_t *)ix->d_kmer;
+    ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text; ix->d.kmer17 = (const uint32_t *)ix->d_kmer; ix->d.kmer15x3 = (const unsigned long long *)ix->d_kmer15;
     ix->d.n = (uint32_t)h.n; ix->d.inv_sa0 = (uint32_t)h.inv_sa0; ix->d.sa_interval = h.sa_interval;
     ix->d.sa_shift = 0xFFFFFFFFu;
     for (uint32_t b = 0; b < 31; b++) if ((1u << b) == h.sa_interval) ix->d.sa_shift = b;
@@ -301,6 +317,7 @@ extern "C" int mp_index_close(mp_index *ix)
     if (ix->d_text) (void)hipFree(ix->d_text);
     if (ix->d_kmer) (void)hipFree(ix->d_kmer);
     if (ix->d_lkt16) (void)hipFree(ix->d_lkt16);
+    if (ix->d_kmer15) (void)hipFree(ix->d_kmer15);
     if (ix->d_sa_dense) (void)hipFree(ix->d_sa_dense);
     delete ix;
     return MP_OK;
@@ -474,6 +491,22 @@ extern "C" int mp_index_prefilter(const mp_index *ix, const uint64_t *keys, uint
     return MP_OK;
 }
 
+extern "C" int mp_index_prefilter3(mp_index *ix, const uint64_t *keys, uint64_t n, uint8_t *out)
+{
+    if (!ix || !keys || !out) return MP_EINVAL;
+    if (!ix->d_kmer15) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    uint64_t *d_k = nullptr; uint8_t *d_o = nullptr;
+    if (hipMalloc((void **)&d_k, n * 8) != hipSuccess || hipMalloc((void **)&d_o, n) != hipSuccess) { if (d_k) (void)hipFree(d_k); return MP_ENOMEM; }
+    hipError_t e = hipMemcpy(d_k, keys, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kmer15x3_query_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const unsigned long long *)ix->d_kmer15, d_k, n, d_o);
+        e = hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_k); (void)hipFree(d_o);
+    return e == hipSuccess ? MP_OK : MP_ENODEV;
+}
+
 extern "C" int mp_index_check_lkt16(mp_index *ix, uint64_t n_random, uint64_t *out_checked, uint64_t *out_mismatches)
 {
     if (!ix || !out_checked || !out_mismatches) return MP_EINVAL;
@@ -594,7 +627,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     uint32_t slab_limit = MP_SEED_SLAB;
     if (const char *e = getenv("MP_SEED_SLAB_LIMIT")) { int v = atoi(e); if (v >= 1 && v < MP_SEED_SLAB) slab_limit = (uint32_t)v; }   // test knob
     mp_dev_index dix = c->ix->d;
-    if (!c->use_prefilter) { dix.kmer17 = nullptr; dix.sa_dense = nullptr; dix.lkt16 = nullptr; }
+    if (!c->use_prefilter) { dix.kmer17 = nullptr; dix.kmer15x3 = nullptr; dix.sa_dense = nullptr; dix.lkt16 = nullptr; }
     hipStream_t s = c->stream;
     const uint32_t overflow_cap = n_items;
     if (c->scan.reserve((size_t)n_items * (W + 1) + 16) || c->slabs.reserve((size_t)n_items * MP_SEED_SLAB) || c->seeds_per_rs.reserve(n_items + 2) ||

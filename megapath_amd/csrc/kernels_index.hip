@@ -134,6 +134,45 @@ __global__ void kmer17_build_kernel(const uint32_t *__restrict__ text, uint64_t 
     atomicOr(&bitmap[key >> 5], 1u << (uint32_t)(key & 31));
 }
 
+// The same presence information, arranged so that ONE 8-byte load answers the pre-filter for three consecutive scan
+// positions (a futile strand is probed at every position).  Entry y (a 15-mer) holds, for the 17-mers that contain y,
+//   bits  0..15: y preceded (in scan order) by two bases -- the 17-mer probed at scan position g when y = bases g+2 .. g+16,
+//   bits 16..31: y with one base either side                                        -- position g + 1,
+//   bits 32..47: y followed by two bases                                            -- position g + 2.
+// Keys are in scan order (first scanned base in the low bits; the leftmost text base is scanned last), as in the bitmap:
+// with K the 34-bit key of a reachable 17-mer, y and the bit are K >> 4 & K & 15, K >> 2 & (K & 3 | (K >> 32) << 2),
+// K & (K >> 30).  4^15 entries, 8.6 GB.
+__global__ void kmer15x3_build_kernel(const uint32_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ tab)
+{
+    const uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (n < 5 || p > n - 5) return;
+    const uint64_t q = p >> 4;
+    const uint32_t sh = 2 * (uint32_t)(p & 15);
+    const uint64_t lo = ((uint64_t)text[q + 1] << 32) | text[q];
+    uint64_t v = lo >> sh;
+    if (sh > 30) v |= (uint64_t)text[q + 2] << (64 - sh);
+    v &= (1ull << 34) - 1;
+    uint64_t r = __brevll(v);
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    const uint64_t K = r >> 30;                                    // as in kmer17_build_kernel: base p in bits 33:32
+    const uint64_t m30 = (1ull << 30) - 1;
+    atomicOr(&tab[(K >> 4) & m30], 1ull << (K & 15));
+    atomicOr(&tab[(K >> 2) & m30], 1ull << (16 + ((K & 3) | (((K >> 32) & 3) << 2))));
+    atomicOr(&tab[K & m30], 1ull << (32 + ((K >> 30) & 15)));
+}
+
+// Test aid: answers of the three alignments of the 15-mer table for 17-mer keys (must equal the bitmap's bit)
+__global__ void kmer15x3_query_kernel(const unsigned long long *__restrict__ tab, const uint64_t *__restrict__ keys, uint64_t n, uint8_t *__restrict__ out)
+{
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t K = keys[t] & ((1ull << 34) - 1), m30 = (1ull << 30) - 1;
+    const uint32_t a = (uint32_t)((tab[(K >> 4) & m30] >> (K & 15)) & 1ull);
+    const uint32_t b = (uint32_t)((tab[(K >> 2) & m30] >> (16 + ((K & 3) | (((K >> 32) & 3) << 2)))) & 1ull);
+    const uint32_t c = (uint32_t)((tab[K & m30] >> (32 + ((K >> 30) & 15))) & 1ull);
+    out[t] = (uint8_t)(a | (b << 1) | (c << 2));
+}
+
 __global__ void kmer17_query_kernel(const uint32_t *__restrict__ bitmap, const uint64_t *__restrict__ keys, uint64_t n, uint8_t *__restrict__ out)
 {
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;

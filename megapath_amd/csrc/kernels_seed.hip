@@ -261,6 +261,8 @@ struct mp_mmp_state {
     uint32_t l, r, last_l, last_r, last_seed_len;
     uint32_t cur_w, cur_word;
     uint32_t n_seeds, n_hits;
+    unsigned long long pe;  // pre-filter bits of the 15-mer at scan bases pg + 2 .. pg + 16 (ix.kmer15x3): answers positions pg .. pg + 2
+    int pg;
     uint32_t upos;          // text position of the match when its SA range was a single row and it was extended by text
     bool uvalid;            // comparison (mp_mmp_trip): the record then carries the position instead of the row
 };
@@ -315,7 +317,17 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
             if (ix.kmer17 && P.seed_min_length >= 17) {
                 // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe
                 const uint64_t k17 = (two >> sh) & ((1ull << 34) - 1);
-                futile = ((ix.kmer17[k17 >> 5] >> (uint32_t)(k17 & 31)) & 1u) == 0;
+                if (ix.kmer15x3) {
+                    // one 8-byte entry answers three consecutive positions (kmer15x3_build_kernel): a futile strand is probed
+                    // at every position, so two probes in three need no load
+                    const int a = s.i - s.pg;
+                    if (a < 0 || a > 2) { s.pg = s.i; s.pe = ix.kmer15x3[(k17 >> 4) & ((1ull << 30) - 1)]; }
+                    const int aa = s.i - s.pg;
+                    const uint32_t bit = aa == 0 ? (uint32_t)(k17 & 15) : aa == 1 ? 16u + ((uint32_t)(k17 & 3) | ((uint32_t)(k17 >> 32) & 3u) << 2)
+                                                                                   : 32u + (uint32_t)((k17 >> 30) & 15);
+                    futile = ((s.pe >> bit) & 1ull) == 0;
+                } else
+                    futile = ((ix.kmer17[k17 >> 5] >> (uint32_t)(k17 & 31)) & 1u) == 0;
                 my_kmer++;
             }
             const uint32_t key16 = (uint32_t)(two >> sh);
@@ -417,7 +429,7 @@ __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *sc
     s.sc = scan + (uint64_t)rs * (W + 1);
     s.rs = rs; s.len = (int)lens[rs >> 1]; s.strand = (int)(rs & 1);
     s.i = 0; s.seed_len = 0; s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
-    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.upos = 0; s.uvalid = false;
+    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.upos = 0; s.uvalid = false; s.pe = 0; s.pg = -1000;
 }
 
 __global__ void __launch_bounds__(256)

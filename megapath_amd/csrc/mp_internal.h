@@ -26,6 +26,8 @@ struct mp_dev_index {          // passed by value to kernels
     const uint32_t *sa;        // SA[k*interval]; entry 0 unused (handled as -1, BWT.c:242)
     const uint32_t *text;      // 2-bit text, LSB-first, 16 bases per word
     const uint32_t *lkt16;     // optional: 4^16 inclusive right SA bounds of the 16-mers (nullptr = off); used behind the 17-mer filter
+    const unsigned long long *kmer15x3;   // optional: per 15-mer, the presence bits of the 48 17-mers around it (three alignments, see
+                               // kmer15x3_build_kernel): one load answers the pre-filter for three consecutive scan positions
     const uint32_t *kmer17;    // optional: one bit per 17-mer, set when backward search can reach length 17 with it (nullptr = off)
     const uint32_t *sa_dense;  // optional: SA[k << sa_dense_shift], filled on the device from the file's samples (nullptr = off)
     uint32_t sa_dense_shift;   // 0: the whole suffix array, 1: every 2nd row, 2: every 4th
@@ -41,7 +43,7 @@ struct mp_translate_row { uint64_t start; uint32_t chr; uint64_t corr; };
 struct mp_index {
     int device = 0;
     mp_dev_index d{};
-    void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr, *d_kmer = nullptr, *d_sa_dense = nullptr, *d_lkt16 = nullptr;
+    void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr, *d_kmer = nullptr, *d_sa_dense = nullptr, *d_lkt16 = nullptr, *d_kmer15 = nullptr;
     uint64_t device_bytes = 0;
     uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};
     uint32_t sa_interval = 0;

@@ -96,7 +96,7 @@ class IndexInfo(C.Structure):
 
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
-           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy",
+           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
 
@@ -139,6 +139,7 @@ def load_library():
     lib.mp_index_seq_info.argtypes = [vp, C.c_uint32, u64p, u64p, u64p]
     lib.mp_index_fetch_text.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.mp_index_check_lkt16.argtypes = [vp, C.c_uint64, u64p, u64p]
+    lib.mp_index_prefilter3.argtypes = [vp, vp, C.c_uint64, vp]
     lib.mp_ctx_set_prefilter.argtypes = [vp, C.c_int]
     lib.mp_ctx_set_dp_band.argtypes = [vp, C.c_int]
     lib.mp_ctx_dp_band_stats.argtypes = [vp, u64p, u64p]
@@ -270,6 +271,13 @@ class Index:
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         out = np.zeros(len(keys), dtype=np.uint8)
         _chk(load_library().mp_index_prefilter(self._h, keys.ctypes.data, len(keys), out.ctypes.data), "mp_index_prefilter")
+        return out
+
+    def prefilter3(self, keys):
+        """Per key the answers of the three alignments of the per-15-mer pre-filter table (bits 0..2)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(len(keys), dtype=np.uint8)
+        _chk(load_library().mp_index_prefilter3(self._h, keys.ctypes.data, len(keys), out.ctypes.data), "mp_index_prefilter3")
         return out
 
     def check_lkt16(self, n_random: int = 0):

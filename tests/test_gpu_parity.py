@@ -77,6 +77,7 @@ def test_kmer_prefilter_bitmap_equals_table_plus_four_steps(g1_prefix, monkeypat
     13 scanned bases, then four backward-search steps (DV-DPfunctions.cpp:2245-2262).  Checked for every 17-base window
     of the text (incl. the windows that run into the table's 'A' padding at the text end) and for random 17-mers."""
     monkeypatch.setenv("MP_KMER_FILTER", "1")
+    monkeypatch.setenv("MP_KMER15", "1")
     gix = H.Index(g1_prefix, 0)
     assert gix.info.prefilter_k == 17
     lib = O.oracle()
@@ -105,6 +106,9 @@ def test_kmer_prefilter_bitmap_equals_table_plus_four_steps(g1_prefix, monkeypat
     want = (l <= r).astype(np.uint8)
     assert want[:3040].sum() >= 3030                      # text windows are present (those cut by the text end may not be)
     assert np.array_equal(got, want)
+    # the per-15-mer arrangement of the same bits (one load per three probe positions): all three alignments agree
+    got3 = gix.prefilter3(keys)
+    assert np.array_equal(got3, want * 7)
     gix.close()
     lib.mpo_index_close(oix)
 
@@ -135,6 +139,7 @@ def test_seeds_and_hits_identical_with_prefilter(g1_prefix, golden_dir, monkeypa
     """Same kept seeds and the same deep-DP hits with the 17-mer pre-filter (and the 16-mer table behind it) on and off;
     fewer rank queries with it."""
     monkeypatch.setenv("MP_KMER_FILTER", "1")
+    monkeypatch.setenv("MP_KMER15", "1")
     monkeypatch.setenv("MP_LKT16", "1")
     monkeypatch.setenv("MP_SA_DENSE", "1")
     gix = H.Index(g1_prefix, 0)

@@ -47,6 +47,7 @@ def _build(tmp_path, genome):
 def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg, monkeypatch):
     monkeypatch.setenv("MP_KMER_FILTER", "1")          # the in-process run uses the 17-mer pre-filter and the denser SA
     monkeypatch.setenv("MP_LKT16", "1")                # ... and the 16-mer look-up table behind the pre-filter
+    monkeypatch.setenv("MP_KMER15", "1")               # ... and the per-15-mer arrangement of the pre-filter bits
     monkeypatch.setenv("MP_SA_DENSE", "1")             # samples, the C++ run below neither
     genome = synth.random_genome(cfg["n_bases"], 501, n_seqs=cfg["n_seqs"], repeat_frac=0.12)
     if cfg.get("tandem"):
@@ -92,7 +93,7 @@ def test_whole_path_equals_oracle_on_fresh_data(tmp_path, cfg, monkeypatch):
     import subprocess
     from conftest import ROOT
     cxx_out = tmp_path / "cxx.fq"
-    env = dict(os.environ, MP_BATCH_PAIRS="1300", MP_KMER_FILTER="0", MP_SA_DENSE="0", MP_LKT16="0")
+    env = dict(os.environ, MP_BATCH_PAIRS="1300", MP_KMER_FILTER="0", MP_SA_DENSE="0", MP_LKT16="0", MP_KMER15="0")
     env.pop("MP_SOAP4_PYTHON", None)
     with open(cxx_out, "wb") as fo:
         r = subprocess.run([os.path.join(ROOT, "bin", "soap4"), "pair", prefix, f1, f2, "-o", str(tmp_path / "o"), "-C",

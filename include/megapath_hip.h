@@ -208,7 +208,8 @@ int mp_get_pair_hits_view(mp_ctx *ctx, const mp_pair_hit **out_hits, uint64_t *o
  * Rescue passes for the pairs the deep-DP round left without a hit.  Replaces DPForUnalignSingle2
  * (DV-DPForSingleReads.cpp:321, alignment.cpp:182) and semiGlobalDPForSingleEndDpAlignment (DV-SemiDP.cpp:197,
  * alignment.cpp:250): candidate selection, window arithmetic and both DP batches run on the device; the per-pair
- * bookkeeping that turns the hits into output records stays with the caller.  Call after mp_deep_dp_round. */
+ * bookkeeping that turns the hits into output records stays with the caller.  Call after mp_deep_dp_round of the same batch
+ * (MP_EINVAL otherwise: the pairs to rescue are the ones that round left without a hit). */
 typedef struct {              /* SingleAlgnmtResult (PEAlgnmt.h) of a read whose pair failed the deep-DP round */
     uint32_t read_id;
     uint32_t strand;          /* 1 '+', 2 '-' */
@@ -237,8 +238,20 @@ typedef struct {
 } mp_rescue_stats;
 
 int mp_rescue_round(mp_ctx *ctx, const mp_align_params *params, int skip_default_dp, mp_rescue_stats *out_stats);
+/* The passing instances only, in task order (grouped by read, candidates in the order of singleMerge): they are compacted
+ * on the device and copied to pinned host memory by mp_rescue_round itself, on a copy stream.  The _view calls wait for that
+ * copy and hand out the context's buffers (valid until the next round or mp_set_reads*); the other two copy into
+ * caller-owned arrays (out_hits may be NULL to ask for the count). */
+int mp_get_single_hits_view(mp_ctx *ctx, const mp_single_hit **out_hits, uint64_t *out_n);
+int mp_get_rescue_hits_view(mp_ctx *ctx, const mp_rescue_hit **out_hits, uint64_t *out_n);
 int mp_get_single_hits(mp_ctx *ctx, mp_single_hit *out_hits, uint64_t cap, uint64_t *out_n);
 int mp_get_rescue_hits(mp_ctx *ctx, mp_rescue_hit *out_hits, uint64_t cap, uint64_t *out_n);
+
+/* Test aid.  The candidate order of single-end rescue: std::sort(.., LongerSeedLength()) of singleMerge (DV-DPfunctions.cpp:334)
+ * exactly as the reference's libstdc++ permutes seeds of equal length -- the cut at 200 candidates per read
+ * (DV-DPForSingleReads.cpp:200) makes that order output-visible.  Sorts n_arrays independent lists on the device
+ * (list t = seed_len[off[t] .. off[t+1])); out_perm[off[t] + k] = index inside list t of the seed at rank k. */
+int mp_test_sort_longer_seed(int device, const uint32_t *seed_len, const uint32_t *off, uint32_t n_arrays, uint32_t *out_perm);
 
 /* Measurement aid: `lanes` lanes each load `per_lane` random 64-byte rank blocks (independent loads); reports the mean
  * launch time and the exact bytes one launch requests.  This is the random-64 B-gather ceiling the seed stage is priced

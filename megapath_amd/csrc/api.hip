@@ -97,6 +97,18 @@ struct mp_ctx {
     DevBuf<mp_dp_result> sres, rres;
     uint32_t n_failed_reads = 0, n_stasks = 0;
     bool rescued = false;
+    bool deep_done = false;                      // mp_deep_dp_round ran for the reads now set (mp_rescue_round needs its hits)
+    hipEvent_t ev_round[3] = {};                 // whole-call timing of mp_deep_dp_round / mp_rescue_round
+    // passing instances of the rescue passes, compacted on the device and copied to pinned memory behind the compute stream
+    DevBuf<uint32_t> sh_flag, sh_slot, rh_flag, rh_slot;
+    DevBuf<mp_single_hit> d_single_hits;
+    DevBuf<mp_rescue_hit> d_rescue_hits;
+    mp_single_hit *h_single_hits = nullptr;
+    mp_rescue_hit *h_rescue_hits = nullptr;
+    size_t h_single_cap = 0, h_rescue_cap = 0;
+    uint64_t n_single_hits_host = 0, n_rescue_hits_host = 0;
+    hipEvent_t ev_rescue_ready = nullptr, ev_rescue_copied = nullptr;
+    bool rescue_copy_started = false;
 };
 
 // ------------------------------------------------------------------------------------------------ misc
@@ -556,6 +568,9 @@ extern "C" int mp_ctx_create(mp_index *ix, mp_ctx **out)
     HIPCHK(hipEventCreateWithFlags(&c->ev_hits_ready, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_hits_copied, hipEventDisableTiming));
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    for (auto &e : c->ev_round) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_rescue_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_rescue_copied, hipEventDisableTiming));
     if (c->ctr.reserve(1) || c->n_pair_hits.reserve(1)) { mp_ctx_destroy(c); return MP_ENOMEM; }
     *out = c;
     return MP_OK;
@@ -570,6 +585,16 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     if (c->ev_hits_copied) (void)hipEventDestroy(c->ev_hits_copied);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_round) if (e) (void)hipEventDestroy(e);
+    if (c->ev_rescue_ready) (void)hipEventDestroy(c->ev_rescue_ready);
+    if (c->ev_rescue_copied) (void)hipEventDestroy(c->ev_rescue_copied);
+    if (c->h_single_hits) (void)hipHostFree(c->h_single_hits);
+    if (c->h_rescue_hits) (void)hipHostFree(c->h_rescue_hits);
+    c->sh_flag.release(); c->sh_slot.release(); c->rh_flag.release(); c->rh_slot.release(); c->d_single_hits.release(); c->d_rescue_hits.release();
+    c->band_flag.release(); c->band_idx.release(); c->near_flag.release(); c->near_idx.release(); c->near_list.release(); c->far_flag.release(); c->far_idx.release();
+    c->far_list.release(); c->pre_cls.release(); c->narrow_list.release(); c->wide_list.release(); c->mid_flag.release(); c->mid_idx.release(); c->mid_list.release();
+    c->vfar_flag.release(); c->vfar_idx.release(); c->vfar_list.release(); c->und_list[0].release(); c->und_list[1].release(); c->band_tasks.release();
+    c->band_res.release(); c->band_fill.release();
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     c->reads.release(); c->lens.release(); c->scan.release(); c->seeds.release(); c->slabs.release(); c->big_slabs.release(); c->hits.release();
     c->seedpos.release(); c->hit_row.release(); c->seeds_per_rs.release(); c->hits_per_rs.release(); c->rs_base.release(); c->overflow_rs.release(); c->over_slot.release();
@@ -580,6 +605,18 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
     c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release();
     delete c;
+    return MP_OK;
+}
+
+// A new batch: nothing computed for the previous one may leak into it (seeds, hit lists, failed-pair lists), and copies
+// of its hits still in flight must have landed before their buffers are reused.
+static int forget_batch(mp_ctx *c)
+{
+    if (c->hits_copy_started) { HIPCHK(hipEventSynchronize(c->ev_hits_copied)); c->hits_copy_started = false; }
+    if (c->rescue_copy_started) { HIPCHK(hipEventSynchronize(c->ev_rescue_copied)); c->rescue_copy_started = false; }
+    c->seeded = false; c->deep_done = false; c->rescued = false;
+    c->n_pair_hits_host = 0; c->n_hits_total = 0; c->n_stasks = 0; c->n_failed_reads = 0;
+    c->n_single_hits_host = 0; c->n_rescue_hits_host = 0;
     return MP_OK;
 }
 
@@ -594,16 +631,16 @@ extern "C" int mp_set_reads(mp_ctx *c, const uint32_t *packed, uint32_t W, const
     HIPCHK(hipMemcpyAsync(c->lens.p, lengths, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->d_reads = c->reads.p; c->d_lens = c->lens.p;
-    c->n_reads = n_reads; c->W = W; c->max_len = mx; c->seeded = false;
-    return MP_OK;
+    c->n_reads = n_reads; c->W = W; c->max_len = mx;
+    return forget_batch(c);
 }
 
 extern "C" int mp_set_reads_device(mp_ctx *c, const uint32_t *d_packed, uint32_t W, const uint32_t *d_lengths, uint32_t n_reads, uint32_t max_length)
 {
     if (!c || !d_packed || !d_lengths || W == 0 || (n_reads & 1) || max_length > W * 16) return MP_EINVAL;
     c->d_reads = d_packed; c->d_lens = d_lengths;
-    c->n_reads = n_reads; c->W = W; c->max_len = max_length; c->seeded = false;
-    return MP_OK;
+    c->n_reads = n_reads; c->W = W; c->max_len = max_length;
+    return forget_batch(c);
 }
 
 // ------------------------------------------------------------------------------------------------ seeding
@@ -1205,9 +1242,9 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
     if (!c || !ap || !c->d_reads || c->n_reads == 0) return MP_EINVAL;
     HIPCHK(hipSetDevice(c->ix->device));
     hipStream_t s = c->stream;
+    c->deep_done = false; c->rescued = false;
     mp_round_stats st{};
-    hipEvent_t t0, t1;
-    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    const hipEvent_t t0 = c->ev_round[0], t1 = c->ev_round[1];
     HIPCHK(hipEventRecord(t0, s));
     int rc = MP_OK;
     if (!c->seeded) { rc = mp_seed_batch(c, &ap->mmp, nullptr); if (rc) return rc; }
@@ -1259,7 +1296,7 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
     HIPCHK(hipEventRecord(t1, s));
     HIPCHK(hipEventSynchronize(t1));
     (void)hipEventElapsedTime(&st.ms_total, t0, t1);
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    c->deep_done = true;
     if (out_n_hits) *out_n_hits = c->n_pair_hits_host;
     if (out_stats) *out_stats = st;
     // the hits start their way to the host now (mp_get_pair_hits_view waits for them): a rescue round called in between
@@ -1333,15 +1370,29 @@ static int exclusive_scan_u32(mp_ctx *c, const uint32_t *in, uint32_t *out, uint
     return MP_OK;
 }
 
+// pinned staging buffers of the rescue hit lists
+template <typename T>
+static int reserve_pinned(T *&p, size_t &cap, size_t n)
+{
+    if (n <= cap) return MP_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = n + n / 4 + 1024;
+    if (hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) return MP_ENOMEM;
+    cap = want;
+    return MP_OK;
+}
+
 extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_default_dp, mp_rescue_stats *out_stats)
 {
-    if (!c || !ap || !c->seeded || c->n_reads == 0) return MP_EINVAL;
+    // the pairs to rescue are the ones without a hit of the deep-DP round of THIS batch
+    if (!c || !ap || !c->seeded || !c->deep_done || c->n_reads == 0) return MP_EINVAL;
     HIPCHK(hipSetDevice(c->ix->device));
+    if (c->rescue_copy_started) { HIPCHK(hipEventSynchronize(c->ev_rescue_copied)); c->rescue_copy_started = false; }
     hipStream_t s = c->stream;
     const uint32_t n_reads = c->n_reads, n_pairs = n_reads / 2;
     mp_rescue_stats st{};
-    hipEvent_t t0, t1, t2;
-    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1)); HIPCHK(hipEventCreate(&t2));
+    const hipEvent_t t0 = c->ev_round[0], t1 = c->ev_round[1], t2 = c->ev_round[2];
     HIPCHK(hipEventRecord(t0, s));
     if (c->pair_done.reserve(n_pairs + 1) || c->failed_flag.reserve(n_reads + 2) || c->failed_off.reserve(n_reads + 2)) return MP_ENOMEM;
     HIPCHK(hipMemsetAsync(c->pair_done.p, 0, (size_t)(n_pairs + 1) * 4, s));
@@ -1354,7 +1405,9 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
     HIPCHK(hipMemcpyAsync(&nf, c->failed_off.p + n_reads, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     c->n_failed_reads = nf; c->n_stasks = 0; c->rescued = true;
+    c->n_single_hits_host = 0; c->n_rescue_hits_host = 0;
     st.n_failed_pairs = nf / 2;
+    uint32_t nst = 0, n_rt = 0;
     if (nf) {
         if (c->failed_reads.reserve(nf + 1) || c->n_scand.reserve(nf + 2) || c->s_off.reserve(nf + 2) || c->scand.reserve(c->n_hits_total + 64)) return MP_ENOMEM;
         hipLaunchKernelGGL(list_failed_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, s, c->failed_flag.p, c->failed_off.p, n_reads, c->failed_reads.p);
@@ -1362,7 +1415,6 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
                            c->n_neg.p, c->scand.p, c->n_scand.p);
         rc = exclusive_scan_u32(c, c->n_scand.p, c->s_off.p, nf + 1);
         if (rc) return rc;
-        uint32_t nst = 0;
         HIPCHK(hipMemcpyAsync(&nst, c->s_off.p + nf, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         c->n_stasks = nst;
@@ -1375,7 +1427,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
         const uint32_t max_win = c->max_len + 60;
         rc = run_dp_filtered(c, c->stasks.p, nst, max_win, ap->clip_left, ap->clip_right, c->sres.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
-        if (!skip_default_dp) {
+        if (!skip_default_dp && nst) {
             hipLaunchKernelGGL(mate_rescue_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->s_off.p, c->stasks.p, c->sres.p,
                                c->d_lens, c->ix->n, ap->insert_low, ap->insert_high, c->rtasks.p, c->rsrc.p);
             const uint32_t rwin = (uint32_t)(ap->insert_high - ap->insert_low) + c->max_len + 1;   // HalfEnd maxDNALength (DV-DPfunctions.cpp:1340)
@@ -1383,82 +1435,133 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
             rc = run_dp_filtered(c, c->rtasks.p, 4 * nf, rwin, ap->clip_left, ap->clip_right, c->rres.p, &st.ms_dp_fill, &st.ms_dp_trace,
                                  ap->want_tie_counts != 0);
             if (rc) return rc;
-            st.n_rescue_tasks = 4ull * nf;
+            n_rt = 4 * nf;
+            st.n_rescue_tasks = n_rt;
+        }
+        // ---- the passing instances, compacted in task order
+        uint32_t n_sh = 0, n_rh = 0;
+        if (nst) {
+            if (c->sh_flag.reserve(nst + 2) || c->sh_slot.reserve(nst + 2)) return MP_ENOMEM;
+            hipLaunchKernelGGL(single_hit_flag_kernel, dim3(grid_for(nst + 1, 256)), dim3(256), 0, s, c->stasks.p, c->sres.p, c->d_lens, nst, c->sh_flag.p);
+            rc = exclusive_scan_u32(c, c->sh_flag.p, c->sh_slot.p, nst + 1);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(&n_sh, c->sh_slot.p + nst, 4, hipMemcpyDeviceToHost, s));
+        }
+        if (n_rt) {
+            if (c->rh_flag.reserve(n_rt + 2) || c->rh_slot.reserve(n_rt + 2)) return MP_ENOMEM;
+            hipLaunchKernelGGL(rescue_hit_flag_kernel, dim3(grid_for(n_rt + 1, 256)), dim3(256), 0, s, c->rtasks.p, c->rres.p, c->rsrc.p, c->d_lens, n_rt, c->rh_flag.p);
+            rc = exclusive_scan_u32(c, c->rh_flag.p, c->rh_slot.p, n_rt + 1);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(&n_rh, c->rh_slot.p + n_rt, 4, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        if (c->d_single_hits.reserve(n_sh + 1) || c->d_rescue_hits.reserve(n_rh + 1) || reserve_pinned(c->h_single_hits, c->h_single_cap, n_sh) ||
+            reserve_pinned(c->h_rescue_hits, c->h_rescue_cap, n_rh)) return MP_ENOMEM;
+        if (n_sh) hipLaunchKernelGGL(single_hit_emit_kernel, dim3(grid_for(nst, 256)), dim3(256), 0, s, c->stasks.p, c->sres.p, c->sh_flag.p, c->sh_slot.p, nst, c->d_single_hits.p);
+        if (n_rh) hipLaunchKernelGGL(rescue_hit_emit_kernel, dim3(grid_for(n_rt, 256)), dim3(256), 0, s, c->stasks.p, c->sres.p, c->rtasks.p, c->rres.p, c->rsrc.p,
+                                     c->rh_flag.p, c->rh_slot.p, n_rt, c->d_rescue_hits.p);
+        c->n_single_hits_host = n_sh; c->n_rescue_hits_host = n_rh;
+        st.n_single_hits = n_sh; st.n_rescue_hits = n_rh;
+        if (n_sh || n_rh) {
+            HIPCHK(hipEventRecord(c->ev_rescue_ready, s));
+            HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_rescue_ready, 0));
+            if (n_sh) HIPCHK(hipMemcpyAsync(c->h_single_hits, c->d_single_hits.p, (size_t)n_sh * sizeof(mp_single_hit), hipMemcpyDeviceToHost, c->copy_stream));
+            if (n_rh) HIPCHK(hipMemcpyAsync(c->h_rescue_hits, c->d_rescue_hits.p, (size_t)n_rh * sizeof(mp_rescue_hit), hipMemcpyDeviceToHost, c->copy_stream));
+            HIPCHK(hipEventRecord(c->ev_rescue_copied, c->copy_stream));
+            c->rescue_copy_started = true;
         }
     }
     HIPCHK(hipEventRecord(t2, s));
     HIPCHK(hipEventSynchronize(t2));
     (void)hipEventElapsedTime(&st.ms_total, t0, t2);
     if (nf) (void)hipEventElapsedTime(&st.ms_tasks, t0, t1);
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(t2);
-    c->seeded = c->seeded;   // seeds stay valid for mp_get_seeds
     if (out_stats) *out_stats = st;
+    return MP_OK;
+}
+
+static int wait_rescue_copy(mp_ctx *c)
+{
+    if (c->rescue_copy_started) { HIPCHK(hipEventSynchronize(c->ev_rescue_copied)); c->rescue_copy_started = false; }
+    return MP_OK;
+}
+
+extern "C" int mp_get_single_hits_view(mp_ctx *c, const mp_single_hit **out_hits, uint64_t *out_n)
+{
+    if (!c || !c->rescued || !out_hits || !out_n) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc = wait_rescue_copy(c);
+    if (rc) return rc;
+    *out_hits = c->h_single_hits; *out_n = c->n_single_hits_host;
+    return MP_OK;
+}
+
+extern "C" int mp_get_rescue_hits_view(mp_ctx *c, const mp_rescue_hit **out_hits, uint64_t *out_n)
+{
+    if (!c || !c->rescued || !out_hits || !out_n) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc = wait_rescue_copy(c);
+    if (rc) return rc;
+    *out_hits = c->h_rescue_hits; *out_n = c->n_rescue_hits_host;
     return MP_OK;
 }
 
 extern "C" int mp_get_single_hits(mp_ctx *c, mp_single_hit *out, uint64_t cap, uint64_t *out_n)
 {
-    if (!c || !c->rescued || !out_n) return MP_EINVAL;
-    HIPCHK(hipSetDevice(c->ix->device));
-    const uint32_t n = c->n_stasks;
-    std::vector<mp_dp_task> tasks(n + 1);
-    std::vector<mp_dp_result> res(n + 1);
-    std::vector<uint32_t> lens(c->n_reads);
-    if (n) {
-        HIPCHK(hipMemcpy(tasks.data(), c->stasks.p, (size_t)n * sizeof(mp_dp_task), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(res.data(), c->sres.p, (size_t)n * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(lens.data(), c->d_lens, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
+    const mp_single_hit *v = nullptr;
+    uint64_t n = 0;
+    if (!out_n) return MP_EINVAL;
+    int rc = mp_get_single_hits_view(c, &v, &n);
+    if (rc) return rc;
+    if (out) {
+        if (n > cap) return MP_ERANGE;
+        if (n) memcpy(out, v, (size_t)n * sizeof(mp_single_hit));
     }
-    uint64_t w = 0;
-    for (uint32_t t = 0; t < n; t++) {
-        if (res[t].score <= 0 || res[t].score < mp_dp_cutoff((int)lens[tasks[t].read_id])) continue;
-        if (out) {
-            if (w >= cap) return MP_ERANGE;
-            mp_single_hit h;
-            h.read_id = tasks[t].read_id; h.strand = tasks[t].strand; h.algnmt = tasks[t].win_start + res[t].hit_loc; h.score = res[t].score;
-            h.count = res[t].max_score_count; h.win_start = tasks[t].win_start; h.win_len = tasks[t].win_len; h.reserved = 0;
-            out[w] = h;
-        }
-        w++;
-    }
-    *out_n = w;
+    *out_n = n;
     return MP_OK;
 }
 
 extern "C" int mp_get_rescue_hits(mp_ctx *c, mp_rescue_hit *out, uint64_t cap, uint64_t *out_n)
 {
-    if (!c || !c->rescued || !out_n) return MP_EINVAL;
-    HIPCHK(hipSetDevice(c->ix->device));
-    const uint32_t nf = c->n_failed_reads, n = c->n_stasks;
-    *out_n = 0;
-    if (nf == 0 || n == 0) return MP_OK;
-    std::vector<mp_dp_task> stasks(n), rtasks(4 * (size_t)nf);
-    std::vector<mp_dp_result> sres(n), rres(4 * (size_t)nf);
-    std::vector<uint32_t> rsrc(4 * (size_t)nf), lens(c->n_reads);
-    HIPCHK(hipMemcpy(stasks.data(), c->stasks.p, (size_t)n * sizeof(mp_dp_task), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(sres.data(), c->sres.p, (size_t)n * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(rtasks.data(), c->rtasks.p, rtasks.size() * sizeof(mp_dp_task), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(rres.data(), c->rres.p, rres.size() * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(rsrc.data(), c->rsrc.p, rsrc.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(lens.data(), c->d_lens, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
-    uint64_t w = 0;
-    for (size_t q = 0; q < rtasks.size(); q++) {
-        const uint32_t src = rsrc[q];
-        if (src == 0xFFFFFFFFu) continue;
-        const uint32_t un = rtasks[q].read_id;
-        if (rres[q].score <= 0 || rres[q].score < mp_dp_cutoff((int)lens[un])) continue;
-        if (out) {
-            if (w >= cap) return MP_ERANGE;
-            mp_rescue_hit h;
-            h.aligned_read = stasks[src].read_id; h.pair_id = h.aligned_read >> 1;
-            h.aligned_pos = stasks[src].win_start + sres[src].hit_loc; h.aligned_score = sres[src].score; h.aligned_strand = stasks[src].strand;
-            h.dp_pos = rtasks[q].win_start + rres[q].hit_loc; h.dp_score = rres[q].score; h.dp_strand = rtasks[q].strand;
-            h.aligned_win_start = stasks[src].win_start; h.aligned_win_len = stasks[src].win_len; h.aligned_count = sres[src].max_score_count;
-            h.dp_win_start = rtasks[q].win_start; h.dp_win_len = rtasks[q].win_len; h.dp_count = rres[q].max_score_count;
-            out[w] = h;
-        }
-        w++;
+    const mp_rescue_hit *v = nullptr;
+    uint64_t n = 0;
+    if (!out_n) return MP_EINVAL;
+    int rc = mp_get_rescue_hits_view(c, &v, &n);
+    if (rc) return rc;
+    if (out) {
+        if (n > cap) return MP_ERANGE;
+        if (n) memcpy(out, v, (size_t)n * sizeof(mp_rescue_hit));
     }
-    *out_n = w;
+    *out_n = n;
     return MP_OK;
 }
+
+// Test aid: the order single_cand_kernel sorts n_arrays lists of seed lengths into (array t = seed_len[off[t] .. off[t+1]));
+// out_perm[off[t] + k] = index inside array t of the seed that ends up at rank k.
+extern "C" int mp_test_sort_longer_seed(int device, const uint32_t *seed_len, const uint32_t *off, uint32_t n_arrays, uint32_t *out_perm)
+{
+    if (!seed_len || !off || !out_perm) return MP_EINVAL;
+    if (n_arrays == 0) return MP_OK;
+    int rc = mp_device_check(device, nullptr, 0);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    const uint32_t total = off[n_arrays];
+    std::vector<mp_single_cand> h(total + 1);
+    for (uint32_t t = 0; t < n_arrays; t++)
+        for (uint32_t i = off[t]; i < off[t + 1]; i++) { h[i].pos = i - off[t]; h[i].strand = 1; h[i].seed_len = seed_len[i]; }
+    mp_single_cand *d = nullptr; uint32_t *d_off = nullptr;
+    if (hipMalloc((void **)&d, (size_t)(total + 1) * sizeof(mp_single_cand)) != hipSuccess || hipMalloc((void **)&d_off, (size_t)(n_arrays + 1) * 4) != hipSuccess) {
+        if (d) (void)hipFree(d);
+        return MP_ENOMEM;
+    }
+    hipError_t e = hipMemcpy(d, h.data(), (size_t)total * sizeof(mp_single_cand), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off, off, (size_t)(n_arrays + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(sort_longer_seed_test_kernel, dim3(grid_for(n_arrays, 64)), dim3(64), 0, 0, d, d_off, n_arrays);
+        e = hipMemcpy(h.data(), d, (size_t)total * sizeof(mp_single_cand), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d); (void)hipFree(d_off);
+    if (e != hipSuccess) return MP_ENODEV;
+    for (uint32_t i = 0; i < total; i++) out_perm[i] = (uint32_t)h[i].pos;
+    return MP_OK;
+}
+

@@ -573,7 +573,6 @@ void gpu_stage(mp_ctx *ctx, Params &p, Batch &b, bool &first, bool bam, int thre
         p.insert_low = std::max(p.insert_low, (int)std::max(d1, d2));
         first = false;
     }
-    for (uint32_t r = 0; r < n_reads; r++) if (b.lens[r] < 30) { fprintf(stderr, "[soap4-mi355x] reads shorter than the DP cutoff (30) are undefined in the reference (CPU_DP.cpp:316-324)\n"); exit(1); }
     double t0 = now_s();
     die(mp_set_reads(ctx, b.packed.data(), b.W, b.lens.data(), n_reads), "mp_set_reads");
     st.t_upload += now_s() - t0; t0 = now_s();
@@ -597,14 +596,12 @@ void gpu_stage(mp_ctx *ctx, Params &p, Batch &b, bool &first, bool bam, int thre
         die(mp_rescue_round(ctx, &ap, p.skip_default_dp ? 1 : 0, &rst), "mp_rescue_round");
         b.dp_instances += rst.n_single_tasks + rst.n_rescue_tasks;
         uint64_t ns = 0, nr = 0;
-        die(mp_get_single_hits(ctx, nullptr, 0, &ns), "mp_get_single_hits");
-        b.singles.resize(ns + 1);
-        die(mp_get_single_hits(ctx, b.singles.data(), ns, &ns), "mp_get_single_hits");
-        b.singles.resize(ns);
-        die(mp_get_rescue_hits(ctx, nullptr, 0, &nr), "mp_get_rescue_hits");
-        b.resc.resize(nr + 1);
-        die(mp_get_rescue_hits(ctx, b.resc.data(), nr, &nr), "mp_get_rescue_hits");
-        b.resc.resize(nr);
+        const mp_single_hit *sv = nullptr;
+        const mp_rescue_hit *rv = nullptr;
+        die(mp_get_single_hits_view(ctx, &sv, &ns), "mp_get_single_hits_view");
+        b.singles.assign(sv, sv + ns);
+        die(mp_get_rescue_hits_view(ctx, &rv, &nr), "mp_get_rescue_hits_view");
+        b.resc.assign(rv, rv + nr);
     }
     st.t_rescue += now_s() - t0; t0 = now_s();
     if (bam) {

@@ -35,6 +35,89 @@ struct mp_single_cand { uint64_t pos; uint32_t strand; uint32_t seed_len; };
 
 #define MP_SINGLE_MAX 200      // DV-DPForSingleReads.cpp:200
 
+// std::sort with the comparator "longer seed first" as the reference's libstdc++ (g++ 11) carries it out, on one lane: the
+// permutation of equal-length seeds must be the reference's because only the first 200 candidates of a read are kept
+// (DV-DPForSingleReads.cpp:200).  Introsort: median of (first+1, middle, last-1) to `first`, Hoare partition of the rest,
+// right part first (explicit stack instead of recursion), ranges of <= 16 left alone; heap sort of a range when
+// 2*floor(log2 n) levels are used up; then one insertion pass, guarded for the first 16 elements only.
+#define MP_LSL(x, y) ((x).seed_len > (y).seed_len)
+__device__ __forceinline__ void mp_lsl_swap(mp_single_cand *a, int i, int j) { const mp_single_cand t = a[i]; a[i] = a[j]; a[j] = t; }
+
+__device__ void mp_lsl_sift(mp_single_cand *a, int hole, int len, mp_single_cand v)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (MP_LSL(a[child], a[child - 1])) child--;
+        a[hole] = a[child]; hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[hole] = a[child - 1]; hole = child - 1; }
+    int parent = (hole - 1) / 2;
+    while (hole > top && MP_LSL(a[parent], v)) { a[hole] = a[parent]; hole = parent; parent = (hole - 1) / 2; }
+    a[hole] = v;
+}
+
+__device__ void mp_sort_longer_seed(mp_single_cand *a, int n)
+{
+    if (n <= 1) return;
+    if (n > 16) {
+        int stk_first[64], stk_last[64], stk_depth[64];
+        int sp = 0;
+        stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * (31 - __clz(n)); sp = 1;
+        while (sp > 0) {
+            --sp;
+            const int first = stk_first[sp];
+            int last = stk_last[sp], depth = stk_depth[sp];
+            // the reference recurses into [cut, last) before it goes on with [first, cut): the two ranges are disjoint, so doing
+            // the left ones first and stacking the right ones gives the same array
+            while (last - first > 16) {
+                if (depth == 0) {
+                    mp_single_cand *h = a + first;
+                    const int len = last - first;
+                    for (int parent = (len - 2) / 2;; parent--) { mp_lsl_sift(h, parent, len, h[parent]); if (parent == 0) break; }
+                    for (int e = len; e > 1;) { --e; const mp_single_cand v = h[e]; h[e] = h[0]; mp_lsl_sift(h, 0, e, v); }
+                    break;
+                }
+                --depth;
+                const int x = first + 1, y = first + (last - first) / 2, z = last - 1;
+                if (MP_LSL(a[x], a[y])) { if (MP_LSL(a[y], a[z])) mp_lsl_swap(a, first, y); else if (MP_LSL(a[x], a[z])) mp_lsl_swap(a, first, z); else mp_lsl_swap(a, first, x); }
+                else if (MP_LSL(a[x], a[z])) mp_lsl_swap(a, first, x);
+                else if (MP_LSL(a[y], a[z])) mp_lsl_swap(a, first, z);
+                else mp_lsl_swap(a, first, y);
+                const uint32_t pivot = a[first].seed_len;
+                int lo = first + 1, hi = last;
+                for (;;) {
+                    while (a[lo].seed_len > pivot) ++lo;
+                    --hi;
+                    while (pivot > a[hi].seed_len) --hi;
+                    if (!(lo < hi)) break;
+                    mp_lsl_swap(a, lo, hi);
+                    ++lo;
+                }
+                if (sp < 64) { stk_first[sp] = lo; stk_last[sp] = last; stk_depth[sp] = depth; sp++; }
+                last = lo;
+            }
+        }
+    }
+    const int guarded = n > 16 ? 16 : n;
+    for (int i = 1; i < guarded; i++) {
+        const mp_single_cand v = a[i];
+        int j = i;
+        if (MP_LSL(v, a[0])) { for (; j > 0; j--) a[j] = a[j - 1]; }
+        else while (MP_LSL(v, a[j - 1])) { a[j] = a[j - 1]; j--; }
+        a[j] = v;
+    }
+    for (int i = guarded; i < n; i++) { const mp_single_cand v = a[i]; int j = i; while (MP_LSL(v, a[j - 1])) { a[j] = a[j - 1]; j--; } a[j] = v; }
+}
+
+// Test aid (mp_test_sort_longer_seed): one lane per array; array t holds off[t+1] - off[t] seeds whose `pos` carries the input index
+__global__ void sort_longer_seed_test_kernel(mp_single_cand *__restrict__ cand, const uint32_t *__restrict__ off, uint32_t n_arrays)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_arrays) mp_sort_longer_seed(cand + off[t], (int)(off[t + 1] - off[t]));
+}
+
 // One lane per failed read.  The read's kept seeds (the seed pool) sit at seedpos[rs_base[2r] ..) sorted by
 // (strand, pos), which is the order RadixTraitsCandidateInfo produces (DV-DPForSingleReads.cpp:108-118).
 // Candidates are written to cand[rs_base[2r] ..) (same capacity) and counted in n_cand[slot].
@@ -65,13 +148,9 @@ single_cand_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed,
         }
         out[nm++] = cur;
     }
-    // longest first (stable insertion sort: what std::sort does below 16 elements), drop < 0.6 x best, cap at 200
-    for (int i = 1; i < nm; i++) {
-        mp_single_cand t = out[i];
-        int j = i - 1;
-        while (j >= 0 && out[j].seed_len < t.seed_len) { out[j + 1] = out[j]; j--; }
-        out[j + 1] = t;
-    }
+    // longest first, in the very order std::sort(.., LongerSeedLength()) leaves equal lengths in (DV-DPfunctions.cpp:334):
+    // the cut at 200 below makes that order output-visible.  Then drop < 0.6 x best, cap at 200.
+    mp_sort_longer_seed(out, nm);
     while (nm > 0 && (double)out[nm - 1].seed_len < (double)out[0].seed_len * 0.6) nm--;
     if (nm > MP_SINGLE_MAX) nm = MP_SINGLE_MAX;
     n_cand[slot] = (uint32_t)nm;
@@ -125,7 +204,7 @@ mate_rescue_task_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_fa
     for (int q = 0; q < 4; q++) {
         mp_dp_task k; k.read_id = un; k.strand = 1; k.win_start = 0; k.win_len = 0; k.reserved = 0;
         uint32_t src = 0xFFFFFFFFu;
-        if (q < np) {
+        if (q < np && ulen >= MP_MIN_ALIGNABLE_LEN) {           // a mate below the cutoff floor cannot be rescued: no instance for it
             const uint32_t t = (uint32_t)pick[q];
             const uint64_t algn = stasks[t].win_start + sres[t].hit_loc;
             if (stasks[t].strand == 1) {                       // aligned mate is the left leg (DV-DPfunctions.cpp:1182-1205)
@@ -143,4 +222,50 @@ mate_rescue_task_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_fa
         rtasks[4 * slot + q] = k;
         rsrc[4 * slot + q] = src;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ hit lists of the rescue passes
+// The host wants only the instances that passed (a few per failed pair out of ~60 tasks): flag, exclusive scan, emit -- in task
+// order, so the lists are run-to-run identical -- into a device buffer that travels to pinned host memory in one DMA.
+__global__ void single_hit_flag_kernel(const mp_dp_task *__restrict__ tasks, const mp_dp_result *__restrict__ res, const uint32_t *__restrict__ lens,
+                                       uint32_t n, uint32_t *__restrict__ flag)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n) return;
+    flag[t] = (t < n && res[t].score > 0 && res[t].score >= mp_dp_cutoff((int)lens[tasks[t].read_id])) ? 1u : 0u;
+}
+
+__global__ void single_hit_emit_kernel(const mp_dp_task *__restrict__ tasks, const mp_dp_result *__restrict__ res, const uint32_t *__restrict__ flag,
+                                       const uint32_t *__restrict__ slot, uint32_t n, mp_single_hit *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || !flag[t]) return;
+    mp_single_hit h;
+    h.read_id = tasks[t].read_id; h.strand = tasks[t].strand; h.algnmt = tasks[t].win_start + res[t].hit_loc; h.score = res[t].score;
+    h.count = res[t].max_score_count; h.win_start = tasks[t].win_start; h.win_len = tasks[t].win_len; h.reserved = 0;
+    out[slot[t]] = h;
+}
+
+__global__ void rescue_hit_flag_kernel(const mp_dp_task *__restrict__ rtasks, const mp_dp_result *__restrict__ rres, const uint32_t *__restrict__ rsrc,
+                                       const uint32_t *__restrict__ lens, uint32_t n, uint32_t *__restrict__ flag)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > n) return;
+    flag[q] = (q < n && rsrc[q] != 0xFFFFFFFFu && rres[q].score > 0 && rres[q].score >= mp_dp_cutoff((int)lens[rtasks[q].read_id])) ? 1u : 0u;
+}
+
+__global__ void rescue_hit_emit_kernel(const mp_dp_task *__restrict__ stasks, const mp_dp_result *__restrict__ sres, const mp_dp_task *__restrict__ rtasks,
+                                       const mp_dp_result *__restrict__ rres, const uint32_t *__restrict__ rsrc, const uint32_t *__restrict__ flag,
+                                       const uint32_t *__restrict__ slot, uint32_t n, mp_rescue_hit *__restrict__ out)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n || !flag[q]) return;
+    const uint32_t src = rsrc[q];
+    mp_rescue_hit h;
+    h.aligned_read = stasks[src].read_id; h.pair_id = h.aligned_read >> 1;
+    h.aligned_pos = stasks[src].win_start + sres[src].hit_loc; h.aligned_score = sres[src].score; h.aligned_strand = stasks[src].strand;
+    h.dp_pos = rtasks[q].win_start + rres[q].hit_loc; h.dp_score = rres[q].score; h.dp_strand = rtasks[q].strand;
+    h.aligned_win_start = stasks[src].win_start; h.aligned_win_len = stasks[src].win_len; h.aligned_count = sres[src].max_score_count;
+    h.dp_win_start = rtasks[q].win_start; h.dp_win_len = rtasks[q].win_len; h.dp_count = rres[q].max_score_count;
+    out[slot[q]] = h;
 }

@@ -187,6 +187,7 @@ __global__ void prep_scan_kernel(const uint32_t *reads, const uint32_t *lens, ui
 // Seeds go to a fixed slab of MP_SEED_SLAB records per (read, strand) -- no atomics on the hot path; the rare item with
 // more seeds is listed in `overflow_rs` and redone by seed_overflow_kernel with a full-size slab.
 #define MP_SEED_SLAB 32
+#define MP_MIN_ALIGNABLE_LEN 30   // = mp_dp_cutoff(len) for every len <= 150: shorter reads cannot reach their cutoff
 #define MP_SEED_CHUNK 64
 
 struct mp_seed_rec { uint32_t sa_l; uint16_t query_offset, seed_len; uint32_t sa_diff; };   // 12 bytes
@@ -428,6 +429,10 @@ __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *sc
 {
     s.sc = scan + (uint64_t)rs * (W + 1);
     s.rs = rs; s.len = (int)lens[rs >> 1]; s.strand = (int)(rs & 1);
+    // A read below the DP cutoff floor (30 bases, definitions.h:166-167) can never pass a DP (its best possible score is its
+    // length), so it gets no seeds and therefore no DP instance: it ends up unaligned like any read without a hit.  (The
+    // reference gives up on the whole SIMD group such an instance falls into, CPU_DP.cpp:294-299 -- not reproduced.)
+    if (s.len < MP_MIN_ALIGNABLE_LEN) s.len = 0;
     s.i = 0; s.seed_len = 0; s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
     s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.upos = 0; s.uvalid = false; s.pe = 0; s.pg = -1000;
 }

@@ -98,7 +98,8 @@ class IndexInfo(C.Structure):
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
-           "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_bench_gather64", "mp_device_check", "mp_strerror"]
+           "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
+           "mp_test_sort_longer_seed"]
 
 
 def build_library(force: bool = False) -> str:
@@ -156,8 +157,11 @@ def load_library():
     lib.mp_rescue_round.argtypes = [vp, C.POINTER(AlignParams), C.c_int, C.POINTER(RescueStats)]
     lib.mp_get_single_hits.argtypes = [vp, vp, C.c_uint64, u64p]
     lib.mp_get_rescue_hits.argtypes = [vp, vp, C.c_uint64, u64p]
+    lib.mp_get_single_hits_view.argtypes = [vp, C.POINTER(vp), u64p]
+    lib.mp_get_rescue_hits_view.argtypes = [vp, C.POINTER(vp), u64p]
     lib.mp_bench_gather64.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]
     lib.mp_device_check.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    lib.mp_test_sort_longer_seed.argtypes = [C.c_int, vp, vp, C.c_uint32, vp]
     lib.mp_strerror.restype = C.c_char_p
     lib.mp_strerror.argtypes = [C.c_int]
     _lib = lib
@@ -175,6 +179,16 @@ for _i, _ch in enumerate(b"ACGT"):
     _CODE[_ch + 32] = _i
 _CODE[ord("U")] = _CODE[ord("u")] = 3
 _CODE[ord("N")] = _CODE[ord("n")] = 2
+
+
+def sort_longer_seed(seed_len_lists, device: int = 0):
+    """Test aid: the rank order single_cand_kernel gives each list of seed lengths (indices into the list)."""
+    off = np.zeros(len(seed_len_lists) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([len(x) for x in seed_len_lists])
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32) for x in seed_len_lists]) if len(seed_len_lists) else np.zeros(0, np.uint32))
+    perm = np.zeros(max(int(off[-1]), 1), dtype=np.uint32)
+    _chk(load_library().mp_test_sort_longer_seed(device, flat.ctypes.data, off.ctypes.data, len(seed_len_lists), perm.ctypes.data), "mp_test_sort_longer_seed")
+    return [perm[off[i]:off[i + 1]].copy() for i in range(len(seed_len_lists))]
 
 
 def pack_reads(seqs, max_read_length: int):
@@ -364,15 +378,18 @@ class Context:
         _chk(lib.mp_rescue_round(self._h, C.byref(params), 1 if skip_default_dp else 0, C.byref(st)), "mp_rescue_round")
         if not fetch:
             return None, None, st
-        n = C.c_uint64()
-        _chk(lib.mp_get_single_hits(self._h, None, 0, C.byref(n)), "mp_get_single_hits")
-        singles = (SingleHit * max(n.value, 1))()
-        _chk(lib.mp_get_single_hits(self._h, singles, n.value, C.byref(n)), "mp_get_single_hits")
-        ns = n.value
-        _chk(lib.mp_get_rescue_hits(self._h, None, 0, C.byref(n)), "mp_get_rescue_hits")
-        resc = (RescueHit * max(n.value, 1))()
-        _chk(lib.mp_get_rescue_hits(self._h, resc, n.value, C.byref(n)), "mp_get_rescue_hits")
-        return (singles, ns), (resc, n.value), st
+        return self.single_hits_view(), self.rescue_hits_view(), st
+
+    def single_hits_view(self):
+        """(hits, n): the passing single-end DP instances in the context's pinned buffer (valid until the next round)."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _chk(load_library().mp_get_single_hits_view(self._h, C.byref(ptr), C.byref(n)), "mp_get_single_hits_view")
+        return ((SingleHit * n.value).from_address(ptr.value) if n.value else (SingleHit * 1)()), n.value
+
+    def rescue_hits_view(self):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _chk(load_library().mp_get_rescue_hits_view(self._h, C.byref(ptr), C.byref(n)), "mp_get_rescue_hits_view")
+        return ((RescueHit * n.value).from_address(ptr.value) if n.value else (RescueHit * 1)()), n.value
 
     def deep_dp_round(self, params: AlignParams, fetch: bool = True):
         nh = C.c_uint64()

@@ -232,8 +232,6 @@ class PairAligner:
             d2 = int(lens[1::2][:999999].max()) if n_pairs else 100
             p.insert_low = max(p.insert_low, d1, d2)
             self._first_batch = False
-        if int(lens.min()) < 30:
-            raise ValueError("reads shorter than the DP cutoff (30) are undefined in the reference (CPU_DP.cpp:316-324)")
         ctx = self.ctx
         ctx.set_reads(packed, lens)
         ap = H.AlignParams(p.insert_low, p.insert_high, p.clip_left, p.clip_right, p.mmp)

@@ -160,6 +160,8 @@ typedef struct {
 } mpo_candidate;
 
 void mpo_default_params(mpo_align_params *p);
+/* std::sort(.., LongerSeedLength()) of singleMerge (DV-DPfunctions.cpp:334) as libstdc++ 11 permutes it (test hook) */
+void mpo_sort_longer_seed_perm(const uint32_t *seed_len, int n, int32_t *perm);
 
 #ifdef __cplusplus
 }

@@ -415,15 +415,87 @@ static int cmp_single_cand(const void *a, const void *b)
     return 0;
 }
 
-/* insertion sort by seed length descending: what std::sort does for < 16 elements (stable); longer lists fall back
- * to the same stable order -- libstdc++'s introsort tie order for > 16 equal-length seeds is not reproduced */
+/* std::sort(first, last, LongerSeedLength()) as singleMerge calls it (DV-DPfunctions.cpp:289-293,334).  The order among
+ * seeds of equal length is output-visible: transferSeed keeps the first 200 candidates of a read
+ * (DV-DPForSingleReads.cpp:200), so the permutation is restated here step for step.  The reference is built with
+ * g++ 11 / libstdc++ (oracle/Makefile.ref), whose std::sort is (bits/stl_algo.h: __sort, __introsort_loop,
+ * __unguarded_partition_pivot, __move_median_to_first, __final_insertion_sort; bits/stl_heap.h for the depth-limit
+ * fallback): quicksort on the median of (first+1, middle, last-1) moved to `first`, Hoare partition over
+ * [first+1, last), right part recursed, left part looped, until a range has <= 16 elements or 2*floor(log2 n) levels
+ * are used up (then heap sort of that range); finally one insertion sort pass over the whole array, guarded for the
+ * first 16 elements and unguarded after them.  Pinned by tests/golden/g2 (reads with > 200 tied candidates). */
+#define LSL_LESS(x, y) ((x).seed_len > (y).seed_len)      /* comp(x, y): x sorts before y */
+static void lsl_swap(single_cand *x, single_cand *y) { single_cand t = *x; *x = *y; *y = t; }
+
+static void lsl_sift(single_cand *a, int hole, int len, single_cand v)      /* __adjust_heap + __push_heap */
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (LSL_LESS(a[child], a[child - 1])) child--;
+        a[hole] = a[child]; hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[hole] = a[child - 1]; hole = child - 1; }
+    int parent = (hole - 1) / 2;
+    while (hole > top && LSL_LESS(a[parent], v)) { a[hole] = a[parent]; hole = parent; parent = (hole - 1) / 2; }
+    a[hole] = v;
+}
+
+static void lsl_heap_sort(single_cand *a, int n)            /* __partial_sort(first, last, last) */
+{
+    if (n >= 2) for (int parent = (n - 2) / 2;; parent--) { lsl_sift(a, parent, n, a[parent]); if (parent == 0) break; }
+    for (int last = n; last > 1;) { --last; single_cand v = a[last]; a[last] = a[0]; lsl_sift(a, 0, last, v); }
+}
+
+static void lsl_introsort_loop(single_cand *a, int first, int last, int depth)
+{
+    while (last - first > 16) {
+        if (depth == 0) { lsl_heap_sort(a + first, last - first); return; }
+        --depth;
+        single_cand *x = &a[first + 1], *y = &a[first + (last - first) / 2], *z = &a[last - 1], *res = &a[first];
+        if (LSL_LESS(*x, *y)) { if (LSL_LESS(*y, *z)) lsl_swap(res, y); else if (LSL_LESS(*x, *z)) lsl_swap(res, z); else lsl_swap(res, x); }
+        else if (LSL_LESS(*x, *z)) lsl_swap(res, x);
+        else if (LSL_LESS(*y, *z)) lsl_swap(res, z);
+        else lsl_swap(res, y);
+        int lo = first + 1, hi = last;
+        for (;;) {
+            while (LSL_LESS(a[lo], a[first])) ++lo;
+            --hi;
+            while (LSL_LESS(a[first], a[hi])) --hi;
+            if (!(lo < hi)) break;
+            lsl_swap(&a[lo], &a[hi]);
+            ++lo;
+        }
+        lsl_introsort_loop(a, lo, last, depth);
+        last = lo;
+    }
+}
+
 static void sort_longer_seed(single_cand *a, int n)
 {
-    for (int i = 1; i < n; i++) {
-        single_cand t = a[i]; int j = i - 1;
-        while (j >= 0 && a[j].seed_len < t.seed_len) { a[j + 1] = a[j]; j--; }
-        a[j + 1] = t;
+    if (n <= 0) return;
+    int lg = 0;
+    while ((n >> (lg + 1)) != 0) lg++;
+    lsl_introsort_loop(a, 0, n, 2 * lg);
+    /* __final_insertion_sort */
+    const int guarded = n > 16 ? 16 : n;
+    for (int i = 1; i < guarded; i++) {
+        single_cand v = a[i];
+        if (LSL_LESS(v, a[0])) { memmove(&a[1], &a[0], sizeof(single_cand) * (size_t)i); a[0] = v; }
+        else { int j = i; while (LSL_LESS(v, a[j - 1])) { a[j] = a[j - 1]; j--; } a[j] = v; }
     }
+    for (int i = guarded; i < n; i++) { single_cand v = a[i]; int j = i; while (LSL_LESS(v, a[j - 1])) { a[j] = a[j - 1]; j--; } a[j] = v; }
+}
+
+/* test hook: the permutation sort_longer_seed applies to n seeds of the given lengths (perm[k] = input index at rank k) */
+void mpo_sort_longer_seed_perm(const uint32_t *seed_len, int n, int32_t *perm)
+{
+    single_cand *a = (single_cand *)malloc(sizeof(single_cand) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) { a[i].read_id = (uint32_t)i; a[i].pos = 0; a[i].strand = 1; a[i].seed_len = seed_len[i]; }
+    sort_longer_seed(a, n);
+    for (int i = 0; i < n; i++) perm[i] = (int32_t)a[i].read_id;
+    free(a);
 }
 
 static int cmp_single_result(const void *a, const void *b)

@@ -98,6 +98,7 @@ def oracle():
                                       C.POINTER(C.c_int), C.POINTER(SeedPos), C.POINTER(C.c_int), C.c_int,
                                       C.POINTER(SeedCounters)]
         lib.mpo_default_params.argtypes = [C.POINTER(AlignParams)]
+        lib.mpo_sort_longer_seed_perm.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.mpo_align_fastq.argtypes = [C.c_void_p, C.POINTER(AlignParams), C.c_char_p, C.c_char_p, C.c_char_p,
                                         C.c_char_p, C.POINTER(AlignStats)]
         lib.mpo_align_fastq_bam.argtypes = [C.c_void_p, C.POINTER(AlignParams), C.c_char_p, C.c_char_p, C.c_char_p,

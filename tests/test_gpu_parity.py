@@ -226,11 +226,6 @@ def test_dp_matches_reference_vectors(golden_dir, tmp_path):
     ix.close()
 
 
-def _oracle_pair_hits(oidx, seqs, L, params):
-    """deep-DP hits of the oracle, recomputed stage by stage (seeds -> pairs -> DP) with ctypes calls."""
-    raise NotImplementedError
-
-
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_deep_dp_round_matches_reference_records(gidx, oidx, golden_dir, tmp_path, tag):
     """The deep-DP round on the GPU must reproduce, for every pair the oracle aligns in that round, the same best pair
@@ -274,3 +269,21 @@ def test_deep_dp_round_matches_reference_records(gidx, oidx, golden_dir, tmp_pat
         assert (gidx.seq_name(c1), p1, best[2]) == w[1]
         assert (gidx.seq_name(c2), p2, best[3]) == w[2]
     ctx.close()
+
+
+def test_device_longer_seed_sort_is_the_reference_order(golden_dir):
+    """single_cand_kernel's candidate order (std::sort with LongerSeedLength, DV-DPfunctions.cpp:334): recorded libstdc++
+    permutations and the oracle on random tie-rich arrays."""
+    lib = O.oracle()
+    v = np.load(os.path.join(golden_dir, "sort_vectors.npz"))
+    lists = [v["seed_len"][int(v["off"][a]):int(v["off"][a + 1])] for a in range(len(v["off"]) - 1)]
+    got = H.sort_longer_seed(lists)
+    for a, g in enumerate(got):
+        assert np.array_equal(g.astype(np.int64), v["perm"][int(v["off"][a]):int(v["off"][a + 1])].astype(np.int64)), a
+    rng = np.random.default_rng(11)
+    lists = [(17 + rng.integers(0, int(rng.integers(1, 9)), size=int(rng.integers(0, 1500)))).astype(np.uint32) for _ in range(400)]
+    got = H.sort_longer_seed(lists)
+    for a, (lens, g) in enumerate(zip(lists, got)):
+        perm = np.zeros(max(len(lens), 1), dtype=np.int32)
+        lib.mpo_sort_longer_seed_perm(np.ascontiguousarray(lens).ctypes.data, len(lens), perm.ctypes.data)
+        assert np.array_equal(g.astype(np.int64), perm[:len(lens)].astype(np.int64)), a

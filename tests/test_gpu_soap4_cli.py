@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import oracle_lib as O
@@ -246,3 +247,55 @@ def test_cli_longest_supported_reads(tmp_path):
     open(f4, "wb").write(b"@x/2\n" + b"TGCA" * 97 + b"\n+\n" + b"I" * 388 + b"\n")
     r = subprocess.run(cmd[:3] + [f3, f4] + cmd[5:] + ["-L", "389"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"mp_" in r.stderr
+
+
+@pytest.mark.parametrize("driver", ["cxx", "py"])
+@pytest.mark.parametrize("tag,L", [("t", 301), ("s", 151)])
+def test_cli_g2_tied_candidates_and_unseedable_reads(golden_dir, tmp_path, tag, L, driver):
+    """g2/t: reads with > 200 tied single-end candidates -- the survivors of the cut at 200 depend on the tie order of the
+    reference's std::sort (DV-DPfunctions.cpp:334, DV-DPForSingleReads.cpp:200); g2/s: mates of 1..16 bases.  Both are the
+    real reference's stdout."""
+    d = os.path.join(golden_dir, "g2")
+    out = tmp_path / "out.fq"
+    _run_cli(["pair", os.path.join(d, "ref.fa.index"), os.path.join(d, "reads_%s_1.fq" % tag), os.path.join(d, "reads_%s_2.fq" % tag),
+              "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L), "-T", "2", "-u", "750", "-F", "-nc"],
+             out, driver=driver)
+    assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_%s.fq" % tag))
+
+
+def test_cli_reads_below_the_dp_cutoff_do_not_abort_or_hurt_neighbours(golden_dir, tmp_path):
+    """Reads of 17..29 bases can be seeded but never reach the cutoff floor of 30.  The reference gives up on the whole SIMD
+    group such a DP instance shares (CPU_DP.cpp:294-299): not reproduced.  Here they come out unaligned, every other read
+    as the oracle aligns it, also with -b."""
+    from megapath_amd import synth
+    d = os.path.join(golden_dir, "g1")
+    prefix = os.path.join(d, "ref.fa.index")
+    genome = []
+    name, seq = None, []
+    for line in open(os.path.join(d, "ref.fa"), "rb").read().split(b"\n"):
+        if line.startswith(b">"):
+            if name:
+                genome.append((name, np.frombuffer(b"".join(seq), dtype=np.uint8)))
+            name, seq = line[1:].decode(), []
+        elif line:
+            seq.append(line)
+    genome.append((name, np.frombuffer(b"".join(seq), dtype=np.uint8)))
+    names, r1, r2 = synth.simulate_pairs(genome, 300, 150, 4242, sub=0.01, len_range=(30, 150), broken_mate_frac=0.1)
+    rng = np.random.default_rng(5)
+    for k in range(len(names)):
+        if k % 3 == 0:
+            r1[k] = r1[k][:int(rng.integers(17, 30))]
+        if k % 4 == 0:
+            r2[k] = r2[k][:int(rng.integers(1, 30))]
+    f1, f2 = str(tmp_path / "w_1.fq"), str(tmp_path / "w_2.fq")
+    synth.write_fastq_pair(f1, f2, names, r1, r2)
+    for extra in ([], ["-b"]):
+        cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix, f1, f2, "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
+               "-L", "151", "-T", "2", "-u", "750", "-F", "-nc"] + extra
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        got = tmp_path / "got_short.fq"
+        got.write_bytes(r.stdout)
+        recs = fastq_records(str(got))
+        assert recs == fastq_records(_oracle_stdout(prefix, f1, f2, 151, tmp_path))
+        assert all("SCORE:0;" in x[2] for x in recs if len(x[3]) < 30)

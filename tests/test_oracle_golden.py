@@ -102,3 +102,41 @@ def test_bam_records_match_reference_bam(g1_prefix, golden_dir, tmp_path, tag):
         assert got[k] == want[k], k
     assert want["header"].startswith(got["header"])          # the reference appends its own @PG line
     assert open(tmp_path / "o.fq", "rb").read() == open(os.path.join(g, "expected_%s.fq" % tag), "rb").read()
+
+
+# ------------------------------------------------------------------------------------------------ g2: corners g1 does not reach
+def test_longer_seed_sort_is_libstdcxx_introsort(golden_dir):
+    """singleMerge's std::sort(.., LongerSeedLength()) (DV-DPfunctions.cpp:334): the oracle's restatement of libstdc++'s
+    introsort against permutations recorded from the real std::sort (tests/golden/make_golden_sort.py)."""
+    lib = O.oracle()
+    v = np.load(os.path.join(golden_dir, "sort_vectors.npz"))
+    n_big = 0
+    for a in range(len(v["off"]) - 1):
+        lo, hi = int(v["off"][a]), int(v["off"][a + 1])
+        lens = np.ascontiguousarray(v["seed_len"][lo:hi], dtype=np.uint32)
+        perm = np.zeros(max(hi - lo, 1), dtype=np.int32)
+        lib.mpo_sort_longer_seed_perm(lens.ctypes.data, hi - lo, perm.ctypes.data)
+        assert np.array_equal(perm[:hi - lo], v["perm"][lo:hi]), a
+        n_big += hi - lo > 16 and not np.array_equal(perm[:hi - lo], np.argsort(-lens.astype(np.int64), kind="stable"))
+    assert n_big > 20          # the fixture does contain arrays a stable sort orders differently
+
+
+@pytest.mark.parametrize("tag,L", [("t", 301), ("s", 151)])
+def test_g2_tied_candidates_and_unseedable_reads(golden_dir, tmp_path, tag, L):
+    """g2/t: reads with > 200 single-end candidates of equal seed length -- which 200 survive the cut
+    (DV-DPForSingleReads.cpp:200) depends on std::sort's tie order; g2/s: mates of 1..16 bases."""
+    lib = O.oracle()
+    d = os.path.join(golden_dir, "g2")
+    ix = lib.mpo_index_open(os.path.join(d, "ref.fa.index").encode())
+    p = O.default_params(L=L, insert_high=750, mode=1, top=95)
+    st = O.AlignStats()
+    out = tmp_path / "out.fq"
+    rc = lib.mpo_align_fastq(ix, C.byref(p), os.path.join(d, "reads_%s_1.fq" % tag).encode(), os.path.join(d, "reads_%s_2.fq" % tag).encode(),
+                             str(out).encode(), None, C.byref(st))
+    lib.mpo_index_close(ix)
+    assert rc == 0
+    got, want = fastq_records(str(out)), fastq_records(os.path.join(d, "expected_%s.fq" % tag))
+    assert got == want
+    if tag == "t":
+        capped = [r for r in want if r[0].startswith("f") and r[2].count(",") == 200]
+        assert len(capped) == 10       # every tied read was cut at 200 candidates

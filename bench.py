@@ -2,15 +2,28 @@
 """bench.py -- paired 150 bp reads aligned per second against a 2BWT index on MI355X (BASELINE.json metric).
 
 One process per GPU (`torchrun`-style env: RANK / LOCAL_RANK / WORLD_SIZE).  Reads shard across ranks, the index is
-replicated into every GPU's HBM, no data-path collective: `"scaling": "weak"`.  A *step* is one
-pass of the hot path over one batch of synthetic pairs whose packed reads already sit in HBM.
+replicated into every GPU's HBM, no data-path collective: `"scaling": "weak"`; the per-reference
+hit counters of the step are what the ranks all-reduce afterwards (RCCL), as the `reassign` pass 1 they feed would.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields `roofline` and `cpu_baseline`).
+A *step* is one pass of the whole hot path over one batch of synthetic pairs: upload of the packed reads (pinned host
+memory -> HBM), deep-DP round (MMP seeding, locate, merge, pairing, both DP legs with traceback, hit assembly), rescue
+round (single-end DP, mate rescue) and the arrival of all three hit lists in pinned host memory.
+
+Prints ONE JSON line on rank 0.  Besides the contract fields:
+  roofline        seed stage (K1 + K2), priced with the bytes of the events that really load memory; `traffic` = HBM bytes
+                  per launch from rocprofv3 counters collected LIVE in two child runs of this script (FETCH_SIZE,
+                  WRITE_SIZE in separate passes); the work the short cuts stand for is in `equivalent_work`, not in `frac`
+  dp              cells the DP kernels really compute (device census of one untimed step) over their time
+  cpu_baseline    the real reference soap4 (oracle/_ref, when it travelled with the snapshot) on all host cores
+  parity_sample   the same 100 k pairs through the product executable, record by record against that soap4's stdout
+  legs            C3 / C4 / C5 workload shapes, two steps each, with their kernel split
 """
 from __future__ import annotations
 
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
 import shutil
@@ -26,61 +39,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SEED_STAGE_KERNELS = ("seed_kernel", "seed_overflow_kernel", "expand_hits_kernel", "locate_kernel")
+PMC_REGEX = "gather64_kernel|seed_kernel|seed_overflow_kernel|locate_kernel|expand_hits_kernel"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
-
-
-def cpu_baseline(args, text_cpu, arrs, sample_codes, tmpdir, lkt_table=None):
-    """Times the CPU path on a bounded sample of the same workload, on the host cores of this box.
-    kind = "reference": the real soap4 built by oracle/Makefile.ref (oracle/_ref/soap4 travels with the snapshot);
-    kind = "port": the plain-C oracle when that binary is absent."""
-    from megapath_amd import index_builder, simulate
-    n_pairs = sample_codes.shape[0] // 2
-    fq1, fq2 = os.path.join(tmpdir, "s_1.fq"), os.path.join(tmpdir, "s_2.fq")
-    codes = sample_codes.cpu().numpy()
-    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-    qual = b"I" * codes.shape[1]
-    with open(fq1, "wb") as f1, open(fq2, "wb") as f2:
-        for p in range(n_pairs):
-            f1.write(b"@r%d/1\n" % p + lut[codes[2 * p]].tobytes() + b"\n+\n" + qual + b"\n")
-            f2.write(b"@r%d/2\n" % p + lut[codes[2 * p + 1]].tobytes() + b"\n+\n" + qual + b"\n")
-    prefix = os.path.join(tmpdir, "ref.index")
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "soap4")
-    use_ref = os.path.exists(ref_bin)
-    index_builder.write_index_files(prefix, arrs, write_lkt=use_ref, lkt_table=lkt_table if use_ref else None)
-    cores = min(os.cpu_count() or 1, 16)
-    if use_ref:
-        ini = os.path.join(tmpdir, "soap4-nt2.ini")
-        with open(ini, "w") as f:
-            f.write(NT2_INI)
-        cmd = [ref_bin, "pair", prefix, fq1, fq2, "-o", os.path.join(tmpdir, "out"), "-C", ini, "-L", str(args.read_len + 1),
-               "-T", str(cores), "-u", "750", "-F", "-nc"]
-        t0 = time.time()
-        with open(os.path.join(tmpdir, "ref.out"), "wb") as fo, open(os.path.join(tmpdir, "ref.err"), "wb") as fe:
-            rc = subprocess.call(cmd, stdout=fo, stderr=fe)
-        wall = time.time() - t0
-        align_s = None
-        for line in open(os.path.join(tmpdir, "ref.err"), errors="replace"):
-            if "Overall alignment time" in line:
-                align_s = float(line.split(":")[1].split()[0])
-        if rc != 0 or not align_s:
-            log("[bench] reference soap4 failed (rc=%d); wall %.1fs" % (rc, wall))
-            return None
-        return {"value": n_pairs / align_s, "unit": "pairs/s", "cores": cores, "kind": "reference",
-                "sample": "%d pairs of the same workload, real soap4 (-T %d), alignment phase only (index/read load excluded)" % (n_pairs, cores)}
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    lib = O.oracle()
-    ix = lib.mpo_index_open(prefix.encode())
-    p = O.default_params(L=args.read_len + 1)
-    st = O.AlignStats()
-    t0 = time.time()
-    lib.mpo_align_fastq(ix, C.byref(p), fq1.encode(), fq2.encode(), os.path.join(tmpdir, "o.fq").encode(), None, C.byref(st))
-    dt = time.time() - t0
-    return {"value": n_pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": "%d pairs of the same workload, scalar C oracle, whole path" % n_pairs}
 
 
 NT2_INI = """[Database]
@@ -137,6 +101,235 @@ mmpShortSeedRatio=0.5
 """
 
 
+# ------------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """A batch of synthetic pairs in pinned host memory (what a reader thread hands to the device stage)."""
+
+    def __init__(self, text, n_pairs, seed, read_len=150, L=None, **sim):
+        from megapath_amd import simulate
+        codes, lens = simulate.paired_reads(text, n_pairs, read_len, seed=seed, **sim)
+        self.max_len = int(codes.shape[1])
+        self.L = L if L is not None else self.max_len + 1             # the -L value: maxReadLength, reads are cut to L - 1
+        self.W = (self.L + 15) // 16
+        packed = simulate.pack_codes(codes, self.W)
+        self.codes = codes
+        self.n_pairs = n_pairs
+        self.sum_len = int(lens.sum().item())
+        self.packed_h = packed.cpu().pin_memory()
+        self.lens_h = lens.cpu().pin_memory()
+        self.packed_np = self.packed_h.numpy().view(np.uint32)
+        self.lens_np = self.lens_h.numpy().view(np.uint32)
+        del packed
+
+
+def step(ctx, wl, params, fetch_all=True):
+    """One pass of the hot path over a batch (see the module docstring)."""
+    ctx.set_reads(wl.packed_np, wl.lens_np)                      # H2D of the packed reads
+    _, nh, st = ctx.deep_dp_round(params, fetch=False)           # the pair hits start travelling to the host ...
+    _, _, rst = ctx.rescue_round(params, False, fetch=False)     # ... while the rescue passes run; their hits follow
+    hits, nh = ctx.pair_hits_view()                              # the step ends when all three lists have arrived
+    singles = resc = None
+    if fetch_all:
+        singles, ns = ctx.single_hits_view()
+        resc, nr = ctx.rescue_hits_view()
+    return hits, nh, st, rst
+
+
+def run_steps(ctx, wl, params, n_steps, barrier=None):
+    acc = {}
+
+    def add(k, v):
+        acc[k] = acc.get(k, 0) + v
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        _, nh, st, rst = step(ctx, wl, params)
+        for k, v in (("seed", st.seed.ms_seed), ("locate", st.seed.ms_locate), ("merge", st.seed.ms_merge), ("pair", st.ms_pair),
+                     ("fill", st.ms_dp_fill), ("trace", st.ms_dp_trace), ("rescue_tasks", rst.ms_tasks), ("rescue_fill", rst.ms_dp_fill),
+                     ("rescue_trace", rst.ms_dp_trace)):
+            add("ms_" + k, v)
+        s = st.seed
+        for k in ("n_occ", "n_occ_loaded", "n_lkt", "n_lkt16", "n_sa", "n_seedpos", "n_prefilter", "n_prefilter_loads", "n_text_words", "n_steps_skipped",
+                  "n_seeds", "n_hits"):
+            add(k, int(getattr(s, k)))
+        add("cand", int(st.n_candidates)); add("pair_hits", int(st.n_pair_hits))
+        add("failed", int(rst.n_failed_pairs)); add("stasks", int(rst.n_single_tasks)); add("rtasks", int(rst.n_rescue_tasks))
+        add("single_hits", int(rst.n_single_hits)); add("rescue_hits", int(rst.n_rescue_hits))
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, acc
+
+
+def loaded_bytes(acc, sum_len_per_step, n_steps):
+    """Bytes the seed stage's kernels request from memory, by event (each counted by the kernels themselves):
+    64 B per rank block loaded, 8 B per look-up in the 13-mer / 16-mer tables (two adjacent 32-bit bounds), 8 B per pre-filter
+    entry loaded, 4 B per suffix-array entry, 8 B per 16-base text word compared, 0.25 B per read base (2-bit reads),
+    16 B per kept seed position written."""
+    return (64 * acc["n_occ_loaded"] + 8 * (acc["n_lkt"] + acc["n_lkt16"]) + 8 * acc["n_prefilter_loads"] + 4 * acc["n_sa"] + 8 * acc["n_text_words"]
+            + 0.25 * sum_len_per_step * n_steps + 16 * acc["n_seedpos"])
+
+
+# ------------------------------------------------------------------------------------------------ PMC child runs
+def pmc_pass(counter, args, tmpdir):
+    """Runs this script once more under rocprofv3 with ONE counter (separate passes, MI355X_MICROARCH.md) and returns
+    {kernel: [value per launch]}.  The child does one step of the same workload; its last launch of each seed-stage kernel is
+    the timed configuration."""
+    out_dir = os.path.join(tmpdir, "pmc_" + counter)
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-include-regex", PMC_REGEX, "--output-format", "csv", "-d", out_dir, "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "0", "--genome-mbp", str(args.genome_mbp),
+           "--pairs-per-step", str(args.pairs_per_step), "--read-len", str(args.read_len)]
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    if r.returncode != 0:
+        log("[bench] rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-400:]))
+        return None
+    per = {}
+    for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row.get("Counter_Name") == counter:
+                per.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+    log("[bench] PMC pass %s: %.0f s, kernels %s" % (counter, time.time() - t0, {k: len(v) for k, v in per.items()}))
+    return per
+
+
+def live_traffic(args, tmpdir):
+    if shutil.which("rocprofv3") is None:
+        return None
+    fetch = pmc_pass("FETCH_SIZE", args, tmpdir)
+    write = pmc_pass("WRITE_SIZE", args, tmpdir) if fetch else None
+    if not fetch or not write:
+        return None
+    per_kernel = {}
+    total = 0.0
+    for k in SEED_STAGE_KERNELS:
+        f = fetch.get(k, [0.0])[-1] * 1024.0                       # the counters are in KiB
+        w = write.get(k, [0.0])[-1] * 1024.0
+        per_kernel[k] = {"fetch_bytes": f, "write_bytes": w}
+        total += f + w
+    g = fetch.get("gather64_kernel")
+    calib = (sum(g) / len(g)) * 1024.0 / float(1 << 33) if g else None    # the calibration kernel requests exactly 2^33 B per launch
+    return {"bytes_per_launch": total, "per_kernel": per_kernel, "gather64_calibration_ratio": calib,
+            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate child runs of this script (one step each), last launch of each "
+                      "seed-stage kernel; KiB x 1024; not rescaled (FETCH_SIZE reads 1.0x the requested bytes for random 64-B sector gathers, see the ratio)"}
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline + parity sample
+def write_fastq(codes, n_pairs, fq1, fq2):
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    qual = b"I" * codes.shape[1]
+    with open(fq1, "wb") as f1, open(fq2, "wb") as f2:
+        for p in range(n_pairs):
+            f1.write(b"@r%d/1\n" % p + lut[codes[2 * p]].tobytes() + b"\n+\n" + qual + b"\n")
+            f2.write(b"@r%d/2\n" % p + lut[codes[2 * p + 1]].tobytes() + b"\n+\n" + qual + b"\n")
+
+
+def fastq_records(path):
+    """annotated FASTQ -> {(name, occurrence): (header, seq, qual)}; record order is not part of the contract."""
+    out, seen = {}, {}
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    for i in range(0, len(lines) - 3, 4):
+        name = lines[i][1:].split(b"\t")[0]
+        seen[name] = seen.get(name, 0) + 1
+        out[(name, seen[name])] = (lines[i], lines[i + 1], lines[i + 3])
+    return out
+
+
+def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device, read_L):
+    """Real soap4 (oracle/_ref, built by oracle/Makefile.ref and shipped with the snapshot) on a bounded sample of the bench
+    workload, on all host cores; then the same sample through the product executable, compared record by record."""
+    from megapath_amd import index_builder
+    n_pairs = sample_codes.shape[0] // 2
+    fq1, fq2 = os.path.join(tmpdir, "s_1.fq"), os.path.join(tmpdir, "s_2.fq")
+    write_fastq(sample_codes.cpu().numpy(), n_pairs, fq1, fq2)
+    prefix = os.path.join(tmpdir, "ref.index")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "soap4")
+    use_ref = os.path.exists(ref_bin)
+    index_builder.write_index_files(prefix, arrs, write_lkt=use_ref, lkt_table=lkt_table if use_ref else None)
+    cores = os.cpu_count() or 1
+    ini = os.path.join(tmpdir, "soap4-nt2.ini")
+    with open(ini, "w") as f:
+        f.write(NT2_INI)
+    cb, parity = None, None
+    ref_out = os.path.join(tmpdir, "ref.out")
+    if use_ref:
+        # all host cores, as the north star asks, and a second run at 32 threads (soap4's own thread scaling flattens long before
+        # the 256 hardware threads of such a node); the faster one is the baseline, both are listed
+        runs = []
+        for T in sorted({cores, min(cores, 32)}, reverse=True):
+            cmd = [ref_bin, "pair", prefix, fq1, fq2, "-o", os.path.join(tmpdir, "out"), "-C", ini, "-L", str(read_L), "-T", str(T), "-u", "750", "-F", "-nc"]
+            t0 = time.time()
+            with open(ref_out + ".T%d" % T, "wb") as fo, open(os.path.join(tmpdir, "ref.err"), "wb") as fe:
+                rc = subprocess.call(cmd, stdout=fo, stderr=fe)
+            wall = time.time() - t0
+            align_s = None
+            for line in open(os.path.join(tmpdir, "ref.err"), errors="replace"):
+                if "Overall alignment time" in line:
+                    align_s = float(line.split(":")[1].split()[0])
+            if rc != 0 or not align_s:
+                log("[bench] reference soap4 -T %d failed (rc=%d); wall %.1fs" % (T, rc, wall))
+                continue
+            runs.append({"threads": T, "pairs_per_s": n_pairs / align_s, "alignment_s": align_s, "process_s": wall})
+            if not os.path.exists(ref_out):
+                os.replace(ref_out + ".T%d" % T, ref_out)
+        if runs:
+            best = max(runs, key=lambda r: r["pairs_per_s"])
+            cb = {"value": best["pairs_per_s"], "unit": "pairs/s", "cores": best["threads"], "host_cores": cores, "kind": "reference", "runs": runs,
+                  "sample": "%d pairs of the same workload, real soap4 (oracle/_ref), alignment phase only (index/read load excluded), best of -T %s on "
+                            "this box's %d host cores" % (n_pairs, "/".join(str(r["threads"]) for r in runs), cores)}
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        lib = O.oracle()
+        ix = lib.mpo_index_open(prefix.encode())
+        p = O.default_params(L=read_L)
+        st = O.AlignStats()
+        few = min(n_pairs, 4000)
+        f1s, f2s = os.path.join(tmpdir, "few_1.fq"), os.path.join(tmpdir, "few_2.fq")
+        write_fastq(sample_codes.cpu().numpy(), few, f1s, f2s)
+        t0 = time.time()
+        lib.mpo_align_fastq(ix, C.byref(p), f1s.encode(), f2s.encode(), ref_out.encode(), None, C.byref(st))
+        dt = time.time() - t0
+        cb = {"value": few / dt, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": "%d pairs of the same workload, scalar C oracle, whole path" % few}
+        fq1, fq2, n_pairs = f1s, f2s, few
+    # ---- parity at the benchmarked scale: the drop-in executable on the same files, every optional table on
+    exe = os.path.join(ROOT, "bin", "soap4-mi355x")
+    if os.path.exists(exe) and os.path.exists(ref_out) and os.path.getsize(ref_out) > 0:
+        prod_out = os.path.join(tmpdir, "prod.out")
+        env = dict(os.environ)
+        env["MP_DEVICE"] = str(device)
+        env.pop("LOCAL_RANK", None)
+        cmd = [exe, "pair", prefix, fq1, fq2, "-o", os.path.join(tmpdir, "pout"), "-C", ini, "-L", str(read_L), "-T", str(min(cores, 32)), "-u", "750", "-F", "-nc"]
+        t0 = time.time()
+        with open(prod_out, "wb") as fo, open(os.path.join(tmpdir, "prod.err"), "wb") as fe:
+            rc = subprocess.call(cmd, stdout=fo, stderr=fe, env=env)
+        if rc != 0:
+            parity = {"pairs": n_pairs, "records_equal": False, "first_diff": "product executable failed (rc %d): %s" % (
+                rc, open(os.path.join(tmpdir, "prod.err"), errors="replace").read()[-300:])}
+        else:
+            want, got = fastq_records(ref_out), fastq_records(prod_out)
+            diff = [k for k in want if got.get(k) != want[k]] + [k for k in got if k not in want]
+            first = None
+            if diff:
+                k = sorted(diff)[0]
+                first = {"record": "%s #%d" % (k[0].decode(), k[1]), "reference": want.get(k, (b"<absent>",))[0].decode(errors="replace")[:300],
+                         "product": got.get(k, (b"<absent>",))[0].decode(errors="replace")[:300]}
+            aligned = sum(1 for v in want.values() if b"SCORE:0;" not in v[0])
+            parity = {"pairs": n_pairs, "records": len(want), "records_equal": not diff, "records_differing": len(diff), "first_diff": first,
+                      "reference_records_with_a_hit": aligned, "against": cb["kind"] if cb else None,
+                      "how": "bin/soap4-mi355x pair <same index files> <same FASTQ> -L %d -u 750 -F -nc (whole-process %.0f s), stdout compared with the "
+                             "CPU run's, record by record, order-insensitive" % (read_L, time.time() - t0)}
+    return cb, parity
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,8 +339,13 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=int(os.environ.get("MP_BENCH_PAIRS", str(1 << 20))))
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MP_BENCH_CPU_PAIRS", "100000")))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity sample")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs (roofline.traffic = null)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the C3/C4/C5 workload legs")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        args.no_cpu_baseline = args.no_pmc = args.no_legs = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,9 +365,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    barrier = dist.barrier if world > 1 else None
 
     from megapath_amd import hipapi as H
-    from megapath_amd import index_builder, simulate
+    from megapath_amd import index_builder, simulate, taxcount
 
     n_bases = int(args.genome_mbp * 1e6)
     t0 = time.time()
@@ -193,80 +392,45 @@ def main():
         log("[bench] random 64-B gather ceiling over the rank blocks: %.0f GB/s" % gather_gbs)
 
     P = args.pairs_per_step
-    W = (args.read_len + 1 + 15) // 16
-    codes, lens = simulate.paired_reads(text, P, args.read_len, seed=1000 + rank)
-    packed = simulate.pack_codes(codes, W)
-    lens_i = lens.contiguous()
+    wl = Workload(text, P, seed=1000 + rank, read_len=args.read_len)
     ctx = H.Context(gix)
-    ctx.set_reads_device(packed.data_ptr(), W, lens_i.data_ptr(), 2 * P, args.read_len, keep=(packed, lens_i))
     params = H.AlignParams(args.read_len, 750, 130, 130, H.MmpParams.nt2())
-    lib = H.load_library()
 
-    def one_step():
-        # a new batch arrives: forget the seeds of the previous one, then run the whole path on the device:
-        # deep-DP round (seed, locate, merge, pair, both DP legs) and the rescue passes of the pairs it left unaligned
-        ctx.set_reads_device(packed.data_ptr(), W, lens_i.data_ptr(), 2 * P, args.read_len, keep=(packed, lens_i))
-        _, nh, st = ctx.deep_dp_round(params, fetch=False)             # the hits start travelling to the host ...
-        _, _, rst = ctx.rescue_round(params, False, fetch=False)       # ... while the rescue passes run
-        hits, nh = ctx.pair_hits_view()                                # the step ends when they have arrived
-        return hits, nh, st, rst
-
-    for _ in range(args.warmup):
-        one_step()
-    # Event counts of the reference algorithm for this batch (every table look-up and rank query soap4 itself issues):
-    # one untimed step with the index's 17-mer pre-filter ignored.  SURVEY 8d prices the seed stage with these.
-    ref_events = None
-    if gix.info.prefilter_k:
-        ctx.set_prefilter(False)
-        _, _, st0, _ = one_step()
-        ref_events = dict(occ=int(st0.seed.n_occ), lkt=int(st0.seed.n_lkt), sa=int(st0.seed.n_sa), seedpos=int(st0.seed.n_seedpos))
-        ctx.set_prefilter(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    tstart = time.perf_counter()
-    acc = dict(seed=0.0, locate=0.0, merge=0.0, pair=0.0, fill=0.0, trace=0.0, occ=0, lkt=0, sa=0, seedpos=0, kmer=0, cand=0, hits=0,
-               rescue_fill=0.0, rescue_trace=0.0, rescue_tasks=0.0, failed=0, stasks=0, rtasks=0)
+    for _ in range(max(args.warmup, 0 if args.pmc_child else 1)):
+        step(ctx, wl, params)
+    census = ref_events = None
+    if not args.pmc_child:
+        # two untimed steps over the same resident batch: (1) the cells every DP launch computes, counted on the device;
+        # (2) the look-ups of the reference algorithm itself -- every optional table ignored -- for `equivalent_work`
+        ctx.set_dp_census(True)
+        step(ctx, wl, params)
+        census = ctx.dp_census()
+        ctx.set_dp_census(False)
+        if gix.info.prefilter_k:
+            ctx.set_prefilter(False)
+            _, _, st0, _ = step(ctx, wl, params)
+            ref_events = dict(occ=int(st0.seed.n_occ), lkt=int(st0.seed.n_lkt), sa=int(st0.seed.n_sa), seedpos=int(st0.seed.n_seedpos))
+            ctx.set_prefilter(True)
     band0 = ctx.dp_band_stats()
-    for _ in range(args.steps):
-        hits, nh, st, rst = one_step()
-        acc["rescue_fill"] += rst.ms_dp_fill; acc["rescue_trace"] += rst.ms_dp_trace; acc["rescue_tasks"] += rst.ms_tasks
-        acc["failed"] += rst.n_failed_pairs; acc["stasks"] += rst.n_single_tasks; acc["rtasks"] += rst.n_rescue_tasks
-        acc["seed"] += st.seed.ms_seed; acc["locate"] += st.seed.ms_locate; acc["merge"] += st.seed.ms_merge
-        acc["pair"] += st.ms_pair; acc["fill"] += st.ms_dp_fill; acc["trace"] += st.ms_dp_trace
-        acc["occ"] += st.seed.n_occ; acc["lkt"] += st.seed.n_lkt; acc["sa"] += st.seed.n_sa; acc["seedpos"] += st.seed.n_seedpos
-        acc["kmer"] += st.seed.n_prefilter; acc["blk"] = acc.get("blk", 0) + st.seed.n_occ_loaded
-        acc["cand"] += st.n_candidates; acc["hits"] += st.n_pair_hits
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - tstart
+    elapsed, acc = run_steps(ctx, wl, params, args.steps, barrier)
+    band1 = ctx.dp_band_stats()
+    # the exchange step of the path: per-reference hit counts of this rank's last step, summed over the ranks
+    hits, nh = ctx.pair_hits_view()
+    ref_counts = taxcount.count_pair_hits_per_reference(gix, hits, nh)
     if world > 1:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ref_counts = taxcount.allreduce_counts(ref_counts, dev if backend == "nccl" else "cpu")
 
-    band1 = ctx.dp_band_stats()
     if rank == 0:
         K = args.steps
         total_pairs = world * K * P
-        # ---- roofline of the seed stage (K1 + K2): algorithmic bytes from the event counters the kernels emit
-        # B_seed = 64*N_occ + 16*N_lkt + 8*N_sa + 0.25*sum(read_len) + 16*N_seedpos   
-        # with the events of the reference algorithm (every step processes the same resident batch); what the kernels
-        # actually issued (fewer look-ups when the 17-mer pre-filter is resident, 4 B per bit probe) is reported next to it
-        ev = ref_events if ref_events else dict(occ=acc["occ"] / K, lkt=acc["lkt"] / K, sa=acc["sa"] / K, seedpos=acc["seedpos"] / K)
-        b_seed = K * (64 * ev["occ"] + 16 * ev["lkt"] + 8 * ev["sa"] + 0.25 * (2 * P * args.read_len) + 16 * ev["seedpos"])
-        b_exec = 64 * acc["occ"] + 16 * acc["lkt"] + 8 * acc["sa"] + 0.25 * (2 * P * K * args.read_len) + 16 * acc["seedpos"] + 4 * acc["kmer"]
-        t_seed_s = (acc["seed"] + acc["locate"]) / 1e3
-        # `achieved` is priced with the events the kernels themselves performed and counted ("counters the kernel emits",
-        # N_occ = 2 per backward-extension step performed -- whether the step loaded rank blocks or was taken by the 16-mer table or by
-        # comparing with the text; starts the 17-mer pre-filter rejects perform no steps).  The rank blocks actually loaded are in
-        # events_per_pair.rank_blocks_loaded; the rate at which the reference algorithm's look-ups are delivered is reported next to it
-        achieved = b_exec / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
-        achieved_ref = b_seed / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
-        kernel_ms = {k: acc[k] / K for k in ("seed", "locate", "merge", "pair", "fill", "trace", "rescue_tasks", "rescue_fill", "rescue_trace")}
-        n_inst = 2 * acc["cand"] + acc["stasks"] + acc["rtasks"]
-        cells = (2 * acc["cand"] + acc["stasks"]) * (args.read_len + 61) * args.read_len + acc["rtasks"] * (750 - args.read_len + args.read_len + 1) * args.read_len
+        t_seed_s = (acc["ms_seed"] + acc["ms_locate"]) / 1e3
+        b_loaded = loaded_bytes(acc, wl.sum_len, K)
+        achieved = b_loaded / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
+        kernel_ms = {k[3:]: acc[k] / K for k in acc if k.startswith("ms_")}
+        per_pair = lambda k: acc[k] / (K * P)      # noqa: E731
         out = {
             "metric": "paired 150bp reads aligned/sec vs 2BWT index",
             "value": total_pairs / elapsed,
@@ -275,57 +439,113 @@ def main():
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "2x%dbp synthetic pairs vs synthetic %.0f Mbp genome in 24 sequences (human-filter stage; GRCh38 indexes ~2.95 Gbp of non-N bases), %d pairs/step/GPU, "
-                                   "whole path on the device: deep-DP round (MMP seeding, pairing, both DP legs + traceback) and rescue passes (single-end DP, mate rescue)" % (args.read_len, args.genome_mbp, P),
+            "config": {"workload": "2x%dbp synthetic pairs vs synthetic %.0f Mbp genome in 24 sequences (BASELINE configs[1], human-filter stage; GRCh38 indexes ~2.95 Gbp of "
+                                   "non-N bases), %d pairs/step/GPU; a step = upload of the packed reads + deep-DP round (MMP seeding, pairing, both DP legs + traceback) + "
+                                   "rescue round (single-end DP, mate rescue) + all three hit lists back in pinned host memory" % (args.read_len, args.genome_mbp, P),
                        "index_replicated_per_gpu": True, "pairs_per_step_per_gpu": P, "genome_mbp": args.genome_mbp,
-                       "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750},
-            "roofline": {"bound": "hbm", "kernel": "seed_kernel+locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "random64_gather_ceiling_gbs": gather_gbs, "frac_of_gather_ceiling": achieved / gather_gbs,
-                         "algorithmic_bytes_per_pair": b_exec / (K * P), "algorithmic_bytes_per_launch": b_exec / K,
-                         "launch_ms": (acc["seed"] + acc["locate"]) / K,
-                         "reference_algorithm": {"bytes_per_pair": b_seed / (K * P), "bytes_per_launch": b_seed / K, "delivered_gbs": achieved_ref,
-                                                 "frac_of_peak": achieved_ref / HBM_PEAK_GBS,
-                                                 "note": "look-ups soap4 itself issues for this batch (one untimed step with the 17-mer pre-filter "
-                                                         "and the dense SA samples ignored); the timed kernels skip most of them"},
-                         "prefilter_k": int(gix.info.prefilter_k)},
+                       "index_bytes_in_hbm": int(gix.info.device_bytes), "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750},
+            "roofline": {"bound": "hbm", "kernel": "seed_kernel+seed_overflow_kernel+expand_hits_kernel+locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": b_loaded / K, "bytes_per_pair": b_loaded / (K * P), "launch_ms": (acc["ms_seed"] + acc["ms_locate"]) / K,
+                         "formula": "64*rank_blocks_loaded + 8*(lkt13 + lkt16 look-ups) + 8*prefilter_entries_loaded + 4*sa_reads + 8*text_words_compared + "
+                                    "0.25*read_bases + 16*seed_positions_out; every count is emitted by the kernels (events_per_pair) and only events "
+                                    "that load memory are priced",
+                         "random64_gather_ceiling_gbs": gather_gbs,
+                         "note": "dependent random 4..64-byte gathers: the physical ceiling of this access shape is the measured random-64-B-gather rate, "
+                                 "not the streaming peak; traffic_frac / frac_of_gather_ceiling say how close the sectors actually moved come to either"},
             "kernel_ms_per_step": kernel_ms,
-            "dp": {"bound": "valu", "unit": "Gcells/s", "achieved": cells / ((acc["fill"] + acc["rescue_fill"]) / 1e3) / 1e9 if acc["fill"] else 0.0,
-                   "instances_per_step": n_inst / K,
-                   "band_instances_per_step": (band1[0] - band0[0]) / K, "band_left_to_full_table_per_step": (band1[1] - band0[1]) / K,
-                   "note": "integer max/add recurrences: VALU-bound, no MFMA, not an HBM roofline (SURVEY 8d).  `achieved` counts the "
-                           "full-table cells of every instance (SURVEY 8d) over the DP fill time; the deep-DP legs run exact banded kernels (a "
-                           "block-match pre-filter confines each alignment to 27 of its window's ~211 diagonals, perfect matches need no "
-                           "table) and hand the instances they cannot decide to the full-table kernels; the rescue batches go through a "
-                           "score-only filter first"},
-            "events_per_pair": {"occ": ev["occ"] / P, "lkt": ev["lkt"] / P, "sa": ev["sa"] / P,
-                                "executed_occ": acc["occ"] / (K * P), "rank_blocks_loaded": acc.get("blk", 0) / (K * P), "executed_lkt": acc["lkt"] / (K * P),
-                                "prefilter_probes": acc["kmer"] / (K * P),
-                                "candidates": acc["cand"] / (K * P), "pair_hits": acc["hits"] / (K * P),
-                                "failed_pairs": acc["failed"] / (K * P), "single_dp_tasks": acc["stasks"] / (K * P), "rescue_dp_tasks": acc["rtasks"] / (K * P)},
+            "events_per_pair": {"rank_queries_issued": per_pair("n_occ"), "rank_blocks_loaded": per_pair("n_occ_loaded"), "lkt13_lookups": per_pair("n_lkt"),
+                                "lkt16_lookups": per_pair("n_lkt16"), "sa_reads": per_pair("n_sa"), "prefilter_probes": per_pair("n_prefilter"),
+                                "prefilter_entries_loaded": per_pair("n_prefilter_loads"), "text_words_compared": per_pair("n_text_words"),
+                                "extension_steps_skipped": per_pair("n_steps_skipped"), "seeds": per_pair("n_seeds"), "located_hits": per_pair("n_hits"),
+                                "seed_positions_out": per_pair("n_seedpos"), "candidates": per_pair("cand"), "pair_hits": per_pair("pair_hits"),
+                                "failed_pairs": per_pair("failed"), "single_dp_tasks": per_pair("stasks"), "rescue_dp_slots": per_pair("rtasks"),
+                                "single_hits": per_pair("single_hits"), "rescue_hits": per_pair("rescue_hits")},
+            "hit_count_allreduce": {"references": int(len(ref_counts)), "pair_hits_counted": int(ref_counts.sum()), "ranks": world},
         }
-        # HBM traffic of the seed stage from the committed PMC passes (separate rocprofv3 --pmc runs of this very command,
-        # profiles/r01_pmc_seed_stage.json); only quoted when the workload is the one those passes measured
+        # ---- what the short cuts stand for (NOT in frac): the same walk priced as if every step had issued its rank queries,
+        # and the reference algorithm's own look-ups (SURVEY 8d formula, reference layouts: 64 B/occ, 16 B/lkt, 8 B/sa)
+        eq_occ = acc["n_occ"] + 2 * acc["n_steps_skipped"]
+        eq = {"rank_queries_incl_skipped_steps_per_pair": eq_occ / (K * P),
+              "note": "extension steps the 16-mer table and the in-text comparison stand for, counted as 2 rank queries each; no memory is touched for them"}
+        if ref_events:
+            b_ref = 64 * ref_events["occ"] + 16 * ref_events["lkt"] + 8 * ref_events["sa"] + 0.25 * wl.sum_len + 16 * ref_events["seedpos"]
+            eq["reference_algorithm"] = {"bytes_per_pair": b_ref / P, "events_per_pair": {k: v / P for k, v in ref_events.items()},
+                                         "delivered_gbs": b_ref * K / t_seed_s / 1e9 if t_seed_s > 0 else 0.0,
+                                         "note": "every table look-up and rank query soap4 itself issues for this batch (one untimed step with the optional "
+                                                 "tables ignored), SURVEY 8d prices; 'delivered' = those bytes over the timed kernels' duration -- a work-"
+                                                 "equivalent rate, not a bandwidth"}
+        out["equivalent_work"] = eq
+        # ---- DP: cells the kernels really compute (census step) over the DP fill time
+        t_dp_s = (acc["ms_fill"] + acc["ms_rescue_fill"]) / 1e3 / K
+        if census is not None and t_dp_s > 0:
+            computed = census.cells_band_score + census.cells_band_trace + census.cells_full_score + census.cells_full_trace
+            out["dp"] = {"bound": "valu", "unit": "Gcells/s", "achieved": computed / t_dp_s / 1e9,
+                         "cells_computed_per_step": {"band_score_pass": int(census.cells_band_score), "band_traceback_pass": int(census.cells_band_trace),
+                                                     "full_table_score_only": int(census.cells_full_score), "full_table_with_traceback": int(census.cells_full_trace)},
+                         "instances_per_step": int(census.instances),
+                         "full_table_equivalent": {"cells_per_step": int(census.cells_full_table), "gcells_per_s": census.cells_full_table / t_dp_s / 1e9,
+                                                   "note": "(window+1) x read length of every instance submitted (SURVEY 8d; what callDP computes): a work-equivalent "
+                                                           "rate, the kernels skip most of these cells"},
+                         "band_instances_per_step": (band1[0] - band0[0]) / K, "band_left_to_full_table_per_step": (band1[1] - band0[1]) / K,
+                         "fill_ms_per_step": t_dp_s * 1e3,
+                         "note": "integer max/add recurrences: VALU-bound, no MFMA, not an HBM roofline (SURVEY 8d).  Cells counted on the device by "
+                                 "mp_ctx_set_dp_census in one untimed step of the same batch; empty mate-rescue slots and instances the block-match "
+                                 "pre-filter finishes as exact matches compute no cells.  VALU occupancy per kernel: profiles/ (SQ counter pass)"}
+        tmpdir = tempfile.mkdtemp(prefix="mpbench_")
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_seed_stage.json")))
-            wl = pmc["workload"]
-            if wl["genome_mbp"] == args.genome_mbp and wl["pairs_per_step"] == P and wl["read_len"] == args.read_len:
-                out["roofline"]["traffic"] = pmc["seed_stage_hbm_bytes_per_launch"]
-                # VALU occupancy of the DP kernels from the committed SQ-counter pass of this command (profiles/r01_pmc_dp_valu.json)
-                valu = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dp_valu.json")))["per_kernel"]
-                out["dp"]["valu_busy_frac"] = {k.replace("void ", ""): round(v["valu_busy_frac"], 3) for k, v in valu.items()}
-        except Exception:  # noqa: BLE001
-            pass
-        cb = None
-        if world == 1 and not args.no_cpu_baseline:
-            tmpdir = tempfile.mkdtemp(prefix="mpbench_")
-            try:
-                cb = cpu_baseline(args, text_cpu, arrs, codes[: 2 * min(args.cpu_sample_pairs, P)], tmpdir, lkt_table=gix.lkt_table())
-            except Exception as e:  # noqa: BLE001 -- the baseline is auxiliary; report its absence, never hide the GPU number
-                log("[bench] cpu baseline failed: %r" % (e,))
-            finally:
-                shutil.rmtree(tmpdir, ignore_errors=True)
-        out["cpu_baseline"] = cb
+            if world == 1 and not args.no_pmc:
+                try:
+                    tr = live_traffic(args, tmpdir)
+                except Exception as e:  # noqa: BLE001
+                    log("[bench] PMC passes failed: %r" % (e,))
+                    tr = None
+                if tr:
+                    rf = out["roofline"]
+                    rf["traffic"] = tr["bytes_per_launch"]
+                    t_launch = rf["launch_ms"] / 1e3
+                    rf["traffic_gbs"] = tr["bytes_per_launch"] / t_launch / 1e9
+                    rf["traffic_frac"] = rf["traffic_gbs"] / HBM_PEAK_GBS
+                    rf["frac_of_gather_ceiling"] = rf["traffic_gbs"] / gather_gbs
+                    rf["traffic_over_requested"] = tr["bytes_per_launch"] / rf["bytes_per_launch"]
+                    rf["traffic_detail"] = tr
+            cb = parity = None
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    cb, parity = cpu_baseline_and_parity(args, arrs, wl.codes[: 2 * min(args.cpu_sample_pairs, P)], tmpdir, gix.lkt_table(), local_rank, args.read_len + 1)
+                except Exception as e:  # noqa: BLE001 -- the baseline is auxiliary; report its absence, never hide the GPU number
+                    log("[bench] cpu baseline / parity sample failed: %r" % (e,))
+            out["cpu_baseline"] = cb
+            out["parity_sample"] = parity
+        finally:
+            shutil.rmtree(tmpdir, ignore_errors=True)
+        # ---- workload legs: the other configs' read shapes against the same index (sensitivity of the fast paths)
+        if world == 1 and not args.no_legs:
+            legs = {}
+            specs = [
+                ("C3_divergent", "2x150 bp, per-pair divergence uniform 0-8 %, 40 % random pairs (NT-stage read mix)", dict(read_len=150, sub_max=0.08, random_frac=0.4)),
+                ("C4_2x250", "2x250 bp, -L 251, fragments ~N(450,50): 311-row windows, 32-lane DP shapes", dict(read_len=250, frag_mean=450.0, frag_sd=50.0, frag_max=700)),
+                ("C5_mixed_rescue", "lengths uniform 75-300 (-L 301), 30 % of pairs with one mate random: rescue stress", dict(
+                    read_len=300, len_range=(75, 300), broken_mate_frac=0.3, frag_mean=450.0, frag_sd=50.0, frag_max=700)),
+            ]
+            for name, desc, sim in specs:
+                try:
+                    lp = max(P // 4, 1 << 16)
+                    lw = Workload(text, lp, seed=2000 + len(legs), **sim)
+                    lpar = H.AlignParams(lw.max_len, 750, 130, 130, H.MmpParams.nt2())
+                    lctx = H.Context(gix)
+                    step(lctx, lw, lpar)
+                    el, la = run_steps(lctx, lw, lpar, 2)
+                    legs[name] = {"workload": desc, "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3,
+                                  "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")},
+                                  "per_pair": {"candidates": la["cand"] / (2 * lp), "pair_hits": la["pair_hits"] / (2 * lp), "failed_pairs": la["failed"] / (2 * lp),
+                                               "single_dp_tasks": la["stasks"] / (2 * lp), "rank_blocks_loaded": la["n_occ_loaded"] / (2 * lp)}}
+                    lctx.close()
+                    del lw
+                except Exception as e:  # noqa: BLE001
+                    legs[name] = {"workload": desc, "error": repr(e)}
+                    log("[bench] leg %s failed: %r" % (name, e))
+            out["legs"] = legs
         print(json.dumps(out), flush=True)
     ctx.close()
     gix.close()

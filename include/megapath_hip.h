@@ -118,13 +118,22 @@ typedef struct {              /* DeepDP_Space::SeedPos (SeedPool.h:52-57) */
 } mp_seedpos;
 
 typedef struct {
-    uint64_t n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos;   /* event counts for the roofline */
+    /* Event counts of the seed stage (K1 + K2), emitted by the kernels.  Only events that touch memory are counted here:
+     *   n_occ        rank queries issued: 2 per backward-extension step carried out on the rank blocks, 1 per LF step of locate
+     *   n_occ_loaded 64-byte rank blocks loaded for them (the two queries of a step share one block when the SA range is narrow)
+     *   n_lkt        13-mer table look-ups (LT.h:49-55), n_lkt16: look-ups in the optional 16-mer table
+     *   n_sa         suffix-array entries read (BWTSaValue, BWT.c:968-998; and the position of a single-row match)
+     * With every optional table off (mp_ctx_set_prefilter(ctx, 0)) these are the reference algorithm's own counts. */
+    uint64_t n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos;
     float ms_seed, ms_locate, ms_merge;                        /* HIP-event kernel times of this call */
     float reserved;
-    uint64_t n_prefilter;                                      /* 17-mer bitmap probes (0 when the pre-filter is off) */
-    uint64_t n_occ_loaded;     /* rank queries that loaded a rank block.  n_occ counts, as SURVEY 8d defines it, 2 per backward-
-                                * extension step (+1 per LF step of locate) whichever way the step was carried out: steps taken by
-                                * the 16-mer table or by comparing with the text load no rank block */
+    uint64_t n_prefilter;                                      /* pre-filter probes answered (0 when the pre-filter is off) */
+    uint64_t n_occ_loaded;
+    uint64_t n_lkt16;
+    uint64_t n_prefilter_loads;    /* table entries loaded for the probes (one 8-byte entry per 15-mer answers up to three) */
+    uint64_t n_text_words;         /* 16-base text words compared in place of rank queries (single-row matches) */
+    uint64_t n_steps_skipped;      /* extension steps never carried out: 3 per 16-mer look-up + 1 per base matched in the text;
+                                    * n_occ + 2 * n_steps_skipped = rank queries of the same walk without those short cuts */
 } mp_seed_stats;
 
 int mp_seed_batch(mp_ctx *ctx, const mp_mmp_params *params, mp_seed_stats *out_stats);
@@ -198,6 +207,18 @@ int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n
  * how many instances went through the band kernel and how many of those were re-run, since the context was created. */
 int mp_ctx_set_dp_band(mp_ctx *ctx, int on);
 int mp_ctx_dp_band_stats(mp_ctx *ctx, uint64_t *out_n_band, uint64_t *out_n_full);
+/* Measurement aid.  While on, every DP launch of the rounds also adds up the cells it computes (one small extra kernel per
+ * launch, so leave it off in timed runs): `cells_full_table` = (window + 1) x read length of every instance submitted --
+ * the work SURVEY 8d defines and the reference's callDP does -- next to what the kernels here really compute: band kernels
+ * band-width x read length per pass (score pass, traceback pass), the full-table kernels all of it (score-only filter,
+ * fill with traceback).  Instances the block-match pre-filter finishes as exact matches compute nothing.  Switching it on
+ * clears the counters. */
+typedef struct {
+    uint64_t instances, cells_full_table;
+    uint64_t cells_band_score, cells_band_trace, cells_full_score, cells_full_trace;
+} mp_dp_census;
+int mp_ctx_set_dp_census(mp_ctx *ctx, int on);
+int mp_ctx_get_dp_census(mp_ctx *ctx, mp_dp_census *out);
 int mp_get_pair_hits(mp_ctx *ctx, mp_pair_hit *out_hits, uint64_t cap);
 /* Same without a pageable copy: the hits land in a pinned buffer owned by the context (valid until the next round).  The
  * transfer is started by mp_deep_dp_round itself on a copy stream; this call waits for it, so a mp_rescue_round issued in

@@ -36,6 +36,8 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+enum { CENSUS_INSTANCES = 0, CENSUS_FULL_EQUIV = 1, CENSUS_BAND_SCORE = 2, CENSUS_BAND_TRACE = 3, CENSUS_FULL_SCORE = 4, CENSUS_FULL_TRACE = 5, CENSUS_SLOTS = 6 };
+
 inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 }  // namespace
@@ -97,6 +99,8 @@ struct mp_ctx {
     DevBuf<mp_dp_result> sres, rres;
     uint32_t n_failed_reads = 0, n_stasks = 0;
     bool rescued = false;
+    bool census_on = false;                      // mp_ctx_set_dp_census: count the cells each DP kernel family computes
+    DevBuf<unsigned long long> census;           // [instances, full-table cells, band score, band trace, full score, full trace]
     bool deep_done = false;                      // mp_deep_dp_round ran for the reads now set (mp_rescue_round needs its hits)
     hipEvent_t ev_round[3] = {};                 // whole-call timing of mp_deep_dp_round / mp_rescue_round
     // passing instances of the rescue passes, compacted on the device and copied to pinned memory behind the compute stream
@@ -590,6 +594,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     if (c->ev_rescue_copied) (void)hipEventDestroy(c->ev_rescue_copied);
     if (c->h_single_hits) (void)hipHostFree(c->h_single_hits);
     if (c->h_rescue_hits) (void)hipHostFree(c->h_rescue_hits);
+    c->census.release();
     c->sh_flag.release(); c->sh_slot.release(); c->rh_flag.release(); c->rh_slot.release(); c->d_single_hits.release(); c->d_rescue_hits.release();
     c->band_flag.release(); c->band_idx.release(); c->near_flag.release(); c->near_idx.release(); c->near_list.release(); c->far_flag.release(); c->far_idx.release();
     c->far_list.release(); c->pre_cls.release(); c->narrow_list.release(); c->wide_list.release(); c->mid_flag.release(); c->mid_idx.release(); c->mid_list.release();
@@ -717,8 +722,10 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     mp_seed_stats st{};
-    st.n_occ = h.n_occ; st.n_lkt = h.n_lkt; st.n_sa = h.n_sa; st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
+    st.n_occ = h.n_occ; st.n_lkt = h.n_lkt;
+    st.n_sa = h.n_sa + (h.n_hits - h.n_located);      // seed_kernel's reads for single-row matches + one per hit locate had to look up st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
     st.n_seeds = h.n_seeds; st.n_prefilter = h.n_kmer; st.n_occ_loaded = h.n_occ_loaded;
+    st.n_lkt16 = h.n_lkt16; st.n_prefilter_loads = h.n_kmer_loads; st.n_text_words = h.n_text_words; st.n_steps_skipped = h.n_steps_skipped;
     float ms_over = 0;
     (void)hipEventElapsedTime(&st.ms_seed, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&ms_over, c->ev[8], c->ev[9]);     // items redone with the full-size slab belong to K1
@@ -741,6 +748,30 @@ extern "C" int mp_ctx_set_dp_band(mp_ctx *c, int on)
 {
     if (!c) return MP_EINVAL;
     c->use_band = on != 0;
+    return MP_OK;
+}
+
+extern "C" int mp_ctx_set_dp_census(mp_ctx *c, int on)
+{
+    if (!c) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    if (on) {
+        if (c->census.reserve(CENSUS_SLOTS)) return MP_ENOMEM;
+        HIPCHK(hipMemsetAsync(c->census.p, 0, CENSUS_SLOTS * sizeof(unsigned long long), c->stream));
+    }
+    c->census_on = on != 0;
+    return MP_OK;
+}
+
+extern "C" int mp_ctx_get_dp_census(mp_ctx *c, mp_dp_census *out)
+{
+    if (!c || !out || !c->census.p) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    unsigned long long h[CENSUS_SLOTS];
+    HIPCHK(hipMemcpyAsync(h, c->census.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    out->instances = h[CENSUS_INSTANCES]; out->cells_full_table = h[CENSUS_FULL_EQUIV]; out->cells_band_score = h[CENSUS_BAND_SCORE];
+    out->cells_band_trace = h[CENSUS_BAND_TRACE]; out->cells_full_score = h[CENSUS_FULL_SCORE]; out->cells_full_trace = h[CENSUS_FULL_TRACE];
     return MP_OK;
 }
 
@@ -779,6 +810,14 @@ extern "C" int mp_get_seeds(mp_ctx *c, mp_seedpos *out_seeds, uint64_t cap, uint
 
 // ------------------------------------------------------------------------------------------------ DP
 namespace {
+
+// adds the cells one kernel launch computes to the census (no-op unless the caller switched the census on)
+void census_add(mp_ctx *c, int family, const mp_dp_task *d_tasks, const uint32_t *list, uint32_t n, uint32_t band_w)
+{
+    if (!c->census_on || n == 0 || !c->census.p) return;
+    hipLaunchKernelGGL(dp_census_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_tasks, list, n, c->d_lens, band_w, c->census.p + family,
+                       family == CENSUS_FULL_EQUIV ? c->census.p + CENSUS_INSTANCES : (unsigned long long *)nullptr);
+}
 
 struct DpShape { int lpi, c, nw; };
 
@@ -877,6 +916,7 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
     MP_DP_DISPATCH(fill_round, c, count, &round);
     if (round >= 2 && chunk > round && chunk < n) chunk = chunk / round * round;      // whole rounds of resident blocks per launch
     if (c->flags.reserve(((size_t)chunk / 2 + 1) * per_pair) || c->fill.reserve(chunk + 2)) return MP_ENOMEM;
+    census_add(c, CENSUS_FULL_TRACE, d_tasks, nullptr, n, 0);
     float tf = 0, tt = 0;
     const size_t n_chunks = (n + chunk - 1) / chunk;
     while (c->ev_pool.size() < 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
@@ -917,6 +957,7 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     hipStream_t s = c->stream;
     if (c->fill.reserve(n + 2) || c->sel_flag.reserve(n + 2) || c->sel_idx.reserve(n + 2)) return MP_ENOMEM;
     while (c->ev_pool.size() < 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    census_add(c, CENSUS_FULL_SCORE, d_tasks, nullptr, n, 0);
     HIPCHK(hipEventRecord(c->ev_pool[0], s));
     MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p);
     HIPCHK(hipEventRecord(c->ev_pool[1], s));
@@ -959,6 +1000,7 @@ int band_second_pass(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *list,
     // and read by the caller once the stream has drained
     if (n_c == 0) return MP_OK;
     hipStream_t s = c->stream;
+    census_add(c, CENSUS_BAND_TRACE, d_tasks, list, n_c, W2);
     const uint32_t ncols = c->max_len;
     const bool small = c->max_len <= 160;
     const size_t per_block = (size_t)ncols * ((W2 + 2) / 3) * 64 * 4;
@@ -1030,6 +1072,7 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     if (n_narrow) {
         hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->narrow_list.p, in_list);
         const dim3 g1((n_narrow + 127) / 128);
+        census_add(c, CENSUS_BAND_SCORE, d_tasks, c->narrow_list.p, n_narrow, 2 * GBUD + 1);
         if (small)
             hipLaunchKernelGGL((dp_band_kernel<2 * GBUD + 1, GBUD, 160, 3>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_narrow, cl, cr,
                                (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p, (const uint32_t *)c->narrow_list.p);
@@ -1042,6 +1085,7 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     if (TIER1 && n_wide >= 1024) {
         hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->wide_list.p, in_list);
         const dim3 g1((n_wide + 127) / 128);
+        census_add(c, CENSUS_BAND_SCORE, d_tasks, c->wide_list.p, n_wide, MP_BAND_W);
         if (small)
             hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, 160, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                                d_tasks, n_wide, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->wide_list.p);
@@ -1155,6 +1199,7 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
         while (c->ev_pool.size() < 3 * n_chunks) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
         uint32_t *slab = (uint32_t *)c->flags.p;
         size_t ci = 0;
+        census_add(c, CENSUS_BAND_TRACE, d_tasks, nullptr, n, MP_BAND_W);
         for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks, ci++) {
             const uint32_t off = b0 * 128u;
             const uint32_t cnt = (uint32_t)std::min<uint64_t>((uint64_t)chunk_blocks * 128u, n - off);
@@ -1276,11 +1321,13 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         const uint32_t max_win = c->max_len + margin2;
         const bool use_band = band_applicable(c, max_win, ap->clip_left, ap->clip_right);
         hipLaunchKernelGGL(build_left_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, c->tasks_l.p);
+        census_add(c, CENSUS_FULL_EQUIV, c->tasks_l.p, nullptr, nc, 0);
         rc = use_band ? run_dp_band(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0)
                       : run_dp(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         hipLaunchKernelGGL(build_right_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, ap->insert_high,
                            c->tasks_l.p, c->res_l.p, c->tasks_r.p);
+        census_add(c, CENSUS_FULL_EQUIV, c->tasks_r.p, nullptr, nc, 0);
         rc = use_band ? run_dp_band(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0)
                       : run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
@@ -1424,6 +1471,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
         hipLaunchKernelGGL(single_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->scand.p, c->rs_base.p, c->n_scand.p,
                            c->s_off.p, c->d_lens, c->ix->n, c->stasks.p);
         HIPCHK(hipEventRecord(t1, s));
+        census_add(c, CENSUS_FULL_EQUIV, c->stasks.p, nullptr, nst, 0);
         const uint32_t max_win = c->max_len + 60;
         rc = run_dp_filtered(c, c->stasks.p, nst, max_win, ap->clip_left, ap->clip_right, c->sres.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
@@ -1432,6 +1480,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
                                c->d_lens, c->ix->n, ap->insert_low, ap->insert_high, c->rtasks.p, c->rsrc.p);
             const uint32_t rwin = (uint32_t)(ap->insert_high - ap->insert_low) + c->max_len + 1;   // HalfEnd maxDNALength (DV-DPfunctions.cpp:1340)
             if (rwin > MP_DP_MAX_WIN) return MP_ERANGE;
+            census_add(c, CENSUS_FULL_EQUIV, c->rtasks.p, nullptr, 4 * nf, 0);
             rc = run_dp_filtered(c, c->rtasks.p, 4 * nf, rwin, ap->clip_left, ap->clip_right, c->rres.p, &st.ms_dp_fill, &st.ms_dp_trace,
                                  ap->want_tie_counts != 0);
             if (rc) return rc;

@@ -499,3 +499,31 @@ __global__ void dp_scatter_list_kernel(const mp_dp_result *__restrict__ sel, con
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) res[list[t]] = sel[t];
 }
+
+// Measurement aid (mp_ctx_set_dp_census): cells a kernel family computes for the instances of a list (nullptr: all n tasks).
+// band_w > 0: a band kernel computes band_w cells per read column; band_w == 0: a full-table kernel computes
+// (window + 1) x read length.  slot 0 of `out` counts the instances with a window, slots 1.. the cells per family.
+__global__ void __launch_bounds__(256)
+dp_census_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ list, uint32_t n, const uint32_t *__restrict__ lens, uint32_t band_w,
+                 unsigned long long *__restrict__ out_cells, unsigned long long *__restrict__ out_instances)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cells = 0, inst = 0;
+    if (t < n) {
+        const mp_dp_task k = tasks[list ? list[t] : t];
+        if (k.win_len) {
+            const unsigned long long L = lens[k.read_id];
+            cells = band_w ? (unsigned long long)band_w * L : ((unsigned long long)k.win_len + 1ull) * L;
+            inst = 1;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { cells += __shfl_down(cells, o); inst += __shfl_down(inst, o); }
+    __shared__ unsigned long long s_c[4], s_i[4];
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = cells; s_i[threadIdx.x >> 6] = inst; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long c = s_c[0] + s_c[1] + s_c[2] + s_c[3], i = s_i[0] + s_i[1] + s_i[2] + s_i[3];
+        if (c) atomicAdd(out_cells, c);
+        if (i && out_instances) atomicAdd(out_instances, i);
+    }
+}

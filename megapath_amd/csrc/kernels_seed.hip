@@ -261,7 +261,7 @@ struct mp_mmp_state {
     int len, strand, i, seed_len;
     uint32_t l, r, last_l, last_r, last_seed_len;
     uint32_t cur_w, cur_word;
-    uint32_t n_seeds, n_hits;
+    uint32_t n_seeds, n_hits, n_located;   // n_located: seeds reported by text position (one hit each, no suffix-array read in locate)
     unsigned long long pe;  // pre-filter bits of the 15-mer at scan bases pg + 2 .. pg + 16 (ix.kmer15x3): answers positions pg .. pg + 2
     int pg;
     uint32_t upos;          // text position of the match when its SA range was a single row and it was extended by text
@@ -291,7 +291,8 @@ __device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp 
             slab[s.n_seeds] = rec;
         }
         s.n_seeds++;
-        s.n_hits += sa_diff + 1;
+        s.n_hits += located ? 1u : sa_diff + 1;
+        s.n_located += located ? 1u : 0u;
     }
     s.i -= diff;
     s.i -= s.seed_len < P.seed_min_length ? s.seed_len : P.seed_min_length;
@@ -300,10 +301,24 @@ __device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp 
     s.uvalid = false;
 }
 
+// Per-lane event counters of the seeding kernel: only events that touch memory are priced by the roofline (bench.py);
+// `skipped` records the backward-search steps that never happened because a table or the text stood in for them.
+struct mp_lane_events {
+    uint32_t occ;        // rank queries issued (2 per extension step carried out on the rank blocks)
+    uint32_t blk;        // 64-byte rank blocks loaded for them (1 when both queries fall into one block)
+    uint32_t lkt;        // 13-mer table look-ups (two adjacent words)
+    uint32_t lkt16;      // 16-mer table look-ups (two adjacent words)
+    uint32_t kmer;       // pre-filter probes answered
+    uint32_t kload;      // pre-filter entries loaded for them (one 8-byte entry answers up to three probes)
+    uint32_t text;       // 16-base text words compared in place of rank queries
+    uint32_t sa;         // suffix-array entries read to find the text position of a single-row match
+    uint32_t skipped;    // extension steps not carried out: three per 16-mer look-up, one per base matched in the text
+    uint32_t located;    // seeds handed to locate by their text position: their hit needs no suffix-array read there
+};
+
 // Runs one item to completion or for one trip.  Returns true when the item is finished.
 template <int SLAB>
-__device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev_mmp &P, mp_mmp_state &s, mp_seed_rec *slab,
-                                            uint32_t &my_occ, uint32_t &my_lkt, uint32_t &my_kmer, uint32_t &my_blk)
+__device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev_mmp &P, mp_mmp_state &s, mp_seed_rec *slab, mp_lane_events &ev)
 {
     const uint32_t n = ix.n;
     bool finished = false;
@@ -322,14 +337,16 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
                     // one 8-byte entry answers three consecutive positions (kmer15x3_build_kernel): a futile strand is probed
                     // at every position, so two probes in three need no load
                     const int a = s.i - s.pg;
-                    if (a < 0 || a > 2) { s.pg = s.i; s.pe = ix.kmer15x3[(k17 >> 4) & ((1ull << 30) - 1)]; }
+                    if (a < 0 || a > 2) { s.pg = s.i; s.pe = ix.kmer15x3[(k17 >> 4) & ((1ull << 30) - 1)]; ev.kload++; }
                     const int aa = s.i - s.pg;
                     const uint32_t bit = aa == 0 ? (uint32_t)(k17 & 15) : aa == 1 ? 16u + ((uint32_t)(k17 & 3) | ((uint32_t)(k17 >> 32) & 3u) << 2)
                                                                                    : 32u + (uint32_t)((k17 >> 30) & 15);
                     futile = ((s.pe >> bit) & 1ull) == 0;
-                } else
+                } else {
                     futile = ((ix.kmer17[k17 >> 5] >> (uint32_t)(k17 & 31)) & 1u) == 0;
-                my_kmer++;
+                    ev.kload++;
+                }
+                ev.kmer++;
             }
             const uint32_t key16 = (uint32_t)(two >> sh);
             if (futile) {
@@ -339,8 +356,8 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
                 // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
                 // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
                 const uint32_t nextl = ix.lkt16[key16 - 1] + 1, nextr = ix.lkt16[key16];
-                my_lkt++;
-                my_occ += 6;                                  // the three extension steps the table stands for (2 rank queries each)
+                ev.lkt16++;
+                ev.skipped += 3;                              // the three extension steps the table stands for
                 s.i += 15;
                 s.seed_len = 15;
                 if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
@@ -351,7 +368,7 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
                 const uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
                 const uint32_t nextl = key ? ix.lkt[key - 1] + 1 : 1;
                 const uint32_t nextr = ix.lkt[key];
-                my_lkt++;
+                ev.lkt++;
                 s.i += MP_LKT_K - 1;
                 s.seed_len = MP_LKT_K - 1;
                 if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
@@ -367,6 +384,7 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
     // stands still) and the seed is reported by its text position (MP_SEED_LOCATED).  Needs the whole suffix array.
     if (!finished && s.seed_len > 0 && s.l == s.r && ix.sa_dense && ix.sa_dense_shift == 0 && s.l != 0) {
         const uint32_t pos = s.uvalid ? s.upos : ix.sa_dense[s.l];
+        if (!s.uvalid) ev.sa++;
         const int avail = min(s.len - s.i, (int)min(pos, (uint32_t)1 << 20));    // scan bases left / text bases in front of the match
         int matched = 0;
         bool stop = false;
@@ -386,6 +404,7 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
                 trev = 0;
                 for (int u = 0; u < nn; u++) { const uint32_t pp = pend - (uint32_t)u; trev |= ((ix.text[pp >> 4] >> (2 * (pp & 15))) & 3u) << (2 * u); }
             }
+            ev.text++;
             const uint32_t x = scan16 ^ trev;
             int same = x ? (__ffs((int)x) - 1) >> 1 : 16;
             if (same >= nn) same = nn; else stop = true;
@@ -393,8 +412,7 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
         }
         s.upos = pos - (uint32_t)matched; s.uvalid = true;
         s.seed_len += matched; s.i += matched;
-        // SURVEY 8d counts 2 rank queries per backward-extension step, however the step is carried out (n_occ); none was issued
-        my_occ += 2u * (uint32_t)(matched + (s.i < s.len ? 1 : 0));
+        ev.skipped += (uint32_t)(matched + (s.i < s.len ? 1 : 0));     // steps the comparison stands for (the last one is the failing step)
         if (s.i >= s.len) finished = true;
         else {
             // the base at s.i does not extend the match (or the text starts here): what the failing rank query reports
@@ -410,7 +428,12 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
         const uint32_t c = (s.cur_word >> (2 * ((uint32_t)s.i & 15))) & 3u;
         uint32_t o1, o2;
         mp_occ_pair(ix, s.l, s.r + 1, c, o1, o2);
-        my_occ += 2; my_blk += 2;
+        ev.occ += 2;
+        {
+            uint32_t k1 = s.l, k2 = s.r + 1;
+            k1 -= (k1 > ix.inv_sa0); k2 -= (k2 > ix.inv_sa0);
+            ev.blk += (k1 / MP_OCC_SYMS == k2 / MP_OCC_SYMS) ? 1u : 2u;
+        }
         const uint32_t nextl = ix.cum[c] + o1 + 1, nextr = ix.cum[c] + o2;
         if (nextl <= nextr) {
             if (s.seed_len >= P.seed_min_length && nextr - nextl < s.r - s.l) { s.last_r = s.r; s.last_l = s.l; s.last_seed_len = (uint32_t)s.seed_len; }
@@ -434,7 +457,7 @@ __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *sc
     // reference gives up on the whole SIMD group such an instance falls into, CPU_DP.cpp:294-299 -- not reproduced.)
     if (s.len < MP_MIN_ALIGNABLE_LEN) s.len = 0;
     s.i = 0; s.seed_len = 0; s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
-    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.upos = 0; s.uvalid = false; s.pe = 0; s.pg = -1000;
+    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.upos = 0; s.uvalid = false; s.pe = 0; s.pg = -1000;
 }
 
 __global__ void __launch_bounds__(256)
@@ -444,7 +467,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             uint32_t slab_limit /* <= MP_SEED_SLAB; smaller only to exercise the overflow path */)
 {
     const int lane = threadIdx.x & (MP_WAVE - 1);
-    uint32_t my_occ = 0, my_lkt = 0, my_kmer = 0, my_blk = 0;
+    mp_lane_events ev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mp_mmp_state s;
     bool have = false;
     // Work queue: one global counter, but a wavefront takes MP_SEED_CHUNK items per atomic into a private range and hands
@@ -473,9 +496,10 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
         if (!__any(have)) { if (drained && pool_next == pool_end) break; else continue; }   // nothing to do this trip
         if (have) {
             mp_seed_rec *slab = slabs + (uint64_t)s.rs * MP_SEED_SLAB;
-            if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, my_occ, my_lkt, my_kmer, my_blk)) {
+            if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, ev)) {
                 seeds_per_rs[s.rs] = s.n_seeds;
                 hits_per_rs[s.rs] = s.n_hits;
+                ev.located += s.n_located;
                 if (s.n_seeds > slab_limit) {
                     uint32_t slot = (uint32_t)atomicAdd(&ctr->overflow, 1ull);
                     if (slot < overflow_cap) { overflow_rs[slot] = s.rs; over_slot[s.rs] = slot; }
@@ -484,12 +508,15 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             }
         }
     }
-    for (int o = MP_WAVE / 2; o > 0; o >>= 1) { my_occ += __shfl_down(my_occ, o); my_lkt += __shfl_down(my_lkt, o); my_kmer += __shfl_down(my_kmer, o); my_blk += __shfl_down(my_blk, o); }
+    uint32_t tot[10] = {ev.occ, ev.blk, ev.lkt, ev.lkt16, ev.kmer, ev.kload, ev.text, ev.sa, ev.skipped, ev.located};
+#pragma unroll
+    for (int q = 0; q < 10; q++)
+        for (int o = MP_WAVE / 2; o > 0; o >>= 1) tot[q] += __shfl_down(tot[q], o);
     if (lane == 0) {
-        if (my_occ) atomicAdd(&ctr->n_occ, (unsigned long long)my_occ);
-        if (my_lkt) atomicAdd(&ctr->n_lkt, (unsigned long long)my_lkt);
-        if (my_kmer) atomicAdd(&ctr->n_kmer, (unsigned long long)my_kmer);
-        if (my_blk) atomicAdd(&ctr->n_occ_loaded, (unsigned long long)my_blk);
+        unsigned long long *dst[10] = {&ctr->n_occ, &ctr->n_occ_loaded, &ctr->n_lkt, &ctr->n_lkt16, &ctr->n_kmer, &ctr->n_kmer_loads, &ctr->n_text_words, &ctr->n_sa,
+                                       &ctr->n_steps_skipped, &ctr->n_located};
+#pragma unroll
+        for (int q = 0; q < 10; q++) if (tot[q]) atomicAdd(dst[q], (unsigned long long)tot[q]);
     }
 }
 
@@ -504,9 +531,9 @@ seed_overflow_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const u
     if (t >= n_over) return;
     mp_mmp_state s;
     mp_mmp_begin(s, scan, lens, W, overflow_rs[t], ix.n);
-    uint32_t a = 0, b = 0, c = 0, d = 0;
+    mp_lane_events ev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // already counted by seed_kernel: the events of the rerun add HBM traffic, not work
     mp_seed_rec *slab = big_slabs + (uint64_t)t * MP_SEED_BIG;
-    while (!mp_mmp_trip<MP_SEED_BIG>(ix, P, s, slab, a, b, c, d)) {}
+    while (!mp_mmp_trip<MP_SEED_BIG>(ix, P, s, slab, ev)) {}
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -540,7 +567,7 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
               const uint32_t *__restrict__ lens, mp_dev_mmp P, mp_seed_hit *__restrict__ hits, mp_counters *ctr)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t my_occ = 0;
+    uint32_t my_lf = 0;
     if (t < n_tasks) {
         const mp_sa_seed s = seeds[t];
         const uint32_t read = s.read_strand >> 1, strand = s.read_strand & 1;
@@ -548,7 +575,7 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
         uint32_t steps = 0;
         const bool located = s.sa_diff == MP_SEED_LOCATED;          // the seeding kernel already knows the text position
         const uint64_t sav = located ? (uint64_t)hit_row[t] : mp_sa_value(ix, hit_row[t], &steps);
-        my_occ = steps;
+        my_lf = steps;
         const uint32_t off = s.query_offset, seedlen = s.seed_len;
         // unsigned 64-bit arithmetic: the projection may wrap exactly as in the reference (DV-DPfunctions.cpp:2489)
         const uint64_t target = strand == 0 ? sav - off : sav - ((uint64_t)len - seedlen - off);
@@ -562,16 +589,18 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
     }
     // one counter update per block: a single address takes only ~100 M atomics per second chip-wide, and a launch of
     // 57 M hits has 890 k wavefronts
-    __shared__ uint32_t s_occ[256 / MP_WAVE];
-    for (int o = MP_WAVE / 2; o > 0; o >>= 1) my_occ += __shfl_down(my_occ, o);
-    if ((threadIdx.x & (MP_WAVE - 1)) == 0) s_occ[threadIdx.x / MP_WAVE] = my_occ;
+    __shared__ uint32_t s_lf[256 / MP_WAVE];
+    for (int o = MP_WAVE / 2; o > 0; o >>= 1) my_lf += __shfl_down(my_lf, o);
+    if ((threadIdx.x & (MP_WAVE - 1)) == 0) s_lf[threadIdx.x / MP_WAVE] = my_lf;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < 256 / MP_WAVE; w++) tot += s_occ[w];
-        if (tot) { atomicAdd(&ctr->n_occ, (unsigned long long)tot); atomicAdd(&ctr->n_occ_loaded, (unsigned long long)tot); }
+        uint32_t lf = 0;
+        for (int w = 0; w < 256 / MP_WAVE; w++) lf += s_lf[w];
+        // an LF step is one rank query = one rank block (mp_lf).  Suffix-array reads are not counted here (one atomic per
+        // block on one address would cost more than the kernel): n_sa = hits - located seeds, known after seed_kernel
+        if (lf) { atomicAdd(&ctr->n_occ, (unsigned long long)lf); atomicAdd(&ctr->n_occ_loaded, (unsigned long long)lf); }
     }
-    if (t == 0) { atomicAdd(&ctr->n_sa, (unsigned long long)n_tasks); atomicAdd(&ctr->n_hits, (unsigned long long)n_tasks); }
+    if (t == 0) atomicAdd(&ctr->n_hits, (unsigned long long)n_tasks);
 }
 
 // ------------------------------------------------------------------------------------------------ K3

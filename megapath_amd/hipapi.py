@@ -43,7 +43,13 @@ class SeedPos(C.Structure):
 class SeedStats(C.Structure):
     _fields_ = [("n_occ", C.c_uint64), ("n_lkt", C.c_uint64), ("n_sa", C.c_uint64), ("n_seeds", C.c_uint64),
                 ("n_hits", C.c_uint64), ("n_seedpos", C.c_uint64), ("ms_seed", C.c_float), ("ms_locate", C.c_float),
-                ("ms_merge", C.c_float), ("reserved", C.c_float), ("n_prefilter", C.c_uint64), ("n_occ_loaded", C.c_uint64)]
+                ("ms_merge", C.c_float), ("reserved", C.c_float), ("n_prefilter", C.c_uint64), ("n_occ_loaded", C.c_uint64),
+                ("n_lkt16", C.c_uint64), ("n_prefilter_loads", C.c_uint64), ("n_text_words", C.c_uint64), ("n_steps_skipped", C.c_uint64)]
+
+
+class DpCensus(C.Structure):
+    _fields_ = [("instances", C.c_uint64), ("cells_full_table", C.c_uint64), ("cells_band_score", C.c_uint64),
+                ("cells_band_trace", C.c_uint64), ("cells_full_score", C.c_uint64), ("cells_full_trace", C.c_uint64)]
 
 
 class DpTask(C.Structure):
@@ -97,7 +103,7 @@ class IndexInfo(C.Structure):
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy",
-           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
+           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
            "mp_test_sort_longer_seed"]
 
@@ -144,6 +150,8 @@ def load_library():
     lib.mp_ctx_set_prefilter.argtypes = [vp, C.c_int]
     lib.mp_ctx_set_dp_band.argtypes = [vp, C.c_int]
     lib.mp_ctx_dp_band_stats.argtypes = [vp, u64p, u64p]
+    lib.mp_ctx_set_dp_census.argtypes = [vp, C.c_int]
+    lib.mp_ctx_get_dp_census.argtypes = [vp, C.POINTER(DpCensus)]
     lib.mp_ctx_create.argtypes = [vp, C.POINTER(vp)]
     lib.mp_ctx_destroy.argtypes = [vp]
     lib.mp_set_reads.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
@@ -342,6 +350,14 @@ class Context:
 
     def set_dp_band(self, on: bool):
         _chk(load_library().mp_ctx_set_dp_band(self._h, int(bool(on))), "mp_ctx_set_dp_band")
+
+    def set_dp_census(self, on: bool):
+        _chk(load_library().mp_ctx_set_dp_census(self._h, int(bool(on))), "mp_ctx_set_dp_census")
+
+    def dp_census(self) -> DpCensus:
+        out = DpCensus()
+        _chk(load_library().mp_ctx_get_dp_census(self._h, C.byref(out)), "mp_ctx_get_dp_census")
+        return out
 
     def dp_band_stats(self):
         """(instances run through the band kernel, instances of those re-run by the full kernels)"""

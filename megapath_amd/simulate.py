@@ -47,32 +47,72 @@ def _mutated_read(text, start, length, g, sub, indel_frac, device):
     rnd = torch.randint(0, 4, (n, length), dtype=torch.uint8, device=device, generator=g)
     inserted = ins & (i >= p) & (i < p + glen)
     codes = torch.where(inserted, rnd, codes)
-    subm = torch.rand(n, length, device=device, generator=g) < sub
+    subm = torch.rand(n, length, device=device, generator=g) < sub          # sub: a rate or one rate per row ([n, 1])
     codes = torch.where(subm, (codes + 1 + (rnd % 3)) & 3, codes)
     return codes.to(torch.uint8)
 
 
+def _revcomp_prefix(fwd: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+    """Row r: reverse complement of fwd[r, :lens[r]], left-aligned, zero padded."""
+    n, L = fwd.shape
+    j = torch.arange(L, device=fwd.device, dtype=torch.int64).unsqueeze(0)
+    src = (lens.unsqueeze(1) - 1 - j).clamp_(min=0)
+    out = 3 - torch.gather(fwd, 1, src)
+    return torch.where(j < lens.unsqueeze(1), out, torch.zeros_like(out))
+
+
 def paired_reads(text: torch.Tensor, n_pairs: int, read_len: int, seed: int, frag_mean: float = 350.0, frag_sd: float = 40.0,
-                 sub: float = 0.01, indel_frac: float = 0.12, random_frac: float = 0.05):
-    """Returns (codes [2*n_pairs, read_len] uint8, lengths int32 [2*n_pairs]); rows 2p / 2p+1 are the mates of pair p."""
+                 sub: float = 0.01, indel_frac: float = 0.12, random_frac: float = 0.05, sub_max=None, len_range=None,
+                 broken_mate_frac: float = 0.0, frag_max: int = 600):
+    """Returns (codes [2*n_pairs, Lmax] uint8, lengths int32 [2*n_pairs]); rows 2p / 2p+1 are the mates of pair p.
+
+    sub_max: per-pair substitution rate drawn uniformly from [0, sub_max] instead of the fixed `sub` (config C3: 0-8 %
+    divergence); len_range=(lo, hi): every mate's length uniform in [lo, hi] (config C5; rows are zero padded to hi);
+    broken_mate_frac: share of pairs with one mate replaced by random sequence (config C5)."""
     device = text.device
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     n = text.numel()
-    flen = (torch.randn(n_pairs, device=device, generator=g) * frag_sd + frag_mean).clamp_(read_len + 8, 600).to(torch.int64)
-    pos = (torch.rand(n_pairs, device=device, generator=g) * (n - 700)).to(torch.int64)
-    left = _mutated_read(text, pos, read_len, g, sub, indel_frac, device)
-    right_fwd = _mutated_read(text, pos + flen - read_len, read_len, g, sub, indel_frac, device)
-    right = (3 - right_fwd).flip(1)
+    Lmax = read_len if len_range is None else int(len_range[1])
+    if len_range is None:
+        l1 = torch.full((n_pairs,), read_len, dtype=torch.int64, device=device)
+        l2 = l1.clone()
+    else:
+        l1 = torch.randint(int(len_range[0]), int(len_range[1]) + 1, (n_pairs,), device=device, generator=g)
+        l2 = torch.randint(int(len_range[0]), int(len_range[1]) + 1, (n_pairs,), device=device, generator=g)
+    flen = (torch.randn(n_pairs, device=device, generator=g) * frag_sd + frag_mean).to(torch.int64)
+    flen = torch.maximum(flen, torch.maximum(l1, l2) + 8).clamp_(max=frag_max)
+    pos = (torch.rand(n_pairs, device=device, generator=g) * (n - frag_max - Lmax - 100)).to(torch.int64)
+    if sub_max is not None:
+        sub = (torch.rand(n_pairs, device=device, generator=g) * float(sub_max)).unsqueeze(1)
+    left = _mutated_read(text, pos, Lmax, g, sub, indel_frac, device)
+    right_fwd = _mutated_read(text, pos + flen - l2, Lmax, g, sub, indel_frac, device)
+    col = torch.arange(Lmax, device=device, dtype=torch.int64).unsqueeze(0)
+    left = torch.where(col < l1.unsqueeze(1), left, torch.zeros_like(left))
+    right = _revcomp_prefix(right_fwd, l2)
     flip = torch.rand(n_pairs, device=device, generator=g) < 0.5
-    r1 = torch.where(flip.unsqueeze(1), right, left)
-    r2 = torch.where(flip.unsqueeze(1), left, right)
+    if len_range is not None:
+        # after the flip read 1 has the right mate's length: draw the fragment from the strand instead, lengths stay put
+        left_as_2 = _revcomp_prefix(_mutated_read(text, pos + flen - l1, Lmax, g, sub, indel_frac, device), l1)
+        right_as_1 = torch.where(col < l2.unsqueeze(1), _mutated_read(text, pos, Lmax, g, sub, indel_frac, device), torch.zeros_like(left))
+        r1 = torch.where(flip.unsqueeze(1), left_as_2, left)
+        r2 = torch.where(flip.unsqueeze(1), right_as_1, right)
+        # flipped pairs: read 1 (length l1) is the reverse-strand mate at the fragment's end, read 2 (length l2) its start
+    else:
+        r1 = torch.where(flip.unsqueeze(1), right, left)
+        r2 = torch.where(flip.unsqueeze(1), left, right)
+    rr = torch.randint(0, 4, (2, n_pairs, Lmax), dtype=torch.uint8, device=device, generator=g)
     rnd_pair = torch.rand(n_pairs, device=device, generator=g) < random_frac
-    rr = torch.randint(0, 4, (2, n_pairs, read_len), dtype=torch.uint8, device=device, generator=g)
-    r1 = torch.where(rnd_pair.unsqueeze(1), rr[0], r1)
-    r2 = torch.where(rnd_pair.unsqueeze(1), rr[1], r2)
-    codes = torch.stack([r1, r2], dim=1).reshape(2 * n_pairs, read_len).contiguous()
-    lens = torch.full((2 * n_pairs,), read_len, dtype=torch.int32, device=device)
+    rnd1, rnd2 = rnd_pair.clone(), rnd_pair.clone()
+    if broken_mate_frac > 0:
+        broken = torch.rand(n_pairs, device=device, generator=g) < broken_mate_frac
+        which = torch.rand(n_pairs, device=device, generator=g) < 0.5
+        rnd1 |= broken & which
+        rnd2 |= broken & ~which
+    r1 = torch.where(rnd1.unsqueeze(1) & (col < l1.unsqueeze(1)), rr[0], r1)
+    r2 = torch.where(rnd2.unsqueeze(1) & (col < l2.unsqueeze(1)), rr[1], r2)
+    codes = torch.stack([r1, r2], dim=1).reshape(2 * n_pairs, Lmax).contiguous()
+    lens = torch.stack([l1, l2], dim=1).reshape(2 * n_pairs).to(torch.int32).contiguous()
     return codes, lens
 
 

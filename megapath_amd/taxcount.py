@@ -43,6 +43,29 @@ def all_reduce_counts(counts: np.ndarray, uniq: np.ndarray, device=None):
     return out[0], out[1]
 
 
+PAIR_HIT_DTYPE = np.dtype([("pair_id", "<u4"), ("left_is_mate", "<u4"), ("algnmt_1", "<u8"), ("algnmt_2", "<u8"), ("score_1", "<i4"), ("score_2", "<i4"),
+                           ("start_1", "<u4"), ("start_2", "<u4"), ("dplen_1", "<u2"), ("dplen_2", "<u2"), ("count_1", "<u2"), ("count_2", "<u2")])   # mp_pair_hit
+
+
+def count_pair_hits_per_reference(index, hits, n_hits: int) -> np.ndarray:
+    """int64[num_seq]: deep-DP pair hits per reference sequence (by the left mate's position) of one batch -- the dense
+    per-rank vector of the exchange step."""
+    n_seq = int(index.info.num_seq)
+    if n_hits == 0:
+        return np.zeros(n_seq, dtype=np.int64)
+    import ctypes as C
+    arr = np.frombuffer((C.c_char * (n_hits * PAIR_HIT_DTYPE.itemsize)).from_address(C.addressof(hits)), dtype=PAIR_HIT_DTYPE, count=n_hits)
+    _, chrom = index.chr_and_pos_batch(np.ascontiguousarray(arr["algnmt_1"]))
+    return np.bincount(chrom.astype(np.int64) - 1, minlength=n_seq).astype(np.int64)
+
+
+def allreduce_counts(counts: np.ndarray, device) -> np.ndarray:
+    """Sum of a dense per-rank counter vector over the process group (RCCL when the group's backend is nccl)."""
+    t = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)).to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
 def shard_bounds(n_pairs: int, world: int, rank: int):
     """Contiguous block of pairs of one rank (keeps outputs mergeable in input order)."""
     base, rem = divmod(n_pairs, world)

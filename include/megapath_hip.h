@@ -92,6 +92,10 @@ int mp_index_check_lkt16(mp_index *index, uint64_t n_random, uint64_t *out_check
  * Context and reads. */
 int mp_ctx_create(mp_index *ix, mp_ctx **out);
 int mp_ctx_destroy(mp_ctx *ctx);
+/* Binds the context to another index resident on the same GPU -- the next chunk of a database kept in HBM whole (the NT loop
+ * of runMegaPath.sh:191-227 walks the chunks one soap4 process after the other).  The reads of the current batch stay set;
+ * seeds and hit lists of the previous index are dropped.  MP_EINVAL if the index lives on another device. */
+int mp_ctx_set_index(mp_ctx *ctx, mp_index *ix);
 
 /* Reads of one batch, 2 per pair (read 2p, mate 2p+1), as the reference stores them after appendToQueryArrays
  * (QueryParser.cpp:184-234) except that each read's words are contiguous: base i of read r at bits 2*(i%16) of

@@ -17,6 +17,12 @@
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     fprintf(stderr, "[megapath_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MP_ENODEV; } } while (0)
 
+// MP_TRACE_KERNELS=1: after every kernel launch of the rounds, wait for it and name it on stderr -- a faulting kernel is then
+// the last one named (debugging aid; serialises everything)
+static const bool g_trace_kernels = getenv("MP_TRACE_KERNELS") != nullptr;
+#define MP_TRACE(stream, what) do { if (g_trace_kernels) { hipError_t te_ = hipStreamSynchronize(stream); \
+    fprintf(stderr, "[megapath_hip] %s: %s\n", what, te_ == hipSuccess ? "ok" : hipGetErrorString(te_)); fflush(stderr); } } while (0)
+
 namespace {
 
 template <typename T>
@@ -625,6 +631,19 @@ static int forget_batch(mp_ctx *c)
     return MP_OK;
 }
 
+extern "C" int mp_ctx_set_index(mp_ctx *c, mp_index *ix)
+{
+    if (!c || !ix) return MP_EINVAL;
+    if (ix->device != c->ix->device) return MP_EINVAL;          // streams, events and buffers of a context live on one GPU
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t n_reads = c->n_reads;
+    int rc = forget_batch(c);                                   // seeds and hit lists belong to the index they were computed on
+    c->n_reads = n_reads;                                       // the reads stay
+    c->ix = ix;
+    return rc;
+}
+
 extern "C" int mp_set_reads(mp_ctx *c, const uint32_t *packed, uint32_t W, const uint32_t *lengths, uint32_t n_reads)
 {
     if (!c || !packed || !lengths || W == 0 || (n_reads & 1)) return MP_EINVAL;
@@ -676,6 +695,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
         c->hits_per_rs.reserve(n_items + 2) || c->rs_base.reserve(n_items + 2) || c->overflow_rs.reserve(overflow_cap) || c->over_slot.reserve(n_items + 1) || c->queue.reserve(1) ||
         c->n_pos.reserve(n_reads + 1) || c->n_neg.reserve(n_reads + 1)) return MP_ENOMEM;
     hipLaunchKernelGGL(prep_scan_kernel, dim3(grid_for((uint64_t)n_items * (W + 1), 256)), dim3(256), 0, s, c->d_reads, c->d_lens, n_reads, W, c->scan.p);
+    MP_TRACE(s, "prep_scan_kernel");
     HIPCHK(hipMemsetAsync(c->ctr.p, 0, sizeof(mp_counters), s));
     HIPCHK(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), s));
     HIPCHK(hipMemsetAsync(c->hits_per_rs.p + n_items, 0, 2 * sizeof(uint32_t), s));
@@ -686,6 +706,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipEventRecord(c->ev[0], s));
     hipLaunchKernelGGL(seed_kernel, dim3(blocks), dim3(256), 0, s, dix, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
                        c->hits_per_rs.p, c->overflow_rs.p, c->over_slot.p, overflow_cap, c->queue.p, c->ctr.p, slab_limit);
+    MP_TRACE(s, "seed_kernel");
     HIPCHK(hipEventRecord(c->ev[1], s));
     mp_counters h{};
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
@@ -705,6 +726,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
         if (c->big_slabs.reserve((size_t)n_over * MP_SEED_BIG)) return MP_ENOMEM;
         hipLaunchKernelGGL(seed_overflow_kernel, dim3(grid_for(n_over, 64)), dim3(64), 0, s, dix, c->scan.p, c->d_lens, W, P, c->overflow_rs.p, n_over,
                            c->big_slabs.p);
+        MP_TRACE(s, "seed_overflow_kernel");
     }
     if (c->seeds.reserve((size_t)n_hits + 64) || c->hit_row.reserve((size_t)n_hits + 64) || c->hits.reserve((size_t)n_hits + 64) ||
         c->seedpos.reserve((size_t)n_hits + 64)) return MP_ENOMEM;
@@ -712,18 +734,22 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(expand_hits_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, c->slabs.p, c->seeds_per_rs.p, c->rs_base.p, n_items,
                        c->over_slot.p, c->big_slabs.p, c->seeds.p, c->hit_row.p, c->ctr.p, slab_limit);
+    MP_TRACE(s, "expand_hits_kernel");
     if (n_hits)
         hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, dix, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
                            c->ctr.p);
+        MP_TRACE(s, "locate_kernel");
     HIPCHK(hipEventRecord(c->ev[3], s));
     hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_BLOCK), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, (int)((c->max_len + 63) / 64), c->seedpos.p, c->n_pos.p,
                        c->n_neg.p, c->ctr.p);
+    MP_TRACE(s, "merge_kernel");
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     mp_seed_stats st{};
     st.n_occ = h.n_occ; st.n_lkt = h.n_lkt;
-    st.n_sa = h.n_sa + (h.n_hits - h.n_located);      // seed_kernel's reads for single-row matches + one per hit locate had to look up st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
+    st.n_sa = h.n_sa + (h.n_hits - h.n_located);      // seed_kernel's reads for single-row matches + one per hit locate had to look up
+    st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
     st.n_seeds = h.n_seeds; st.n_prefilter = h.n_kmer; st.n_occ_loaded = h.n_occ_loaded;
     st.n_lkt16 = h.n_lkt16; st.n_prefilter_loads = h.n_kmer_loads; st.n_text_words = h.n_text_words; st.n_steps_skipped = h.n_steps_skipped;
     float ms_over = 0;
@@ -817,6 +843,7 @@ void census_add(mp_ctx *c, int family, const mp_dp_task *d_tasks, const uint32_t
     if (!c->census_on || n == 0 || !c->census.p) return;
     hipLaunchKernelGGL(dp_census_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, d_tasks, list, n, c->d_lens, band_w, c->census.p + family,
                        family == CENSUS_FULL_EQUIV ? c->census.p + CENSUS_INSTANCES : (unsigned long long *)nullptr);
+    MP_TRACE(c->stream, "dp_census_kernel");
 }
 
 struct DpShape { int lpi, c, nw; };
@@ -844,6 +871,7 @@ void launch_fill(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32
     else
         hipLaunchKernelGGL((dp_fill_kernel<LPI, C, 0>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                            tasks, n, cl, cr, flags, flag_rows, fill);
+    MP_TRACE(s, "dp_fill_kernel");
 }
 // instances one "round" of resident blocks of the fill kernel covers on this device: launches sized in whole rounds
 // leave no partly filled last round (blocks of one launch take the same time, so they finish round by round)
@@ -866,11 +894,13 @@ void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint3
         const unsigned pairs8 = (n + 1) / 2, groups8 = MP_DP_BLOCK / 8;
         hipLaunchKernelGGL((dp_score_kernel<8, 20>), dim3(grid_for(pairs8, groups8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                            tasks, n, fill);
+        MP_TRACE(s, "dp_score_kernel");
         return;
     }
     const unsigned pairs = (n + 1) / 2, groups = MP_DP_BLOCK / LPI;
     hipLaunchKernelGGL((dp_fill_kernel<LPI, C, 2>), dim3(grid_for(pairs, groups)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                        tasks, n, cl, cr, (uint32_t *)nullptr, 0u, fill);
+    MP_TRACE(s, "dp_fill_kernel");
 }
 
 template <int LPI, int C>
@@ -878,6 +908,7 @@ void launch_trace(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint3
                   const mp_fill_result *fill, mp_dp_result *res, uint8_t *ops, uint32_t ops_stride)
 {
     hipLaunchKernelGGL((dp_trace_kernel<LPI, C>), dim3(grid_for(n, 64)), dim3(64), 0, s, tasks, c->d_lens, n, cl, cr, flags, flag_rows, fill, res, ops, ops_stride);
+    MP_TRACE(s, "dp_trace_kernel");
 }
 
 #define MP_DP_DISPATCH(FN, ...)                                   \
@@ -900,6 +931,19 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
     if (pick_shape(c->max_len, shape)) return MP_ERANGE;
     if (max_win > MP_DP_MAX_WIN) return MP_ERANGE;
     hipStream_t s = c->stream;
+    if (g_trace_kernels) {
+        std::vector<mp_dp_task> ht(n);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(ht.data(), d_tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyDeviceToHost);
+        uint32_t bad = 0;
+        for (uint32_t q = 0; q < n; q++)
+            if (ht[q].read_id >= c->n_reads || ht[q].win_start + ht[q].win_len > c->ix->n || ht[q].win_len > MP_DP_MAX_WIN) {
+                if (bad++ < 4) fprintf(stderr, "[megapath_hip] run_dp: BAD task %u of %u: read %u strand %u start %llu len %u (text %llu, tasks %p)\n", q, n, ht[q].read_id,
+                                       ht[q].strand, (unsigned long long)ht[q].win_start, ht[q].win_len, (unsigned long long)c->ix->n, (const void *)d_tasks);
+            }
+        fprintf(stderr, "[megapath_hip] run_dp: %u tasks, %u bad\n", n, bad);
+        if (bad) return MP_ERANGE;
+    }
     const uint32_t flag_rows = (max_win + (uint32_t)shape.lpi + MP_DP_FLUSH - 1) / MP_DP_FLUSH * MP_DP_FLUSH;   // whole 8-step runs
     const size_t per_pair = (size_t)flag_rows * (size_t)shape.lpi * shape.nw * 4;
     // traceback slab: a quarter of the free HBM, between 2 and 24 GiB (with a 260 GB index replica little is left; with a
@@ -931,6 +975,7 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
         if (ops_here)
             hipLaunchKernelGGL(dp_ops_fix_kernel, dim3(grid_for(cnt, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks + off, cnt,
                                c->fill.p, d_res + off, ops_here, ops_stride);
+            MP_TRACE(s, "dp_ops_fix_kernel");
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
     }
     HIPCHK(hipStreamSynchronize(s));
@@ -962,6 +1007,7 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p);
     HIPCHK(hipEventRecord(c->ev_pool[1], s));
     hipLaunchKernelGGL(dp_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->fill.p, c->d_lens, n, c->sel_flag.p, d_res);
+    MP_TRACE(s, "dp_select_kernel");
     {
         size_t tmp_bytes = 0;
         (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, c->sel_flag.p, c->sel_idx.p, (int)n, s);
@@ -977,9 +1023,11 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     if (n_sel == 0) return MP_OK;
     if (c->sel_tasks.reserve(n_sel + 2) || c->sel_res.reserve(n_sel + 2)) return MP_ENOMEM;
     hipLaunchKernelGGL(dp_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->sel_flag.p, c->sel_idx.p, n, c->sel_tasks.p);
+    MP_TRACE(s, "dp_compact_kernel");
     int rc = run_dp(c, c->sel_tasks.p, n_sel, max_win, cl, cr, c->sel_res.p, nullptr, 0, ms_fill, ms_trace, count);
     if (rc) return rc;
     hipLaunchKernelGGL(dp_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, c->sel_res.p, n, d_res);
+    MP_TRACE(s, "dp_scatter_kernel");
     return MP_OK;
 }
 
@@ -1023,9 +1071,11 @@ int band_second_pass(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *list,
         else
             hipLaunchKernelGGL((dp_band_kernel<W2, G2, MP_BAND_MAXL, 2>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, cnt, cl, cr, slab,
                                ncols, (const mp_fill_result *)c->band_fill.p, (mp_fill_result *)nullptr, list + off);
+        MP_TRACE(s, "dp_band_kernel");
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
         hipLaunchKernelGGL((dp_trace_kernel<16, 5, W2, G2, true>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks, c->d_lens, cnt, cl, cr, (const uint32_t *)slab,
                            ncols, (const mp_fill_result *)c->band_fill.p, d_res, (uint8_t *)nullptr, 0u, list + off);
+        MP_TRACE(s, "dp_trace_kernel");
         HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
     }
     return MP_OK;
@@ -1061,8 +1111,11 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     // block-match pre-filter: finished (exact diagonal), narrow first pass, whole band, or no qualifying alignment at all
     hipLaunchKernelGGL((dp_prefilter_kernel<GBUD, MINB>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n,
                        c->band_fill.p, c->pre_cls.p, in_list);
+    MP_TRACE(s, "dp_prefilter_kernel");
     hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_NARROW, c->near_flag.p);
+    MP_TRACE(s, "dp_class_flag_kernel");
     hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_WIDE, c->far_flag.p);
+    MP_TRACE(s, "dp_class_flag_kernel");
     { int rc0 = scan(c->near_flag.p, c->near_idx.p); if (rc0) return rc0; rc0 = scan(c->far_flag.p, c->far_idx.p); if (rc0) return rc0; }
     uint32_t n_narrow = 0, n_wide = 0;
     HIPCHK(hipMemcpyAsync(&n_narrow, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
@@ -1071,6 +1124,7 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     if (c->narrow_list.reserve(n_narrow + 130) || c->wide_list.reserve(n_wide + 130)) return MP_ENOMEM;
     if (n_narrow) {
         hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->narrow_list.p, in_list);
+        MP_TRACE(s, "dp_band_list_kernel");
         const dim3 g1((n_narrow + 127) / 128);
         census_add(c, CENSUS_BAND_SCORE, d_tasks, c->narrow_list.p, n_narrow, 2 * GBUD + 1);
         if (small)
@@ -1079,11 +1133,13 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
         else
             hipLaunchKernelGGL((dp_band_kernel<2 * GBUD + 1, GBUD, MP_BAND_MAXL, 3>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_narrow,
                                cl, cr, (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p, (const uint32_t *)c->narrow_list.p);
+        MP_TRACE(s, "dp_band_kernel");
     }
     // whole-band instances (repeats inside the window, reads too short for the block test): first tier only, and only when
     // they are worth a launch of their own -- otherwise they stay undecided (the pre-filter left score -1)
     if (TIER1 && n_wide >= 1024) {
         hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->far_flag.p, c->far_idx.p, n, c->wide_list.p, in_list);
+        MP_TRACE(s, "dp_band_list_kernel");
         const dim3 g1((n_wide + 127) / 128);
         census_add(c, CENSUS_BAND_SCORE, d_tasks, c->wide_list.p, n_wide, MP_BAND_W);
         if (small)
@@ -1092,6 +1148,7 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
         else
             hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 1>), g1, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                                d_tasks, n_wide, cl, cr, (uint32_t *)nullptr, 0u, none, c->band_fill.p, (const uint32_t *)c->wide_list.p);
+        MP_TRACE(s, "dp_band_kernel");
     }
     static const bool verbose2 = getenv("MP_DP_BAND_STATS") != nullptr;
     if (verbose2) fprintf(stderr, "[band] tier %d pre-filter: %u narrow, %u whole band, of %u\n", TIER1 ? 1 : 2, n_narrow, n_wide, n);
@@ -1099,6 +1156,7 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     // classes by distance from the best cell's diagonal; perfect matches and instances below their cutoff are finished here
     hipLaunchKernelGGL(dp_band_classify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, (const mp_fill_result *)c->band_fill.p, n,
                        c->near_flag.p, c->far_flag.p, c->band_flag.p, d_res, in_list, TIER1 ? (uint32_t *)nullptr : c->vfar_flag.p, c->mid_flag.p);
+    MP_TRACE(s, "dp_band_classify_kernel");
     int rc = scan(c->near_flag.p, c->near_idx.p); if (rc) return rc;
     rc = scan(c->far_flag.p, c->far_idx.p); if (rc) return rc;
     rc = scan(c->band_flag.p, c->band_idx.p); if (rc) return rc;
@@ -1211,12 +1269,15 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
             else
                 hipLaunchKernelGGL((dp_band_kernel<MP_BAND_W, MP_BAND_GB, MP_BAND_MAXL, 0>), grid, block, 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
                                    d_tasks + off, cnt, cl, cr, slab, ncols, none, c->band_fill.p + off);
+            MP_TRACE(s, "dp_band_kernel");
             HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 1], s));
             hipLaunchKernelGGL((dp_trace_kernel<16, 5, MP_BAND_W, MP_BAND_GB, false>), dim3(grid_for(cnt, 64)), dim3(64), 0, s, d_tasks + off, c->d_lens, cnt, cl, cr,
                                (const uint32_t *)slab, ncols, c->band_fill.p + off, d_res + off, (uint8_t *)nullptr, 0u);
+            MP_TRACE(s, "dp_trace_kernel");
             HIPCHK(hipEventRecord(c->ev_pool[3 * ci + 2], s));
         }
         hipLaunchKernelGGL(dp_band_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->band_fill.p, n, c->band_flag.p);
+        MP_TRACE(s, "dp_band_select_kernel");
         {
             size_t tmp_bytes = 0;
             (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, c->band_flag.p, c->band_idx.p, (int)n, s);
@@ -1243,10 +1304,12 @@ int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_w
     if (n_sel == 0) return MP_OK;
     if (c->band_tasks.reserve(n_sel + 2) || c->band_res.reserve(n_sel + 2)) return MP_ENOMEM;
     hipLaunchKernelGGL(dp_gather_tasks_kernel, dim3(grid_for(n_sel, 256)), dim3(256), 0, s, d_tasks, und, n_sel, c->band_tasks.p);
+    MP_TRACE(s, "dp_gather_tasks_kernel");
     // what the band leaves over are mostly real alignments with several differences: no score-only pre-pass for them
     int rc = run_dp(c, c->band_tasks.p, n_sel, max_win, cl, cr, c->band_res.p, nullptr, 0, ms_fill, ms_trace, count);
     if (rc) return rc;
     hipLaunchKernelGGL(dp_scatter_list_kernel, dim3(grid_for(n_sel, 256)), dim3(256), 0, s, (const mp_dp_result *)c->band_res.p, und, n_sel, d_res);
+    MP_TRACE(s, "dp_scatter_list_kernel");
     return MP_OK;
 }
 
@@ -1304,6 +1367,7 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         HIPCHK(hipEventRecord(c->ev[0], s));
         hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n_pairs, 128)), dim3(128), 0, s, c->seedpos.p, c->rs_base.p, c->n_pos.p, c->n_neg.p, c->d_lens, n_pairs,
                            ap->insert_low, ap->insert_high, c->cands.p, (uint32_t)c->cands.cap, c->ctr.p);
+        MP_TRACE(s, "pair_kernel");
         HIPCHK(hipEventRecord(c->ev[1], s));
         HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1321,12 +1385,14 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         const uint32_t max_win = c->max_len + margin2;
         const bool use_band = band_applicable(c, max_win, ap->clip_left, ap->clip_right);
         hipLaunchKernelGGL(build_left_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, c->tasks_l.p);
+        MP_TRACE(s, "build_left_tasks_kernel");
         census_add(c, CENSUS_FULL_EQUIV, c->tasks_l.p, nullptr, nc, 0);
         rc = use_band ? run_dp_band(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0)
                       : run_dp(c, c->tasks_l.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_l.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
         hipLaunchKernelGGL(build_right_tasks_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->ix->n, ap->insert_high,
                            c->tasks_l.p, c->res_l.p, c->tasks_r.p);
+        MP_TRACE(s, "build_right_tasks_kernel");
         census_add(c, CENSUS_FULL_EQUIV, c->tasks_r.p, nullptr, nc, 0);
         rc = use_band ? run_dp_band(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0)
                       : run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
@@ -1334,6 +1400,7 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         HIPCHK(hipMemsetAsync(c->n_pair_hits.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(collect_pair_hits_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,
                            c->res_r.p, c->pair_hits.p, c->n_pair_hits.p, (uint32_t)c->pair_hits.cap);
+        MP_TRACE(s, "collect_pair_hits_kernel");
         unsigned long long nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, c->n_pair_hits.p, sizeof nh, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1445,7 +1512,9 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
     HIPCHK(hipMemsetAsync(c->pair_done.p, 0, (size_t)(n_pairs + 1) * 4, s));
     if (c->n_pair_hits_host)
         hipLaunchKernelGGL(mark_done_kernel, dim3(grid_for(c->n_pair_hits_host, 256)), dim3(256), 0, s, c->pair_hits.p, (uint32_t)c->n_pair_hits_host, c->pair_done.p);
+        MP_TRACE(s, "mark_done_kernel");
     hipLaunchKernelGGL(failed_flag_kernel, dim3(grid_for(n_reads + 1, 256)), dim3(256), 0, s, c->pair_done.p, n_reads, c->failed_flag.p);
+    MP_TRACE(s, "failed_flag_kernel");
     int rc = exclusive_scan_u32(c, c->failed_flag.p, c->failed_off.p, n_reads + 1);
     if (rc) return rc;
     uint32_t nf = 0;
@@ -1458,8 +1527,10 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
     if (nf) {
         if (c->failed_reads.reserve(nf + 1) || c->n_scand.reserve(nf + 2) || c->s_off.reserve(nf + 2) || c->scand.reserve(c->n_hits_total + 64)) return MP_ENOMEM;
         hipLaunchKernelGGL(list_failed_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, s, c->failed_flag.p, c->failed_off.p, n_reads, c->failed_reads.p);
+        MP_TRACE(s, "list_failed_kernel");
         hipLaunchKernelGGL(single_cand_kernel, dim3(grid_for(nf + 1, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->seedpos.p, c->rs_base.p, c->n_pos.p,
                            c->n_neg.p, c->scand.p, c->n_scand.p);
+        MP_TRACE(s, "single_cand_kernel");
         rc = exclusive_scan_u32(c, c->n_scand.p, c->s_off.p, nf + 1);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(&nst, c->s_off.p + nf, 4, hipMemcpyDeviceToHost, s));
@@ -1470,6 +1541,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
             c->rsrc.reserve(4 * (size_t)nf + 2)) return MP_ENOMEM;
         hipLaunchKernelGGL(single_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->scand.p, c->rs_base.p, c->n_scand.p,
                            c->s_off.p, c->d_lens, c->ix->n, c->stasks.p);
+        MP_TRACE(s, "single_task_kernel");
         HIPCHK(hipEventRecord(t1, s));
         census_add(c, CENSUS_FULL_EQUIV, c->stasks.p, nullptr, nst, 0);
         const uint32_t max_win = c->max_len + 60;
@@ -1478,6 +1550,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
         if (!skip_default_dp && nst) {
             hipLaunchKernelGGL(mate_rescue_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->s_off.p, c->stasks.p, c->sres.p,
                                c->d_lens, c->ix->n, ap->insert_low, ap->insert_high, c->rtasks.p, c->rsrc.p);
+            MP_TRACE(s, "mate_rescue_task_kernel");
             const uint32_t rwin = (uint32_t)(ap->insert_high - ap->insert_low) + c->max_len + 1;   // HalfEnd maxDNALength (DV-DPfunctions.cpp:1340)
             if (rwin > MP_DP_MAX_WIN) return MP_ERANGE;
             census_add(c, CENSUS_FULL_EQUIV, c->rtasks.p, nullptr, 4 * nf, 0);
@@ -1492,6 +1565,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
         if (nst) {
             if (c->sh_flag.reserve(nst + 2) || c->sh_slot.reserve(nst + 2)) return MP_ENOMEM;
             hipLaunchKernelGGL(single_hit_flag_kernel, dim3(grid_for(nst + 1, 256)), dim3(256), 0, s, c->stasks.p, c->sres.p, c->d_lens, nst, c->sh_flag.p);
+            MP_TRACE(s, "single_hit_flag_kernel");
             rc = exclusive_scan_u32(c, c->sh_flag.p, c->sh_slot.p, nst + 1);
             if (rc) return rc;
             HIPCHK(hipMemcpyAsync(&n_sh, c->sh_slot.p + nst, 4, hipMemcpyDeviceToHost, s));
@@ -1499,6 +1573,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
         if (n_rt) {
             if (c->rh_flag.reserve(n_rt + 2) || c->rh_slot.reserve(n_rt + 2)) return MP_ENOMEM;
             hipLaunchKernelGGL(rescue_hit_flag_kernel, dim3(grid_for(n_rt + 1, 256)), dim3(256), 0, s, c->rtasks.p, c->rres.p, c->rsrc.p, c->d_lens, n_rt, c->rh_flag.p);
+            MP_TRACE(s, "rescue_hit_flag_kernel");
             rc = exclusive_scan_u32(c, c->rh_flag.p, c->rh_slot.p, n_rt + 1);
             if (rc) return rc;
             HIPCHK(hipMemcpyAsync(&n_rh, c->rh_slot.p + n_rt, 4, hipMemcpyDeviceToHost, s));
@@ -1594,6 +1669,7 @@ extern "C" int mp_test_sort_longer_seed(int device, const uint32_t *seed_len, co
     if (rc) return rc;
     HIPCHK(hipSetDevice(device));
     const uint32_t total = off[n_arrays];
+    for (uint32_t t = 0; t < n_arrays; t++) if (off[t + 1] - off[t] >= 4096) return MP_ERANGE;      // a read has < 2 * MP_SEED_BIG candidates
     std::vector<mp_single_cand> h(total + 1);
     for (uint32_t t = 0; t < n_arrays; t++)
         for (uint32_t i = off[t]; i < off[t + 1]; i++) { h[i].pos = i - off[t]; h[i].strand = 1; h[i].seed_len = seed_len[i]; }

@@ -14,10 +14,14 @@
 // A reader thread parses and packs the next batch while the GPU works on the current one (the reference's IO thread,
 // aio_thread.cpp:247).  With -b the BAM side files are written too (bam_out.h).
 #include <zlib.h>
+#include <stdarg.h>
+#include <unistd.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <errno.h>
 #include <ctype.h>
 #include <algorithm>
 #include <chrono>
@@ -70,15 +74,21 @@ struct Batch {
     uint32_t W = 0, n_reads = 0;
     bool last = false;
     const Rec &rec(uint32_t r) const { return recs[r & 1u][r >> 1]; }
-    // ---- stage 2: what the device found
-    std::vector<mp_pair_hit> hits;          // deep-DP round
-    std::vector<mp_single_hit> singles;     // rescue round: single-end hits of the failed pairs
-    std::vector<mp_rescue_hit> resc;        //               mate rescues
-    std::vector<RescueRow> rows;
-    std::vector<char> done;                 // per pair: 1 deep, 2 rescued
-    std::vector<std::string> cig, rcig, scig;   // -b: special CIGARs of hits / rows / singles, in list order
-    bool lists_ready = false;               // hit lists already sorted and de-duplicated (done early when -b needs CIGARs)
-    uint64_t dp_instances = 0;
+    Rec &rec_mut(uint32_t r) { return recs[r & 1u][r >> 1]; }
+    // ---- stage 2: what the device found, per index chunk (one entry unless several chunks are resident, see main)
+    struct ChunkHits {
+        std::vector<mp_pair_hit> hits;          // deep-DP round
+        std::vector<mp_single_hit> singles;     // rescue round: single-end hits of the failed pairs
+        std::vector<mp_rescue_hit> resc;        //               mate rescues
+        std::vector<RescueRow> rows;
+        std::vector<char> done;                 // per pair: 1 deep, 2 rescued
+        std::vector<std::string> cig, rcig, scig;   // -b: special CIGARs of hits / rows / singles, in list order
+        bool lists_ready = false;               // hit lists already sorted and de-duplicated (done early when -b needs CIGARs)
+        uint64_t dp_instances = 0;
+        void clear() { hits.clear(); singles.clear(); resc.clear(); rows.clear(); cig.clear(); rcig.clear(); scig.clear(); lists_ready = false; dp_instances = 0; }
+    };
+    std::vector<ChunkHits> ch;
+    uint64_t seq = 0;                       // position of the batch in the input: the printer writes batches in this order
 };
 
 unsigned char g_code[256];
@@ -119,14 +129,27 @@ bool load_ini(const std::string &path, Ini &ini)
 int ini_int(const Ini &ini, const char *key, int dflt) { auto it = ini.find(key); return it == ini.end() ? dflt : atoi(it->second.c_str()); }
 double ini_dbl(const Ini &ini, const char *key, double dflt) { auto it = ini.find(key); return it == ini.end() ? dflt : atof(it->second.c_str()); }
 
+// Errors end the process from whichever thread meets them.  exit() would run the atexit handlers and flush stdio while the
+// other stages are still writing; _exit() after the message does not.
+[[noreturn]] void fatal(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fflush(stderr);
+    _exit(1);
+}
+
 // ------------------------------------------------------------------------------------------------ FASTQ (plain or gz)
 // Four-line FASTQ or two-line FASTA records through zlib (as the reference's kseq does), read in 4 MiB gulps.
 struct FqReader {
     gzFile f = nullptr;
+    std::string path;
     std::vector<char> buf;
     size_t pos = 0, end = 0;
     bool eof = false;
-    bool open(const char *path) { f = gzopen(path, "rb"); if (f) gzbuffer(f, 1 << 20); buf.resize(1 << 24); return f != nullptr; }
+    bool open(const char *file) { path = file; f = gzopen(file, "rb"); if (f) gzbuffer(f, 1 << 20); buf.resize(1 << 24); return f != nullptr; }
     // Drops what earlier batches consumed.  Within a batch the buffer only grows, so offsets handed out by line() stay
     // valid until the next begin_batch() (the buffer may be reallocated: use data() + offset, never a kept pointer).
     void begin_batch()
@@ -143,7 +166,18 @@ struct FqReader {
             if (eof) { if (pos >= end) return false; off = pos; n = end - pos; pos = end; break; }
             if (end + (1u << 22) > buf.size()) buf.resize(buf.size() * 2);
             const int got = gzread(f, buf.data() + end, (unsigned)std::min(buf.size() - end, (size_t)1 << 28));
-            if (got <= 0) eof = true; else end += (size_t)got;
+            if (got < 0) {
+                // a corrupt or truncated .gz must not pass for a shorter input
+                int errnum = 0;
+                const char *msg = gzerror(f, &errnum);
+                fatal("[soap4-mi355x] error while reading %s: %s\n", path.c_str(), errnum == Z_ERRNO ? strerror(errno) : (msg ? msg : "zlib error"));
+            }
+            if (got == 0) {
+                int errnum = 0;
+                (void)gzerror(f, &errnum);
+                if (errnum != Z_OK && errnum != Z_STREAM_END) fatal("[soap4-mi355x] error while reading %s: %s\n", path.c_str(), gzerror(f, &errnum));
+                eof = true;
+            } else end += (size_t)got;
         }
         const char *p = buf.data() + off;
         while (n && (p[n - 1] == '\r' || p[n - 1] == '\n')) n--;
@@ -169,11 +203,11 @@ size_t parse_file(FqReader &rd, const Params &p, Batch &out, int k, size_t max_p
         RawRec r;
         do { if (!rd.line(r.h, r.hn)) goto scanned; } while (r.hn == 0);
         r.fasta = rd.data()[r.h] == '>';
-        if (!rd.line(r.s, r.sn)) break;
+        if (!rd.line(r.s, r.sn)) fatal("[soap4-mi355x] %s ends inside a record (header without sequence)\n", rd.path.c_str());
         r.q = 0; r.qn = 0;
         if (!r.fasta) {
             size_t po, pn;
-            if (!rd.line(po, pn) || !rd.line(r.q, r.qn)) break;
+            if (!rd.line(po, pn) || !rd.line(r.q, r.qn)) fatal("[soap4-mi355x] %s ends inside a FASTQ record\n", rd.path.c_str());
         }
         raw.push_back(r);
     }
@@ -235,7 +269,7 @@ bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out, int threa
     std::thread second([&]() { nb = parse_file(b, p, out, 1, bp, per_file); });
     const size_t na = parse_file(a, p, out, 0, bp, per_file);
     second.join();
-    if (na != nb) { fprintf(stderr, "Error: number of sequences of pair-end files not matched.\n"); exit(1); }
+    if (na != nb) fatal("Error: number of sequences of pair-end files not matched.\n");
     out.n_reads = (uint32_t)(2 * na);
     out.last = na < bp;
     const uint32_t W = out.W;
@@ -245,8 +279,7 @@ bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out, int threa
             memcpy(out.packed.data() + (2 * q + k) * (size_t)W, out.packed_m[k].data() + q * (size_t)W, (size_t)W * 4);
             out.lens[2 * q + k] = out.lens_m[k][q];
         }
-    out.hits.clear(); out.singles.clear(); out.resc.clear(); out.rows.clear(); out.cig.clear(); out.rcig.clear(); out.scig.clear();
-    out.lists_ready = false; out.dp_instances = 0;
+    for (auto &c : out.ch) c.clear();
     return na > 0;
 }
 
@@ -279,7 +312,11 @@ struct Writer {
     const mp_index *ix;
     const Params &p;
     std::string out;
-    Writer(const mp_index *i, const Params &pp) : ix(i), p(pp) {}
+    // carry = true: this is not the last resident index chunk.  Instead of printing a record, its new header comment
+    // ("SCORE:..." or "IGNORE") replaces the record's own: exactly what the next run of the chained NT loop would read back
+    // from this run's stdout (runMegaPath.sh:191-227, getMappingFromHeader BGS-IO.cpp:1348-1371), without the file round trip.
+    bool carry;
+    Writer(const mp_index *i, const Params &pp, bool carry_ = false) : ix(i), p(pp), carry(carry_) {}
     // -lsam: the line cc/fastq2lsam would print for a record (print_lsam_line, cc/fastq2lsam.cpp:28-78)
     void lsam_line(const std::string &name, const std::string &comm, const std::string &seq, const std::string &qual, int which_end)
     {
@@ -328,8 +365,9 @@ struct Writer {
     // one output record: the annotated FASTQ header + sequence + qualities, or its LSAM line
     void record(const Rec &r, int best, const std::vector<ChrHit> &hits, const std::vector<HdrMap> &v)
     {
-        std::string &o = p.lsam ? comm_ : out;
-        if (p.lsam) comm_.clear(); else { out += '@'; out += r.name; out += '\t'; }
+        const bool to_comment = p.lsam || carry;
+        std::string &o = to_comment ? comm_ : out;
+        if (to_comment) comm_.clear(); else { out += '@'; out += r.name; out += '\t'; }
         if (r.has_comment && r.comment == "IGNORE") o += "IGNORE";
         else {
             char tmp[64];
@@ -344,6 +382,13 @@ struct Writer {
                 }
             }
             for (const HdrMap &m : v) if (m.score >= best * p.top) { o += m.text; o += ';'; }
+        }
+        if (carry) {
+            // the record is this thread's alone (pairs are split between the formatting threads); v points into the old comment
+            Rec &w = const_cast<Rec &>(r);
+            w.comment.swap(comm_);
+            w.has_comment = true;
+            return;
         }
         if (p.lsam) { lsam_record(r, comm_); return; }
         out += '\n'; out += r.seq; out += "\n+\n"; out += r.qual; out += '\n';
@@ -403,7 +448,7 @@ struct Writer {
     std::vector<ChrHit> h1_, h2_;
 };
 
-void die(int rc, const char *what) { if (rc) { fprintf(stderr, "[soap4-mi355x] %s failed: %s (%d)\n", what, mp_strerror(rc), rc); exit(1); } }
+void die(int rc, const char *what) { if (rc) fatal("[soap4-mi355x] %s failed: %s (%d)\n", what, mp_strerror(rc), rc); }
 
 struct Stats {
     uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0;
@@ -428,7 +473,7 @@ void resolve_cigars(mp_ctx *ctx, const Params &p, int threads, const std::vector
         die(mp_sgdp_batch(ctx, tasks.data() + off, (uint32_t)cnt, p.clip_left, p.clip_right, res.data(), ops.data(), stride, nullptr, nullptr), "mp_sgdp_batch");
         auto convert = [&](size_t t0, size_t t1) {
             for (size_t t = t0; t < t1; t++) {
-                if (res[t].score <= 0 || res[t].n_ops == 0) { fprintf(stderr, "[soap4-mi355x] internal error: a reported hit did not align again\n"); exit(1); }
+                if (res[t].score <= 0 || res[t].n_ops == 0) fatal("[soap4-mi355x] internal error: a reported hit did not align again\n");
                 // CigarStringEncoder (DV-DPfunctions.h:377-427): runs collected in traceback order, printed from the read's start
                 const uint8_t *o = ops.data() + t * (size_t)stride;
                 std::string &cg = out[off + t];
@@ -476,7 +521,7 @@ struct PairText {
 
 // OutputBuffer::ready for the three hit lists of a batch: sorted by (positions, scores), exact duplicates dropped
 // (DV-DPfunctions.h:165-196; :853-866 for the single-end hits; ready(1) also drops failed rescues, which never get here)
-void prepare_lists(Batch &b, int threads)
+void prepare_lists(Batch &bt, Batch::ChunkHits &b, int threads)
 {
     if (b.lists_ready) return;
     auto &hits = b.hits;
@@ -489,7 +534,7 @@ void prepare_lists(Batch &b, int threads)
     };
     // the device hands the hits over in slot order (arbitrary between wavefronts): bucket them by pair with one counting
     // pass, then order the few hits of each pair, slices of the list side by side
-    const uint32_t n_pairs = b.n_reads / 2;
+    const uint32_t n_pairs = bt.n_reads / 2;
     {
         std::vector<uint32_t> start((size_t)n_pairs + 2, 0u);
         for (const mp_pair_hit &h : hits) start[(size_t)h.pair_id + 2]++;
@@ -561,21 +606,20 @@ void prepare_lists(Batch &b, int threads)
     b.lists_ready = true;
 }
 
-// Stage 2: everything that touches the device.  Per batch: upload, deep-DP round, and for the pairs it left without a
-// hit the rescue round (alignment.cpp:29-355); with -b also the CIGARs of every hit that will be written.
-void gpu_stage(mp_ctx *ctx, Params &p, Batch &b, bool &first, bool bam, int threads, Stats &st)
+// Stage 2: everything that touches the device.  Per batch and index chunk: deep-DP round, and for the pairs it left without
+// a hit the rescue round (alignment.cpp:29-355); with -b also the CIGARs of every hit that will be written.  The reads of the
+// batch are uploaded once (upload_reads); the context is bound to one resident chunk after the other.
+void upload_reads(mp_ctx *ctx, Batch &bt, Stats &st)
 {
-    const uint32_t n_reads = b.n_reads, n_pairs = n_reads / 2;
-    if (first) {
-        // SOAP4.cpp:465-474 / QueryParser.cpp:2253-2277: the minimum insert size is at least the detected read lengths
-        uint32_t d1 = 0, d2 = 0;
-        for (uint32_t q = 0; q < n_pairs && q < 999999; q++) { d1 = std::max(d1, b.lens[2 * q]); d2 = std::max(d2, b.lens[2 * q + 1]); }
-        p.insert_low = std::max(p.insert_low, (int)std::max(d1, d2));
-        first = false;
-    }
+    const double t0 = now_s();
+    die(mp_set_reads(ctx, bt.packed.data(), bt.W, bt.lens.data(), bt.n_reads), "mp_set_reads");
+    st.t_upload += now_s() - t0;
+}
+
+void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, bool bam, int threads, Stats &st)
+{
+    const uint32_t n_reads = bt.n_reads, n_pairs = n_reads / 2;
     double t0 = now_s();
-    die(mp_set_reads(ctx, b.packed.data(), b.W, b.lens.data(), n_reads), "mp_set_reads");
-    st.t_upload += now_s() - t0; t0 = now_s();
     mp_align_params ap;
     ap.insert_low = p.insert_low; ap.insert_high = p.insert_high; ap.clip_left = p.clip_left; ap.clip_right = p.clip_right; ap.mmp = p.mmp;
     ap.want_tie_counts = bam ? 1 : 0; ap.reserved = 0;          // num_sameScore only feeds the BAM MAPQ / X0 / X1
@@ -604,8 +648,12 @@ void gpu_stage(mp_ctx *ctx, Params &p, Batch &b, bool &first, bool bam, int thre
         b.resc.assign(rv, rv + nr);
     }
     st.t_rescue += now_s() - t0; t0 = now_s();
+    if (getenv("MP_TIMING"))
+        fprintf(stderr, "[Main] batch %llu: %llu seed positions, %llu candidates, %llu pair hits, %u of %u pairs done, %zu single hits, %zu rescues (insert %d..%d)\n",
+                (unsigned long long)bt.seq, (unsigned long long)rs.seed.n_seedpos, (unsigned long long)rs.n_candidates, (unsigned long long)nh, n_done, n_pairs,
+                b.singles.size(), b.resc.size(), ap.insert_low, ap.insert_high);
     if (bam) {
-        prepare_lists(b, threads);
+        prepare_lists(bt, b, threads);
         st.t_sort += now_s() - t0; t0 = now_s();
         std::vector<mp_dp_task> tasks;
         tasks.reserve(2 * b.hits.size());
@@ -614,17 +662,17 @@ void gpu_stage(mp_ctx *ctx, Params &p, Batch &b, bool &first, bool bam, int thre
             tasks.push_back(mp_dp_task{2 * h.pair_id, s1, h.start_1, h.dplen_1, 0});
             tasks.push_back(mp_dp_task{2 * h.pair_id + 1, 3u - s1, h.start_2, h.dplen_2, 0});
         }
-        resolve_cigars(ctx, p, threads, tasks, b.lens, b.cig);
+        resolve_cigars(ctx, p, threads, tasks, bt.lens, b.cig);
         tasks.clear();
         for (const RescueRow &r : b.rows) {
             const mp_rescue_hit &h = b.resc[r.src];
             tasks.push_back(mp_dp_task{h.aligned_read, h.aligned_strand, h.aligned_win_start, h.aligned_win_len, 0});
             tasks.push_back(mp_dp_task{h.aligned_read ^ 1u, h.dp_strand, h.dp_win_start, h.dp_win_len, 0});
         }
-        resolve_cigars(ctx, p, threads, tasks, b.lens, b.rcig);
+        resolve_cigars(ctx, p, threads, tasks, bt.lens, b.rcig);
         tasks.clear();
         for (const mp_single_hit &h : b.singles) if (b.done[h.read_id >> 1] == 0) tasks.push_back(mp_dp_task{h.read_id, h.strand, h.win_start, h.win_len, 0});
-        resolve_cigars(ctx, p, threads, tasks, b.lens, b.scig);
+        resolve_cigars(ctx, p, threads, tasks, bt.lens, b.scig);
         st.t_cigar += now_s() - t0;
     }
 }
@@ -656,13 +704,15 @@ void for_chunks(size_t n_items, int threads, BamState *bam, F &&body)
     }
 }
 
-void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int threads, Stats &st)
+// `carry`: not the last resident chunk -- the records keep their new header comments for the next chunk instead of being printed.
+void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b, BamState *bam, int threads, Stats &st, bool carry)
 {
-    const uint32_t n_pairs = b.n_reads / 2;
+    const uint32_t n_pairs = bt.n_reads / 2;
     double t0 = now_s();
-    prepare_lists(b, threads);
+    prepare_lists(bt, b, threads);
     st.t_sort += now_s() - t0; t0 = now_s();
-    st.pairs += n_pairs; st.dp += b.dp_instances;
+    if (!carry) st.pairs += n_pairs;
+    st.dp += b.dp_instances;
     const auto &hits = b.hits;
     auto best_of = [](const std::vector<PairAln> &v) {           // first maximum of score_1 + score_2 (OutputDPResult.cpp:156-232)
         size_t best = 0;
@@ -670,11 +720,11 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
         return best;
     };
     auto emit_pair = [&](Writer &w, Sink &sink, PairText &text, std::vector<PairAln> &res, uint32_t q, int file, int stage) {
-        const Rec &r1 = b.rec(2 * q), &r2 = b.rec(2 * q + 1);
+        const Rec &r1 = bt.rec(2 * q), &r2 = bt.rec(2 * q + 1);
         const size_t best = best_of(res);
-        w.pair(r1, r2, b.lens[2 * q], b.lens[2 * q + 1], res);
+        w.pair(r1, r2, bt.lens[2 * q], bt.lens[2 * q + 1], res);
         if (!bam) return;
-        const mpbam::ReadView rd[2] = {view_of(r1, b.lens[2 * q]), view_of(r2, b.lens[2 * q + 1])};
+        const mpbam::ReadView rd[2] = {view_of(r1, bt.lens[2 * q]), view_of(r2, bt.lens[2 * q + 1])};
         if (bam->w->wants_text()) { const Side *bs[2] = {&res[best].m[0], &res[best].m[1]}; text.fetch(ix, bs); }
         bam->w->pair(sink.bam[file], stage, rd, res, best, text.ref);
     };
@@ -683,7 +733,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
     for (size_t i = 0; i < hits.size(); i++) if (i == 0 || hits[i].pair_id != hits[i - 1].pair_id) grp.push_back(i);
     grp.push_back(hits.size());
     for_chunks(grp.size() - 1, threads, bam, [&](size_t g0, size_t g1, Sink &sink) {
-        Writer w(ix, p);
+        Writer w(ix, p, carry);
         PairText text;
         std::vector<PairAln> res;
         for (size_t g = g0; g < g1; g++) {
@@ -696,7 +746,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
                 r.m[0].strand = h.left_is_mate ? 2 : 1; r.m[1].strand = 3 - r.m[0].strand;
                 if (bam) {
                     // the reference computes both edit distances with the right leg's read length (DV-DPfunctions.cpp:3466, :2999)
-                    const int right_len = (int)b.lens[2 * q + (h.left_is_mate ? 0 : 1)], right_side = h.left_is_mate ? 0 : 1;
+                    const int right_len = (int)bt.lens[2 * q + (h.left_is_mate ? 0 : 1)], right_side = h.left_is_mate ? 0 : 1;
                     int dis[2];
                     for (int k = 0; k < 2; k++) {
                         r.m[k].cigar = b.cig[2 * j + k].c_str();
@@ -713,7 +763,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
         w.finish();
         sink.text.swap(w.out);
     });
-    st.deep += grp.size() - 1;
+    if (!carry) st.deep += grp.size() - 1;
     st.t_emit_deep += now_s() - t0; t0 = now_s();
     // ---- rescued pairs
     const auto &rows = b.rows;
@@ -721,7 +771,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
     for (size_t i = 0; i < rows.size(); i++) if (i == 0 || rows[i].pair != rows[i - 1].pair) grp.push_back(i);
     grp.push_back(rows.size());
     for_chunks(grp.size() - 1, threads, bam, [&](size_t g0, size_t g1, Sink &sink) {
-        Writer w(ix, p);
+        Writer w(ix, p, carry);
         PairText text;
         std::vector<PairAln> res;
         for (size_t g = g0; g < g1; g++) {
@@ -736,12 +786,12 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
                 if (bam) {
                     int dis = 0;
                     r.m[al].cigar = b.rcig[2 * j].c_str(); r.m[un].cigar = b.rcig[2 * j + 1].c_str();
-                    r.m[al].editdist = mpbam::edit_dist(r.m[al].cigar, (int)b.lens[h.aligned_read], h.aligned_score, nullptr);
-                    r.m[un].editdist = mpbam::edit_dist(r.m[un].cigar, (int)b.lens[h.aligned_read ^ 1u], h.dp_score, &dis);
+                    r.m[al].editdist = mpbam::edit_dist(r.m[al].cigar, (int)bt.lens[h.aligned_read], h.aligned_score, nullptr);
+                    r.m[un].editdist = mpbam::edit_dist(r.m[un].cigar, (int)bt.lens[h.aligned_read ^ 1u], h.dp_score, &dis);
                     r.m[al].count = (int)h.aligned_count; r.m[un].count = (int)h.dp_count;
                     // DV-DPfunctions.cpp:1553-1565
-                    if (h.dp_pos < h.aligned_pos) r.insert = (long long)(h.aligned_pos - h.dp_pos) + b.lens[h.aligned_read];
-                    else r.insert = (long long)(h.dp_pos - h.aligned_pos) + b.lens[h.aligned_read ^ 1u] + dis;
+                    if (h.dp_pos < h.aligned_pos) r.insert = (long long)(h.aligned_pos - h.dp_pos) + bt.lens[h.aligned_read];
+                    else r.insert = (long long)(h.dp_pos - h.aligned_pos) + bt.lens[h.aligned_read ^ 1u] + dis;
                 }
                 res.push_back(r);
             }
@@ -750,7 +800,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
         w.finish();
         sink.text.swap(w.out);
     });
-    st.rescued += grp.size() - 1;
+    if (!carry) st.rescued += grp.size() - 1;
     // ---- the unpaired rest: per pair where its single-end hits (and their CIGARs) start
     const auto &singles = b.singles;
     struct Rest { uint32_t q; size_t si, ci; };
@@ -765,7 +815,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
         }
     }
     for_chunks(rest.size(), threads, bam, [&](size_t i0, size_t i1, Sink &sink) {
-        Writer w(ix, p);
+        Writer w(ix, p, carry);
         std::vector<Side> lst[2];
         std::vector<mpbam::Writer::RefText> ref_of[2];
         std::vector<uint8_t> tbuf[2];
@@ -779,13 +829,13 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
                     const mp_single_hit &h = singles[si];
                     Side s;
                     s.pos = h.algnmt; s.score = h.score; s.strand = (int)h.strand; s.count = (int)h.count;
-                    if (bam) { s.cigar = b.scig[ci++].c_str(); s.editdist = mpbam::edit_dist(s.cigar, (int)b.lens[r], h.score, nullptr); }
+                    if (bam) { s.cigar = b.scig[ci++].c_str(); s.editdist = mpbam::edit_dist(s.cigar, (int)bt.lens[r], h.score, nullptr); }
                     lst[k].push_back(s);
                 }
-                w.single(b.rec(r), b.lens[r], lst[k]);
+                w.single(bt.rec(r), bt.lens[r], lst[k]);
             }
             if (!bam) continue;
-            const mpbam::ReadView rd[2] = {view_of(b.rec(2 * q), b.lens[2 * q]), view_of(b.rec(2 * q + 1), b.lens[2 * q + 1])};
+            const mpbam::ReadView rd[2] = {view_of(bt.rec(2 * q), bt.lens[2 * q]), view_of(bt.rec(2 * q + 1), bt.lens[2 * q + 1])};
             const mpbam::Writer::RefText *rp[2] = {nullptr, nullptr};
             if (bam->w->wants_text())
                 for (int k = 0; k < 2; k++) {
@@ -807,7 +857,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &b, BamState *bam, int th
         w.finish();
         sink.text.swap(w.out);
     });
-    st.unpaired += rest.size();
+    if (!carry) st.unpaired += rest.size();
     st.t_emit_rest += now_s() - t0;
 }
 
@@ -826,6 +876,30 @@ struct BatchQueue {
         Batch *b = q.front(); q.erase(q.begin());
         return b;
     }
+    // the batch with sequence number `seq`, whenever the workers get it done (they finish out of order)
+    Batch *pop_seq(uint64_t seq)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            for (size_t i = 0; i < q.size(); i++) if (q[i]->seq == seq) { Batch *b = q[i]; q.erase(q.begin() + (long)i); return b; }
+            if (closed) return nullptr;
+            cv.wait(lk);
+        }
+    }
+};
+
+std::vector<std::string> split_commas(const std::string &v)
+{
+    std::vector<std::string> out;
+    size_t a = 0;
+    while (a <= v.size()) { size_t b = v.find(',', a); if (b == std::string::npos) b = v.size(); if (b > a) out.push_back(v.substr(a, b - a)); a = b + 1; }
+    return out;
+}
+
+// One GPU of the node: every index chunk resident in its HBM (a replica per GPU), and the contexts of its workers.
+struct Device {
+    int id = 0;
+    std::vector<mp_index *> chunks;
 };
 
 }  // namespace
@@ -833,13 +907,20 @@ struct BatchQueue {
 int main(int argc, char **argv)
 {
     if (argc < 5 || strcmp(argv[1], "pair") != 0) {
-        fprintf(stderr, "usage: %s pair <indexPrefix> <r1.fq[.gz]> <r2.fq[.gz]> -o <outPrefix> -C <ini> -L <maxReadLen> [-T n] [-u maxInsert] [-v minInsert] -F|-P [-nc] [-top N] [-b]\n", argv[0]);
+        fprintf(stderr, "usage: %s pair <indexPrefix[,indexPrefix...]> <r1.fq[.gz]> <r2.fq[.gz]> -o <outPrefix> -C <ini> -L <maxReadLen> [-T n] [-u maxInsert] [-v minInsert] -F|-P [-nc] [-top N]\n"
+                        "          [-b [-p] [-D rg -A sample [-R opt]]]   BAM side files; implemented for output option -h 2 (the default) with BWALikeScore=1 (both shipped ini files)\n"
+                        "          [-c gpu[,gpu...]]                      GPUs of this node to use (default 0, or $MP_GPUS): pair blocks are spread over them, output stays in input order\n"
+                        "       several comma-separated index prefixes = the chunks of one database (the NT loop of runMegaPath.sh:191-227 in one process): all are kept in HBM,\n"
+                        "       every batch is aligned against each, and the per-reference hits are merged as the chained runs would merge them through the SCORE: comments\n", argv[0]);
         return 1;
     }
     Params p;
     std::string ini_path;
-    int cli_device = -1, threads = 4, out_type = 2;                       // IniParam.cpp:627-648
-    const char *prefix = argv[2], *fq1 = argv[3], *fq2 = argv[4];
+    int threads = 4, out_type = 2;                                        // IniParam.cpp:627-648
+    std::vector<int> gpu_ids;
+    const char *fq1 = argv[3], *fq2 = argv[4];
+    const std::vector<std::string> prefixes = split_commas(argv[2]);
+    if (prefixes.empty()) { fprintf(stderr, "[soap4-mi355x] no index prefix given\n"); return 1; }
     std::string out_prefix = fq1;                                         // IniParam.cpp:633
     mpbam::Options bopt;
     bool have_d = false, have_a = false, have_r = false;
@@ -857,7 +938,10 @@ int main(int argc, char **argv)
         else if (a == "-R") { bopt.rg_option = unescape(val()); have_r = true; }
         else if (a == "-h") { out_type = atoi(val()); if (out_type < 1 || out_type > 4) { fprintf(stderr, "The output option should be 1, 2, 3 or 4\n"); return 1; } }
         else if (a == "-s") { if (i + 1 < argc && isdigit((unsigned char)argv[i + 1][0])) i++; }   // IniParam.cpp:738-757
-        else if (a == "-c") { cli_device = atoi(val()); if (cli_device < 0) { fprintf(stderr, "The GPU device ID should not be less than 0\n"); return 1; } }
+        else if (a == "-c") {
+            // -c <GPU device id> (IniParam.cpp:822-838); a comma-separated list names several GPUs of the node
+            for (const std::string &g : split_commas(val())) { const int id = atoi(g.c_str()); if (id < 0 || !isdigit((unsigned char)g[0])) { fprintf(stderr, "The GPU device ID should not be less than 0\n"); return 1; } gpu_ids.push_back(id); }
+        }
         else if (a == "-p") bopt.print_mdnm = true;                                                   // NM / MD tags
         else if (a == "-I") {}                                                                       // flag without a value
         else if (a == "-C") ini_path = val();
@@ -900,70 +984,125 @@ int main(int argc, char **argv)
         bopt.threads = threads;
         if (const char *e = getenv("MP_BGZF_LEVEL")) bopt.level = atoi(e);
     }
-    int device = 0;
-    if (cli_device >= 0) device = cli_device;                              // -c <GPU device id>, IniParam.cpp:822-838
-    else if (const char *e = getenv("MP_DEVICE")) device = atoi(e); else if (const char *e2 = getenv("LOCAL_RANK")) device = atoi(e2);
+    if (gpu_ids.empty()) {
+        if (const char *e = getenv("MP_GPUS")) for (const std::string &g : split_commas(e)) gpu_ids.push_back(atoi(g.c_str()));
+        else if (const char *e1 = getenv("MP_DEVICE")) gpu_ids.push_back(atoi(e1));
+        else if (const char *e2 = getenv("LOCAL_RANK")) gpu_ids.push_back(atoi(e2));
+        else gpu_ids.push_back(0);
+    }
+    // Test aid for the host plumbing (reader -> workers -> ordered output) on a machine without a GPU: no index is opened, nothing is
+    // aligned, every pair is printed as unaligned.  Never a substitute for the device path: it says so on stderr.
+    const bool plumbing_only = getenv("MP_PLUMBING_TEST") != nullptr;
+    if (plumbing_only) fprintf(stderr, "[soap4-mi355x] MP_PLUMBING_TEST: NO ALIGNMENT IS DONE -- host plumbing test only, every pair is reported unaligned\n");
+    int workers_per_gpu = 2;                   // two contexts per GPU: the latency-bound seeding of one batch overlaps with the VALU-bound DP of another
+    if (const char *e = getenv("MP_WORKERS_PER_GPU")) workers_per_gpu = std::max(1, atoi(e));
     fill_char_map();
 
-    mp_index *ix = nullptr;
-    die(mp_index_open(prefix, device, &ix), "mp_index_open");
-    mp_index_info info;
-    mp_index_get_info(ix, &info);
-    fprintf(stderr, "[Main] index %s in HBM: %.2f GB, %u sequences\n", prefix, info.device_bytes / 1e9, info.num_seq);
-    mp_ctx *ctx = nullptr;
-    die(mp_ctx_create(ix, &ctx), "mp_ctx_create");
+    const size_t n_chunks = prefixes.size();
+    std::vector<Device> devices(gpu_ids.size());
+    if (!plumbing_only) {
+        // every GPU loads its own replica of every chunk, the GPUs side by side
+        std::vector<std::thread> loaders;
+        for (size_t d = 0; d < devices.size(); d++) {
+            devices[d].id = gpu_ids[d];
+            devices[d].chunks.assign(n_chunks, nullptr);
+            loaders.emplace_back([&, d]() {
+                for (size_t c = 0; c < n_chunks; c++) {
+                    die(mp_index_open(prefixes[c].c_str(), devices[d].id, &devices[d].chunks[c]), "mp_index_open");
+                    mp_index_info info;
+                    mp_index_get_info(devices[d].chunks[c], &info);
+                    fprintf(stderr, "[Main] GPU %d: index %s in HBM: %.2f GB, %u sequences\n", devices[d].id, prefixes[c].c_str(), info.device_bytes / 1e9, info.num_seq);
+                }
+            });
+        }
+        for (auto &t : loaders) t.join();
+    } else
+        for (size_t d = 0; d < devices.size(); d++) { devices[d].id = gpu_ids[d]; devices[d].chunks.assign(n_chunks, nullptr); }
 
     FqReader ra, rb;
     if (!ra.open(fq1) || !rb.open(fq2)) { fprintf(stderr, "[soap4-mi355x] cannot open read files\n"); return 1; }
-    Stats st;
     BamState bam_state, *bam = nullptr;
-    if (p.want_bam) {
-        bam_state.w.reset(new mpbam::Writer(ix, bopt));
-        if (!bam_state.w->open(out_prefix, "@PG\tID:soap4-mi355x\tPN:soap4-mi355x\tVN:r1\n")) return 1;
+    if (p.want_bam && !plumbing_only) {
+        // as in the chained runs of runMegaPath.sh:191-227 -- every run writes the same -o prefix -- the files that remain are the last chunk's
+        bam_state.w.reset(new mpbam::Writer(devices[0].chunks[n_chunks - 1], bopt));
+        if (!bam_state.w->open(out_prefix, "@PG\tID:soap4-mi355x\tPN:soap4-mi355x\tVN:r2\n")) return 1;
         bam_state.stage_unpaired = p.skip_default_dp ? 2 : 3;
         bam = &bam_state;
     }
-    // Three stages over three recycled batch objects: the reader threads parse and pack batch k+1 (the reference's IO
-    // thread, aio_thread.cpp:247) and the output thread prints batch k-1 while the device aligns batch k.
-    Batch pool[3];
+    // Stages: the reader threads parse and pack batches (the reference's IO thread, aio_thread.cpp:247); every worker of every
+    // GPU takes the next batch -- a contiguous block of pairs --, aligns it against all resident chunks and hands it on; the
+    // printer writes the batches in input order.  Batch objects are recycled.
+    const size_t n_workers = devices.size() * (size_t)workers_per_gpu;
+    std::vector<Batch> pool(n_workers + 2);
+    for (Batch &b : pool) b.ch.resize(n_chunks);
     BatchQueue free_q, filled_q, aligned_q;
     for (Batch &b : pool) free_q.push(&b);
     const double t_start = now_s();
+    Stats st_reader, st_printer;
+    std::vector<Stats> st_worker(n_workers);
     std::thread reader([&]() {
+        uint64_t seq = 0;
         for (;;) {
             Batch *b = free_q.pop();
             if (!b) break;
             const double tr = now_s();
             const bool got = fill_batch(ra, rb, p, *b, threads);
-            st.t_read += now_s() - tr;
-            if (got) filled_q.push(b);
+            st_reader.t_read += now_s() - tr;
+            if (got && seq == 0) {
+                // SOAP4.cpp:465-474 / QueryParser.cpp:2253-2277: the minimum insert size is at least the read lengths detected in the
+                // first batch.  Settled here, before any worker sees a batch (the queue's mutex orders the write before their reads).
+                const uint32_t n_pairs = b->n_reads / 2;
+                uint32_t d1 = 0, d2 = 0;
+                for (uint32_t q = 0; q < n_pairs && q < 999999; q++) { d1 = std::max(d1, b->lens[2 * q]); d2 = std::max(d2, b->lens[2 * q + 1]); }
+                p.insert_low = std::max(p.insert_low, (int)std::max(d1, d2));
+            }
+            if (got) { b->seq = seq++; filled_q.push(b); }
             if (!got || b->last) break;
         }
         filled_q.close();
     });
     std::thread printer([&]() {
-        for (;;) {
-            Batch *b = aligned_q.pop();
+        for (uint64_t seq = 0;; seq++) {
+            Batch *b = aligned_q.pop_seq(seq);
             if (!b) break;
-            output_stage(ix, p, *b, bam, threads, st);
+            // the chunks in database order: each one's per-reference hits join the header comments the earlier ones left
+            for (size_t c = 0; c < n_chunks; c++) {
+                const bool last = c + 1 == n_chunks;
+                output_stage(devices[0].chunks[c], p, *b, b->ch[c], last ? bam : nullptr, threads, st_printer, !last);
+            }
             free_q.push(b);
         }
     });
-    bool first = true;
-    int n_batches = 0;
-    double t_steady = 0; uint64_t pairs_before_steady = 0, pairs_seen = 0;
-    for (;;) {
-        Batch *b = filled_q.pop();
-        if (!b) break;
-        const double tb = now_s();
-        // the three recycled batch objects are first-touched (page faults, hipMalloc of the device buffers) during the
-        // first three batches: MP_TIMING also reports the rate from the fourth batch on
-        if (++n_batches == 4) { t_steady = tb; pairs_before_steady = pairs_seen; }
-        pairs_seen += b->n_reads / 2;
-        gpu_stage(ctx, p, *b, first, bam != nullptr, threads, st);
-        if (getenv("MP_TIMING")) fprintf(stderr, "[Main] device stage of a batch of %u pairs: %.3f s\n", b->n_reads / 2, now_s() - tb);
-        aligned_q.push(b);
+    std::atomic<uint64_t> pairs_seen{0};
+    std::vector<std::thread> workers;
+    for (size_t w = 0; w < n_workers; w++) {
+        workers.emplace_back([&, w]() {
+            Device &dev = devices[w / (size_t)workers_per_gpu];
+            Stats &st = st_worker[w];
+            mp_ctx *ctx = nullptr;
+            if (!plumbing_only) die(mp_ctx_create(dev.chunks[0], &ctx), "mp_ctx_create");
+            for (;;) {
+                Batch *b = filled_q.pop();
+                if (!b) break;
+                const double tb = now_s();
+                pairs_seen += b->n_reads / 2;
+                if (!plumbing_only) {
+                    upload_reads(ctx, *b, st);
+                    for (size_t c = 0; c < n_chunks; c++) {
+                        if (n_chunks > 1 || c > 0) die(mp_ctx_set_index(ctx, dev.chunks[c]), "mp_ctx_set_index");
+                        gpu_stage(ctx, p, *b, b->ch[c], bam != nullptr && c + 1 == n_chunks, threads, st);
+                    }
+                } else {
+                    for (auto &c : b->ch) c.done.assign(b->n_reads / 2, 0);
+                    if (const char *e = getenv("MP_PLUMBING_JITTER_US")) usleep((useconds_t)((b->seq * 7919u + w * 104729u) % (uint64_t)std::max(1, atoi(e))));
+                }
+                if (getenv("MP_TIMING")) fprintf(stderr, "[Main] GPU %d: device stage of batch %llu (%u pairs): %.3f s\n", dev.id, (unsigned long long)b->seq, b->n_reads / 2, now_s() - tb);
+                aligned_q.push(b);
+            }
+            if (ctx) mp_ctx_destroy(ctx);
+        });
     }
+    for (auto &t : workers) t.join();
     aligned_q.close();
     printer.join();
     free_q.close();
@@ -971,16 +1110,17 @@ int main(int argc, char **argv)
     const double t_loop = now_s() - t_start;
     fflush(stdout);
     if (bam && !bam->w->close()) { fprintf(stderr, "[soap4-mi355x] error while writing the BAM files\n"); return 1; }
+    // every stage kept its own counters: summed only now that the threads are gone
+    Stats st = st_printer;
+    st.t_read = st_reader.t_read;
+    for (const Stats &w : st_worker) { st.t_upload += w.t_upload; st.t_deep += w.t_deep; st.t_rescue += w.t_rescue; st.t_sort += w.t_sort; st.t_cigar += w.t_cigar; }
     fprintf(stderr, "[Main] %llu pairs: %llu aligned by deep DP, %llu by mate rescue, %llu unpaired; %llu DP instances\n", (unsigned long long)st.pairs,
             (unsigned long long)st.deep, (unsigned long long)st.rescued, (unsigned long long)st.unpaired, (unsigned long long)st.dp);
-    fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped)\n", t_loop, st.pairs / std::max(t_loop, 1e-9));
-    if (getenv("MP_TIMING") && t_steady > 0)
-        fprintf(stderr, "[Main] from the fourth batch on: %.0f pairs/s (%llu pairs in %.2f s)\n", (double)(pairs_seen - pairs_before_steady) / std::max(t_start + t_loop - t_steady, 1e-9),
-                (unsigned long long)(pairs_seen - pairs_before_steady), t_start + t_loop - t_steady);
+    fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped; %zu GPU(s) x %d worker(s), %zu index chunk(s))\n", t_loop,
+            st.pairs / std::max(t_loop, 1e-9), devices.size(), workers_per_gpu, n_chunks);
     if (getenv("MP_TIMING"))
         fprintf(stderr, "[Main] seconds: reading and packing %.2f (own threads), upload %.2f, deep-DP round %.2f, sort %.2f, BAM CIGARs %.2f, output of deep pairs %.2f, rescue round %.2f, output of the rest %.2f\n",
                 st.t_read, st.t_upload, st.t_deep, st.t_sort, st.t_cigar, st.t_emit_deep, st.t_rescue, st.t_emit_rest);
-    mp_ctx_destroy(ctx);
-    mp_index_close(ix);
+    for (Device &d : devices) for (mp_index *ix : d.chunks) if (ix) mp_index_close(ix);
     return 0;
 }

@@ -359,8 +359,11 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             }
         }
         outB = inB;
-        if (FLAGS && ((t & (MP_DP_FLUSH - 1)) == 0 || t == steps)) {
-            // flush this lane's last (up to) 8 steps as one contiguous run
+        if (FLAGS && mmax > 0 && ((t & (MP_DP_FLUSH - 1)) == 0 || t == steps)) {
+            // flush this lane's last (up to) 8 steps as one contiguous run.  `steps` is the maximum over the whole wavefront (the
+            // DPP hand-over needs every lane in the loop), so lane groups without an instance -- the tail of a launch -- come
+            // through here too: they own no slot of the slab (it holds the launch's instance pairs, not the wavefront's) and
+            // must not write
             uint32_t *dst = frow + (uint64_t)((t - 1) & ~(MP_DP_FLUSH - 1)) * NW;
 #pragma unroll
             for (int w = 0; w < MP_DP_FLUSH * NW; w += 4) {

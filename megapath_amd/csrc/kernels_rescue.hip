@@ -40,82 +40,95 @@ struct mp_single_cand { uint64_t pos; uint32_t strand; uint32_t seed_len; };
 // (DV-DPForSingleReads.cpp:200).  Introsort: median of (first+1, middle, last-1) to `first`, Hoare partition of the rest,
 // right part first (explicit stack instead of recursion), ranges of <= 16 left alone; heap sort of a range when
 // 2*floor(log2 n) levels are used up; then one insertion pass, guarded for the first 16 elements only.
-#define MP_LSL(x, y) ((x).seed_len > (y).seed_len)
-__device__ __forceinline__ void mp_lsl_swap(mp_single_cand *a, int i, int j) { const mp_single_cand t = a[i]; a[i] = a[j]; a[j] = t; }
+// Records move as one 16-byte register quad (x, y = pos; z = strand; w = seed_len): no struct temporaries, no scratch memory.
+typedef uint4 mp_cand_q;
+__device__ __forceinline__ mp_cand_q mp_lsl_ld(const mp_single_cand *a, int i) { return *reinterpret_cast<const mp_cand_q *>(a + i); }
+__device__ __forceinline__ void mp_lsl_st(mp_single_cand *a, int i, mp_cand_q v) { *reinterpret_cast<mp_cand_q *>(a + i) = v; }
+__device__ __forceinline__ uint32_t mp_lsl_len(const mp_single_cand *a, int i) { return a[i].seed_len; }
+__device__ __forceinline__ void mp_lsl_swap(mp_single_cand *a, int i, int j) { const mp_cand_q t = mp_lsl_ld(a, i); mp_lsl_st(a, i, mp_lsl_ld(a, j)); mp_lsl_st(a, j, t); }
+static_assert(sizeof(mp_single_cand) == 16, "candidates move as 16-byte quads");
 
-__device__ void mp_lsl_sift(mp_single_cand *a, int hole, int len, mp_single_cand v)
+// __adjust_heap + __push_heap of libstdc++ (bits/stl_heap.h) with "longer seed first" as the order
+__device__ __forceinline__ void mp_lsl_sift(mp_single_cand *a, int hole, int len, mp_cand_q v)
 {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (MP_LSL(a[child], a[child - 1])) child--;
-        a[hole] = a[child]; hole = child;
+        if (mp_lsl_len(a, child) > mp_lsl_len(a, child - 1)) child--;
+        mp_lsl_st(a, hole, mp_lsl_ld(a, child)); hole = child;
     }
-    if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[hole] = a[child - 1]; hole = child - 1; }
+    if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); mp_lsl_st(a, hole, mp_lsl_ld(a, child - 1)); hole = child - 1; }
     int parent = (hole - 1) / 2;
-    while (hole > top && MP_LSL(a[parent], v)) { a[hole] = a[parent]; hole = parent; parent = (hole - 1) / 2; }
-    a[hole] = v;
+    while (hole > top && mp_lsl_len(a, parent) > v.w) { mp_lsl_st(a, hole, mp_lsl_ld(a, parent)); hole = parent; parent = (hole - 1) / 2; }
+    mp_lsl_st(a, hole, v);
 }
 
-__device__ void mp_sort_longer_seed(mp_single_cand *a, int n)
+// The stack of pending ranges lives in LDS (`stk`, one column per lane, MP_LSL_STACK entries `stride` words apart): private
+// arrays would be scratch memory, which no kernel of this library uses.  An entry packs first | last << 12 | depth << 24
+// (a read has < 4096 candidates: at most MP_SEED_BIG seeds per strand); at most one entry per partition level is pending.
+#define MP_LSL_STACK 26
+__device__ __forceinline__ void mp_sort_longer_seed(mp_single_cand *a, int n, uint32_t *stk, int stride)
 {
     if (n <= 1) return;
-    if (n > 16) {
-        int stk_first[64], stk_last[64], stk_depth[64];
+    if (n > 16 && n < 4096) {
         int sp = 0;
-        stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * (31 - __clz(n)); sp = 1;
+        stk[0] = (uint32_t)n << 12 | (uint32_t)(2 * (31 - __clz(n))) << 24; sp = 1;
         while (sp > 0) {
             --sp;
-            const int first = stk_first[sp];
-            int last = stk_last[sp], depth = stk_depth[sp];
+            const uint32_t e = stk[sp * stride];
+            const int first = (int)(e & 4095u);
+            int last = (int)((e >> 12) & 4095u), depth = (int)(e >> 24);
             // the reference recurses into [cut, last) before it goes on with [first, cut): the two ranges are disjoint, so doing
             // the left ones first and stacking the right ones gives the same array
             while (last - first > 16) {
                 if (depth == 0) {
                     mp_single_cand *h = a + first;
                     const int len = last - first;
-                    for (int parent = (len - 2) / 2;; parent--) { mp_lsl_sift(h, parent, len, h[parent]); if (parent == 0) break; }
-                    for (int e = len; e > 1;) { --e; const mp_single_cand v = h[e]; h[e] = h[0]; mp_lsl_sift(h, 0, e, v); }
+                    for (int parent = (len - 2) / 2;; parent--) { mp_lsl_sift(h, parent, len, mp_lsl_ld(h, parent)); if (parent == 0) break; }
+                    for (int e2 = len; e2 > 1;) { --e2; const mp_cand_q v = mp_lsl_ld(h, e2); mp_lsl_st(h, e2, mp_lsl_ld(h, 0)); mp_lsl_sift(h, 0, e2, v); }
                     break;
                 }
                 --depth;
                 const int x = first + 1, y = first + (last - first) / 2, z = last - 1;
-                if (MP_LSL(a[x], a[y])) { if (MP_LSL(a[y], a[z])) mp_lsl_swap(a, first, y); else if (MP_LSL(a[x], a[z])) mp_lsl_swap(a, first, z); else mp_lsl_swap(a, first, x); }
-                else if (MP_LSL(a[x], a[z])) mp_lsl_swap(a, first, x);
-                else if (MP_LSL(a[y], a[z])) mp_lsl_swap(a, first, z);
-                else mp_lsl_swap(a, first, y);
-                const uint32_t pivot = a[first].seed_len;
+                const uint32_t lx = mp_lsl_len(a, x), ly = mp_lsl_len(a, y), lz = mp_lsl_len(a, z);
+                // __move_median_to_first with comp(p, q) = len(p) > len(q)
+                int med;
+                if (lx > ly) med = ly > lz ? y : (lx > lz ? z : x);
+                else med = lx > lz ? x : (ly > lz ? z : y);
+                mp_lsl_swap(a, first, med);
+                const uint32_t pivot = mp_lsl_len(a, first);
                 int lo = first + 1, hi = last;
                 for (;;) {
-                    while (a[lo].seed_len > pivot) ++lo;
+                    while (mp_lsl_len(a, lo) > pivot) ++lo;
                     --hi;
-                    while (pivot > a[hi].seed_len) --hi;
+                    while (pivot > mp_lsl_len(a, hi)) --hi;
                     if (!(lo < hi)) break;
                     mp_lsl_swap(a, lo, hi);
                     ++lo;
                 }
-                if (sp < 64) { stk_first[sp] = lo; stk_last[sp] = last; stk_depth[sp] = depth; sp++; }
+                if (sp < MP_LSL_STACK) { stk[sp * stride] = (uint32_t)lo | (uint32_t)last << 12 | (uint32_t)depth << 24; sp++; }
                 last = lo;
             }
         }
     }
+    // __final_insertion_sort: guarded for the first 16 elements, unguarded after them
     const int guarded = n > 16 ? 16 : n;
-    for (int i = 1; i < guarded; i++) {
-        const mp_single_cand v = a[i];
+    for (int i = 1; i < n; i++) {
+        const mp_cand_q v = mp_lsl_ld(a, i);
         int j = i;
-        if (MP_LSL(v, a[0])) { for (; j > 0; j--) a[j] = a[j - 1]; }
-        else while (MP_LSL(v, a[j - 1])) { a[j] = a[j - 1]; j--; }
-        a[j] = v;
+        if (i < guarded && v.w > mp_lsl_len(a, 0)) { for (; j > 0; j--) mp_lsl_st(a, j, mp_lsl_ld(a, j - 1)); }
+        else while (v.w > mp_lsl_len(a, j - 1)) { mp_lsl_st(a, j, mp_lsl_ld(a, j - 1)); j--; }
+        mp_lsl_st(a, j, v);
     }
-    for (int i = guarded; i < n; i++) { const mp_single_cand v = a[i]; int j = i; while (MP_LSL(v, a[j - 1])) { a[j] = a[j - 1]; j--; } a[j] = v; }
 }
 
 // Test aid (mp_test_sort_longer_seed): one lane per array; array t holds off[t+1] - off[t] seeds whose `pos` carries the input index
 __global__ void sort_longer_seed_test_kernel(mp_single_cand *__restrict__ cand, const uint32_t *__restrict__ off, uint32_t n_arrays)
 {
+    __shared__ uint32_t s_stk[MP_LSL_STACK][64];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_arrays) mp_sort_longer_seed(cand + off[t], (int)(off[t + 1] - off[t]));
+    if (t < n_arrays) mp_sort_longer_seed(cand + off[t], (int)(off[t + 1] - off[t]), &s_stk[0][threadIdx.x], 64);
 }
 
 // One lane per failed read.  The read's kept seeds (the seed pool) sit at seedpos[rs_base[2r] ..) sorted by
@@ -126,6 +139,7 @@ single_cand_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed,
                    const uint32_t *__restrict__ rs_base, const uint32_t *__restrict__ n_pos, const uint32_t *__restrict__ n_neg,
                    mp_single_cand *__restrict__ cand, uint32_t *__restrict__ n_cand)
 {
+    __shared__ uint32_t s_stk[MP_LSL_STACK][128];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot > n_failed) return;
     if (slot == n_failed) { n_cand[slot] = 0; return; }
@@ -150,7 +164,7 @@ single_cand_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed,
     }
     // longest first, in the very order std::sort(.., LongerSeedLength()) leaves equal lengths in (DV-DPfunctions.cpp:334):
     // the cut at 200 below makes that order output-visible.  Then drop < 0.6 x best, cap at 200.
-    mp_sort_longer_seed(out, nm);
+    mp_sort_longer_seed(out, nm, &s_stk[0][threadIdx.x], 128);
     while (nm > 0 && (double)out[nm - 1].seed_len < (double)out[0].seed_len * 0.6) nm--;
     if (nm > MP_SINGLE_MAX) nm = MP_SINGLE_MAX;
     n_cand[slot] = (uint32_t)nm;

@@ -102,7 +102,7 @@ class IndexInfo(C.Structure):
 
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
-           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy",
+           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy", "mp_ctx_set_index",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
            "mp_test_sort_longer_seed"]
@@ -154,6 +154,7 @@ def load_library():
     lib.mp_ctx_get_dp_census.argtypes = [vp, C.POINTER(DpCensus)]
     lib.mp_ctx_create.argtypes = [vp, C.POINTER(vp)]
     lib.mp_ctx_destroy.argtypes = [vp]
+    lib.mp_ctx_set_index.argtypes = [vp, vp]
     lib.mp_set_reads.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.mp_set_reads_device.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32]
     lib.mp_seed_batch.argtypes = [vp, C.POINTER(MmpParams), C.POINTER(SeedStats)]
@@ -328,6 +329,11 @@ class Context:
         if self._h:
             load_library().mp_ctx_destroy(self._h)
             self._h = None
+
+    def set_index(self, index: Index):
+        """Bind the context to another index chunk resident on the same GPU; the reads of the batch stay set."""
+        _chk(load_library().mp_ctx_set_index(self._h, index._h), "mp_ctx_set_index")
+        self.index = index
 
     def set_reads(self, packed: np.ndarray, lens: np.ndarray):
         packed = np.ascontiguousarray(packed, dtype=np.uint32)

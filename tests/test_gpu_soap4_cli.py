@@ -299,3 +299,41 @@ def test_cli_reads_below_the_dp_cutoff_do_not_abort_or_hurt_neighbours(golden_di
         recs = fastq_records(str(got))
         assert recs == fastq_records(_oracle_stdout(prefix, f1, f2, 151, tmp_path))
         assert all("SCORE:0;" in x[2] for x in recs if len(x[3]) < 30)
+
+
+@pytest.mark.parametrize("tag,L", [("a", 151), ("c", 301)])
+def test_cli_resident_chunks_equal_reference_chain(golden_dir, tmp_path, tag, L):
+    """Row f2: three index chunks resident in one process, every batch aligned against each, per-reference hits merged as the
+    chained reference runs merge them through the SCORE: comments -- equals the last stdout of the real three-run chain (g3)."""
+    g1, g3 = os.path.join(golden_dir, "g1"), os.path.join(golden_dir, "g3")
+    out = tmp_path / "out.fq"
+    prefixes = ",".join(os.path.join(g3, "c%d.fa.index" % k) for k in range(3))
+    err = _run_cli(["pair", prefixes, os.path.join(g1, "reads_%s_1.fq" % tag), os.path.join(g1, "reads_%s_2.fq" % tag), "-o", str(tmp_path / "o"),
+                    "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L), "-T", "2", "-u", "750", "-F", "-nc", "-top", "95"], out, batch_pairs=50)
+    assert fastq_records(str(out)) == fastq_records(os.path.join(g3, "expected_chain_%s.fq" % tag))
+    assert b"3 index chunk(s)" in err
+
+
+def test_cli_same_chunk_twice_equals_chained_golden_e(golden_dir, tmp_path):
+    """The chained two-run golden of g1 (set e: run 2 reads run 1's stdout with its comments) from ONE process holding the index twice."""
+    d = os.path.join(golden_dir, "g1")
+    out = tmp_path / "out.fq"
+    prefix = os.path.join(d, "ref.fa.index")
+    _run_cli(["pair", prefix + "," + prefix, os.path.join(d, "reads_a_1.fq"), os.path.join(d, "reads_a_2.fq"), "-o", str(tmp_path / "o"),
+              "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "2", "-u", "750", "-F", "-nc", "-top", "95"], out)
+    assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_e.fq"))
+
+
+def test_cli_two_workers_keep_input_order_of_batches(golden_dir, tmp_path):
+    """Several workers finish batches out of order; the printer writes them in input order: with one pair per read name the
+    sequence of batches in the output is the input's."""
+    d = os.path.join(golden_dir, "g1")
+    out = tmp_path / "out.fq"
+    _run_cli(["pair", os.path.join(d, "ref.fa.index"), os.path.join(d, "reads_a_1.fq"), os.path.join(d, "reads_a_2.fq"), "-o", str(tmp_path / "o"),
+              "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "2", "-u", "750", "-F", "-nc"], out, batch_pairs=16)
+    names = [l.split(b"\t")[0][1:] for l in open(out, "rb") if l.startswith(b"@r")][0::2]
+    src = [l.split()[0][1:-2] for l in open(os.path.join(d, "reads_a_1.fq"), "rb") if l.startswith(b"@r")]
+    batch_of = {n: i // 16 for i, n in enumerate(src)}
+    seq = [batch_of[n] for n in names]
+    assert seq == sorted(seq) and len(names) == len(src)
+    assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_a.fq"))

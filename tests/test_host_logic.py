@@ -112,3 +112,33 @@ def test_lsam_restatement_matches_reference_tool(golden_dir):
     for tag, seq in (("a", True), ("d", True), ("e", True), ("g", True), ("h", True), ("a.noseq", False)):
         src = open(os.path.join(g, "expected_%s.fq" % tag.split(".")[0]), "rb").read()
         assert lsam.fastq_to_lsam(src, seq) == open(os.path.join(g, "expected_%s.lsam" % tag), "rb").read(), tag
+
+
+def test_driver_plumbing_keeps_input_order_across_fake_gpus(tmp_path):
+    """bin/soap4-mi355x with MP_PLUMBING_TEST (no device, nothing aligned): three 'GPUs' x two workers with jittered batch
+    times and two 'chunks'; the printer must still write the batches -- contiguous blocks of pairs -- in input order."""
+    exe = os.path.join(ROOT, "bin", "soap4-mi355x")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "megapath_amd", "csrc")])
+    d = os.path.join(ROOT, "tests", "golden", "g1")
+    env = dict(os.environ, MP_PLUMBING_TEST="1", MP_PLUMBING_JITTER_US="4000", MP_BATCH_PAIRS="7")
+    r = subprocess.run([exe, "pair", "x,y", os.path.join(d, "reads_a_1.fq"), os.path.join(d, "reads_a_2.fq"), "-o", str(tmp_path / "o"),
+                        "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "3", "-u", "750", "-F", "-nc", "-c", "0,1,2"],
+                       env=env, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"NO ALIGNMENT IS DONE" in r.stderr and b"3 GPU(s) x 2 worker(s), 2 index chunk(s)" in r.stderr
+    names = [l.split(b"\t")[0][1:] for l in r.stdout.split(b"\n") if l.startswith(b"@r")]
+    src = [l.split()[0][1:-2] for l in open(os.path.join(d, "reads_a_1.fq"), "rb") if l.startswith(b"@r")]
+    assert names[0::2] == src and names[1::2] == src
+
+
+def test_driver_reports_corrupt_gzip_instead_of_truncating(tmp_path):
+    import gzip
+    d = os.path.join(ROOT, "tests", "golden", "g1")
+    exe = os.path.join(ROOT, "bin", "soap4-mi355x")
+    raw = gzip.compress(open(os.path.join(d, "reads_a_1.fq"), "rb").read())
+    bad = tmp_path / "bad_1.fq.gz"
+    bad.write_bytes(raw[: len(raw) // 2])                       # truncated stream
+    env = dict(os.environ, MP_PLUMBING_TEST="1")
+    r = subprocess.run([exe, "pair", "x", str(bad), os.path.join(d, "reads_a_2.fq"), "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
+                        "-L", "151", "-F", "-nc"], env=env, capture_output=True)
+    assert r.returncode == 1 and b"error while reading" in r.stderr

@@ -140,3 +140,29 @@ def test_g2_tied_candidates_and_unseedable_reads(golden_dir, tmp_path, tag, L):
     if tag == "t":
         capped = [r for r in want if r[0].startswith("f") and r[2].count(",") == 200]
         assert len(capped) == 10       # every tied read was cut at 200 candidates
+
+
+@pytest.mark.parametrize("tag,L", [("a", 151), ("c", 301)])
+def test_three_chained_chunks_match_reference_chain(golden_dir, tmp_path, tag, L):
+    """g3: the NT loop (runMegaPath.sh:191-227) over three index chunks, three chained reference runs; the oracle is chained
+    the same way -- each run reads the previous run's de-interleaved stdout and merges its SCORE: comments."""
+    lib = O.oracle()
+    g1, g3 = os.path.join(golden_dir, "g1"), os.path.join(golden_dir, "g3")
+    in1, in2 = os.path.join(g1, "reads_%s_1.fq" % tag), os.path.join(g1, "reads_%s_2.fq" % tag)
+    out = None
+    for k in range(3):
+        ix = lib.mpo_index_open(os.path.join(g3, "c%d.fa.index" % k).encode())
+        p = O.default_params(L=L, insert_high=750, mode=1, top=95, nc=(k == 0))
+        st = O.AlignStats()
+        out = str(tmp_path / ("chain_%d.fq" % k))
+        assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), out.encode(), None, C.byref(st)) == 0
+        lib.mpo_index_close(ix)
+        lines = open(out, "rb").read().split(b"\n")
+        in1, in2 = out + ".1", out + ".2"
+        with open(in1, "wb") as a, open(in2, "wb") as b:
+            for i in range(0, len(lines) - 7, 8):
+                a.write(b"\n".join(lines[i:i + 4]) + b"\n")
+                b.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
+    got, want = fastq_records(out), fastq_records(os.path.join(g3, "expected_chain_%s.fq" % tag))
+    assert got == want
+    assert sum(1 for r in want if r[2].count(",") >= 2) > 0 or tag == "c"      # some reads do carry hits from more than one chunk

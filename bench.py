@@ -122,6 +122,45 @@ class Workload:
         del packed
 
 
+class WorkloadSlice:
+    """A contiguous block of a workload's pairs (same pinned arrays, no copy): what one of several contexts works on."""
+
+    def __init__(self, wl, lo_pair, hi_pair):
+        self.packed_np = wl.packed_np[2 * lo_pair:2 * hi_pair]
+        self.lens_np = wl.lens_np[2 * lo_pair:2 * hi_pair]
+        self.n_pairs = hi_pair - lo_pair
+        self.max_len, self.L, self.W = wl.max_len, wl.L, wl.W
+
+
+def run_overlapped(ctxs, slices, params, n_steps, barrier=None):
+    """The same batch cut into len(ctxs) contiguous blocks, one context (own HIP streams) and one host thread per block: the
+    latency-bound seeding of one block overlaps with the VALU-bound DP of another.  Returns the wall time of n_steps steps."""
+    import threading
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(n_steps):
+                step(ctxs[i], slices[i], params)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(ctxs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    if errs:
+        raise errs[0]
+    return time.perf_counter() - t0
+
+
 def step(ctx, wl, params, fetch_all=True):
     """One pass of the hot path over a batch (see the module docstring)."""
     ctx.set_reads(wl.packed_np, wl.lens_np)                      # H2D of the packed reads
@@ -341,7 +380,10 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MP_BENCH_CPU_PAIRS", "100000")))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity sample")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs (roofline.traffic = null)")
-    ap.add_argument("--no-legs", action="store_true", help="skip the C3/C4/C5 workload legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the C3/C4/C5 workload legs, the lean-layout leg and the resident-chunks leg")
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "2")),
+                    help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")
+    ap.add_argument("--nt-chunks", type=int, default=int(os.environ.get("MP_BENCH_NT_CHUNKS", "4")), help="index chunks of the resident-chunks leg")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -412,8 +454,20 @@ def main():
             ref_events = dict(occ=int(st0.seed.n_occ), lkt=int(st0.seed.n_lkt), sa=int(st0.seed.n_sa), seedpos=int(st0.seed.n_seedpos))
             ctx.set_prefilter(True)
     band0 = ctx.dp_band_stats()
-    elapsed, acc = run_steps(ctx, wl, params, args.steps, barrier)
+    elapsed_single, acc = run_steps(ctx, wl, params, args.steps, barrier)
     band1 = ctx.dp_band_stats()
+    elapsed = elapsed_single
+    n_ctx = max(1, args.contexts) if not args.pmc_child else 1
+    if n_ctx > 1:
+        # the configuration the drop-in executable runs in (MP_WORKERS_PER_GPU): the batch cut into contiguous blocks, one context each
+        cuts = [P * i // n_ctx for i in range(n_ctx + 1)]
+        slices = [WorkloadSlice(wl, cuts[i], cuts[i + 1]) for i in range(n_ctx)]
+        ctxs = [ctx] + [H.Context(gix) for _ in range(n_ctx - 1)]
+        run_overlapped(ctxs, slices, params, 1)                      # first touch of the new contexts' buffers
+        elapsed = run_overlapped(ctxs, slices, params, args.steps, barrier)
+        for c in ctxs[1:]:
+            c.close()
+        step(ctx, wl, params)                                        # leave the whole batch's hit lists in ctx for the exchange step below
     # the exchange step of the path: per-reference hit counts of this rank's last step, summed over the ranks
     hits, nh = ctx.pair_hits_view()
     ref_counts = taxcount.count_pair_hits_per_reference(gix, hits, nh)
@@ -437,11 +491,16 @@ def main():
             "unit": "pairs/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3,
+            "contexts_per_gpu": n_ctx,
+            "single_context": {"pairs_per_s": world * K * P / elapsed_single, "ms_per_step": elapsed_single / K * 1e3,
+                               "note": "the same %d steps with ONE context doing the whole batch on one stream: the run the per-kernel HIP-event times, "
+                                       "event counts and the roofline below come from (kernels of two contexts would overlap and stretch each other)" % K},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "2x%dbp synthetic pairs vs synthetic %.0f Mbp genome in 24 sequences (BASELINE configs[1], human-filter stage; GRCh38 indexes ~2.95 Gbp of "
                                    "non-N bases), %d pairs/step/GPU; a step = upload of the packed reads + deep-DP round (MMP seeding, pairing, both DP legs + traceback) + "
-                                   "rescue round (single-end DP, mate rescue) + all three hit lists back in pinned host memory" % (args.read_len, args.genome_mbp, P),
+                                   "rescue round (single-end DP, mate rescue) + all three hit lists back in pinned host memory; the batch is cut into %d contiguous blocks "
+                                   "that as many contexts work on side by side" % (args.read_len, args.genome_mbp, P, n_ctx),
                        "index_replicated_per_gpu": True, "pairs_per_step_per_gpu": P, "genome_mbp": args.genome_mbp,
                        "index_bytes_in_hbm": int(gix.info.device_bytes), "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750},
             "roofline": {"bound": "hbm", "kernel": "seed_kernel+seed_overflow_kernel+expand_hits_kernel+locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -545,6 +604,65 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     legs[name] = {"workload": desc, "error": repr(e)}
                     log("[bench] leg %s failed: %r" % (name, e))
+            # ---- lean layout: what a chunk of a 250 GB NT replica gets -- rank blocks, 13-mer table, the file's SA samples, text
+            # (1.09 B/base), none of the optional tables -- and N such chunks resident at once, every batch aligned against each
+            try:
+                knobs = {"MP_KMER_FILTER": "0", "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}
+                saved = {k: os.environ.get(k) for k in knobs}
+                os.environ.update(knobs)
+                nchunks = max(1, args.nt_chunks)
+                lean = []
+                t0 = time.time()
+                for _ in range(nchunks):
+                    lean.append(H.Index.from_arrays(local_rank, **arrs))
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                lean_bytes = sum(int(x.info.device_bytes) for x in lean)
+                lp = max(P // 4, 1 << 16)
+                lw = WorkloadSlice(wl, 0, lp)
+                lctx = H.Context(lean[0])
+                step(lctx, lw, params)
+                el, la = run_steps(lctx, lw, params, 2)
+                legs["lean_layout"] = {"workload": "the default workload against ONE index in the lean layout (no 17-mer pre-filter, no 16-mer table, SA samples every 16th row as in "
+                                                   "the index files): %.2f B/base in HBM" % (lean[0].info.device_bytes / n_bases),
+                                       "index_bytes_in_hbm": int(lean[0].info.device_bytes), "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3,
+                                       "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")},
+                                       "per_pair": {"rank_blocks_loaded": la["n_occ_loaded"] / (2 * lp), "lkt13_lookups": la["n_lkt"] / (2 * lp), "sa_reads": la["n_sa"] / (2 * lp)}}
+
+                def chunk_step():
+                    lctx.set_reads(lw.packed_np, lw.lens_np)
+                    tot = 0
+                    for ix in lean:
+                        lctx.set_index(ix)
+                        _, nh, _ = lctx.deep_dp_round(params, fetch=False)
+                        lctx.rescue_round(params, False, fetch=False)
+                        lctx.pair_hits_view(); lctx.single_hits_view(); lctx.rescue_hits_view()
+                        tot += nh
+                    return tot
+                chunk_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                hits_all = chunk_step()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t1
+                legs["resident_chunks"] = {"workload": "%d index chunks of %.0f Mbp each resident at once in the lean layout (%.1f Gbp, %.1f GB of HBM; the same synthetic genome "
+                                                       "loaded %d times -- every chunk finds the same hits, the work per chunk is what a distinct chunk of that size costs), every batch "
+                                                       "aligned against each chunk in turn by one context (mp_ctx_set_index), hit lists of every chunk fetched" % (
+                                                           nchunks, args.genome_mbp, nchunks * args.genome_mbp / 1e3, lean_bytes / 1e9, nchunks),
+                                           "chunks": nchunks, "bases_resident": nchunks * n_bases, "index_bytes_in_hbm": lean_bytes, "bytes_per_base": lean_bytes / (nchunks * n_bases),
+                                           "load_s": time.time() - t0, "pairs_per_step": lp, "ms_per_step": el * 1e3, "pairs_per_s": lp / el,
+                                           "chunk_pair_alignments_per_s": lp * nchunks / el, "pair_hits_over_all_chunks": int(hits_all),
+                                           "extrapolation": "a 250 GB replica at this layout holds %.0f Gbp; one batch against all of it costs (bases / %.2f Gbp) x %.1f ms at this "
+                                                            "rate" % (250e9 / (lean_bytes / (nchunks * n_bases)) / 1e9, args.genome_mbp / 1e3, el * 1e3 / nchunks)}
+                lctx.close()
+                for x in lean:
+                    x.close()
+            except Exception as e:  # noqa: BLE001
+                legs["resident_chunks"] = {"error": repr(e)}
+                log("[bench] lean / resident-chunks leg failed: %r" % (e,))
             out["legs"] = legs
         print(json.dumps(out), flush=True)
     ctx.close()

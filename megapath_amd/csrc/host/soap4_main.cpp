@@ -27,11 +27,14 @@
 #include <chrono>
 #include <condition_variable>
 #include <map>
+#include <unordered_map>
+#include <unordered_set>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 #include <memory>
+#include <functional>
 #include "../../../include/megapath_hip.h"
 #include "bam_out.h"
 
@@ -48,6 +51,8 @@ struct Params {
     double top = 0.95;
     bool skip_default_dp = false, want_bam = false, ignore_comments = false;   // -nc: SOAP4.cpp:537-547
     int lsam = 0;                 // extension: 1 = print LSAM lines instead of annotated FASTQ (what `| fastq2lsam 1` yields), 2 = without sequences
+    const struct Taxonomy *tax = nullptr;   // extension -lsamid: the lines are LSAM.id lines, what `| taxLookupAcc acc2tid nodes names -` makes of them
+    double pass1_t = 40;          // extension -pass1: reassign's -t (cc/reassign.cpp:19)
     mp_mmp_params mmp = {30, 17, 6, 5, 27, 18, 0.85, 4, 0.5};       // defaults of ParseIniFile (IniParam.cpp:427-435)
     size_t batch_pairs = 1u << 20;                                   // SOAP4.cpp:206
 };
@@ -283,6 +288,135 @@ bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out, int threa
     return na > 0;
 }
 
+// ------------------------------------------------------------------------------------------------ taxonomy (extension -lsamid / -pass1)
+// What cc/taxLookupAcc does to an LSAM line (cc/taxLookupAcc.cpp:49-93): every listed accession becomes the taxid of its
+// species (TaxDB::popUpToSpecies, cc/taxonomy.h:125-130), a species keeps the best of its accessions' scores, the hits are
+// printed in ascending taxid order and the scientific names of the hits' super-kingdoms are appended.  Only accessions that
+// name a sequence of the resident index chunks can ever be looked up, so only those rows of the accession2taxid file are kept.
+struct Taxonomy {
+    std::vector<int> parent;
+    std::vector<uint8_t> rank;                    // 1 species, 2 superkingdom
+    std::vector<std::string> sci_name;
+    std::unordered_map<std::string, int> acc2tid;
+    mutable std::mutex mu;
+    mutable std::unordered_map<std::string, int> species_of_name;   // sequence name -> species taxid, -1 = accession unknown (memo)
+
+    // removeVersion / getCorrectAcc (cc/taxonomy.h:14-24, cc/misc.h:29-45)
+    static std::string remove_version(const std::string &a)
+    {
+        for (int i = (int)a.size() - 1; i >= 0; --i) {
+            if (a[i] == '.') return a.substr(0, (size_t)i);
+            if (!isdigit((unsigned char)a[i])) return a;
+        }
+        return a;
+    }
+    static std::string correct_acc(const std::string &h)
+    {
+        size_t s0 = h.find('|');
+        if (s0 == std::string::npos || h.substr(0, s0) != "gi") return h;
+        s0 = h.find('|', s0 + 1);
+        s0 = h.find('|', s0 + 1);
+        const size_t s1 = h.find('|', s0 + 1);
+        return h.substr(s0 + 1, s1 - s0 - 1);
+    }
+    void ensure(int id) { if (id >= (int)parent.size()) { const size_t n = (size_t)((id + 1) * 1.5); parent.resize(n, 0); rank.resize(n, 0); sci_name.resize(n); } }
+    static bool read_lines(const std::string &path, const std::function<void(char *)> &fn)
+    {
+        gzFile f = gzopen(path.c_str(), "rb");
+        if (!f) return false;
+        gzbuffer(f, 1 << 20);
+        std::vector<char> line(1 << 16);
+        while (gzgets(f, line.data(), (int)line.size())) fn(line.data());
+        gzclose(f);
+        return true;
+    }
+    bool load(const std::string &acc_path, const std::string &nodes_path, const std::string &names_path, const std::unordered_set<std::string> &wanted)
+    {
+        parent.assign(2000000, 0); rank.assign(2000000, 0); sci_name.assign(2000000, std::string());        // TaxDB::kInitNumTax
+        bool ok = read_lines(nodes_path, [&](char *l) {                                  // tid | parent | rank | ...   (TaxDB::readNode)
+            char *sv = nullptr;
+            const char *t0 = strtok_r(l, " \t\r\n", &sv); (void)strtok_r(nullptr, " \t\r\n", &sv);
+            const char *t2 = strtok_r(nullptr, " \t\r\n", &sv); (void)strtok_r(nullptr, " \t\r\n", &sv);
+            const char *t4 = strtok_r(nullptr, " \t\r\n", &sv);
+            if (!t0 || !t2 || !t4) return;
+            const int id = atoi(t0);
+            if (id < 0) return;
+            ensure(id);
+            parent[(size_t)id] = atoi(t2);
+            rank[(size_t)id] = !strcmp(t4, "species") ? 1 : !strcmp(t4, "superkingdom") ? 2 : 0;
+        });
+        ok = ok && read_lines(names_path, [&](char *l) {                                 // TaxDB::readName: the "scientific name" rows
+            if (!strstr(l, "scientific name")) return;
+            char *sv = nullptr;
+            const char *t0 = strtok_r(l, " \t\r\n", &sv);
+            if (!t0) return;
+            const int id = atoi(t0);
+            (void)strtok_r(nullptr, " \t\r\n", &sv);                                   // the '|' after the id
+            std::string name;
+            for (const char *w = strtok_r(nullptr, " \t\r\n", &sv); w && strcmp(w, "|") != 0; w = strtok_r(nullptr, " \t\r\n", &sv)) { if (!name.empty()) name += ' '; name += w; }
+            if (id >= 0) { ensure(id); sci_name[(size_t)id] = name; }
+        });
+        ok = ok && read_lines(acc_path, [&](char *l) {                                   // accession  accession.version  taxid  gi  (TaxDB::initAccToTax)
+            char *sv = nullptr;
+            (void)strtok_r(l, " \t\r\n", &sv);
+            const char *acc = strtok_r(nullptr, " \t\r\n", &sv), *tid = strtok_r(nullptr, " \t\r\n", &sv);
+            if (!acc || !tid) return;
+            const std::string key = remove_version(acc);
+            if (wanted.empty() || wanted.count(key)) acc2tid[key] = atoi(tid);        // an empty set asks for every row
+        });
+        return ok;
+    }
+    int species_tid(int tid) const { while (tid != 1 && tid != 0 && !(tid < (int)rank.size() && rank[(size_t)tid] == 1)) tid = tid < (int)parent.size() ? parent[(size_t)tid] : 0; return tid; }
+    int superkingdom(int tid) const { while (tid != 1 && tid != 0) { if (tid < (int)rank.size() && rank[(size_t)tid] == 2) return tid; tid = tid < (int)parent.size() ? parent[(size_t)tid] : 0; } return -1; }
+    int species_of(const std::string &seq_name) const
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = species_of_name.find(seq_name);
+        if (it != species_of_name.end()) return it->second;
+        auto a = acc2tid.find(remove_version(correct_acc(seq_name)));
+        int sp = -1;
+        if (a != acc2tid.end()) sp = species_tid(a->second);
+        else fprintf(stderr, "Error: Taxid not found for %s\n", correct_acc(seq_name).c_str());
+        species_of_name.emplace(seq_name, sp);
+        return sp;
+    }
+};
+
+// Pass 1 of cc/reassign (cc/reassign.cpp:64-110) over the LSAM.id lines as they are produced: per species taxid the reads that
+// list it, the reads that list only it, and per pair of taxids the reads that list both -- the counters the ranks of a
+// multi-process run all-reduce (megapath_amd/taxcount.py).
+struct Pass1 {
+    std::map<int, long long> counts, uniq;
+    std::map<std::pair<int, int>, long long> intersect;      // (larger taxid, smaller taxid): pairup(), cc/reassign.cpp:29-32
+    void line(int best_score, const std::map<int, double> &hits, double t)
+    {
+        if (best_score < t || hits.empty()) return;
+        std::vector<int> seen;
+        for (const auto &h : hits) {
+            counts[h.first]++;
+            if (hits.size() == 1) uniq[h.first]++;
+            else for (int s : seen) intersect[{std::max(s, h.first), std::min(s, h.first)}]++;
+            seen.push_back(h.first);
+        }
+    }
+    void add(const Pass1 &o)
+    {
+        for (const auto &x : o.counts) counts[x.first] += x.second;
+        for (const auto &x : o.uniq) uniq[x.first] += x.second;
+        for (const auto &x : o.intersect) intersect[x.first] += x.second;
+    }
+    bool write(const std::string &path, double t) const
+    {
+        FILE *f = fopen(path.c_str(), "w");
+        if (!f) return false;
+        fprintf(f, "#reassign-pass1\tt=%g\n", t);
+        for (const auto &x : counts) fprintf(f, "counts\t%d\t%lld\n", x.first, x.second);
+        for (const auto &x : uniq) fprintf(f, "uniq\t%d\t%lld\n", x.first, x.second);
+        for (const auto &x : intersect) fprintf(f, "intersect\t%d\t%d\t%lld\n", x.first.first, x.first.second, x.second);
+        return fclose(f) == 0;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ output
 struct ChrHit { int chr, neg; bool operator<(const ChrHit &o) const { return chr != o.chr ? chr < o.chr : neg < o.neg; } };
 struct HdrMap { int score; std::string text; };
@@ -327,6 +461,43 @@ struct Writer {
         const int score = ignore ? -1 : (comm.size() > 6 ? atoi(comm.c_str() + 6) : 0);
         snprintf(tmp, sizeof tmp, "%d\t", score); out += tmp;
         if (p.lsam == 1) { out += seq; out += '\t'; out += qual; out += '\t'; } else out += "*\t*\t";
+        if (p.tax) {
+            // taxLookupAcc (cc/taxLookupAcc.cpp:59-90): species taxid of every listed accession, best score per species, ascending taxid
+            std::map<int, double> by_tid;
+            if (score > 0) {
+                size_t i = comm.find(';');
+                while (i != std::string::npos && i + 1 < comm.size()) {
+                    size_t j = comm.find(';', i + 1);
+                    if (j == std::string::npos) j = comm.size();
+                    size_t c0 = comm.find(',', i + 1);
+                    if (c0 != std::string::npos && c0 < j) {
+                        const double sc = atof(comm.c_str() + i + 1);
+                        for (size_t a = c0; a < j;) {
+                            size_t b = comm.find(',', a + 1);
+                            if (b == std::string::npos || b > j) b = j;
+                            const int sp = p.tax->species_of(comm.substr(a + 1, b - a - 1));
+                            if (sp >= 0) { double &v = by_tid[sp]; v = std::max(v, sc); }
+                            a = b;
+                        }
+                    }
+                    i = j;
+                }
+            }
+            if (by_tid.empty()) out += '*';
+            else {
+                bool first = true;
+                for (const auto &h : by_tid) { if (!first) out += ';'; first = false; snprintf(tmp, sizeof tmp, "%g,%d", h.second, h.first); out += tmp; }
+            }
+            if (ignore) out += "\tIGNORE";
+            std::vector<int> sk;
+            for (const auto &h : by_tid) { const int k = p.tax->superkingdom(h.first); if (k >= 0) sk.push_back(k); }
+            std::sort(sk.begin(), sk.end());
+            sk.erase(std::unique(sk.begin(), sk.end()), sk.end());
+            for (int k : sk) { out += '\t'; out += p.tax->sci_name[(size_t)k]; }
+            out += '\n';
+            pass1.line(score, by_tid, p.pass1_t);
+            return;
+        }
         if (score <= 0) out += '*';
         else {
             bool first = true;
@@ -395,6 +566,7 @@ struct Writer {
     }
     const Rec *held_ = nullptr;
     std::string held_comm_, comm_;
+    Pass1 pass1;                  // counters of the lines this writer printed (-lsamid)
     // decideTargetChr (BGS-IO.cpp:1312-1341)
     int target_chr(uint64_t pos, uint32_t len) const
     {
@@ -681,10 +853,10 @@ void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, boo
 // the reference: pairs of the deep-DP round, then every rescued pair, then the unpaired rest (alignment.cpp:105-330).
 // Pairs are independent, so each section is cut into chunks that worker threads format into their own buffers; the
 // buffers go out in chunk order.
-struct Sink { std::string text, bam[3]; uint64_t n = 0; };
+struct Sink { std::string text, bam[3]; uint64_t n = 0; Pass1 pass1; };
 
 template <typename F>
-void for_chunks(size_t n_items, int threads, BamState *bam, F &&body)
+void for_chunks(size_t n_items, int threads, BamState *bam, Pass1 *pass1, F &&body)
 {
     const size_t chunk = 4096;
     const size_t n_chunks = (n_items + chunk - 1) / chunk;
@@ -692,7 +864,7 @@ void for_chunks(size_t n_items, int threads, BamState *bam, F &&body)
     std::vector<Sink> sinks(wave);
     for (size_t c0 = 0; c0 < n_chunks; c0 += wave) {
         const size_t nc = std::min(wave, n_chunks - c0);
-        auto run = [&](size_t t) { Sink &s = sinks[t]; s.text.clear(); for (auto &x : s.bam) x.clear(); body((c0 + t) * chunk, std::min(n_items, (c0 + t + 1) * chunk), s); };
+        auto run = [&](size_t t) { Sink &s = sinks[t]; s.text.clear(); s.pass1 = Pass1(); for (auto &x : s.bam) x.clear(); body((c0 + t) * chunk, std::min(n_items, (c0 + t + 1) * chunk), s); };
         std::vector<std::thread> pool;
         for (size_t t = 1; t < nc; t++) pool.emplace_back(run, t);
         run(0);
@@ -700,12 +872,13 @@ void for_chunks(size_t n_items, int threads, BamState *bam, F &&body)
         for (size_t t = 0; t < nc; t++) {
             fwrite(sinks[t].text.data(), 1, sinks[t].text.size(), stdout);
             if (bam) for (int k = 0; k < 3; k++) bam->w->append(k, sinks[t].bam[k]);
+            if (pass1) pass1->add(sinks[t].pass1);
         }
     }
 }
 
 // `carry`: not the last resident chunk -- the records keep their new header comments for the next chunk instead of being printed.
-void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b, BamState *bam, int threads, Stats &st, bool carry)
+void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b, BamState *bam, int threads, Stats &st, bool carry, Pass1 *pass1)
 {
     const uint32_t n_pairs = bt.n_reads / 2;
     double t0 = now_s();
@@ -732,7 +905,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
     std::vector<size_t> grp;
     for (size_t i = 0; i < hits.size(); i++) if (i == 0 || hits[i].pair_id != hits[i - 1].pair_id) grp.push_back(i);
     grp.push_back(hits.size());
-    for_chunks(grp.size() - 1, threads, bam, [&](size_t g0, size_t g1, Sink &sink) {
+    for_chunks(grp.size() - 1, threads, bam, pass1, [&](size_t g0, size_t g1, Sink &sink) {
         Writer w(ix, p, carry);
         PairText text;
         std::vector<PairAln> res;
@@ -762,6 +935,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
         }
         w.finish();
         sink.text.swap(w.out);
+        sink.pass1.add(w.pass1);
     });
     if (!carry) st.deep += grp.size() - 1;
     st.t_emit_deep += now_s() - t0; t0 = now_s();
@@ -770,7 +944,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
     grp.clear();
     for (size_t i = 0; i < rows.size(); i++) if (i == 0 || rows[i].pair != rows[i - 1].pair) grp.push_back(i);
     grp.push_back(rows.size());
-    for_chunks(grp.size() - 1, threads, bam, [&](size_t g0, size_t g1, Sink &sink) {
+    for_chunks(grp.size() - 1, threads, bam, pass1, [&](size_t g0, size_t g1, Sink &sink) {
         Writer w(ix, p, carry);
         PairText text;
         std::vector<PairAln> res;
@@ -799,6 +973,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
         }
         w.finish();
         sink.text.swap(w.out);
+        sink.pass1.add(w.pass1);
     });
     if (!carry) st.rescued += grp.size() - 1;
     // ---- the unpaired rest: per pair where its single-end hits (and their CIGARs) start
@@ -814,7 +989,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
             si = e;
         }
     }
-    for_chunks(rest.size(), threads, bam, [&](size_t i0, size_t i1, Sink &sink) {
+    for_chunks(rest.size(), threads, bam, pass1, [&](size_t i0, size_t i1, Sink &sink) {
         Writer w(ix, p, carry);
         std::vector<Side> lst[2];
         std::vector<mpbam::Writer::RefText> ref_of[2];
@@ -856,6 +1031,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
         }
         w.finish();
         sink.text.swap(w.out);
+        sink.pass1.add(w.pass1);
     });
     if (!carry) st.unpaired += rest.size();
     st.t_emit_rest += now_s() - t0;
@@ -923,6 +1099,7 @@ int main(int argc, char **argv)
     if (prefixes.empty()) { fprintf(stderr, "[soap4-mi355x] no index prefix given\n"); return 1; }
     std::string out_prefix = fq1;                                         // IniParam.cpp:633
     mpbam::Options bopt;
+    std::string tax_files[3], pass1_path;
     bool have_d = false, have_a = false, have_r = false;
     // updateUserInputText (IniParam.cpp:199-226): "\t" and "\n" typed on the command line become the characters
     auto unescape = [](const char *v) { std::string o; for (const char *c = v; *c; c++) { if (c[0] == '\\' && (c[1] == 't' || c[1] == 'n')) { o += c[1] == 't' ? '\t' : '\n'; c++; } else o += *c; } return o; };
@@ -955,6 +1132,9 @@ int main(int argc, char **argv)
         else if (a == "-nc") p.ignore_comments = true;
         else if (a == "-lsam") p.lsam = 1;                     // not in the reference: stdout = LSAM, saves the fastq2lsam pipe stage
         else if (a == "-lsam-noseq") p.lsam = 2;
+        else if (a == "-lsamid") { tax_files[0] = val(); tax_files[1] = val(); tax_files[2] = val(); }   // not in the reference: stdout = LSAM.id (fastq2lsam | taxLookupAcc in-process)
+        else if (a == "-pass1") pass1_path = val();                                                        // not in the reference: counters of reassign's pass 1 over those lines
+        else if (a == "-pass1-t") p.pass1_t = atof(val());
     }
     if (p.insert_low > p.insert_high) { fprintf(stderr, "The minimum value of insert size should not be greater than the maximum value of insert size.\n"); return 1; }
     // IniParam.cpp:918-940: -R needs -D and -A; -A and -D come together
@@ -1019,6 +1199,25 @@ int main(int argc, char **argv)
     } else
         for (size_t d = 0; d < devices.size(); d++) { devices[d].id = gpu_ids[d]; devices[d].chunks.assign(n_chunks, nullptr); }
 
+    Taxonomy tax;
+    if (!tax_files[0].empty()) {
+        if (plumbing_only) { fprintf(stderr, "[soap4-mi355x] -lsamid needs the index (sequence names)\n"); return 1; }
+        // accessions that can turn up: the names of the resident sequences -- and, when header comments of earlier runs are merged
+        // (no -nc), anything those list: then every row of the table is kept
+        std::unordered_set<std::string> wanted;
+        if (p.ignore_comments)
+            for (mp_index *ix : devices[0].chunks) {
+                mp_index_info info;
+                mp_index_get_info(ix, &info);
+                for (uint32_t q = 1; q <= info.num_seq; q++) wanted.insert(Taxonomy::remove_version(Taxonomy::correct_acc(mp_index_seq_name(ix, q))));
+            }
+        const double t0 = now_s();
+        if (!tax.load(tax_files[0], tax_files[1], tax_files[2], wanted)) { fprintf(stderr, "[soap4-mi355x] cannot read the taxonomy files given to -lsamid\n"); return 1; }
+        fprintf(stderr, "[Main] taxonomy: %zu accessions kept, loaded in %.1f s\n", tax.acc2tid.size(), now_s() - t0);
+        p.tax = &tax;
+        if (p.lsam == 0) p.lsam = 1;
+    } else if (!pass1_path.empty()) { fprintf(stderr, "[soap4-mi355x] -pass1 counts taxids: it needs -lsamid\n"); return 1; }
+    Pass1 pass1_total;
     FqReader ra, rb;
     if (!ra.open(fq1) || !rb.open(fq2)) { fprintf(stderr, "[soap4-mi355x] cannot open read files\n"); return 1; }
     BamState bam_state, *bam = nullptr;
@@ -1068,7 +1267,7 @@ int main(int argc, char **argv)
             // the chunks in database order: each one's per-reference hits join the header comments the earlier ones left
             for (size_t c = 0; c < n_chunks; c++) {
                 const bool last = c + 1 == n_chunks;
-                output_stage(devices[0].chunks[c], p, *b, b->ch[c], last ? bam : nullptr, threads, st_printer, !last);
+                output_stage(devices[0].chunks[c], p, *b, b->ch[c], last ? bam : nullptr, threads, st_printer, !last, p.tax ? &pass1_total : nullptr);
             }
             free_q.push(b);
         }
@@ -1110,6 +1309,7 @@ int main(int argc, char **argv)
     const double t_loop = now_s() - t_start;
     fflush(stdout);
     if (bam && !bam->w->close()) { fprintf(stderr, "[soap4-mi355x] error while writing the BAM files\n"); return 1; }
+    if (!pass1_path.empty() && !pass1_total.write(pass1_path, p.pass1_t)) { fprintf(stderr, "[soap4-mi355x] cannot write %s\n", pass1_path.c_str()); return 1; }
     // every stage kept its own counters: summed only now that the threads are gone
     Stats st = st_printer;
     st.t_read = st_reader.t_read;

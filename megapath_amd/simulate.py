@@ -63,7 +63,7 @@ def _revcomp_prefix(fwd: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
 
 def paired_reads(text: torch.Tensor, n_pairs: int, read_len: int, seed: int, frag_mean: float = 350.0, frag_sd: float = 40.0,
                  sub: float = 0.01, indel_frac: float = 0.12, random_frac: float = 0.05, sub_max=None, len_range=None,
-                 broken_mate_frac: float = 0.0, frag_max: int = 600):
+                 broken_mate_frac: float = 0.0, frag_max: int = 600, return_truth: bool = False):
     """Returns (codes [2*n_pairs, Lmax] uint8, lengths int32 [2*n_pairs]); rows 2p / 2p+1 are the mates of pair p.
 
     sub_max: per-pair substitution rate drawn uniformly from [0, sub_max] instead of the fixed `sub` (config C3: 0-8 %
@@ -113,6 +113,9 @@ def paired_reads(text: torch.Tensor, n_pairs: int, read_len: int, seed: int, fra
     r2 = torch.where(rnd2.unsqueeze(1) & (col < l2.unsqueeze(1)), rr[1], r2)
     codes = torch.stack([r1, r2], dim=1).reshape(2 * n_pairs, Lmax).contiguous()
     lens = torch.stack([l1, l2], dim=1).reshape(2 * n_pairs).to(torch.int32).contiguous()
+    if return_truth:
+        # where the fragment came from: text position of its first base, its length, and whether read 1 is the reverse-strand mate
+        return codes, lens, dict(pos=pos, flen=flen, flip=flip, random1=rnd1, random2=rnd2)
     return codes, lens
 
 

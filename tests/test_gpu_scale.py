@@ -294,3 +294,61 @@ def test_banded_dp_on_tandem_repeats(rnd, monkeypatch):
     assert len(res[(True, 1)]) > 1000
     assert res[(True, 0)] == res[(False, 0)]
     assert res[(True, 1)] == res[(False, 1)]
+
+
+def test_parity_properties_at_human_genome_scale():
+    """A 2.3 Gbp synthetic genome -- positions beyond 2^31, every optional table at its real size (2 GiB bitmap, 8.6 GB per-15-mer
+    bits, 17 GB 16-mer table, the whole suffix array).  No oracle can run here; what must hold regardless of size:
+    the 16-mer table equals 13-mer table + three steps for the 16-mer at EVERY text position; error-free pairs come back at
+    exactly their simulated coordinates with score = read length on both mates, also beyond 2^31; the hits are the same with
+    every optional table ignored (the reference's own walk); random pairs find nothing."""
+    import torch
+    from megapath_amd import index_builder, simulate
+    dev = torch.device("cuda", 0)
+    n = 2_300_000_000
+    text = simulate.genome(n, seed=11, device=dev, repeat_frac=0.0)      # no copied repeats: every error-free pair has exactly one home
+    tc = text.cpu().numpy()
+    cuts = np.linspace(0, n, 9).astype(np.int64)
+    arrs = index_builder.build_index_arrays([("c%d" % i, tc[cuts[i]:cuts[i + 1]]) for i in range(8)], sa_interval=16, device=dev)
+    del tc
+    torch.cuda.empty_cache()
+    gix = H.Index.from_arrays(0, **arrs)
+    del arrs
+    assert gix.info.prefilter_k == 17
+    checked, bad = gix.check_lkt16(1 << 20)
+    assert checked > n - 100 and bad == 0
+    P, L = 1 << 17, 150
+    codes, lens, truth = simulate.paired_reads(text, P, L, seed=5, sub=0.0, indel_frac=0.0, random_frac=0.1, return_truth=True)
+    W = (L + 1 + 15) // 16
+    packed = simulate.pack_codes(codes, W).cpu().numpy().view(np.uint32)
+    lens_np = lens.cpu().numpy().view(np.uint32)
+    params = H.AlignParams(L, 750, 130, 130, H.MmpParams.nt2())
+    ctx = H.Context(gix)
+    res = {}
+    for on in (True, False):
+        ctx.set_prefilter(on)
+        ctx.set_reads(packed, lens_np)
+        hits, nh, st = ctx.deep_dp_round(params)
+        arr = np.frombuffer((C.c_char * (nh * 48)).from_address(C.addressof(hits)), dtype=taxcount_dtype(), count=nh).copy()
+        res[on] = np.sort(arr, order=["pair_id", "algnmt_1", "algnmt_2", "score_1", "score_2"])
+    assert len(res[True]) == len(res[False]) and (res[True] == res[False]).all()
+    arr = res[True]
+    pos = truth["pos"].cpu().numpy(); flen = truth["flen"].cpu().numpy(); flip = truth["flip"].cpu().numpy()
+    rnd = (truth["random1"] | truth["random2"]).cpu().numpy()
+    # the forward mate sits at the fragment's start, the reverse-strand mate at its end - L; a flipped pair has read 1 as the reverse one
+    exp_left, exp_right = pos, pos + flen - L
+    exp1, exp2 = np.where(flip, exp_right, exp_left), np.where(flip, exp_left, exp_right)
+    ok = np.zeros(P, dtype=bool)
+    is_exp = (arr["algnmt_1"] == exp1[arr["pair_id"]]) & (arr["algnmt_2"] == exp2[arr["pair_id"]]) & (arr["score_1"] == L) & (arr["score_2"] == L)
+    ok[arr["pair_id"][is_exp]] = True
+    assert ok[~rnd].all(), int((~ok[~rnd]).sum())
+    assert not np.isin(np.nonzero(rnd)[0], arr["pair_id"]).any()
+    assert (arr["algnmt_1"] > (1 << 31)).sum() > 1000 and int(arr["algnmt_1"].max()) > 2_290_000_000
+    # the mate whose read is read 1 sits left exactly when the pair was not flipped
+    assert ((arr["left_is_mate"][is_exp] == 1) == flip[arr["pair_id"][is_exp]]).all()
+    ctx.close(); gix.close()
+
+
+def taxcount_dtype():
+    from megapath_amd import taxcount
+    return taxcount.PAIR_HIT_DTYPE

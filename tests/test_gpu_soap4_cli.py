@@ -337,3 +337,22 @@ def test_cli_two_workers_keep_input_order_of_batches(golden_dir, tmp_path):
     seq = [batch_of[n] for n in names]
     assert seq == sorted(seq) and len(names) == len(src)
     assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_a.fq"))
+
+
+def test_cli_lsam_id_and_pass1_counters_equal_reference_tools(golden_dir, tmp_path):
+    """Row f3: -lsamid prints what `soap4 | cc/fastq2lsam 1 | cc/taxLookupAcc` prints (species-level taxids, super-kingdom names),
+    -pass1 leaves the counters of cc/reassign's pass 1 over those lines; tests/golden/g4 holds the real tools' outputs."""
+    from megapath_amd import taxcount
+    g4 = os.path.join(golden_dir, "g4")
+    out = tmp_path / "out.lsam.id"
+    counters = tmp_path / "pass1.txt"
+    _run_cli(["pair", os.path.join(g4, "ref.fa.index"), os.path.join(g4, "reads_1.fq"), os.path.join(g4, "reads_2.fq"), "-o", str(tmp_path / "o"),
+              "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "3", "-u", "750", "-F", "-nc", "-top", "95",
+              "-lsamid", os.path.join(g4, "acc2tid.txt"), os.path.join(g4, "nodes.dmp"), os.path.join(g4, "names.dmp"), "-pass1", str(counters)], out, batch_pairs=100)
+    want = open(os.path.join(g4, "expected.lsam.id"), "rb").read().splitlines()
+    got = open(out, "rb").read().splitlines()
+    assert sorted(got) == sorted(want)
+    assert any(b";" in l.split(b"\t")[5] for l in want) and any(l.endswith(b"\tViruses") for l in want)
+    p = taxcount.read_pass1_file(str(counters))
+    assert p == taxcount.pass1_from_lsam_id([l + b"\n" for l in want], 40)
+    assert sorted("%d explains %d" % e for e in taxcount.explains(p)) == sorted(l for l in open(os.path.join(g4, "expected.explains")).read().split("\n") if l)

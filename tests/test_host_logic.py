@@ -74,27 +74,34 @@ def test_shard_bounds_cover_all_pairs():
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-import numpy as np, torch.distributed as dist
+import torch.distributed as dist
 from megapath_amd import taxcount
-from conftest import fastq_records
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
-lines = [l for l in open(os.path.join(sys.argv[1], "tests", "golden", "g1", "expected_a.fq"), "rb") if l.startswith(b"@r")]
+g4 = os.path.join(sys.argv[1], "tests", "golden", "g4")
+lines = open(os.path.join(g4, "expected.lsam.id"), "rb").read().splitlines(keepends=True)
 pairs = len(lines) // 2
-lo, hi = taxcount.shard_bounds(pairs, world, rank)
-idx = {"seq1": 0, "seq2": 1, "seq3": 2}
-c, u = taxcount.counts_from_fastq(lines[2 * lo:2 * hi], idx, 3)
-gc, gu = taxcount.all_reduce_counts(c, u)
-fc, fu = taxcount.counts_from_fastq(lines, idx, 3)
-assert np.array_equal(gc, fc) and np.array_equal(gu, fu), (gc, fc)
-assert gc.sum() > 0
+lo, hi = taxcount.shard_bounds(pairs, world, rank)            # contiguous block of pairs: 2 LSAM.id lines each
+mine = lines[2 * lo:2 * hi]
+total = taxcount.all_reduce_pass1(taxcount.pass1_from_lsam_id(mine, 40))
+whole = taxcount.pass1_from_lsam_id(lines, 40)
+assert total == whole, (total, whole)
+expl = taxcount.explains(total)
+want = sorted(l for l in open(os.path.join(g4, "expected.explains")).read().split("\n") if l)
+assert sorted("%d explains %d" % e for e in expl) == want, (expl, want)
+# pass 2 on this rank's shard; the shards in rank order are what the real reassign prints for the whole file
+out = b"".join(taxcount.apply_explains(mine, expl))
+ref = open(os.path.join(g4, "expected.ra.lsam.id"), "rb").read().splitlines(keepends=True)
+assert out == b"".join(ref[2 * lo:2 * hi])
 dist.destroy_process_group()
-print("rank", rank, "ok", gc.tolist())
+print("rank", rank, "ok", sorted(total.counts.items()))
 '''
 
 
-def test_two_rank_sharding_and_count_allreduce_over_gloo(tmp_path):
-    """N>1: shard the pairs over 2 ranks, count hits per reference on each shard, all-reduce; must equal 1-rank counts."""
+def test_two_rank_pass1_allreduce_equals_real_reassign(tmp_path):
+    # N>1: the LSAM.id lines shard over 2 ranks by contiguous pair blocks; pass-1 counters (cc/reassign.cpp:64-110) are
+    # all-reduced (dense vectors + gathered pair table); the derived `explains` relation equals the real reassign's and each
+    # rank's pass-2 output equals its slice of the real reassign's stdout (tests/golden/g4, made by the reference tools).
     w = tmp_path / "worker.py"
     w.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -102,6 +109,15 @@ def test_two_rank_sharding_and_count_allreduce_over_gloo(tmp_path):
                         "--master-port", "29577", str(w), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_pass1_restatement_single_process(golden_dir):
+    g4 = os.path.join(golden_dir, "g4")
+    lines = open(os.path.join(g4, "expected.lsam.id"), "rb").read().splitlines(keepends=True)
+    p = taxcount.pass1_from_lsam_id(lines, 40)
+    assert p.counts and p.uniq and p.intersect                     # the fixture exercises all three counters
+    assert sorted("%d explains %d" % e for e in taxcount.explains(p)) == sorted(l for l in open(os.path.join(g4, "expected.explains")).read().split("\n") if l)
+    assert b"".join(taxcount.apply_explains(lines, taxcount.explains(p))) == open(os.path.join(g4, "expected.ra.lsam.id"), "rb").read()
 
 
 def test_lsam_restatement_matches_reference_tool(golden_dir):

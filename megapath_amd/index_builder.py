@@ -126,10 +126,132 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
         h *= 2
 
 
+# ---- FASTA parsing as the reference builder does it (HSPParseFASTAToPacked, 2bwt-lib/HSP.c:354-567)
+_DNA_CHAR = b"ACGTMRSVWYHKDBN"        # dnaChar[0..14] (HSP.h:154); 'L' = nonMatchDnaCharIndex and everything else is skipped
+
+
+def parse_fasta_reference_style(data: bytes):
+    """-> dict(names, gi, seqs [uint8 codes 0..3], ambiguity [(startPos, rightOfEndPos)], first_amb_index [per sequence],
+    actual [(startPos, length) per sequence incl. removed runs]).  Rules (HSP.c:441-547): the name is the header up to the first
+    white space; letters outside IUPAC are skipped (so is 'U'); lower case counts as upper case; a run of ambiguity letters
+    (anything but ACGT, white space inside it ignored) shorter than 10 becomes that many 'G', a run of 10 or more is REMOVED from
+    the packed text and recorded; any '>' starts the next record."""
+    kind = np.zeros(256, dtype=np.uint8)                 # 0 skip, 1..4 = A C G T (code + 1), 5 = ambiguity letter
+    for i, ch in enumerate(_DNA_CHAR):
+        v = i + 1 if i < 4 else 5
+        kind[ch] = v
+        kind[ch + 32] = v
+    buf = np.frombuffer(data, dtype=np.uint8)
+    gt = np.flatnonzero(buf == ord(">"))
+    if len(buf) == 0 or buf[0] != ord(">"):
+        raise ValueError("FASTA file does not begin with '>'")
+    names, gis, seqs, ambiguity, first_amb, actual = [], [], [], [], [], []
+    total, discarded = 0, 0
+    for r, h0 in enumerate(gt):
+        rec_end = int(gt[r + 1]) if r + 1 < len(gt) else len(buf)
+        nl = data.find(b"\n", int(h0), rec_end)
+        if nl < 0:
+            nl = rec_end
+        header = data[int(h0) + 1:nl]
+        name = header.split()[0] if header.split() else b""
+        name = name[:255]                                 # MAX_SEQ_NAME_LENGTH
+        gi = 0
+        if len(name) > 3 and name[:3] == b"gi|":
+            digits = b""
+            for ch in name[3:]:
+                if 48 <= ch <= 57:
+                    digits += bytes([ch])
+                else:
+                    break
+            gi = int(digits) if digits else 0
+        k = kind[buf[nl + 1:rec_end]] if nl + 1 < rec_end else np.zeros(0, dtype=np.uint8)
+        k = k[k != 0]
+        amb = k == 5
+        codes = (k - 1).astype(np.uint8)
+        start_total, start_actual = total, total + discarded
+        keep = np.ones(len(k), dtype=bool)
+        if amb.any():
+            d = np.diff(np.concatenate([[0], amb.view(np.int8), [0]]))
+            run_s, run_e = np.flatnonzero(d == 1), np.flatnonzero(d == -1)
+            removed_before = 0
+            for s0, e0 in zip(run_s, run_e):
+                ln = int(e0 - s0)
+                if ln < 10:
+                    codes[s0:e0] = 2                      # 'G'
+                else:
+                    keep[s0:e0] = False
+                    discarded += ln
+                    pos = total + int(s0) - removed_before
+                    ambiguity.append((pos, pos + discarded - 1))
+                    removed_before += ln
+        codes = codes[keep]
+        names.append(name.decode())
+        gis.append(gi)
+        seqs.append(codes)
+        total += len(codes)
+        first_amb.append(len(ambiguity))
+        actual.append((start_actual, total + discarded - start_actual))
+    return dict(names=names, gi=gis, seqs=seqs, ambiguity=ambiguity, first_amb_index=first_amb, actual=actual)
+
+
+def translate_table(n, starts, ambiguity, first_amb_index):
+    """The .tra body as HSP.c:569-640 computes it: grid (one entry per 2^18 packed bases) and the merged list of removed-run
+    and sequence-start rows with their coordinate corrections, in 64-bit unsigned arithmetic, quirks included (a sequence start
+    that coincides with a removed run gets no row of its own; the list is padded with copies of its last row).  One read of
+    the reference is out of bounds (ambiguity[-1] when no run precedes sequence k-2, :585-586): the value it finds there made the
+    term 1 in every build tried, which is what is used here."""
+    M = (1 << 64) - 1
+    n_seq, n_amb = len(starts), len(ambiguity)
+    grid_entries = (n >> 18) + 1
+    grid = [0] * grid_entries
+    rows = []
+
+    def amb_row(j, k):
+        a0, a1 = ambiguity[j]
+        if k - 1 > 0:
+            q = first_amb_index[k - 2] - 1
+            corr = (ambiguity[q][1] - ambiguity[q][0] + 1) if q >= 0 else 1
+            c = (int(starts[k - 1]) + corr - (a1 - a0 + 1) - 1) & M
+        else:
+            c = (-a1 + a0 - 2) & M
+        grid[a0 >> 18] += 1
+        rows.append((a0, k, c))
+    j = k = 0
+    while j < n_amb and k < n_seq:
+        if ambiguity[j][0] < int(starts[k]):
+            amb_row(j, k)
+            j += 1
+        elif ambiguity[j][0] > int(starts[k]):
+            grid[int(starts[k]) >> 18] += 1
+            rows.append((int(starts[k]), k + 1, (int(starts[k]) - 1) & M))
+            k += 1
+        else:
+            k += 1
+    while j < n_amb:
+        amb_row(j, k)
+        j += 1
+    while k < n_seq:
+        grid[int(starts[k]) >> 18] += 1
+        rows.append((int(starts[k]), k + 1, (int(starts[k]) - 1) & M))
+        k += 1
+    while len(rows) < n_amb + n_seq:
+        rows.append(rows[-1] if rows else (0, 0, 0))
+    acc, out_grid = 0, []
+    for g in grid:
+        acc += g
+        out_grid.append((acc - 1) & 0xFFFFFFFF)
+    return out_grid, rows
+
+
 def build_index_arrays(seqs, sa_interval: int = 16, device=None):
-    """seqs: list of (name, uint8 array of base codes 0..3 or ASCII letters).  Returns the keyword arguments of
-    `megapath_amd.hipapi.Index.from_arrays` (host numpy arrays in the reference's file layouts)."""
+    """seqs: list of (name, uint8 array of base codes 0..3 or ASCII letters), or the dict parse_fasta_reference_style() returns
+    (then runs of >= 10 ambiguity letters are already removed and recorded for .tra).  Returns the keyword arguments of
+    `megapath_amd.hipapi.Index.from_arrays` (host numpy arrays in the reference's file layouts) plus what write_index_files needs."""
     dev = device or _device()
+    parsed = None
+    if isinstance(seqs, dict):
+        parsed = seqs
+        seqs = list(zip(parsed["names"], parsed["seqs"]))
     names, starts, lengths, parts = [], [], [], []
     pos = 0
     for name, arr in seqs:
@@ -175,8 +297,16 @@ def build_index_arrays(seqs, sa_interval: int = 16, device=None):
     sh4 = (2 * (3 - torch.arange(4, device=dev, dtype=torch.int64)))
     pac = (p4.view(-1, 4) << sh4).sum(dim=1).to(torch.uint8).cpu().numpy()
     pac = np.concatenate([pac, np.zeros(8, dtype=np.uint8)])
-    return dict(n=n, inv_sa0=inv_sa0, cum=cum, bwt_words=bwt_words, sa_samples=samples, sa_interval=sa_interval, pac=pac,
-                names=names, starts=np.asarray(starts, dtype=np.uint64), lengths=np.asarray(lengths, dtype=np.uint64))
+    out = dict(n=n, inv_sa0=inv_sa0, cum=cum, bwt_words=bwt_words, sa_samples=samples, sa_interval=sa_interval, pac=pac,
+               names=names, starts=np.asarray(starts, dtype=np.uint64), lengths=np.asarray(lengths, dtype=np.uint64))
+    if parsed is not None:
+        out["_fasta"] = dict(gi=parsed["gi"], ambiguity=parsed["ambiguity"], first_amb_index=parsed["first_amb_index"], actual=parsed["actual"])
+    return out
+
+
+def index_kwargs(arrs):
+    """The subset of build_index_arrays' result that hipapi.Index.from_arrays takes."""
+    return {k: v for k, v in arrs.items() if not k.startswith("_")}
 
 
 def write_index_files(prefix: str, arrs, write_lkt: bool = False, lkt_table=None) -> None:
@@ -234,24 +364,22 @@ def write_index_files(prefix: str, arrs, write_lkt: bool = False, lkt_table=None
             f.write(b"\0")
         f.write(bytes([n % 4]))
     names, starts, lengths = arrs["names"], arrs["starts"], arrs["lengths"]
-    with open(prefix + ".ann", "w") as f:
+    fasta = arrs.get("_fasta") or dict(gi=[0] * len(names), ambiguity=[], first_amb_index=[0] * len(names),
+                                      actual=[(int(s), int(l)) for s, l in zip(starts, lengths)])
+    with open(prefix + ".ann", "w") as f:                                   # HSP.c:653-657 (the third number is the builder's random seed)
         f.write("%d %d %d\n" % (n, len(names), 11))
-        for nm, s, l in zip(names, starts, lengths):
-            f.write("0 %s\n%d %d 0\n" % (nm, int(s), int(l)))
-    with open(prefix + ".amb", "w") as f:
+        for nm, gi, s, l in zip(names, fasta["gi"], starts, lengths):
+            f.write("%d %s\n%d %d 0\n" % (gi, nm, int(s), int(l)))
+    with open(prefix + ".amb", "w") as f:                                   # HSP.c:670: the list itself is disabled
         f.write("%d %d 0\n" % (n, len(names)))
-    grid = (n >> 18) + 1
-    with open(prefix + ".tra", "w") as f:
-        f.write("%d %d 0 %d\n" % (n, len(names), grid))
-        for g in range(grid):
-            last = (g << 18) + (1 << 18) - 1
-            v = 0
-            while v + 1 < len(names) and int(starts[v + 1]) <= last:
-                v += 1
-            f.write("%d\n" % v)
-        for i, s in enumerate(starts):
-            f.write("%d %d %d\n" % (int(s), i + 1, (int(s) - 1) % (1 << 64)))
-        for s, l in zip(starts, lengths):
+    grid, rows = translate_table(n, starts, fasta["ambiguity"], fasta["first_amb_index"])
+    with open(prefix + ".tra", "w") as f:                                   # HSP.c:679-690
+        f.write("%d %d %d %d\n" % (n, len(names), len(fasta["ambiguity"]), len(grid)))
+        for g in grid:
+            f.write("%d\n" % g)
+        for a, c, corr in rows:
+            f.write("%d %d %d\n" % (a, c, corr))
+        for s, l in fasta["actual"]:
             f.write("%d %d\n" % (int(s), int(l)))
     if lkt_table is not None:
         # the 13-mer table as a loader already built it (mp_index_copy_lkt): inclusive right bounds, written as u64

@@ -83,3 +83,19 @@ def test_rank_near_text_end_from_builder_files(tmp_path):
             k = idx - (1 if idx > inv else 0)           # the '$' row is not part of the stored BWT (BWT.c:605)
             assert lib.mpo_occ(ix, idx, c) == int(cs[k]), (idx, c)
     lib.mpo_index_close(ix)
+
+
+def test_builder_removes_long_n_runs_like_the_reference(golden_dir, tmp_path):
+    """tests/golden/nrun: a FASTA with runs of >= 10 ambiguity letters (removed and recorded in .tra, HSP.c:486-527), shorter runs
+    (-> 'G'), IUPAC codes, lower case, 'U' (skipped), a gi| header, runs at the very start / end of a sequence -- and the index
+    files the REAL 2bwt-builder wrote for it.  Everything byte-identical (.ann apart from the builder's random seed)."""
+    from megapath_amd.index_builder import parse_fasta_reference_style
+    d = os.path.join(golden_dir, "nrun")
+    parsed = parse_fasta_reference_style(open(os.path.join(d, "n.fa"), "rb").read())
+    assert len(parsed["ambiguity"]) == 5 and parsed["gi"][1] == 12345
+    arrs = build_index_arrays(parsed, sa_interval=16)
+    prefix = str(tmp_path / "mine.index")
+    write_index_files(prefix, arrs, write_lkt=False)
+    for ext in (".pac", ".bwt", ".fmv", ".sa", ".tra", ".amb"):
+        assert open(prefix + ext, "rb").read() == open(os.path.join(d, "n.fa.index" + ext), "rb").read(), ext
+    assert open(prefix + ".ann").read().split()[3:] == open(os.path.join(d, "n.fa.index.ann")).read().split()[3:]

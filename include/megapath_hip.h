@@ -283,6 +283,24 @@ int mp_test_sort_longer_seed(int device, const uint32_t *seed_len, const uint32_
  * against and the calibration workload for the FETCH_SIZE counter. */
 int mp_bench_gather64(const mp_index *ix, uint32_t lanes, uint32_t per_lane, uint32_t repeats, float *out_ms, uint64_t *out_bytes);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Coverage per reference and the spike filter.  Replaces the file pipeline of runMegaPath.sh:211-222:
+ * samtools merge/sort | bedtools genomecov -bga | cc/genomeCovFilter (mean + k * stdev of the depth per sequence,
+ * cc/genomeCovFilter.cpp:58-92) | bedtools bamtobed + annotate (fraction of each alignment on spike bases).  Intervals are
+ * what the BAM side files hold: 1-based sequence id, 0-based start in the sequence's own coordinates, reference span. */
+typedef struct mp_coverage mp_coverage;
+int mp_coverage_create(const mp_index *ix, mp_coverage **out);
+int mp_coverage_destroy(mp_coverage *cov);
+int mp_coverage_add(mp_coverage *cov, const uint32_t *seq_id_1based, const uint64_t *start0, const uint32_t *ref_span, uint64_t n);
+/* depth = prefix sum of the events; per sequence mean and population variance of the depth over all its bases;
+ * max_depth = mean + stdev_k * sqrt(variance); spike bases = depth > max_depth.  No more intervals can be added afterwards. */
+int mp_coverage_finish(mp_coverage *cov, double stdev_k);
+int mp_coverage_seq_stats(const mp_coverage *cov, uint32_t seq_id_1based, double *out_mean, double *out_variance, double *out_max_depth);
+/* the maximal runs of spike bases (the union of the lines cc/genomeCovFilter prints); out_* may be NULL to ask for the count */
+int mp_coverage_spike_intervals(mp_coverage *cov, uint32_t *out_seq_id, uint64_t *out_start0, uint64_t *out_end0, uint64_t cap, uint64_t *out_n);
+/* per interval the number of its bases that are spike bases (bedtools annotate's numerator) */
+int mp_coverage_spike_bases(mp_coverage *cov, const uint32_t *seq_id_1based, const uint64_t *start0, const uint32_t *ref_span, uint64_t n, uint32_t *out_covered);
+
 /* Library / device probe: fails loudly (MP_ENODEV) when no gfx950 device is usable. */
 int mp_device_check(int device, char *out_name, size_t name_cap);
 const char *mp_strerror(int code);

@@ -13,6 +13,7 @@
 #include "kernels_dp.hip"
 #include "kernels_dp_band.hip"
 #include "kernels_rescue.hip"
+#include "kernels_cov.hip"
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     fprintf(stderr, "[megapath_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MP_ENODEV; } } while (0)
@@ -1690,3 +1691,202 @@ extern "C" int mp_test_sort_longer_seed(int device, const uint32_t *seed_len, co
     return MP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ coverage / spike filter
+struct mp_coverage {
+    const mp_index *ix = nullptr;
+    uint32_t n_seq = 0;
+    uint64_t total = 0;                       // slots: every sequence's actual length + 1
+    std::vector<uint64_t> h_off, h_len;
+    uint64_t *d_off = nullptr, *d_len = nullptr;
+    int32_t *d_depth = nullptr;               // difference array, then depth
+    uint32_t *d_mask = nullptr;               // spike mask, then its inclusive prefix sum
+    double *d_max = nullptr;
+    std::vector<double> mean, var, max_depth;
+    bool finished = false, mask_scanned = false;
+    uint64_t n_added = 0;
+};
+
+// inclusive prefix sum over more entries than the library's int count allows: parts of 2^30 with the carry added
+static int scan_u32_inplace(uint32_t *d, uint64_t n)
+{
+    const uint64_t part = 1ull << 30;
+    size_t tb = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, d, d, (int)std::min<uint64_t>(n, part), 0);
+    void *tmp = nullptr;
+    if (hipMalloc(&tmp, tb + 256) != hipSuccess) return MP_ENOMEM;
+    uint32_t carry = 0;
+    for (uint64_t lo = 0; lo < n; lo += part) {
+        const uint64_t cnt = std::min<uint64_t>(part, n - lo);
+        (void)hipcub::DeviceScan::InclusiveSum(tmp, tb, d + lo, d + lo, (int)cnt, 0);
+        if (carry) hipLaunchKernelGGL(add_offset_kernel, dim3(grid_for(cnt, 256)), dim3(256), 0, 0, d + lo, cnt, carry);
+        if (hipMemcpy(&carry, d + lo + cnt - 1, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(tmp); return MP_ENODEV; }
+    }
+    (void)hipFree(tmp);
+    return hipDeviceSynchronize() == hipSuccess ? MP_OK : MP_ENODEV;
+}
+
+extern "C" int mp_coverage_create(const mp_index *ix, mp_coverage **out)
+{
+    if (!ix || !out || ix->seq_names.empty()) return MP_EINVAL;
+    HIPCHK(hipSetDevice(ix->device));
+    mp_coverage *c = new (std::nothrow) mp_coverage();
+    if (!c) return MP_ENOMEM;
+    c->ix = ix; c->n_seq = (uint32_t)ix->seq_names.size();
+    c->h_off.resize(c->n_seq); c->h_len.resize(c->n_seq);
+    uint64_t at = 0;
+    for (uint32_t s = 0; s < c->n_seq; s++) {
+        // the coordinates of a BAM record: positions in the sequence as the FASTA had it, removed N-runs included (.tra tail)
+        c->h_len[s] = s < ix->seq_actual_len.size() && ix->seq_actual_len[s] ? ix->seq_actual_len[s] : ix->seq_len[s];
+        c->h_off[s] = at; at += c->h_len[s] + 1;
+    }
+    c->total = at;
+    if (hipMalloc((void **)&c->d_off, c->n_seq * 8) != hipSuccess || hipMalloc((void **)&c->d_len, c->n_seq * 8) != hipSuccess ||
+        hipMalloc((void **)&c->d_depth, c->total * 4) != hipSuccess || hipMalloc((void **)&c->d_max, c->n_seq * 8) != hipSuccess) { mp_coverage_destroy(c); return MP_ENOMEM; }
+    HIPCHK(hipMemcpy(c->d_off, c->h_off.data(), c->n_seq * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_len, c->h_len.data(), c->n_seq * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->d_depth, 0, c->total * 4));
+    *out = c;
+    return MP_OK;
+}
+
+extern "C" int mp_coverage_destroy(mp_coverage *c)
+{
+    if (!c) return MP_OK;
+    (void)hipSetDevice(c->ix->device);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->d_len) (void)hipFree(c->d_len);
+    if (c->d_depth) (void)hipFree(c->d_depth);
+    if (c->d_mask) (void)hipFree(c->d_mask);
+    if (c->d_max) (void)hipFree(c->d_max);
+    delete c;
+    return MP_OK;
+}
+
+// uploads n intervals and runs `fn(d_seq, d_start, d_len)` on them
+template <typename F>
+static int with_intervals(const mp_coverage *c, const uint32_t *seq_id_1based, const uint64_t *start0, const uint32_t *len, uint64_t n, F &&fn)
+{
+    std::vector<uint32_t> s0(n);
+    for (uint64_t i = 0; i < n; i++) { if (seq_id_1based[i] == 0 || seq_id_1based[i] > c->n_seq) return MP_EINVAL; s0[i] = seq_id_1based[i] - 1; }
+    uint32_t *d_seq = nullptr, *d_l = nullptr; uint64_t *d_st = nullptr;
+    int rc = MP_OK;
+    if (hipMalloc((void **)&d_seq, n * 4) != hipSuccess || hipMalloc((void **)&d_l, n * 4) != hipSuccess || hipMalloc((void **)&d_st, n * 8) != hipSuccess) rc = MP_ENOMEM;
+    if (!rc && (hipMemcpy(d_seq, s0.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_l, len, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_st, start0, n * 8, hipMemcpyHostToDevice) != hipSuccess)) rc = MP_ENODEV;
+    if (!rc) rc = fn(d_seq, d_st, d_l);
+    if (d_seq) (void)hipFree(d_seq);
+    if (d_l) (void)hipFree(d_l);
+    if (d_st) (void)hipFree(d_st);
+    return rc;
+}
+
+extern "C" int mp_coverage_add(mp_coverage *c, const uint32_t *seq_id_1based, const uint64_t *start0, const uint32_t *len, uint64_t n)
+{
+    if (!c || c->finished || (n && (!seq_id_1based || !start0 || !len))) return MP_EINVAL;
+    if (n == 0) return MP_OK;
+    HIPCHK(hipSetDevice(c->ix->device));
+    c->n_added += n;
+    return with_intervals(c, seq_id_1based, start0, len, n, [&](const uint32_t *d_seq, const uint64_t *d_st, const uint32_t *d_l) {
+        hipLaunchKernelGGL(cov_add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d_seq, d_st, d_l, n, c->d_off, c->d_len, c->d_depth);
+        return hipDeviceSynchronize() == hipSuccess ? MP_OK : MP_ENODEV;
+    });
+}
+
+extern "C" int mp_coverage_finish(mp_coverage *c, double stdev_k)
+{
+    if (!c || c->finished) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc = scan_u32_inplace((uint32_t *)c->d_depth, c->total);                     // difference array -> depth
+    if (rc) return rc;
+    unsigned long long *d_sums = nullptr;
+    HIPCHK(hipMalloc((void **)&d_sums, (size_t)c->n_seq * 16));
+    HIPCHK(hipMemset(d_sums, 0, (size_t)c->n_seq * 16));
+    const uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4096, (c->total / c->n_seq) / 65536 + 1));
+    hipLaunchKernelGGL(cov_moments_kernel, dim3(c->n_seq * slices), dim3(256), 0, 0, c->d_depth, c->d_off, c->d_len, c->n_seq, slices, d_sums);
+    std::vector<unsigned long long> sums((size_t)c->n_seq * 2);
+    hipError_t e = hipMemcpy(sums.data(), d_sums, sums.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_sums);
+    if (e != hipSuccess) return MP_ENODEV;
+    c->mean.resize(c->n_seq); c->var.resize(c->n_seq); c->max_depth.resize(c->n_seq);
+    for (uint32_t s = 0; s < c->n_seq; s++) {
+        // mean and population variance over ALL bases of the sequence (genomecov -bga lists the zero-depth stretches too,
+        // cc/genomeCovFilter.cpp:58-76 weights every interval by its length); exact integer sums, one rounding at the end
+        const long double N = (long double)c->h_len[s];
+        const long double m = N > 0 ? (long double)sums[2 * (size_t)s] / N : 0.0L;
+        long double v = N > 0 ? (long double)sums[2 * (size_t)s + 1] / N - m * m : 0.0L;
+        if (v < 0) v = 0;
+        c->mean[s] = (double)m; c->var[s] = (double)v;
+        c->max_depth[s] = (double)(m + (long double)stdev_k * sqrtl(v));
+    }
+    HIPCHK(hipMemcpy(c->d_max, c->max_depth.data(), (size_t)c->n_seq * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&c->d_mask, c->total * 4));
+    hipLaunchKernelGGL(cov_mask_kernel, dim3(grid_for(c->total, 256)), dim3(256), 0, 0, c->d_depth, c->d_off, c->d_len, c->d_max, c->n_seq, c->total, c->d_mask);
+    HIPCHK(hipDeviceSynchronize());
+    c->finished = true;
+    return MP_OK;
+}
+
+extern "C" int mp_coverage_seq_stats(const mp_coverage *c, uint32_t seq_id_1based, double *out_mean, double *out_variance, double *out_max_depth)
+{
+    if (!c || !c->finished || seq_id_1based == 0 || seq_id_1based > c->n_seq) return MP_EINVAL;
+    if (out_mean) *out_mean = c->mean[seq_id_1based - 1];
+    if (out_variance) *out_variance = c->var[seq_id_1based - 1];
+    if (out_max_depth) *out_max_depth = c->max_depth[seq_id_1based - 1];
+    return MP_OK;
+}
+
+extern "C" int mp_coverage_spike_intervals(mp_coverage *c, uint32_t *out_seq_id, uint64_t *out_start0, uint64_t *out_end0, uint64_t cap, uint64_t *out_n)
+{
+    if (!c || !c->finished || !out_n) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t edge_cap = 1u << 22;
+    unsigned long long *d_edges = nullptr; unsigned int *d_n = nullptr, n_e = 0;
+    if (hipMalloc((void **)&d_edges, (size_t)edge_cap * 8) != hipSuccess || hipMalloc((void **)&d_n, 4) != hipSuccess) { if (d_edges) (void)hipFree(d_edges); return MP_ENOMEM; }
+    HIPCHK(hipMemset(d_n, 0, 4));
+    // the mask may already be prefix-summed (after a query): edges are where the running count changes -- recompute from the depth
+    uint32_t *d_m = nullptr;
+    if (hipMalloc((void **)&d_m, c->total * 4) != hipSuccess) { (void)hipFree(d_edges); (void)hipFree(d_n); return MP_ENOMEM; }
+    hipLaunchKernelGGL(cov_mask_kernel, dim3(grid_for(c->total, 256)), dim3(256), 0, 0, c->d_depth, c->d_off, c->d_len, c->d_max, c->n_seq, c->total, d_m);
+    hipLaunchKernelGGL(cov_edges_kernel, dim3(grid_for(c->total, 256)), dim3(256), 0, 0, d_m, c->total, d_edges, edge_cap, d_n);
+    hipError_t e = hipMemcpy(&n_e, d_n, 4, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> edges(std::min<uint32_t>(n_e, edge_cap));
+    if (e == hipSuccess && !edges.empty()) e = hipMemcpy(edges.data(), d_edges, edges.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_edges); (void)hipFree(d_n); (void)hipFree(d_m);
+    if (e != hipSuccess) return MP_ENODEV;
+    if (n_e > edge_cap) return MP_ERANGE;
+    std::sort(edges.begin(), edges.end());
+    uint64_t w = 0;
+    for (size_t i = 0; i + 1 < edges.size() + 1 && i < edges.size(); i += 2) {
+        if (!(edges[i] & 1ull) || i + 1 >= edges.size()) return MP_ERANGE;         // starts and ends alternate (a sequence's last slot is never a spike)
+        const uint64_t a = edges[i] >> 1, b = edges[i + 1] >> 1;
+        const uint32_t s = (uint32_t)(std::upper_bound(c->h_off.begin(), c->h_off.end(), a) - c->h_off.begin()) - 1;
+        if (out_seq_id && out_start0 && out_end0) {
+            if (w >= cap) return MP_ERANGE;
+            out_seq_id[w] = s + 1; out_start0[w] = a - c->h_off[s]; out_end0[w] = b - c->h_off[s];
+        }
+        w++;
+    }
+    *out_n = w;
+    return MP_OK;
+}
+
+extern "C" int mp_coverage_spike_bases(mp_coverage *c, const uint32_t *seq_id_1based, const uint64_t *start0, const uint32_t *len, uint64_t n, uint32_t *out_covered)
+{
+    if (!c || !c->finished || (n && (!seq_id_1based || !start0 || !len || !out_covered))) return MP_EINVAL;
+    if (n == 0) return MP_OK;
+    HIPCHK(hipSetDevice(c->ix->device));
+    if (!c->mask_scanned) {                   // first query: the mask becomes its own inclusive prefix sum
+        int rc = scan_u32_inplace(c->d_mask, c->total);
+        if (rc) return rc;
+        c->mask_scanned = true;
+    }
+    uint32_t *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_out, n * 4));
+    int rc = with_intervals(c, seq_id_1based, start0, len, n, [&](const uint32_t *d_seq, const uint64_t *d_st, const uint32_t *d_l) {
+        hipLaunchKernelGGL(cov_query_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d_seq, d_st, d_l, n, c->d_off, c->d_len, c->d_mask, d_out);
+        return hipMemcpy(out_covered, d_out, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? MP_OK : MP_ENODEV;
+    });
+    (void)hipFree(d_out);
+    return rc;
+}

@@ -122,6 +122,9 @@ struct Side {                      // one mate of one alignment
 };
 struct PairAln { Side m[2]; long long insert = 0; };
 
+// what bedtools bamtobed would print for a mapped record of the merged BAM (runMegaPath.sh:212-215): the spike filter's input
+struct CovRec { uint32_t seq_id; uint64_t start0; uint32_t span; uint8_t mate; std::string name; };
+
 struct ReadView { const char *name; const char *seq; const char *qual; uint32_t len; };   // seq = "ACGT" text, qual = raw ASCII
 
 struct Options {
@@ -196,7 +199,7 @@ public:
 
     // Properly paired output.  `res` already went through the annotated-FASTQ writer (the reference mutates the
     // results there first, BGS-IO.cpp:2103-2111); `best` was chosen before that (OutputDPResult.cpp:156-232).
-    void pair(std::string &sink, int stage, const ReadView rd[2], const std::vector<PairAln> &res, size_t best, const RefText ref[2]) const
+    void pair(std::string &sink, int stage, const ReadView rd[2], const std::vector<PairAln> &res, size_t best, const RefText ref[2], std::vector<CovRec> *cov = nullptr) const
     {
         const PairAln &b = res[best];
         const bool a[2] = {b.m[0].pos != NOT_ALIGNED, b.m[1].pos != NOT_ALIGNED};
@@ -255,6 +258,11 @@ public:
                 else isize = (long long)(tp[o] + (uint64_t)rlen[o] - tp[k]);
             }
             emit(sink, stage, rd[k], flag, chr[k], tp[k], chr[o], tp[o], isize, r[k]);
+            if (cov && r[k].mapped && chr[k]) {
+                uint32_t num = 0, span = 0;                     // reference span of the BAM CIGAR: M and D
+                for (char ch : r[k].cigar) { if (ch >= '0' && ch <= '9') { num = num * 10 + (uint32_t)(ch - '0'); continue; } if (ch == 'M' || ch == 'D') span += num; num = 0; }
+                cov->push_back(CovRec{chr[k], tp[k] - 1, span, (uint8_t)(k + 1), rd[k].name});
+            }
         }
     }
 

@@ -668,6 +668,8 @@ void resolve_cigars(mp_ctx *ctx, const Params &p, int threads, const std::vector
 
 struct BamState {
     std::unique_ptr<mpbam::Writer> w;
+    bool want_cov = false;                                   // -spike: keep what bamtobed would list of the .dpout / .gout records
+    std::vector<mpbam::CovRec> cov;
     int stage_rescue = 2, stage_unpaired = 3;                // hspaux->dpStageId (alignment.cpp:93,228,308)
 };
 
@@ -853,7 +855,7 @@ void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, boo
 // the reference: pairs of the deep-DP round, then every rescued pair, then the unpaired rest (alignment.cpp:105-330).
 // Pairs are independent, so each section is cut into chunks that worker threads format into their own buffers; the
 // buffers go out in chunk order.
-struct Sink { std::string text, bam[3]; uint64_t n = 0; Pass1 pass1; };
+struct Sink { std::string text, bam[3]; uint64_t n = 0; Pass1 pass1; std::vector<mpbam::CovRec> cov; };
 
 template <typename F>
 void for_chunks(size_t n_items, int threads, BamState *bam, Pass1 *pass1, F &&body)
@@ -864,7 +866,7 @@ void for_chunks(size_t n_items, int threads, BamState *bam, Pass1 *pass1, F &&bo
     std::vector<Sink> sinks(wave);
     for (size_t c0 = 0; c0 < n_chunks; c0 += wave) {
         const size_t nc = std::min(wave, n_chunks - c0);
-        auto run = [&](size_t t) { Sink &s = sinks[t]; s.text.clear(); s.pass1 = Pass1(); for (auto &x : s.bam) x.clear(); body((c0 + t) * chunk, std::min(n_items, (c0 + t + 1) * chunk), s); };
+        auto run = [&](size_t t) { Sink &s = sinks[t]; s.text.clear(); s.pass1 = Pass1(); s.cov.clear(); for (auto &x : s.bam) x.clear(); body((c0 + t) * chunk, std::min(n_items, (c0 + t + 1) * chunk), s); };
         std::vector<std::thread> pool;
         for (size_t t = 1; t < nc; t++) pool.emplace_back(run, t);
         run(0);
@@ -872,6 +874,7 @@ void for_chunks(size_t n_items, int threads, BamState *bam, Pass1 *pass1, F &&bo
         for (size_t t = 0; t < nc; t++) {
             fwrite(sinks[t].text.data(), 1, sinks[t].text.size(), stdout);
             if (bam) for (int k = 0; k < 3; k++) bam->w->append(k, sinks[t].bam[k]);
+            if (bam && bam->want_cov) bam->cov.insert(bam->cov.end(), sinks[t].cov.begin(), sinks[t].cov.end());
             if (pass1) pass1->add(sinks[t].pass1);
         }
     }
@@ -899,7 +902,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
         if (!bam) return;
         const mpbam::ReadView rd[2] = {view_of(r1, bt.lens[2 * q]), view_of(r2, bt.lens[2 * q + 1])};
         if (bam->w->wants_text()) { const Side *bs[2] = {&res[best].m[0], &res[best].m[1]}; text.fetch(ix, bs); }
-        bam->w->pair(sink.bam[file], stage, rd, res, best, text.ref);
+        bam->w->pair(sink.bam[file], stage, rd, res, best, text.ref, bam->want_cov ? &sink.cov : nullptr);
     };
     // ---- pairs of the deep-DP round: groups of equal pair_id in the sorted hit list
     std::vector<size_t> grp;
@@ -1100,6 +1103,8 @@ int main(int argc, char **argv)
     std::string out_prefix = fq1;                                         // IniParam.cpp:633
     mpbam::Options bopt;
     std::string tax_files[3], pass1_path;
+    double spike_k = 60, spike_overlap = 0.5;                  // SPIKE_STDEV / SPIKE_OVERLAP (runMegaPath.sh:52-53)
+    bool want_spike = false;
     bool have_d = false, have_a = false, have_r = false;
     // updateUserInputText (IniParam.cpp:199-226): "\t" and "\n" typed on the command line become the characters
     auto unescape = [](const char *v) { std::string o; for (const char *c = v; *c; c++) { if (c[0] == '\\' && (c[1] == 't' || c[1] == 'n')) { o += c[1] == 't' ? '\t' : '\n'; c++; } else o += *c; } return o; };
@@ -1133,6 +1138,7 @@ int main(int argc, char **argv)
         else if (a == "-lsam") p.lsam = 1;                     // not in the reference: stdout = LSAM, saves the fastq2lsam pipe stage
         else if (a == "-lsam-noseq") p.lsam = 2;
         else if (a == "-lsamid") { tax_files[0] = val(); tax_files[1] = val(); tax_files[2] = val(); }   // not in the reference: stdout = LSAM.id (fastq2lsam | taxLookupAcc in-process)
+        else if (a == "-spike") { spike_k = atof(val()); spike_overlap = atof(val()); want_spike = true; }         // not in the reference: the spike filter of runMegaPath.sh:211-218 in-process
         else if (a == "-pass1") pass1_path = val();                                                        // not in the reference: counters of reassign's pass 1 over those lines
         else if (a == "-pass1-t") p.pass1_t = atof(val());
     }
@@ -1226,8 +1232,10 @@ int main(int argc, char **argv)
         bam_state.w.reset(new mpbam::Writer(devices[0].chunks[n_chunks - 1], bopt));
         if (!bam_state.w->open(out_prefix, "@PG\tID:soap4-mi355x\tPN:soap4-mi355x\tVN:r2\n")) return 1;
         bam_state.stage_unpaired = p.skip_default_dp ? 2 : 3;
+        bam_state.want_cov = want_spike;
         bam = &bam_state;
     }
+    if (want_spike && !bam) { fprintf(stderr, "[soap4-mi355x] -spike works on the alignments of the BAM side files: it needs -b\n"); return 1; }
     // Stages: the reader threads parse and pack batches (the reference's IO thread, aio_thread.cpp:247); every worker of every
     // GPU takes the next batch -- a contiguous block of pairs --, aligns it against all resident chunks and hands it on; the
     // printer writes the batches in input order.  Batch objects are recycled.
@@ -1309,6 +1317,40 @@ int main(int argc, char **argv)
     const double t_loop = now_s() - t_start;
     fflush(stdout);
     if (bam && !bam->w->close()) { fprintf(stderr, "[soap4-mi355x] error while writing the BAM files\n"); return 1; }
+    if (want_spike) {
+        // coverage of the last chunk's .dpout / .gout records (the files `samtools merge *[0-9]` picks up), spikes, reads to drop
+        mp_index *ix = devices[0].chunks[n_chunks - 1];
+        mp_coverage *cov = nullptr;
+        die(mp_coverage_create(ix, &cov), "mp_coverage_create");
+        const size_t n = bam->cov.size();
+        std::vector<uint32_t> seq(n), span(n), covered(n);
+        std::vector<uint64_t> start(n);
+        for (size_t i = 0; i < n; i++) { seq[i] = bam->cov[i].seq_id; start[i] = bam->cov[i].start0; span[i] = bam->cov[i].span; }
+        die(mp_coverage_add(cov, seq.data(), start.data(), span.data(), n), "mp_coverage_add");
+        die(mp_coverage_finish(cov, spike_k), "mp_coverage_finish");
+        uint64_t n_iv = 0;
+        die(mp_coverage_spike_intervals(cov, nullptr, nullptr, nullptr, 0, &n_iv), "mp_coverage_spike_intervals");
+        std::vector<uint32_t> iv_seq(n_iv + 1); std::vector<uint64_t> iv_a(n_iv + 1), iv_b(n_iv + 1);
+        die(mp_coverage_spike_intervals(cov, iv_seq.data(), iv_a.data(), iv_b.data(), n_iv, &n_iv), "mp_coverage_spike_intervals");
+        FILE *f = fopen((out_prefix + ".genomecovFilter").c_str(), "w");
+        if (!f) { fprintf(stderr, "[soap4-mi355x] cannot write %s.genomecovFilter\n", out_prefix.c_str()); return 1; }
+        for (uint64_t i = 0; i < n_iv; i++) fprintf(f, "%s\t%llu\t%llu\n", mp_index_seq_name(ix, iv_seq[i]), (unsigned long long)iv_a[i], (unsigned long long)iv_b[i]);
+        fclose(f);
+        die(mp_coverage_spike_bases(cov, seq.data(), start.data(), span.data(), n, covered.data()), "mp_coverage_spike_bases");
+        f = fopen((out_prefix + ".readFilter").c_str(), "w");
+        if (!f) { fprintf(stderr, "[soap4-mi355x] cannot write %s.readFilter\n", out_prefix.c_str()); return 1; }
+        uint64_t n_drop = 0;
+        for (size_t i = 0; i < n; i++) {
+            // bedtools annotate prints the fraction with six decimals and awk compares that number with the threshold (runMegaPath.sh:218)
+            char buf[32];
+            snprintf(buf, sizeof buf, "%f", span[i] ? (double)covered[i] / (double)span[i] : 0.0);
+            if (atof(buf) >= spike_overlap) { fprintf(f, "%s/%d\n", bam->cov[i].name.c_str(), (int)bam->cov[i].mate); n_drop++; }
+        }
+        fclose(f);
+        fprintf(stderr, "[Main] spike filter: %zu alignments, %llu spike intervals (depth > mean + %g stdev), %llu alignments >= %g on spikes\n", n, (unsigned long long)n_iv, spike_k,
+                (unsigned long long)n_drop, spike_overlap);
+        mp_coverage_destroy(cov);
+    }
     if (!pass1_path.empty() && !pass1_total.write(pass1_path, p.pass1_t)) { fprintf(stderr, "[soap4-mi355x] cannot write %s\n", pass1_path.c_str()); return 1; }
     // every stage kept its own counters: summed only now that the threads are gone
     Stats st = st_printer;

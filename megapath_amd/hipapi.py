@@ -105,7 +105,8 @@ EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy", "mp_ctx_set_index",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
-           "mp_test_sort_longer_seed"]
+           "mp_test_sort_longer_seed", "mp_coverage_create", "mp_coverage_destroy", "mp_coverage_add", "mp_coverage_finish", "mp_coverage_seq_stats",
+           "mp_coverage_spike_intervals", "mp_coverage_spike_bases"]
 
 
 def build_library(force: bool = False) -> str:
@@ -171,6 +172,13 @@ def load_library():
     lib.mp_bench_gather64.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]
     lib.mp_device_check.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     lib.mp_test_sort_longer_seed.argtypes = [C.c_int, vp, vp, C.c_uint32, vp]
+    lib.mp_coverage_create.argtypes = [vp, C.POINTER(vp)]
+    lib.mp_coverage_destroy.argtypes = [vp]
+    lib.mp_coverage_add.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    lib.mp_coverage_finish.argtypes = [vp, C.c_double]
+    lib.mp_coverage_seq_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mp_coverage_spike_intervals.argtypes = [vp, vp, vp, vp, C.c_uint64, u64p]
+    lib.mp_coverage_spike_bases.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]
     lib.mp_strerror.restype = C.c_char_p
     lib.mp_strerror.argtypes = [C.c_int]
     _lib = lib
@@ -315,6 +323,48 @@ class Index:
         r = np.zeros(len(keys), dtype=np.uint64)
         _chk(load_library().mp_index_lkt(self._h, keys.ctypes.data, len(keys), l.ctypes.data, r.ctypes.data), "mp_index_lkt")
         return l, r
+
+
+class Coverage:
+    """Per-reference coverage and spike filter on the device (mp_coverage_*)."""
+
+    def __init__(self, index: Index):
+        self._h = C.c_void_p()
+        _chk(load_library().mp_coverage_create(index._h, C.byref(self._h)), "mp_coverage_create")
+
+    @staticmethod
+    def _arrs(seq, start, span):
+        return (np.ascontiguousarray(seq, dtype=np.uint32), np.ascontiguousarray(start, dtype=np.uint64), np.ascontiguousarray(span, dtype=np.uint32))
+
+    def add(self, seq_id_1based, start0, span):
+        a, b, c = self._arrs(seq_id_1based, start0, span)
+        _chk(load_library().mp_coverage_add(self._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, len(a)), "mp_coverage_add")
+
+    def finish(self, stdev_k: float):
+        _chk(load_library().mp_coverage_finish(self._h, float(stdev_k)), "mp_coverage_finish")
+
+    def seq_stats(self, seq_id_1based: int):
+        m, v, x = C.c_double(), C.c_double(), C.c_double()
+        _chk(load_library().mp_coverage_seq_stats(self._h, seq_id_1based, C.byref(m), C.byref(v), C.byref(x)), "mp_coverage_seq_stats")
+        return m.value, v.value, x.value
+
+    def spike_intervals(self):
+        n = C.c_uint64()
+        _chk(load_library().mp_coverage_spike_intervals(self._h, None, None, None, 0, C.byref(n)), "mp_coverage_spike_intervals")
+        s = np.zeros(n.value + 1, dtype=np.uint32); a = np.zeros(n.value + 1, dtype=np.uint64); b = np.zeros(n.value + 1, dtype=np.uint64)
+        _chk(load_library().mp_coverage_spike_intervals(self._h, s.ctypes.data, a.ctypes.data, b.ctypes.data, n.value, C.byref(n)), "mp_coverage_spike_intervals")
+        return [(int(s[i]), int(a[i]), int(b[i])) for i in range(n.value)]
+
+    def spike_bases(self, seq_id_1based, start0, span):
+        a, b, c = self._arrs(seq_id_1based, start0, span)
+        out = np.zeros(max(len(a), 1), dtype=np.uint32)
+        _chk(load_library().mp_coverage_spike_bases(self._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, len(a), out.ctypes.data), "mp_coverage_spike_bases")
+        return out[:len(a)]
+
+    def close(self):
+        if self._h:
+            load_library().mp_coverage_destroy(self._h)
+            self._h = None
 
 
 class Context:

@@ -54,6 +54,19 @@ KERN(k_mad_u24, BODY3, "v_mad_u32_u24")
 KERN(k_xad, BODY3, "v_xad_u32")
 KERN(k_min3_u32, BODY3, "v_min3_u32")
 KERN(k_med3_i32, BODY3, "v_med3_i32")
+// floating-point forms: small integers (|x| <= 2048) are exact in f16, so max/add recurrences could run on them
+KERN(k_pk_add_f16, BODY, "v_pk_add_f16")
+KERN(k_pk_max_f16, BODY, "v_pk_max_f16")
+KERN(k_pk_min_f16, BODY, "v_pk_min_f16")
+KERN(k_pk_mul_f16, BODY, "v_pk_mul_f16")
+KERN(k_pk_fma_f16, BODY3, "v_pk_fma_f16")
+KERN(k_max_f32, BODY, "v_max_f32")
+KERN(k_add_f32, BODY, "v_add_f32")
+KERN(k_max_f16, BODY, "v_max_f16")
+KERN(k_max3_f32, BODY3, "v_max3_f32")
+KERN(k_sad_u8, BODY3, "v_sad_u8")
+KERN(k_max_i16, BODY, "v_max_i16")
+KERN(k_max_u16, BODY, "v_max_u16")
 // dependent chain (1 accumulator) to see the latency one wave pays
 __global__ void k_dep_pk(int *out, int k) { int a = threadIdx.x; for (int it = 0; it < ITER * REP; it++) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a) : "v"(k)); out[blockIdx.x * blockDim.x + threadIdx.x] = a; }
 __global__ void k_dep_u32(int *out, int k) { int a = threadIdx.x; for (int it = 0; it < ITER * REP; it++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(k)); out[blockIdx.x * blockDim.x + threadIdx.x] = a; }
@@ -81,6 +94,8 @@ int main() {
             run("v_pk_mul_lo_u16", k_pk_mul16, d, w); run("v_mul_u32_u24", k_mul_u24, d, w); run("v_bfi_b32", k_bfi, d, w); run("v_and_or_b32", k_and_or, d, w);
             run("v_or3_b32", k_or3, d, w); run("v_perm_b32", k_perm, d, w); run("v_alignbit_b32", k_alignbit, d, w); run("v_lshl_add_u32", k_lshl_add, d, w);
             run("v_mad_u32_u24", k_mad_u24, d, w); run("v_xad_u32", k_xad, d, w); run("v_min3_u32", k_min3_u32, d, w); run("v_med3_i32", k_med3_i32, d, w);
+            run("v_pk_add_f16", k_pk_add_f16, d, w); run("v_pk_max_f16", k_pk_max_f16, d, w); run("v_pk_min_f16", k_pk_min_f16, d, w); run("v_pk_mul_f16", k_pk_mul_f16, d, w);
+            run("v_max_f16", k_max_f16, d, w); run("v_max3_f32", k_max3_f32, d, w); run("v_sad_u8", k_sad_u8, d, w); run("v_max_i16", k_max_i16, d, w); run("v_max_u16", k_max_u16, d, w);
         }
     }
     return 0;

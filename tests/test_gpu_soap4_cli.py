@@ -356,3 +356,45 @@ def test_cli_lsam_id_and_pass1_counters_equal_reference_tools(golden_dir, tmp_pa
     p = taxcount.read_pass1_file(str(counters))
     assert p == taxcount.pass1_from_lsam_id([l + b"\n" for l in want], 40)
     assert sorted("%d explains %d" % e for e in taxcount.explains(p)) == sorted(l for l in open(os.path.join(g4, "expected.explains")).read().split("\n") if l)
+
+
+@pytest.mark.parametrize("k,overlap", [(1, 0.5), (2, 0.3)])
+def test_cli_spike_filter_equals_the_file_pipeline(golden_dir, tmp_path, k, overlap):
+    """Row f4: -spike k overlap (with -b) leaves <prefix>.genomecovFilter and <prefix>.readFilter computed on the device -- what
+    samtools merge *[0-9] | bedtools genomecov -bga | cc/genomeCovFilter k | bedtools bamtobed + annotate | awk would leave
+    (runMegaPath.sh:211-218).  Checker: tests/spike_check.py on the BAM files the same run wrote (record-identical to the
+    reference's, see test_cli_bam_files_equal_reference); the mean + k*stdev step runs the REAL cc/genomeCovFilter when its binary
+    is here, the bedtools steps are restated (third-party binary, absent)."""
+    import bamtext
+    import spike_check as S
+    d = os.path.join(golden_dir, "g1")
+    prefix = str(tmp_path / "bam")
+    # a pile-up so that spikes exist: every 10th pair of set "a" repeated eight times
+    src1 = open(os.path.join(d, "reads_a_1.fq"), "rb").read().split(b"\n")
+    src2 = open(os.path.join(d, "reads_a_2.fq"), "rb").read().split(b"\n")
+    f1, f2 = tmp_path / "p_1.fq", tmp_path / "p_2.fq"
+    with open(f1, "wb") as a, open(f2, "wb") as b:
+        for i in range(0, len(src1) - 3, 4):
+            reps = 8 if (i // 4) % 10 == 0 else 1
+            for r in range(reps):
+                tag = b"" if r == 0 else b"x%d" % r
+                a.write(src1[i].replace(b"/1", tag + b"/1") + b"\n" + b"\n".join(src1[i + 1:i + 4]) + b"\n")
+                b.write(src2[i].replace(b"/2", tag + b"/2") + b"\n" + b"\n".join(src2[i + 1:i + 4]) + b"\n")
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", os.path.join(d, "ref.fa.index"), str(f1), str(f2), "-o", prefix, "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
+           "-L", "151", "-T", "2", "-u", "750", "-F", "-nc", "-b", "-spike", str(k), str(overlap)]
+    r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, MP_BATCH_PAIRS="97"))
+    assert r.returncode == 0, r.stderr.decode()
+    _, refs, dp = bamtext.read_bam(prefix + ".dpout.1")
+    recs = dp + bamtext.read_bam(prefix + ".gout.1")[2] + bamtext.read_bam(prefix + ".gout.2")[2]
+    bed = S.bed_from_bam_text(recs)
+    genome = [(n, ln) for n, ln in refs]
+    bg = S.bedgraph_bga(genome, bed)
+    mine, _ = S.genome_cov_filter(genome, bg, k)
+    if os.path.exists(S.REAL):
+        assert S.real_genome_cov_filter(genome, bg, k, str(tmp_path)) == mine
+    want_iv = S.union(mine)
+    got_iv = [(l.split("\t")[0], int(l.split("\t")[1]), int(l.split("\t")[2])) for l in open(prefix + ".genomecovFilter").read().splitlines()]
+    assert got_iv == want_iv and len(want_iv) > 0
+    want_names = sorted(S.read_filter(bed, mine, overlap))
+    got_names = sorted(open(prefix + ".readFilter").read().split())
+    assert got_names == want_names and 0 < len(want_names) < len(bed)

@@ -158,3 +158,29 @@ def test_driver_reports_corrupt_gzip_instead_of_truncating(tmp_path):
     r = subprocess.run([exe, "pair", "x", str(bad), os.path.join(d, "reads_a_2.fq"), "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
                         "-L", "151", "-F", "-nc"], env=env, capture_output=True)
     assert r.returncode == 1 and b"error while reading" in r.stderr
+
+
+def test_genome_cov_filter_restatement_matches_the_real_tool(tmp_path):
+    """tests/spike_check.py::genome_cov_filter (the checker of the device spike filter) against cc/genomeCovFilter itself
+    (oracle/_ref, built by oracle/Makefile.ref) on random coverage profiles."""
+    import spike_check as S
+    if not os.path.exists(S.REAL):
+        pytest.skip("oracle/_ref/genomeCovFilter not built (needs /root/reference)")
+    rng = np.random.default_rng(1)
+    n_spikes = 0
+    for trial in range(40):
+        genome = [("s%d" % i, int(rng.integers(50, 3000))) for i in range(int(rng.integers(1, 5)))]
+        bed = []
+        for n, ln in genome:
+            for _ in range(int(rng.integers(0, 60))):
+                a = int(rng.integers(0, ln))
+                b = min(ln, a + int(rng.integers(1, 200)))
+                if rng.random() < 0.3:
+                    a = int(ln * 0.4); b = min(ln, a + 100)
+                bed.append((n, a, b, "r"))
+        bg = S.bedgraph_bga(genome, bed)
+        for k in (1, 2, 5):
+            mine, _ = S.genome_cov_filter(genome, bg, k)
+            assert S.real_genome_cov_filter(genome, bg, k, str(tmp_path)) == mine
+            n_spikes += len(mine)
+    assert n_spikes > 100

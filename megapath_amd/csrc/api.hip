@@ -298,6 +298,25 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
             ix->device_bytes += (size_t)rows * 4;
         }
     }
+    if (ix->d_lkt16 && ix->d_sa_dense && ix->d.sa_dense_shift == 0) {
+        // the 16-mer table with 16-byte entries {l, r, pos, prev16} (kernels_index.hip): 69 GB; a seed start behind the pre-filter
+        // then touches one sector instead of three.  Automatic when that leaves >= 16 GiB free, MP_LKT16U=0 / 1 overrides.
+        const char *e = getenv("MP_LKT16U");
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const size_t entries = (size_t)1 << 32, bytes = entries * sizeof(uint4);
+        bool on = n >= (1ull << 25) && free_b >= bytes + (16ull << 30);
+        if (e) on = atoi(e) != 0;
+        if (on && hipMalloc(&ix->d_lkt16u, bytes) == hipSuccess) {
+            hipLaunchKernelGGL(lkt16u_init_kernel, dim3(1u << 20), dim3(256), 0, 0, (uint4 *)ix->d_lkt16u, (uint64_t)entries);
+            if (hipGetLastError() != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
+            hipLaunchKernelGGL(lkt16u_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, (const uint32_t *)ix->d_sa_dense,
+                               (const uint32_t *)ix->d_lkt16, (uint4 *)ix->d_lkt16u);
+            if (hipDeviceSynchronize() != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
+            ix->d.lkt16u = (const uint4 *)ix->d_lkt16u;
+            ix->device_bytes += bytes;
+        }
+    }
     *out = ix;
     return MP_OK;
 }
@@ -342,6 +361,7 @@ extern "C" int mp_index_close(mp_index *ix)
     if (ix->d_lkt16) (void)hipFree(ix->d_lkt16);
     if (ix->d_kmer15) (void)hipFree(ix->d_kmer15);
     if (ix->d_sa_dense) (void)hipFree(ix->d_sa_dense);
+    if (ix->d_lkt16u) (void)hipFree(ix->d_lkt16u);
     delete ix;
     return MP_OK;
 }
@@ -689,7 +709,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     uint32_t slab_limit = MP_SEED_SLAB;
     if (const char *e = getenv("MP_SEED_SLAB_LIMIT")) { int v = atoi(e); if (v >= 1 && v < MP_SEED_SLAB) slab_limit = (uint32_t)v; }   // test knob
     mp_dev_index dix = c->ix->d;
-    if (!c->use_prefilter) { dix.kmer17 = nullptr; dix.kmer15x3 = nullptr; dix.sa_dense = nullptr; dix.lkt16 = nullptr; }
+    if (!c->use_prefilter) { dix.kmer17 = nullptr; dix.kmer15x3 = nullptr; dix.sa_dense = nullptr; dix.lkt16 = nullptr; dix.lkt16u = nullptr; }
     hipStream_t s = c->stream;
     const uint32_t overflow_cap = n_items;
     if (c->scan.reserve((size_t)n_items * (W + 1) + 16) || c->slabs.reserve((size_t)n_items * MP_SEED_SLAB) || c->seeds_per_rs.reserve(n_items + 2) ||
@@ -721,7 +741,12 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     HIPCHK(hipStreamSynchronize(s));
     const uint32_t n_over = (uint32_t)h.overflow;
     if (n_over > overflow_cap) return MP_ERANGE;
-    if (getenv("MP_DEBUG")) fprintf(stderr, "[megapath_hip] seed: %u items, %u overflowed the %d-seed slab, %u hits\n", n_items, n_over, MP_SEED_SLAB, n_hits);
+    if (getenv("MP_DEBUG")) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        fprintf(stderr, "[megapath_hip] seed: %u items, %u overflowed the %d-seed slab, %u hits; seed_kernel %.3f ms, %llu wave trips (%.1f per item-lane slot), %llu lane trips (%.1f per item), "
+                        "lane occupancy of trips %.2f\n", n_items, n_over, MP_SEED_SLAB, n_hits, ms, h.n_wave_trips, (double)h.n_wave_trips * 64 / n_items, h.n_lane_trips,
+                (double)h.n_lane_trips / n_items, (double)h.n_lane_trips / ((double)h.n_wave_trips * 64));
+    }
     HIPCHK(hipEventRecord(c->ev[8], s));
     if (n_over) {
         if (c->big_slabs.reserve((size_t)n_over * MP_SEED_BIG)) return MP_ENOMEM;

@@ -178,3 +178,38 @@ __global__ void kmer17_query_kernel(const uint32_t *__restrict__ bitmap, const u
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t < n) { const uint64_t k = keys[t] & ((1ull << 34) - 1); out[t] = (uint8_t)((bitmap[k >> 5] >> (uint32_t)(k & 31)) & 1u); }
 }
+
+// The 16-mer table once more with 16-byte entries {l, r, pos, prev16} (see mp_dev_index::lkt16u).  One lane per suffix-array row i >= 1:
+// the row that opens its 16-mer's bucket (i == l) writes the entry.  Needs the whole suffix array (sa_full[i] = SA[i]) and the
+// 16-mer table (inclusive right bounds).  Keys are in scan order like the 16-mer table's (leftmost text base in the top bits).
+__global__ void lkt16u_init_kernel(uint4 *__restrict__ tab, uint64_t n_entries)
+{
+    // grid-stride: 2^32 entries are one work-item more than a launch dimension may have
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_entries; k += (uint64_t)gridDim.x * blockDim.x)
+        tab[k] = make_uint4(1u, 0u, 0xFFFFFFFFu, 0u);                           // empty range
+}
+
+__device__ __forceinline__ uint32_t mp_prev16_scan_order(const uint32_t *__restrict__ text, uint32_t pos)
+{
+    // text bases pos-1, pos-2, ..., pos-16 in bits 1:0, 3:2, ... (pos >= 16)
+    const uint32_t p0 = pos - 16;
+    const uint32_t t16 = (uint32_t)((((uint64_t)text[(p0 >> 4) + 1] << 32) | text[p0 >> 4]) >> (2 * (p0 & 15)));
+    const uint32_t r = __brev(t16);
+    return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+
+__global__ void lkt16u_build_kernel(const uint32_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ sa_full, const uint32_t *__restrict__ lkt16, uint4 *__restrict__ tab)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1;     // rows 1 .. n
+    if (i > n) return;
+    const uint32_t pos = sa_full[i];
+    const uint64_t q = pos >> 4;
+    const uint32_t sh = 2 * (pos & 15);
+    const uint64_t two = ((uint64_t)text[q + 1] << 32) | text[q];
+    const uint32_t key = mp_rev2((uint32_t)(two >> sh));                          // as lkt16_hist_kernel: 'A' beyond the text end
+    const uint32_t l = key ? lkt16[key - 1] + 1 : 1, r = lkt16[key];
+    if ((uint32_t)i != l) return;
+    uint4 e = make_uint4(l, r, 0xFFFFFFFFu, 0u);
+    if (l == r && pos >= 16 && (uint64_t)pos + 16 <= n) { e.z = pos; e.w = mp_prev16_scan_order(text, pos); }
+    tab[key] = e;
+}

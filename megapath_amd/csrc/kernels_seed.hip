@@ -249,7 +249,22 @@ __global__ void lkt16_check_kernel(mp_dev_index ix, uint64_t n_text, uint64_t n_
         l = ix.cum[c] + o1 + 1; r = ix.cum[c] + o2;
     }
     const uint32_t tl = ix.lkt16[key16 - 1] + 1, tr = ix.lkt16[key16];
-    const bool same = l <= r ? (tl == l && tr == r) : tl > tr;
+    bool same = l <= r ? (tl == l && tr == r) : tl > tr;
+    if (ix.lkt16u) {
+        // the 16-byte entries must say the same, and for a 16-mer that occurs once: its position and the 16 bases in front of it
+        const uint4 e = ix.lkt16u[key16];
+        if (l <= r) {
+            same = same && e.x == l && e.y == r;
+            if (l == r) {
+                const uint32_t pos = ix.sa_dense[l];
+                if (pos >= 16 && (uint64_t)pos + 16 <= ix.n) {
+                    uint32_t prev = 0;
+                    for (int u = 0; u < 16; u++) { const uint32_t pp = pos - 1 - (uint32_t)u; prev |= ((ix.text[pp >> 4] >> (2 * (pp & 15))) & 3u) << (2 * u); }
+                    same = same && e.z == pos && e.w == prev;
+                } else same = same && e.z == 0xFFFFFFFFu;
+            }
+        } else same = same && e.x > e.y;
+    }
     atomicAdd(&out[0], 1ull);
     if (!same) atomicAdd(&out[1], 1ull);
 }
@@ -266,6 +281,8 @@ struct mp_mmp_state {
     int pg;
     uint32_t upos;          // text position of the match when its SA range was a single row and it was extended by text
     bool uvalid;            // comparison (mp_mmp_trip): the record then carries the position instead of the row
+    uint32_t uprev;         // the 16 text bases in front of upos (scan order), when the 16-byte table entry supplied them
+    bool uprev_valid;
 };
 #define MP_SEED_LOCATED 0xFFFFFFFFu     // mp_seed_rec::sa_diff / mp_sa_seed::sa_diff: sa_l is a text position, one hit
 
@@ -298,7 +315,7 @@ __device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp 
     s.i -= s.seed_len < P.seed_min_length ? s.seed_len : P.seed_min_length;
     s.l = 0; s.r = n; s.seed_len = 0;
     s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
-    s.uvalid = false;
+    s.uvalid = false; s.uprev_valid = false;
 }
 
 // Per-lane event counters of the seeding kernel: only events that touch memory are priced by the roofline (bench.py);
@@ -322,61 +339,73 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
 {
     const uint32_t n = ix.n;
     bool finished = false;
-    // ---- at most one LKT (re)start
-    if (s.seed_len == 0) {
-        if (s.len - s.i < P.seed_min_length) {
-            finished = true;                                  // `break` of the scan loop
-        } else {
-            const uint32_t wq = (uint32_t)s.i >> 4, sh = 2 * ((uint32_t)s.i & 15);
-            const uint64_t two = ((uint64_t)s.sc[wq + 1] << 32) | s.sc[wq];
-            bool futile = false;
-            if (ix.kmer17 && P.seed_min_length >= 17) {
-                // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe
-                const uint64_t k17 = (two >> sh) & ((1ull << 34) - 1);
-                if (ix.kmer15x3) {
-                    // one 8-byte entry answers three consecutive positions (kmer15x3_build_kernel): a futile strand is probed
-                    // at every position, so two probes in three need no load
-                    const int a = s.i - s.pg;
-                    if (a < 0 || a > 2) { s.pg = s.i; s.pe = ix.kmer15x3[(k17 >> 4) & ((1ull << 30) - 1)]; ev.kload++; }
-                    const int aa = s.i - s.pg;
-                    const uint32_t bit = aa == 0 ? (uint32_t)(k17 & 15) : aa == 1 ? 16u + ((uint32_t)(k17 & 3) | ((uint32_t)(k17 >> 32) & 3u) << 2)
-                                                                                   : 32u + (uint32_t)((k17 >> 30) & 15);
-                    futile = ((s.pe >> bit) & 1ull) == 0;
-                } else {
-                    futile = ((ix.kmer17[k17 >> 5] >> (uint32_t)(k17 & 31)) & 1u) == 0;
-                    ev.kload++;
+    // ---- at most one LKT (re)start.  Futile starts (the pre-filter says the next 17 bases occur nowhere) cost no look-up: the scan
+    // moves on one base, and keeps moving within this trip for as long as the pre-filter entry already loaded answers the next
+    // position too (one 8-byte entry covers three consecutive positions) -- a strand that matches nowhere is walked three positions
+    // per trip, with at most one pre-filter load per trip as before.
+    bool loaded_entry = false;
+    while (s.seed_len == 0 && !finished) {
+        if (s.len - s.i < P.seed_min_length) { finished = true; break; }   // `break` of the scan loop
+        const uint32_t wq = (uint32_t)s.i >> 4, sh = 2 * ((uint32_t)s.i & 15);
+        const uint64_t two = ((uint64_t)s.sc[wq + 1] << 32) | s.sc[wq];
+        bool futile = false;
+        if (ix.kmer17 && P.seed_min_length >= 17) {
+            // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe
+            const uint64_t k17 = (two >> sh) & ((1ull << 34) - 1);
+            if (ix.kmer15x3) {
+                const int a = s.i - s.pg;
+                if (a < 0 || a > 2) {
+                    if (loaded_entry) break;                  // the next entry is for the next trip
+                    s.pg = s.i; s.pe = ix.kmer15x3[(k17 >> 4) & ((1ull << 30) - 1)]; ev.kload++; loaded_entry = true;
                 }
-                ev.kmer++;
-            }
-            const uint32_t key16 = (uint32_t)(two >> sh);
-            if (futile) {
-                ++s.i;                                        // a seed shorter than seed_min_length: nothing reported, restart one base on
-            } else if (ix.lkt16 && ix.kmer17 && P.seed_min_length >= 17 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
-                // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
-                // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
-                // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
-                const uint32_t nextl = ix.lkt16[key16 - 1] + 1, nextr = ix.lkt16[key16];
-                ev.lkt16++;
-                ev.skipped += 3;                              // the three extension steps the table stands for
-                s.i += 15;
-                s.seed_len = 15;
-                if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
-                else mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
-                ++s.i;
-                if (s.i >= s.len) finished = true;
+                const int aa = s.i - s.pg;
+                const uint32_t bit = aa == 0 ? (uint32_t)(k17 & 15) : aa == 1 ? 16u + ((uint32_t)(k17 & 3) | ((uint32_t)(k17 >> 32) & 3u) << 2)
+                                                                               : 32u + (uint32_t)((k17 >> 30) & 15);
+                futile = ((s.pe >> bit) & 1ull) == 0;
             } else {
-                const uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
-                const uint32_t nextl = key ? ix.lkt[key - 1] + 1 : 1;
-                const uint32_t nextr = ix.lkt[key];
-                ev.lkt++;
-                s.i += MP_LKT_K - 1;
-                s.seed_len = MP_LKT_K - 1;
-                if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
-                else mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
-                ++s.i;
-                if (s.i >= s.len) finished = true;
+                if (loaded_entry) break;
+                futile = ((ix.kmer17[k17 >> 5] >> (uint32_t)(k17 & 31)) & 1u) == 0;
+                ev.kload++; loaded_entry = true;
             }
+            ev.kmer++;
         }
+        const uint32_t key16 = (uint32_t)(two >> sh);
+        if (futile) {
+            ++s.i;                                            // a seed shorter than seed_min_length: nothing reported, restart one base on
+            continue;
+        }
+        if (ix.lkt16 && ix.kmer17 && P.seed_min_length >= 17 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
+            // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
+            // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
+            // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
+            uint32_t nextl, nextr;
+            if (ix.lkt16u) {
+                // one 16-byte entry: the range and, for a 16-mer that occurs once, where -- and what stands in front of it
+                const uint4 e = ix.lkt16u[key16];
+                nextl = e.x; nextr = e.y;
+                if (nextl == nextr && e.z != 0xFFFFFFFFu) { s.upos = e.z; s.uvalid = true; s.uprev = e.w; s.uprev_valid = true; }
+            } else { nextl = ix.lkt16[key16 - 1] + 1; nextr = ix.lkt16[key16]; }
+            ev.lkt16++;
+            ev.skipped += 3;                              // the three extension steps the table stands for
+            s.i += 15;
+            s.seed_len = 15;
+            if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
+            else mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
+            ++s.i;
+            if (s.i >= s.len) finished = true;
+        } else {
+            const uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
+            const uint32_t nextl = key ? ix.lkt[key - 1] + 1 : 1;
+            const uint32_t nextr = ix.lkt[key];
+            ev.lkt++;
+            s.i += MP_LKT_K - 1;
+            s.seed_len = MP_LKT_K - 1;
+            if (nextl <= nextr) { s.l = nextl; s.r = nextr; ++s.seed_len; }
+            else mp_close_seed<SLAB>(s, P, n, s.strand == 0 ? s.len - s.i : s.i - s.seed_len, slab);
+            ++s.i;
+            if (s.i >= s.len) finished = true;
+        }
+        break;                                                // one look-up per trip
     }
     // ---- a match whose SA range is a single row is extended by comparing the read with the text itself: the next base of
     // the backward search is the text base in front of the match, 16 of them per word instead of one rank block each.  The
@@ -395,7 +424,8 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
             const uint32_t pend = pos - (uint32_t)matched - 1;                    // text base that must equal it
             int nn = avail - matched; if (nn > 16) nn = 16;
             uint32_t trev;
-            if (pend >= 15) {
+            if (matched == 0 && s.uprev_valid) { trev = s.uprev; s.uprev_valid = false; ev.text--; }   // came with the table entry: no text load
+            else if (pend >= 15) {
                 const uint32_t p0 = pend - 15;
                 const uint32_t t16 = (uint32_t)((((uint64_t)ix.text[(p0 >> 4) + 1] << 32) | ix.text[p0 >> 4]) >> (2 * (p0 & 15)));
                 const uint32_t r = __brev(t16);
@@ -457,7 +487,7 @@ __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *sc
     // reference gives up on the whole SIMD group such an instance falls into, CPU_DP.cpp:294-299 -- not reproduced.)
     if (s.len < MP_MIN_ALIGNABLE_LEN) s.len = 0;
     s.i = 0; s.seed_len = 0; s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
-    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.upos = 0; s.uvalid = false; s.pe = 0; s.pg = -1000;
+    s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.upos = 0; s.uvalid = false; s.uprev = 0; s.uprev_valid = false; s.pe = 0; s.pg = -1000;
 }
 
 __global__ void __launch_bounds__(256)
@@ -474,7 +504,9 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
     // them to its lanes as they finish (a single word sustains only ~90 returning atomics per microsecond chip-wide).
     uint32_t pool_next = 0, pool_end = 0;       // wave-uniform
     bool drained = false;
+    uint32_t wave_trips = 0, lane_busy = 0;
     for (;;) {
+        wave_trips++;
         const unsigned long long need = __ballot(!have);
         if (need) {
             if (pool_next == pool_end && !drained) {
@@ -495,6 +527,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
         }
         if (!__any(have)) { if (drained && pool_next == pool_end) break; else continue; }   // nothing to do this trip
         if (have) {
+            lane_busy++;
             mp_seed_rec *slab = slabs + (uint64_t)s.rs * MP_SEED_SLAB;
             if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, ev)) {
                 seeds_per_rs[s.rs] = s.n_seeds;
@@ -508,6 +541,8 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             }
         }
     }
+    { uint32_t lb = lane_busy; for (int o = MP_WAVE / 2; o > 0; o >>= 1) lb += __shfl_down(lb, o);
+      if (lane == 0) { atomicAdd(&ctr->n_wave_trips, (unsigned long long)wave_trips); atomicAdd(&ctr->n_lane_trips, (unsigned long long)lb); } }
     uint32_t tot[10] = {ev.occ, ev.blk, ev.lkt, ev.lkt16, ev.kmer, ev.kload, ev.text, ev.sa, ev.skipped, ev.located};
 #pragma unroll
     for (int q = 0; q < 10; q++)

@@ -1,5 +1,6 @@
 // megapath_amd/csrc/mp_internal.h -- shared host/device definitions of libmegapath_hip (product code).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
@@ -26,6 +27,9 @@ struct mp_dev_index {          // passed by value to kernels
     const uint32_t *sa;        // SA[k*interval]; entry 0 unused (handled as -1, BWT.c:242)
     const uint32_t *text;      // 2-bit text, LSB-first, 16 bases per word
     const uint32_t *lkt16;     // optional: 4^16 inclusive right SA bounds of the 16-mers (nullptr = off); used behind the 17-mer filter
+    const uint4 *lkt16u;       // optional: per 16-mer one 16-byte entry {l, r, pos, prev16} (69 GB): the SA range, and for a 16-mer that occurs once
+                               // its text position and the 16 text bases in front of it (scan order) -- a seed start then costs ONE sector instead of
+                               // three (16-mer table, suffix array, text); pos = 0xFFFFFFFF: no short cut (match within 16 bases of the text start)
     const unsigned long long *kmer15x3;   // optional: per 15-mer, the presence bits of the 48 17-mers around it (three alignments, see
                                // kmer15x3_build_kernel): one load answers the pre-filter for three consecutive scan positions
     const uint32_t *kmer17;    // optional: one bit per 17-mer, set when backward search can reach length 17 with it (nullptr = off)
@@ -43,7 +47,7 @@ struct mp_translate_row { uint64_t start; uint32_t chr; uint64_t corr; };
 struct mp_index {
     int device = 0;
     mp_dev_index d{};
-    void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr, *d_kmer = nullptr, *d_sa_dense = nullptr, *d_lkt16 = nullptr, *d_kmer15 = nullptr;
+    void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr, *d_kmer = nullptr, *d_sa_dense = nullptr, *d_lkt16 = nullptr, *d_kmer15 = nullptr, *d_lkt16u = nullptr;
     uint64_t device_bytes = 0;
     uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};
     uint32_t sa_interval = 0;
@@ -101,7 +105,7 @@ struct mp_dev_mmp {
 
 struct mp_counters {           // device-side event counters
     unsigned long long n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos, n_cand, overflow, n_kmer, n_occ_loaded;
-    unsigned long long n_lkt16, n_kmer_loads, n_text_words, n_steps_skipped, n_located;
+    unsigned long long n_lkt16, n_kmer_loads, n_text_words, n_steps_skipped, n_located, n_wave_trips, n_lane_trips;
 };
 
 struct mp_hit_task { uint32_t seed_slot; uint32_t k; };                         // one SA row to locate

@@ -122,6 +122,8 @@ def test_lkt16_table_equals_table_plus_three_steps(tmp_path, n_bases, monkeypatc
     from megapath_amd import index_builder, synth
     monkeypatch.setenv("MP_KMER_FILTER", "1")
     monkeypatch.setenv("MP_LKT16", "1")
+    monkeypatch.setenv("MP_SA_DENSE", "1")
+    monkeypatch.setenv("MP_LKT16U", "1")                  # the 16-byte entries {l, r, pos, prev16} are verified by the same kernel
     genome = synth.random_genome(n_bases, 91, n_seqs=2)
     if n_bases < 10000:                                   # a poly-A tail: the buckets the kernel leaves to the 13-mer path
         name, arr = genome[-1]
@@ -142,6 +144,7 @@ def test_seeds_and_hits_identical_with_prefilter(g1_prefix, golden_dir, monkeypa
     monkeypatch.setenv("MP_KMER15", "1")
     monkeypatch.setenv("MP_LKT16", "1")
     monkeypatch.setenv("MP_SA_DENSE", "1")
+    monkeypatch.setenv("MP_LKT16U", "1")
     gix = H.Index(g1_prefix, 0)
     d = os.path.join(golden_dir, "g1")
     L = int(open(os.path.join(d, "expected_%s.L" % tag)).read())

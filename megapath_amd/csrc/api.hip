@@ -712,20 +712,23 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     if (!c->use_prefilter) { dix.kmer17 = nullptr; dix.kmer15x3 = nullptr; dix.sa_dense = nullptr; dix.lkt16 = nullptr; dix.lkt16u = nullptr; }
     hipStream_t s = c->stream;
     const uint32_t overflow_cap = n_items;
-    if (c->scan.reserve((size_t)n_items * (W + 1) + 16) || c->slabs.reserve((size_t)n_items * MP_SEED_SLAB) || c->seeds_per_rs.reserve(n_items + 2) ||
+    if (c->scan.reserve((size_t)n_items * mp_scan_stride(W) + 16) || c->slabs.reserve((size_t)n_items * MP_SEED_SLAB) || c->seeds_per_rs.reserve(n_items + 2) ||
         c->hits_per_rs.reserve(n_items + 2) || c->rs_base.reserve(n_items + 2) || c->overflow_rs.reserve(overflow_cap) || c->over_slot.reserve(n_items + 1) || c->queue.reserve(1) ||
         c->n_pos.reserve(n_reads + 1) || c->n_neg.reserve(n_reads + 1)) return MP_ENOMEM;
-    hipLaunchKernelGGL(prep_scan_kernel, dim3(grid_for((uint64_t)n_items * (W + 1), 256)), dim3(256), 0, s, c->d_reads, c->d_lens, n_reads, W, c->scan.p);
+    hipLaunchKernelGGL(prep_scan_kernel, dim3(grid_for((uint64_t)n_items * mp_scan_stride(W), 256)), dim3(256), 0, s, c->d_reads, c->d_lens, n_reads, W, c->scan.p);
     MP_TRACE(s, "prep_scan_kernel");
     HIPCHK(hipMemsetAsync(c->ctr.p, 0, sizeof(mp_counters), s));
     HIPCHK(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), s));
     HIPCHK(hipMemsetAsync(c->hits_per_rs.p + n_items, 0, 2 * sizeof(uint32_t), s));
-    // persistent grid: at most 8 blocks of 256 lanes per CU (seed_kernel holds 8 waves per SIMD)
+    // persistent grid: as many blocks of 256 lanes as the kernel's registers and its LDS rows (one scan row per lane) let a CU hold
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
-    const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * 8u);
+    const size_t seed_lds = (size_t)256 * (mp_scan_stride(W) | 1u) * sizeof(uint32_t);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, seed_kernel, 256, seed_lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * (unsigned)per_cu);
     HIPCHK(hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(seed_kernel, dim3(blocks), dim3(256), 0, s, dix, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
+    hipLaunchKernelGGL(seed_kernel, dim3(blocks), dim3(256), seed_lds, s, dix, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
                        c->hits_per_rs.p, c->overflow_rs.p, c->over_slot.p, overflow_cap, c->queue.p, c->ctr.p, slab_limit);
     MP_TRACE(s, "seed_kernel");
     HIPCHK(hipEventRecord(c->ev[1], s));

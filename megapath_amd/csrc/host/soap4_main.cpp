@@ -898,7 +898,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
     auto emit_pair = [&](Writer &w, Sink &sink, PairText &text, std::vector<PairAln> &res, uint32_t q, int file, int stage) {
         const Rec &r1 = bt.rec(2 * q), &r2 = bt.rec(2 * q + 1);
         const size_t best = best_of(res);
-        w.pair(r1, r2, bt.lens[2 * q], bt.lens[2 * q + 1], res);
+        if (p.mode) w.pair(r1, r2, bt.lens[2 * q], bt.lens[2 * q + 1], res);     // `-b` alone: no annotated FASTQ, and the BAM writer sees the results as they are (BGS-IO.cpp:2103)
         if (!bam) return;
         const mpbam::ReadView rd[2] = {view_of(r1, bt.lens[2 * q]), view_of(r2, bt.lens[2 * q + 1])};
         if (bam->w->wants_text()) { const Side *bs[2] = {&res[best].m[0], &res[best].m[1]}; text.fetch(ix, bs); }
@@ -1010,7 +1010,7 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
                     if (bam) { s.cigar = b.scig[ci++].c_str(); s.editdist = mpbam::edit_dist(s.cigar, (int)bt.lens[r], h.score, nullptr); }
                     lst[k].push_back(s);
                 }
-                w.single(bt.rec(r), bt.lens[r], lst[k]);
+                if (p.mode) w.single(bt.rec(r), bt.lens[r], lst[k]);
             }
             if (!bam) continue;
             const mpbam::ReadView rd[2] = {view_of(bt.rec(2 * q), bt.lens[2 * q]), view_of(bt.rec(2 * q + 1), bt.lens[2 * q + 1])};
@@ -1145,7 +1145,11 @@ int main(int argc, char **argv)
     if (p.insert_low > p.insert_high) { fprintf(stderr, "The minimum value of insert size should not be greater than the maximum value of insert size.\n"); return 1; }
     // IniParam.cpp:918-940: -R needs -D and -A; -A and -D come together
     if ((have_r && (!have_a || !have_d)) || (have_a != have_d)) { fprintf(stderr, "Options '-D' and '-A' have to be specified together ('-R' needs both).\n"); return 1; }
-    if (p.mode == 0) { fprintf(stderr, "[soap4-mi355x] only MegaPath modes -F / -P are implemented (plain mode segfaults in the reference, SURVEY App. D15)\n"); return 1; }
+    // Output modes that work in the reference: -F / -P (with or without -b) and -b alone (BAM side files only, nothing on stdout).
+    // With none of them the reference dies with SIGSEGV after seeding (this is what runSOAP3dp.pl:44-50 would
+    // start): here that invocation is refused before any work is done.
+    if (p.mode == 0 && !p.want_bam) { fprintf(stderr, "[soap4-mi355x] no output mode: give -F or -P (annotated FASTQ on stdout) and/or -b (BAM side files); the reference crashes on this invocation\n"); return 1; }
+    if (p.mode == 0 && (p.lsam || !tax_files[0].empty() || !pass1_path.empty())) { fprintf(stderr, "[soap4-mi355x] -lsam / -lsamid / -pass1 rewrite the stdout of -F / -P: give one of them\n"); return 1; }
     if (ini_path.empty()) ini_path = std::string(argv[0]) + ".ini";       // SOAP4.cpp:150-154
     Ini ini;
     if (!load_ini(ini_path, ini)) { fprintf(stderr, "[soap4-mi355x] cannot read ini file %s\n", ini_path.c_str()); return 1; }

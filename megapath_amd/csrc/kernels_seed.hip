@@ -152,12 +152,15 @@ gather64_kernel(mp_dev_index ix, uint32_t n_blocks, uint32_t per_lane, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ scan-order reads
-// scan[(read*2+strand)*W2 + w]: the read's bases in the order the strand's backward search consumes them
-// (strand 0: right-to-left; strand 1: left-to-right, complemented), LSB-first, zero padded.  W2 = W + 1 words so that a
-// 26-bit key can always be cut from two adjacent words.
+// scan[(read*2+strand)*S + w]: the read's bases in the order the strand's backward search consumes them
+// (strand 0: right-to-left; strand 1: left-to-right, complemented), LSB-first, zero padded.  A row has S = W + 2 words rounded
+// up to a multiple of four: 16-byte aligned rows (seed_kernel fetches them as 64-byte blocks), and a 34-bit key can be cut
+// from two adjacent words at any scan position up to the read's end.
+__host__ __device__ __forceinline__ uint32_t mp_scan_stride(uint32_t W) { return (W + 2u + 3u) & ~3u; }
+
 __global__ void prep_scan_kernel(const uint32_t *reads, const uint32_t *lens, uint32_t n_reads, uint32_t W, uint32_t *scan)
 {
-    const uint32_t W2 = W + 1;
+    const uint32_t W2 = mp_scan_stride(W);
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t total = (uint64_t)n_reads * 2 * W2;
     if (t >= total) return;
@@ -286,8 +289,8 @@ struct mp_mmp_state {
 };
 #define MP_SEED_LOCATED 0xFFFFFFFFu     // mp_seed_rec::sa_diff / mp_sa_seed::sa_diff: sa_l is a text position, one hit
 
-template <int SLAB>
-__device__ __forceinline__ void mp_close_seed(mp_mmp_state &s, const mp_dev_mmp &P, uint32_t n, int x, mp_seed_rec *slab)
+template <int SLAB, class State>
+__device__ __forceinline__ void mp_close_seed(State &s, const mp_dev_mmp &P, uint32_t n, int x, mp_seed_rec *slab)
 {
     // CHECK_AND_ADD_RANGE (DV-DPfunctions.cpp:2197-2219)
     int diff = 0;
@@ -480,7 +483,7 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
 
 __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *scan, const uint32_t *lens, uint32_t W, uint32_t rs, uint32_t n)
 {
-    s.sc = scan + (uint64_t)rs * (W + 1);
+    s.sc = scan + (uint64_t)rs * mp_scan_stride(W);
     s.rs = rs; s.len = (int)lens[rs >> 1]; s.strand = (int)(rs & 1);
     // A read below the DP cutoff floor (30 bases, definitions.h:166-167) can never pass a DP (its best possible score is its
     // length), so it gets no seeds and therefore no DP instance: it ends up unaligned like any read without a hit.  (The
@@ -490,15 +493,59 @@ __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *sc
     s.cur_w = 0xFFFFFFFFu; s.cur_word = 0; s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.upos = 0; s.uvalid = false; s.uprev = 0; s.uprev_valid = false; s.pe = 0; s.pg = -1000;
 }
 
+// ---- seed_kernel: the same state machine as mp_mmp_trip, arranged so that a wavefront waits for memory ONCE per trip.
+// Every step of a backward search is a dependent load (pre-filter entry -> table entry -> rank block -> ... -> text word), and
+// the 64 lanes of a wavefront sit in different steps.  Written as branches that load and then use (mp_mmp_trip), each kind of
+// step costs the wavefront its own full memory latency per trip, one after the other.  Here a lane carries the ADDRESS of its
+// next load in its state: a trip issues the loads of all lanes together (three instruction groups: a 64-byte block, one
+// 16-byte entry, one or two words), waits once, then every lane consumes what it got and derives its next address.  The read's
+// scan-order bases live in LDS (one row per lane), so cutting keys and comparing with the text costs no global load.
+enum { MK_NONE = 0, MK_PRE, MK_LKT13, MK_LKT16, MK_SA, MK_TEXT,      // one or two words
+       MK_LKT16U,                                                     // one 16-byte entry
+       MK_OCC, MK_OCC2, MK_BEGIN };                                   // a 64-byte block
+
+struct mp_lane_state {
+    uint32_t rs;
+    int len, strand, i, seed_len;
+    uint32_t l, r, last_l, last_r, last_seed_len;
+    uint32_t n_seeds, n_hits, n_located;
+    unsigned long long pe;  // pre-filter entry that answers scan positions pg .. pg + 2 (bits per 15-mer) or pg alone (17-mer bitmap word)
+    int pg;
+    uint32_t upos;          // text position of the match once its SA range is a single row
+    bool uvalid, uprev_valid;
+    uint32_t kind;          // the load this lane waits for
+    uint32_t aux;           // MK_OCC*: the symbol; MK_LKT13: key == 0; MK_BEGIN: 64-byte blocks of the row already fetched
+    uint32_t o1;            // MK_OCC2: rank at the range's lower end, from the first block
+    const void *ptr;        // where that load reads
+};
+
+__device__ __forceinline__ uint32_t mp_block_rank(const uint32_t (&w)[12], uint32_t pat, uint32_t off)
+{
+    uint32_t a = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { const int ns = (int)off - 16 * i; if (ns > 0) a += mp_popc_sym(w[i], pat, ns); }
+    return a;
+}
+
 __global__ void __launch_bounds__(256)
 seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t n_items, uint32_t W, mp_dev_mmp P,
             mp_seed_rec *__restrict__ slabs, uint32_t *__restrict__ seeds_per_rs, uint32_t *__restrict__ hits_per_rs,
             uint32_t *__restrict__ overflow_rs, uint32_t *__restrict__ over_slot, uint32_t overflow_cap, unsigned int *queue, mp_counters *ctr,
             uint32_t slab_limit /* <= MP_SEED_SLAB; smaller only to exercise the overflow path */)
 {
+    extern __shared__ uint32_t s_scan[];                 // [256][S | 1]: the scan row of the item each lane works on
     const int lane = threadIdx.x & (MP_WAVE - 1);
+    const uint32_t S = mp_scan_stride(W);
+    uint32_t *const sl = s_scan + threadIdx.x * (S | 1u);
+    const uint32_t n = ix.n;
+    const bool pf = ix.kmer17 && P.seed_min_length >= 17;
+    const bool text_ok = ix.sa_dense && ix.sa_dense_shift == 0;
+    const uint32_t cum0 = ix.cum[0], cum1 = ix.cum[1], cum2 = ix.cum[2], cum3 = ix.cum[3];
     mp_lane_events ev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    mp_mmp_state s;
+    mp_lane_state s;
+    s.rs = 0; s.len = 0; s.strand = 0; s.i = 0; s.seed_len = 0; s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
+    s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.pe = 0; s.pg = -1000; s.upos = 0; s.uvalid = false; s.uprev_valid = false;
+    s.kind = MK_NONE; s.aux = 0; s.o1 = 0; s.ptr = nullptr;
     bool have = false;
     // Work queue: one global counter, but a wavefront takes MP_SEED_CHUNK items per atomic into a private range and hands
     // them to its lanes as they finish (a single word sustains only ~90 returning atomics per microsecond chip-wide).
@@ -520,16 +567,206 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             const uint32_t avail = pool_end - pool_next;
             if (avail) {
                 const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (!have && rank < avail) { mp_mmp_begin(s, scan, lens, W, pool_next + rank, ix.n); have = true; }
+                if (!have && rank < avail) {
+                    // a new item: its first load is its scan row (and its length)
+                    const uint32_t rs = pool_next + rank;
+                    s.rs = rs; s.strand = (int)(rs & 1); s.len = 0; s.i = 0; s.seed_len = 0;
+                    s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
+                    s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.pe = 0; s.pg = -1000; s.upos = 0; s.uvalid = false;
+                    s.kind = MK_BEGIN; s.aux = 0; s.ptr = scan + (uint64_t)rs * S;
+                    have = true;
+                }
                 const uint32_t want = (uint32_t)__popcll(need);
                 pool_next += want < avail ? want : avail;
             }
         }
         if (!__any(have)) { if (drained && pool_next == pool_end) break; else continue; }   // nothing to do this trip
+        // ---------------------------------------------------------------- issue: every lane's pending load, no use in between
+        // (the destinations are written by exactly the lanes that read them below; left unset otherwise so that no copy or wait
+        // is needed to carry a value around the loop)
+        uint4 q0, q1, q2, q3;
+        uint32_t a0, a1, alen;
+        asm volatile("" : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(a0), "=v"(a1), "=v"(alen));    // "some value": nothing is carried over from the trip before
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wconditional-uninitialized"
         if (have) {
             lane_busy++;
+            const uint32_t kind = s.kind;
+            if (kind >= MK_LKT16U) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(s.ptr);
+                q0 = p[0];
+                if (kind != MK_LKT16U) { q1 = p[1]; q2 = p[2]; q3 = p[3]; }
+                if (kind == MK_BEGIN && s.aux == 0) alen = lens[s.rs >> 1];
+            } else if (kind != MK_NONE) {
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(s.ptr);
+                const bool one = kind == MK_SA || (kind == MK_PRE && !ix.kmer15x3) || (kind == MK_LKT13 && s.aux);
+                a0 = p[0];
+                a1 = p[one ? 0 : 1];
+            }
+        }
+        // the one wait of the trip: everything issued above (and the stores of the trip before) has landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt and lgkmcnt left alone
+        // ---------------------------------------------------------------- consume
+        if (have) {
+            const uint32_t kind = s.kind;
+            uint32_t next = MK_NONE;
+            bool fin = false, mid_close = false, text_now = false;
+            uint32_t trev = 0;
+            if (kind == MK_BEGIN) {
+                const uint32_t base = s.aux * 16u;
+                if (base < S) { sl[base] = q0.x; sl[base + 1] = q0.y; sl[base + 2] = q0.z; sl[base + 3] = q0.w; }
+                if (base + 4 < S) { sl[base + 4] = q1.x; sl[base + 5] = q1.y; sl[base + 6] = q1.z; sl[base + 7] = q1.w; }
+                if (base + 8 < S) { sl[base + 8] = q2.x; sl[base + 9] = q2.y; sl[base + 10] = q2.z; sl[base + 11] = q2.w; }
+                if (base + 12 < S) { sl[base + 12] = q3.x; sl[base + 13] = q3.y; sl[base + 14] = q3.z; sl[base + 15] = q3.w; }
+                if (s.aux == 0) {
+                    // A read below the DP cutoff floor (30 bases, definitions.h:166-167) can never pass a DP (its best possible score
+                    // is its length), so it gets no seeds and therefore no DP instance: it ends up unaligned like any read without a
+                    // hit.  (The reference gives up on the whole SIMD group such an instance falls into, CPU_DP.cpp:294-299 -- not reproduced.)
+                    const int ln = (int)alen;
+                    s.len = ln < MP_MIN_ALIGNABLE_LEN ? 0 : ln;
+                }
+                s.aux++;
+                if (s.aux * 16u < S) { next = MK_BEGIN; s.ptr = reinterpret_cast<const uint4 *>(s.ptr) + 4; }
+            } else if (kind == MK_PRE) {
+                s.pe = ix.kmer15x3 ? (((unsigned long long)a1 << 32) | a0) : (unsigned long long)a0;
+                s.pg = s.i;
+            } else if (kind == MK_LKT13 || kind == MK_LKT16 || kind == MK_LKT16U) {
+                // LKT (re)start: the table stands for the first 13 (16) bases of the seed
+                uint32_t nextl, nextr;
+                int k;
+                if (kind == MK_LKT13) { nextl = s.aux ? 1u : a0 + 1; nextr = a1; k = MP_LKT_K - 1; ev.lkt++; }
+                else {
+                    if (kind == MK_LKT16U) { nextl = q0.x; nextr = q0.y; } else { nextl = a0 + 1; nextr = a1; }
+                    k = 15; ev.lkt16++; ev.skipped += 3;                  // the three extension steps the table stands for
+                }
+                s.i += k; s.seed_len = k;
+                if (nextl <= nextr) {
+                    s.l = nextl; s.r = nextr; ++s.seed_len; ++s.i;
+                    if (s.i >= s.len) fin = true;
+                    else if (kind == MK_LKT16U && nextl == nextr && q0.z != 0xFFFFFFFFu) {
+                        // a 16-mer that occurs once: the entry says where, and what stands in front of it -- compared right away
+                        s.upos = q0.z; s.uvalid = true; trev = q0.w; text_now = true;
+                    }
+                } else mid_close = true;
+            } else if (kind == MK_OCC || kind == MK_OCC2) {
+                // one backward extension: rank of the symbol at both ends of the range (one block, or two over two trips)
+                const uint32_t c = s.aux;
+                uint32_t k1 = s.l, k2 = s.r + 1;
+                k1 -= (k1 > ix.inv_sa0); k2 -= (k2 > ix.inv_sa0);
+                const uint32_t b1 = k1 / MP_OCC_SYMS, off1 = k1 - b1 * MP_OCC_SYMS;
+                const uint32_t b2 = k2 / MP_OCC_SYMS, off2 = k2 - b2 * MP_OCC_SYMS;
+                const uint32_t pat = c * 0x55555555u;
+                const uint32_t w[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                const uint32_t cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
+                const uint32_t ca = cnt + mp_block_rank(w, pat, kind == MK_OCC ? off1 : off2);
+                uint32_t o1 = ca, o2 = ca;
+                bool done = true;
+                if (kind == MK_OCC) {
+                    if (b1 == b2) o2 = cnt + mp_block_rank(w, pat, off2);
+                    else { s.o1 = o1; next = MK_OCC2; s.ptr = ix.occ + b2; done = false; }
+                } else o1 = s.o1;
+                if (done) {
+                    ev.occ += 2; ev.blk += b1 == b2 ? 1u : 2u;
+                    const uint32_t cumc = c == 0 ? cum0 : c == 1 ? cum1 : c == 2 ? cum2 : cum3;     // (ix.cum[c] would be a load from the argument block)
+                    const uint32_t nextl = cumc + o1 + 1, nextr = cumc + o2;
+                    if (nextl <= nextr) {
+                        if (s.seed_len >= P.seed_min_length && nextr - nextl < s.r - s.l) { s.last_r = s.r; s.last_l = s.l; s.last_seed_len = (uint32_t)s.seed_len; }
+                        s.l = nextl; s.r = nextr; ++s.seed_len; ++s.i;
+                        if (s.i >= s.len) fin = true;
+                    } else mid_close = true;
+                }
+            } else if (kind == MK_SA) {
+                // the text position of a match whose range became a single row: from here on it is extended by comparing with the text
+                s.upos = a0; s.uvalid = true;
+                if (a0 == 0) { mid_close = true; ev.skipped++; }           // the text starts here: what the failing rank query reports
+            } else if (kind == MK_TEXT) {
+                const uint32_t pend = s.upos - 1;                          // text base that must equal scan base s.i
+                uint32_t t16;                                               // text bases pend-15 .. pend, LSB-first
+                if (pend >= 15) t16 = (uint32_t)((((uint64_t)a1 << 32) | a0) >> (2 * ((pend - 15) & 15)));
+                else t16 = a0 << (2 * (15 - pend));
+                const uint32_t r = __brev(t16);
+                trev = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);    // text base pend in bits 1:0, pend - 1 in 3:2, ...
+                text_now = true; ev.text++;
+            }
+            if (text_now) {
+                // The next base of the backward search is the text base in front of the match, 16 of them per word instead of one
+                // rank block each.  The range cannot shrink any more (the re-seed bookkeeping stands still) and the seed is
+                // reported by its text position (MP_SEED_LOCATED).
+                const int avail = min(s.len - s.i, (int)min(s.upos, (uint32_t)1 << 20));     // scan bases left / text bases in front of the match
+                const int nn = avail < 16 ? avail : 16;
+                const uint32_t wq = (uint32_t)s.i >> 4;
+                const uint32_t scan16 = (uint32_t)((((uint64_t)sl[wq + 1] << 32) | sl[wq]) >> (2 * ((uint32_t)s.i & 15)));
+                const uint32_t x = scan16 ^ trev;
+                int same = x ? (__ffs((int)x) - 1) >> 1 : 16;
+                const bool stop = same < nn;
+                if (!stop) same = nn;
+                s.upos -= (uint32_t)same; s.seed_len += same; s.i += same; ev.skipped += (uint32_t)same;
+                if (stop || same == avail) {
+                    if (s.i >= s.len) fin = true;
+                    else { mid_close = true; ev.skipped++; }               // the failing step
+                }
+            }
             mp_seed_rec *slab = slabs + (uint64_t)s.rs * MP_SEED_SLAB;
-            if (mp_mmp_trip<MP_SEED_SLAB>(ix, P, s, slab, ev)) {
+            if (mid_close || fin) {
+                const int x = mid_close ? (s.strand == 0 ? s.len - s.i : s.i - s.seed_len) : (s.strand == 0 ? 0 : s.len - s.seed_len);
+                mp_close_seed<MP_SEED_SLAB>(s, P, n, x, slab);
+                if (mid_close) { ++s.i; fin = s.i >= s.len; }
+            }
+            // ---- a lane without a seed under way: where does the next one start?  (pre-filter, then the table look-up)
+            if (!fin && next == MK_NONE && s.seed_len == 0) {
+                for (;;) {
+                    if (s.len - s.i < P.seed_min_length) { fin = true; break; }        // `break` of the scan loop
+                    const uint32_t wq = (uint32_t)s.i >> 4, sh = 2 * ((uint32_t)s.i & 15);
+                    const uint64_t two = ((uint64_t)sl[wq + 1] << 32) | sl[wq];
+                    if (pf) {
+                        // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe.  A futile
+                        // start (they occur nowhere) costs no look-up: the scan moves on one base.
+                        const uint64_t k17 = (two >> sh) & ((1ull << 34) - 1);
+                        bool futile;
+                        if (ix.kmer15x3) {
+                            const int a = s.i - s.pg;
+                            if (a < 0 || a > 2) { next = MK_PRE; s.ptr = ix.kmer15x3 + ((k17 >> 4) & ((1ull << 30) - 1)); ev.kload++; break; }
+                            const uint32_t bit = a == 0 ? (uint32_t)(k17 & 15) : a == 1 ? 16u + ((uint32_t)(k17 & 3) | ((uint32_t)(k17 >> 32) & 3u) << 2)
+                                                                                       : 32u + (uint32_t)((k17 >> 30) & 15);
+                            futile = ((s.pe >> bit) & 1ull) == 0;
+                        } else {
+                            if (s.pg != s.i) { next = MK_PRE; s.ptr = ix.kmer17 + (k17 >> 5); ev.kload++; break; }
+                            futile = (((uint32_t)s.pe >> (uint32_t)(k17 & 31)) & 1u) == 0;
+                        }
+                        ev.kmer++;
+                        if (futile) { ++s.i; continue; }          // a seed shorter than seed_min_length: nothing reported, restart one base on
+                    }
+                    const uint32_t key16 = (uint32_t)(two >> sh);
+                    if (pf && ix.lkt16 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
+                        // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
+                        // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
+                        // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
+                        if (ix.lkt16u) { next = MK_LKT16U; s.ptr = ix.lkt16u + key16; }
+                        else { next = MK_LKT16; s.ptr = ix.lkt16 + (key16 - 1); }
+                    } else {
+                        const uint32_t key = key16 & (MP_LKT_ENTRIES - 1);
+                        next = MK_LKT13; s.aux = key == 0; s.ptr = ix.lkt + (key ? key - 1 : 0);
+                    }
+                    break;
+                }
+            }
+            // ---- a lane with a seed under way: its next extension
+            if (!fin && next == MK_NONE) {
+                if (text_ok && s.l == s.r && s.l != 0) {
+                    if (s.uvalid) {
+                        const uint32_t pend = s.upos - 1;
+                        next = MK_TEXT; s.ptr = ix.text + ((pend >= 15 ? pend - 15 : 0u) >> 4);
+                    } else { next = MK_SA; s.ptr = ix.sa_dense + s.l; ev.sa++; }
+                } else {
+                    const uint32_t c = (sl[(uint32_t)s.i >> 4] >> (2 * ((uint32_t)s.i & 15))) & 3u;
+                    uint32_t k1 = s.l;
+                    k1 -= (k1 > ix.inv_sa0);
+                    next = MK_OCC; s.aux = c; s.ptr = ix.occ + k1 / MP_OCC_SYMS;
+                }
+            }
+            if (fin) {
                 seeds_per_rs[s.rs] = s.n_seeds;
                 hits_per_rs[s.rs] = s.n_hits;
                 ev.located += s.n_located;
@@ -537,9 +774,11 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                     uint32_t slot = (uint32_t)atomicAdd(&ctr->overflow, 1ull);
                     if (slot < overflow_cap) { overflow_rs[slot] = s.rs; over_slot[s.rs] = slot; }
                 }
-                have = false;
+                have = false; next = MK_NONE;
             }
+            s.kind = next;
         }
+#pragma clang diagnostic pop
     }
     { uint32_t lb = lane_busy; for (int o = MP_WAVE / 2; o > 0; o >>= 1) lb += __shfl_down(lb, o);
       if (lane == 0) { atomicAdd(&ctr->n_wave_trips, (unsigned long long)wave_trips); atomicAdd(&ctr->n_lane_trips, (unsigned long long)lb); } }

@@ -119,7 +119,10 @@ def test_cli_equals_reference_paired_only_and_chained(golden_dir, tmp_path, tag,
 
 
 # (set, -L, mode flag, extra flags): the commands the BAM goldens were made with (tests/golden/make_golden_bam.py)
-BAM_RUNS = {"a": (151, "-F", ["-nc"]), "c": (301, "-F", ["-nc"]), "d": (151, "-P", []), "g": (151, "-F", ["-p"]), "h": (151, "-F", [])}
+# "<set>.bonly": `-b` alone -- nothing on stdout, BAM records made from the results as the DP left them (BGS-IO.cpp:2103: the
+# MegaPath modes rewrite boundary-spanning mates and the pair scores before the records are made; set h is all boundary pairs)
+BAM_RUNS = {"a": (151, "-F", ["-nc"]), "c": (301, "-F", ["-nc"]), "d": (151, "-P", []), "g": (151, "-F", ["-p"]), "h": (151, "-F", []),
+            "a.bonly": (151, None, []), "g.bonly": (151, None, ["-p"]), "h.bonly": (151, None, [])}
 
 
 @pytest.mark.parametrize("tag", sorted(BAM_RUNS))
@@ -133,8 +136,9 @@ def test_cli_bam_files_equal_reference(golden_dir, tmp_path, tag):
     L, mode, extra = BAM_RUNS[tag]
     out = tmp_path / "out.fq"
     prefix = str(tmp_path / "bam")
-    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", "ref.fa.index", "reads_%s_1.fq" % tag, "reads_%s_2.fq" % tag, "-o", prefix,
-           "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L), "-T", "2", "-u", "750", mode, "-b"] + extra
+    rk = tag.split(".")[0]
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", "ref.fa.index", "reads_%s_1.fq" % rk, "reads_%s_2.fq" % rk, "-o", prefix,
+           "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L), "-T", "2", "-u", "750", "-b"] + ([mode] if mode else []) + extra
     env = dict(os.environ, MP_BATCH_PAIRS="1048576")
     with open(out, "wb") as fo:
         r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, cwd=d, env=env)     # relative names: RG = "reads_<set>_1.fq" as in the golden
@@ -150,7 +154,21 @@ def test_cli_bam_files_equal_reference(golden_dir, tmp_path, tag):
     sq = [l for l in want["header"].splitlines() if not l.startswith("@PG")]
     assert [l for l in text.splitlines() if not l.startswith("@PG")] == sq
     assert [("@SQ\tSN:%s\tLN:%d" % r) for r in refs] == [l for l in sq if l.startswith("@SQ")]
-    assert open(out, "rb").read() == open(os.path.join(d, "expected_%s.fq" % tag), "rb").read()
+    assert open(out, "rb").read() == (open(os.path.join(d, "expected_%s.fq" % tag), "rb").read() if mode else b"")
+
+
+def test_cli_without_an_output_mode_is_refused(golden_dir, tmp_path):
+    """`<aligner> pair <index> <r1> <r2> -o <prefix>` is what runSOAP3dp.pl:44-50 starts: no -F / -P / -b.  The reference dies with
+    SIGSEGV after seeding on that command line (seen again with oracle/_ref/soap4 when the `.bonly` goldens were
+    made); the drop-in refuses it up front: exit code 1, a message that names the missing option, nothing written."""
+    d = os.path.join(golden_dir, "g1")
+    prefix = str(tmp_path / "o")
+    r = subprocess.run([os.path.join(ROOT, "bin", "soap4"), "pair", os.path.join(d, "ref.fa.index"), os.path.join(d, "reads_a_1.fq"), os.path.join(d, "reads_a_2.fq"),
+                        "-o", prefix, "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "1", "-u", "750"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1
+    assert r.stdout == b""
+    assert b"-F" in r.stderr and b"-b" in r.stderr
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("o.")]
 
 
 @pytest.mark.parametrize("tag,L,mode,extra,reads", [("a", 151, "-F", ["-nc", "-lsam"], "a"), ("a.noseq", 151, "-F", ["-nc", "-lsam-noseq"], "a"),

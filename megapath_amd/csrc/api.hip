@@ -769,7 +769,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
                            c->ctr.p);
         MP_TRACE(s, "locate_kernel");
     HIPCHK(hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_BLOCK), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, (int)((c->max_len + 63) / 64), c->seedpos.p, c->n_pos.p,
+    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_THREADS), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, (int)((c->max_len + 63) / 64), c->seedpos.p, c->n_pos.p,
                        c->n_neg.p, c->ctr.p);
     MP_TRACE(s, "merge_kernel");
     HIPCHK(hipEventRecord(c->ev[4], s));

@@ -899,7 +899,8 @@ __device__ __forceinline__ uint64_t key_pos(uint64_t k, uint64_t text_len)
 #define MP_KEY_LEN(k) ((int)(((k) >> 2) & 511u))
 #define MP_KEY_UNIQ(k) ((bool)((k) & 1u))
 
-#define MP_MERGE_BLOCK 64
+#define MP_MERGE_BLOCK 64           // reads per block
+#define MP_MERGE_THREADS 256        // four wavefronts share the block's staged keys
 #define MP_MERGE_CAP 4096          // keys staged per block (32 KB)
 #define MP_MERGE_SMALL 32          // insertion sort up to here when a lane sorts on its own (blocks that do not fit in LDS)
 #define MP_MERGE_COOP 512          // up to here the wavefront sorts a read together, eight keys per lane
@@ -1055,6 +1056,109 @@ __device__ __forceinline__ void wave_sort_read(uint64_t *k, int n, int lane)
     for (int rg = 0; rg < K; rg++) { const int i = rg * 64 + lane; if (i < n) k[i] = key[rg]; }
 }
 
+// Sort of n <= 64 keys, one per lane, by counting: every lane compares its key with each of the n keys (broadcast by v_readlane, no
+// LDS round trip) and writes it to the slot of its rank.  8 instructions per key instead of the 21 dependent exchange stages of the
+// bitonic network; equal keys are ranked by lane, so the ranks are a permutation.
+__device__ __forceinline__ void wave_rank_sort(uint64_t *k, int n, int lane)
+{
+    const uint64_t key = lane < n ? k[lane] : ~0ull;
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint32_t rank = 0;
+    for (int j = 0; j < n; j++) {
+        const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
+        rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+    }
+    if (lane < n) k[rank] = key;
+}
+
+// maximum of a value < 512 over the lanes with `active` set (wave-uniform result): nine ballots, no shuffles
+__device__ __forceinline__ uint32_t wave_max9(uint32_t v, bool active)
+{
+    unsigned long long cand = __ballot(active);
+    uint32_t mx = 0;
+    if (!cand) return 0;
+#pragma unroll
+    for (int b = 8; b >= 0; b--) {
+        const unsigned long long m = __ballot(active && ((v >> b) & 1u)) & cand;
+        if (m) { cand = m; mx |= 1u << b; }
+    }
+    return mx;
+}
+
+// Seed merging of one read by the whole wavefront (same rules as merge_read).  k[0..n) are the read's SORTED keys in LDS.  Sixty-four
+// keys at a time: every lane finds where the group that would start at its key ends (the greedy rule of DV-DPfunctions.cpp:2514 --
+// while next.offset <= first.offset + indelFuzz on the same strand), a scalar walk from group start to group start marks the lanes
+// that really start one, and those lanes union their group's intervals.  Time per read ~ its largest group, not its number of hits.
+// Reads with more than 64 keys are swept twice (the short-seed filter needs the best covered length of the whole read first).
+__device__ __forceinline__ uint32_t merge_read_wave(const uint64_t *k, int n, mp_seedpos *__restrict__ out, uint32_t r, const mp_dev_mmp &P, uint64_t text_len, int cw32,
+                                                    uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, int lane)
+{
+    const int n_chunks = (n + 63) >> 6;
+    uint32_t max_cov = 0, w_out = 0, np = 0, nn = 0;
+    for (int sweep = n_chunks > 1 ? 0 : 1; sweep < 2; sweep++) {
+        int s = 0;                                        // next group start (wave-uniform)
+        for (int c = 0; c < n_chunks; c++) {
+            const int cbase = c << 6, e = cbase + lane;
+            const bool valid = e < n;
+            const uint64_t key = valid ? k[e] : 0;
+            const uint64_t pos = key_pos(key, text_len), group_end = pos + (uint64_t)P.indel_fuzz;
+            int nxt = e + 1;
+            if (valid)
+                while (nxt < n) {
+                    const uint64_t cur = k[nxt];
+                    if (MP_KEY_STRAND(cur) != MP_KEY_STRAND(key) || key_pos(cur, text_len) > group_end) break;
+                    nxt++;
+                }
+            unsigned long long starts = 0;
+            const int cend = cbase + 64 < n ? cbase + 64 : n;
+            while (s < cend) { const int ls = s - cbase; starts |= 1ull << ls; s = __builtin_amdgcn_readlane(nxt, ls); }
+            const bool is_start = (starts >> lane) & 1ull;
+            uint32_t total = 0;
+            bool has_unique = false;
+            if (is_start) {
+                uint32_t cov[MP_SEED_BIG / 32];
+#pragma unroll
+                for (int w = 0; w < MP_SEED_BIG / 32; w++) cov[w] = 0;
+                for (int j = e; j < nxt; j++) {
+                    const uint64_t cur = j == e ? key : k[j];
+                    const int lo = MP_KEY_QO(cur), hi = lo + MP_KEY_LEN(cur);
+                    has_unique |= MP_KEY_UNIQ(cur);
+#pragma unroll
+                    for (int w = 0; w < MP_SEED_BIG / 32; w++) {
+                        if (w >= cw32) break;                  // reads of this batch are no longer than 32 cw32 bases
+                        int a = lo - 32 * w, b = hi - 32 * w;
+                        a = a < 0 ? 0 : (a > 32 ? 32 : a);
+                        b = b < 0 ? 0 : (b > 32 ? 32 : b);
+                        const uint32_t below_b = b >= 32 ? ~0u : ((1u << b) - 1u), below_a = a >= 32 ? ~0u : ((1u << a) - 1u);
+                        cov[w] |= below_b & ~below_a;
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < MP_SEED_BIG / 32; w++) total += (uint32_t)__popc(cov[w]);
+            }
+            if (n_chunks == 1 || sweep == 0) { const uint32_t m = wave_max9(total, is_start); max_cov = m > max_cov ? m : max_cov; }
+            if (sweep == 1) {
+                // kept: a unique or long enough group (:2533) that also passes the short-seed filter against the best covered length of
+                // BOTH strands, rejected groups included (:2547)
+                const bool keep = is_start && (has_unique || total >= (uint32_t)P.good_seed_len) && (double)total >= P.short_seed_ratio * (double)max_cov;
+                const unsigned long long kb = __ballot(keep);
+                const uint32_t strand = MP_KEY_STRAND(key);
+                if (keep) {
+                    mp_seedpos sp;
+                    sp.pos = pos;
+                    sp.paired_seed_length = total;
+                    sp.strand_read_id = (r & ~1u) | (strand << 31);
+                    out[w_out + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))] = sp;
+                }
+                const uint32_t neg = (uint32_t)__popcll(__ballot(keep && strand));
+                w_out += (uint32_t)__popcll(kb); nn += neg; np += (uint32_t)__popcll(kb) - neg;
+            }
+        }
+    }
+    if (lane == 0) { n_pos[r] = np; n_neg[r] = nn; }
+    return w_out;
+}
+
 // Output: seedpos[read_base[r] .. ) holds the kept seeds of read r, '+' first; n_pos[r], n_neg[r] their counts.
 // One lane per read, one wavefront per block.  The hits of a block's 64 reads are one contiguous range: it is read with
 // coalesced loads, packed to 8-byte keys and staged in LDS.  Sorting: a lane-per-read sort makes the wavefront wait for
@@ -1062,56 +1166,59 @@ __device__ __forceinline__ void wave_sort_read(uint64_t *k, int n, int lane)
 // reads are sorted one after the other by all 64 lanes together: a bitonic network over registers and wavefront
 // shuffles, 1 to 8 keys per lane.  The grouping pass is linear and runs one lane per read.  A block whose range does not
 // fit in LDS packs and sorts in place in global memory, lane by lane.
-__global__ void __launch_bounds__(MP_MERGE_BLOCK)
+__global__ void __launch_bounds__(MP_MERGE_THREADS)
 merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P, uint64_t text_len, int cov_words,
              mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
 {
     __shared__ uint64_t s_key[MP_MERGE_CAP];
+    __shared__ uint32_t s_base[MP_MERGE_BLOCK + 1];
     const uint32_t r0 = blockIdx.x * MP_MERGE_BLOCK;
     const uint32_t r1 = min(r0 + MP_MERGE_BLOCK, n_reads);
     const uint32_t b0 = rs_base[2 * r0], T = rs_base[2 * r1] - b0;
     const bool staged = T <= MP_MERGE_CAP;
-    const int lane = threadIdx.x;
-    const uint32_t r = r0 + threadIdx.x;
-    const bool live = r < n_reads;
-    const uint32_t base = live ? rs_base[2 * r] : b0;
-    const int n = live ? (int)(rs_base[2 * r + 2] - base) : 0;
+    const int lane = threadIdx.x & (MP_WAVE - 1), wave = threadIdx.x / MP_WAVE;
     if (!staged) {
-        if (!live) return;
-        // in place: key i overwrites bytes 8i..8i+7 of this read's own records, all of them already consumed
+        // a block whose hits do not fit in LDS: one lane per read, in place in global memory (key i overwrites bytes 8i..8i+7 of the
+        // read's own records, all of them already consumed)
+        const uint32_t r = r0 + threadIdx.x;
+        if (threadIdx.x >= MP_MERGE_BLOCK || r >= n_reads) return;
+        const uint32_t base = rs_base[2 * r];
+        const int n = (int)(rs_base[2 * r + 2] - base);
         uint64_t *k = reinterpret_cast<uint64_t *>(hits + base);
         for (int i = 0; i < n; i++) { const mp_seed_hit h = hits[base + i]; k[i] = hit_key(h, P); }
         sort_keys(k, n);
         merge_read(k, n, seedpos + base, r, P, text_len, cov_words, n_pos, n_neg, ctr);
         return;
     }
+    if (threadIdx.x <= MP_MERGE_BLOCK) { const uint32_t r = min(r0 + threadIdx.x, r1); s_base[threadIdx.x] = rs_base[2 * r] - b0; }
     // four independent 16-byte loads in flight per lane
-    for (uint32_t i0 = 0; i0 < T; i0 += 4 * MP_MERGE_BLOCK) {
+    for (uint32_t i0 = 0; i0 < T; i0 += 4 * MP_MERGE_THREADS) {
         mp_seed_hit h4[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_BLOCK + threadIdx.x; if (i < T) h4[u] = hits[b0 + i]; }
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_THREADS + threadIdx.x; if (i < T) h4[u] = hits[b0 + i]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_BLOCK + threadIdx.x; if (i < T) s_key[i] = hit_key(h4[u], P); }
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_THREADS + threadIdx.x; if (i < T) s_key[i] = hit_key(h4[u], P); }
     }
     __syncthreads();
-    uint64_t *k = s_key + (base - b0);
-    // ---- every read with more than one key, one at a time, by the whole wavefront
-    const bool coop = n > 1 && n <= MP_MERGE_COOP;
-    unsigned long long todo = __ballot(coop);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int ns = __shfl(n, src);
-        uint64_t *ks = s_key + __shfl(base - b0, src);
-        if (ns <= 64) wave_sort_read<1>(ks, ns, lane);
-        else if (ns <= 128) wave_sort_read<2>(ks, ns, lane);
-        else if (ns <= 256) wave_sort_read<4>(ks, ns, lane);
-        else wave_sort_read<8>(ks, ns, lane);
+    // ---- one read after the other, each by a whole wavefront: sort (lane = key), then groups (lane = group); the block's wavefronts
+    // take every fourth read
+    const int cw32 = 2 * cov_words;
+    uint32_t wave_kept = 0;
+    for (uint32_t src = (uint32_t)wave; r0 + src < r1; src += MP_MERGE_THREADS / MP_WAVE) {
+        const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_base[src]);          // wave-uniform: the loops below are scalar loops
+        const int ns = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)s_base[src + 1]) - kb);
+        if (ns == 0) { if (lane == 0) { n_pos[r0 + src] = 0; n_neg[r0 + src] = 0; } continue; }
+        uint64_t *ks = s_key + kb;
+        if (ns > 1) {
+            if (ns <= 64) wave_rank_sort(ks, ns, lane);
+            else if (ns <= 128) wave_sort_read<2>(ks, ns, lane);
+            else if (ns <= 256) wave_sort_read<4>(ks, ns, lane);
+            else if (ns <= MP_MERGE_COOP) wave_sort_read<8>(ks, ns, lane);
+            else { if (lane == 0) sort_keys(ks, ns); }                 // the rare very large read (heap sort by one lane)
+        }
+        wave_kept += merge_read_wave(ks, ns, seedpos + b0 + kb, r0 + src, P, text_len, cw32, n_pos, n_neg, lane);
     }
-    __syncthreads();
-    if (!live) return;
-    if (!coop) sort_keys(k, n);                    // small reads (insertion sort) and the rare very large one (heap sort)
-    merge_read(k, n, seedpos + base, r, P, text_len, cov_words, n_pos, n_neg, ctr);
+    if (lane == 0 && wave_kept) atomicAdd(&ctr->n_seedpos, (unsigned long long)wave_kept);
 }
 
 // ------------------------------------------------------------------------------------------------ K4

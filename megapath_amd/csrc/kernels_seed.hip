@@ -1057,16 +1057,17 @@ __device__ __forceinline__ void wave_sort_read(uint64_t *k, int n, int lane)
 }
 
 // Sort of n <= 64 keys, one per lane, by counting: every lane compares its key with each of the n keys (broadcast by v_readlane, no
-// LDS round trip) and writes it to the slot of its rank.  8 instructions per key instead of the 21 dependent exchange stages of the
-// bitonic network; equal keys are ranked by lane, so the ranks are a permutation.
+// LDS round trip) and writes it to the slot of its rank.  Four instructions per key instead of the 21 dependent exchange stages of
+// the bitonic network; equal keys are ranked by lane, so the ranks are a permutation.
 __device__ __forceinline__ void wave_rank_sort(uint64_t *k, int n, int lane)
 {
     const uint64_t key = lane < n ? k[lane] : ~0ull;
-    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    const uint64_t sk = lane < n ? (key << 6) | (uint64_t)lane : ~0ull;       // keys use 53 bits: the lane number makes them distinct
+    const uint32_t lo = (uint32_t)sk, hi = (uint32_t)(sk >> 32);
     uint32_t rank = 0;
     for (int j = 0; j < n; j++) {
         const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
-        rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+        rank += kj < sk ? 1u : 0u;
     }
     if (lane < n) k[rank] = key;
 }
@@ -1115,7 +1116,8 @@ __device__ __forceinline__ uint32_t merge_read_wave(const uint64_t *k, int n, mp
             const bool is_start = (starts >> lane) & 1ull;
             uint32_t total = 0;
             bool has_unique = false;
-            if (is_start) {
+            if (is_start && nxt == e + 1) { total = (uint32_t)MP_KEY_LEN(key); has_unique = MP_KEY_UNIQ(key); }      // a group of one: its own length
+            else if (is_start) {
                 uint32_t cov[MP_SEED_BIG / 32];
 #pragma unroll
                 for (int w = 0; w < MP_SEED_BIG / 32; w++) cov[w] = 0;

@@ -12,6 +12,17 @@ __device__ __forceinline__ uint32_t mp_rev2(uint32_t x)
     return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
 }
 
+// the sixteen even-numbered bits of a word, packed
+__device__ __forceinline__ uint32_t mp_even_bits(uint32_t x)
+{
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+
 // symbols of block b that exist: the first `valid` of its 192
 __device__ __forceinline__ uint32_t mp_block_word(const uint32_t *__restrict__ bwt_msb, uint64_t n, uint32_t b, int w)
 {
@@ -52,7 +63,12 @@ __global__ void occ_build_kernel(const uint32_t *__restrict__ bwt_msb, uint64_t 
     if (b >= n_blocks) return;
     mp_occ_block blk;
     for (int s = 0; s < 4; s++) blk.cnt[s] = run[(uint64_t)s * n_blocks + b];
-    for (int w = 0; w < 12; w++) blk.bwt[w] = mp_block_word(bwt_msb, n, b, w);
+    for (int j = 0; j < 6; j++) {
+        // two words of sixteen 2-bit symbols -> 32 low bits and 32 high bits (symbols past the end are zero: 'A', never counted)
+        const uint32_t wa = mp_block_word(bwt_msb, n, b, 2 * j), wb = mp_block_word(bwt_msb, n, b, 2 * j + 1);
+        blk.lo[j] = mp_even_bits(wa) | (mp_even_bits(wb) << 16);
+        blk.hi[j] = mp_even_bits(wa >> 1) | (mp_even_bits(wb >> 1) << 16);
+    }
     out[b] = blk;
 }
 

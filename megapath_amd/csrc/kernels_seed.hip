@@ -16,12 +16,44 @@
 #define MP_WAVE 64
 
 // ------------------------------------------------------------------------------------------------ FM-index primitives
-__device__ __forceinline__ uint32_t mp_popc_sym(uint32_t w, uint32_t pat, int nsym)
+// A rank block in registers: running counts, and per 32 symbols one dense mask of the positions that hold symbol c.
+struct mp_blk_view {
+    uint32_t m[6];      // match masks of the symbol
+    uint32_t S[6];      // S[j] = matches in words 0 .. j-1
+    uint32_t cnt;       // occurrences before the block
+};
+
+__device__ __forceinline__ void mp_blk_match(const uint4 &q0, const uint4 &q1, const uint4 &q2, const uint4 &q3, uint32_t c, mp_blk_view &v)
 {
-    uint32_t x = w ^ pat;
-    uint32_t m = ~(x | (x >> 1)) & 0x55555555u;
-    if (nsym < 16) m &= (1u << (2 * nsym)) - 1u;
-    return (uint32_t)__popc(m);
+    const uint32_t lo[6] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y}, hi[6] = {q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    const uint32_t cl = (c & 1u) ? 0u : ~0u, ch = (c & 2u) ? 0u : ~0u;
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { v.m[j] = (lo[j] ^ cl) & (hi[j] ^ ch); v.S[j] = run; run += (uint32_t)__popc(v.m[j]); }
+    v.cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
+}
+
+// occurrences of the symbol among the first `off` (< 192) symbols of the block, plus those before the block
+__device__ __forceinline__ uint32_t mp_blk_rank(const mp_blk_view &v, uint32_t off)
+{
+    const uint32_t wi = off >> 5, pm = (1u << (off & 31u)) - 1u;
+    const bool b0 = wi & 1u, b1 = wi & 2u, b2 = wi & 4u;
+    const uint32_t m01 = b0 ? v.m[1] : v.m[0], m23 = b0 ? v.m[3] : v.m[2], m45 = b0 ? v.m[5] : v.m[4];
+    const uint32_t s01 = b0 ? v.S[1] : v.S[0], s23 = b0 ? v.S[3] : v.S[2], s45 = b0 ? v.S[5] : v.S[4];
+    const uint32_t mw = b2 ? m45 : (b1 ? m23 : m01), sw = b2 ? s45 : (b1 ? s23 : s01);
+    return v.cnt + sw + (uint32_t)__popc(mw & pm);
+}
+
+// the symbol at position so (< 192) of a block
+__device__ __forceinline__ uint32_t mp_blk_symbol(const uint4 &q1, const uint4 &q2, const uint4 &q3, uint32_t so)
+{
+    const uint32_t lo[6] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y}, hi[6] = {q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    const uint32_t wi = so >> 5;
+    const bool b0 = wi & 1u, b1 = wi & 2u, b2 = wi & 4u;
+    const uint32_t l01 = b0 ? lo[1] : lo[0], l23 = b0 ? lo[3] : lo[2], l45 = b0 ? lo[5] : lo[4];
+    const uint32_t h01 = b0 ? hi[1] : hi[0], h23 = b0 ? hi[3] : hi[2], h45 = b0 ? hi[5] : hi[4];
+    const uint32_t lw = b2 ? l45 : (b1 ? l23 : l01), hw = b2 ? h45 : (b1 ? h23 : h01);
+    return ((lw >> (so & 31u)) & 1u) | (((hw >> (so & 31u)) & 1u) << 1);
 }
 
 // rank_c over BWT[0,k) with the '$' row removed from the numbering (BWTOccValue, BWT.c:597-634)
@@ -29,16 +61,10 @@ __device__ __forceinline__ uint32_t mp_occ_raw(const mp_dev_index &ix, uint32_t 
 {
     uint32_t b = k / MP_OCC_SYMS, off = k - b * MP_OCC_SYMS;
     const uint4 *p = reinterpret_cast<const uint4 *>(ix.occ + b);
-    uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    uint32_t cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
-    const uint32_t pat = c * 0x55555555u;
-    const uint32_t w[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        int ns = (int)off - 16 * i;
-        if (ns > 0) cnt += mp_popc_sym(w[i], pat, ns);
-    }
-    return cnt;
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    mp_blk_view v;
+    mp_blk_match(q0, q1, q2, q3, c, v);
+    return mp_blk_rank(v, off);
 }
 
 __device__ __forceinline__ uint32_t mp_occ(const mp_dev_index &ix, uint32_t k, uint32_t c)
@@ -59,18 +85,11 @@ __device__ __forceinline__ uint32_t mp_lf(const mp_dev_index &ix, uint32_t idx)
     const uint32_t b = s / MP_OCC_SYMS, so = s - b * MP_OCC_SYMS;       // block of the symbol; rank wanted at offset so+1
     const uint4 *p = reinterpret_cast<const uint4 *>(ix.occ + b);
     const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    const uint32_t w[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-    const uint32_t wi = so >> 4;
-    uint32_t word = w[0];
-#pragma unroll
-    for (int i = 1; i < 12; i++) word = wi == (uint32_t)i ? w[i] : word;
-    const uint32_t c = (word >> (2 * (so & 15))) & 3u;
-    uint32_t cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
-    const uint32_t pat = c * 0x55555555u;
-    const int off = (int)so + 1;                                         // symbols of this block counted: [0, so]
-#pragma unroll
-    for (int i = 0; i < 12; i++) { int ns = off - 16 * i; if (ns > 0) cnt += mp_popc_sym(w[i], pat, ns); }
-    return ix.cum[c] + cnt;
+    const uint32_t c = mp_blk_symbol(q1, q2, q3, so);
+    mp_blk_view v;
+    mp_blk_match(q0, q1, q2, q3, c, v);
+    // symbols of this block counted: [0, so] -- so + 1 may be 192: the rank up to so, plus the symbol itself
+    return ix.cum[c] + mp_blk_rank(v, so) + 1u;
 }
 
 __global__ void occ_query_kernel(mp_dev_index ix, const uint64_t *idx, const uint32_t *sym, uint64_t n, uint64_t *out)
@@ -202,26 +221,17 @@ __device__ __forceinline__ void mp_occ_pair(const mp_dev_index &ix, uint32_t k1,
     k2 -= (k2 > ix.inv_sa0);
     const uint32_t b1 = k1 / MP_OCC_SYMS, off1 = k1 - b1 * MP_OCC_SYMS;
     const uint32_t b2 = k2 / MP_OCC_SYMS, off2 = k2 - b2 * MP_OCC_SYMS;
-    const uint32_t pat = c * 0x55555555u;
     const uint4 *p = reinterpret_cast<const uint4 *>(ix.occ + b1);
     uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    uint32_t w[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-    uint32_t cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
-    uint32_t a = cnt;
-#pragma unroll
-    for (int i = 0; i < 12; i++) { int ns = (int)off1 - 16 * i; if (ns > 0) a += mp_popc_sym(w[i], pat, ns); }
-    o1 = a;
+    mp_blk_view v;
+    mp_blk_match(q0, q1, q2, q3, c, v);
+    o1 = mp_blk_rank(v, off1);
     if (b2 != b1) {
         const uint4 *pp = reinterpret_cast<const uint4 *>(ix.occ + b2);
         q0 = pp[0]; q1 = pp[1]; q2 = pp[2]; q3 = pp[3];
-        w[0] = q1.x; w[1] = q1.y; w[2] = q1.z; w[3] = q1.w; w[4] = q2.x; w[5] = q2.y; w[6] = q2.z; w[7] = q2.w;
-        w[8] = q3.x; w[9] = q3.y; w[10] = q3.z; w[11] = q3.w;
-        cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
+        mp_blk_match(q0, q1, q2, q3, c, v);
     }
-    uint32_t bsum = cnt;
-#pragma unroll
-    for (int i = 0; i < 12; i++) { int ns = (int)off2 - 16 * i; if (ns > 0) bsum += mp_popc_sym(w[i], pat, ns); }
-    o2 = bsum;
+    o2 = mp_blk_rank(v, off2);
 }
 
 // Test aid: for the 16-mer starting at every text position s <= n - 4 (and for `n_random` arbitrary keys) compares the
@@ -509,23 +519,15 @@ struct mp_lane_state {
     int len, strand, i, seed_len;
     uint32_t l, r, last_l, last_r, last_seed_len;
     uint32_t n_seeds, n_hits, n_located;
-    unsigned long long pe;  // pre-filter entry that answers scan positions pg .. pg + 2 (bits per 15-mer) or pg alone (17-mer bitmap word)
-    int pg;
+    uint32_t nf;            // pre-filter answers for scan positions pg .. pg + 5 (bits per 15-mer: two entries) or pg alone (17-mer bitmap): bit set = the
+    int pg;                 // 17-mer starting there occurs in the text
     uint32_t upos;          // text position of the match once its SA range is a single row
     bool uvalid, uprev_valid;
     uint32_t kind;          // the load this lane waits for
-    uint32_t aux;           // MK_OCC*: the symbol; MK_LKT13: key == 0; MK_BEGIN: 64-byte blocks of the row already fetched
+    uint32_t aux;           // MK_OCC*: the symbol; MK_LKT13: key == 0; MK_BEGIN: 64-byte blocks of the row already fetched; MK_PRE: index of the second entry
     uint32_t o1;            // MK_OCC2: rank at the range's lower end, from the first block
     const void *ptr;        // where that load reads
 };
-
-__device__ __forceinline__ uint32_t mp_block_rank(const uint32_t (&w)[12], uint32_t pat, uint32_t off)
-{
-    uint32_t a = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) { const int ns = (int)off - 16 * i; if (ns > 0) a += mp_popc_sym(w[i], pat, ns); }
-    return a;
-}
 
 __global__ void __launch_bounds__(256)
 seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t n_items, uint32_t W, mp_dev_mmp P,
@@ -544,7 +546,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
     mp_lane_events ev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mp_lane_state s;
     s.rs = 0; s.len = 0; s.strand = 0; s.i = 0; s.seed_len = 0; s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
-    s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.pe = 0; s.pg = -1000; s.upos = 0; s.uvalid = false; s.uprev_valid = false;
+    s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.nf = 0; s.pg = -1000; s.upos = 0; s.uvalid = false; s.uprev_valid = false;
     s.kind = MK_NONE; s.aux = 0; s.o1 = 0; s.ptr = nullptr;
     bool have = false;
     // Work queue: one global counter, but a wavefront takes MP_SEED_CHUNK items per atomic into a private range and hands
@@ -572,7 +574,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                     const uint32_t rs = pool_next + rank;
                     s.rs = rs; s.strand = (int)(rs & 1); s.len = 0; s.i = 0; s.seed_len = 0;
                     s.l = 0; s.r = n; s.last_l = 0; s.last_r = n; s.last_seed_len = 0;
-                    s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.pe = 0; s.pg = -1000; s.upos = 0; s.uvalid = false;
+                    s.n_seeds = 0; s.n_hits = 0; s.n_located = 0; s.nf = 0; s.pg = -1000; s.upos = 0; s.uvalid = false;
                     s.kind = MK_BEGIN; s.aux = 0; s.ptr = scan + (uint64_t)rs * S;
                     have = true;
                 }
@@ -585,8 +587,8 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
         // (the destinations are written by exactly the lanes that read them below; left unset otherwise so that no copy or wait
         // is needed to carry a value around the loop)
         uint4 q0, q1, q2, q3;
-        uint32_t a0, a1, alen;
-        asm volatile("" : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(a0), "=v"(a1), "=v"(alen));    // "some value": nothing is carried over from the trip before
+        uint32_t a0, a1, b0, b1, alen;
+        asm volatile("" : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(a0), "=v"(a1), "=v"(b0), "=v"(b1), "=v"(alen));    // "some value": nothing is carried over from the trip before
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wuninitialized"
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
@@ -604,6 +606,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 const bool one = kind == MK_SA || (kind == MK_PRE && !ix.kmer15x3) || (kind == MK_LKT13 && s.aux);
                 a0 = p[0];
                 a1 = p[one ? 0 : 1];
+                if (kind == MK_PRE && ix.kmer15x3) { const uint2 e2 = *reinterpret_cast<const uint2 *>(ix.kmer15x3 + s.aux); b0 = e2.x; b1 = e2.y; }
             }
         }
         // the one wait of the trip: everything issued above (and the stores of the trip before) has landed
@@ -629,9 +632,6 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 }
                 s.aux++;
                 if (s.aux * 16u < S) { next = MK_BEGIN; s.ptr = reinterpret_cast<const uint4 *>(s.ptr) + 4; }
-            } else if (kind == MK_PRE) {
-                s.pe = ix.kmer15x3 ? (((unsigned long long)a1 << 32) | a0) : (unsigned long long)a0;
-                s.pg = s.i;
             } else if (kind == MK_LKT13 || kind == MK_LKT16 || kind == MK_LKT16U) {
                 // LKT (re)start: the table stands for the first 13 (16) bases of the seed
                 uint32_t nextl, nextr;
@@ -657,14 +657,13 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 k1 -= (k1 > ix.inv_sa0); k2 -= (k2 > ix.inv_sa0);
                 const uint32_t b1 = k1 / MP_OCC_SYMS, off1 = k1 - b1 * MP_OCC_SYMS;
                 const uint32_t b2 = k2 / MP_OCC_SYMS, off2 = k2 - b2 * MP_OCC_SYMS;
-                const uint32_t pat = c * 0x55555555u;
-                const uint32_t w[12] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-                const uint32_t cnt = c == 0 ? q0.x : c == 1 ? q0.y : c == 2 ? q0.z : q0.w;
-                const uint32_t ca = cnt + mp_block_rank(w, pat, kind == MK_OCC ? off1 : off2);
+                mp_blk_view v;
+                mp_blk_match(q0, q1, q2, q3, c, v);
+                const uint32_t ca = mp_blk_rank(v, kind == MK_OCC ? off1 : off2);
                 uint32_t o1 = ca, o2 = ca;
                 bool done = true;
                 if (kind == MK_OCC) {
-                    if (b1 == b2) o2 = cnt + mp_block_rank(w, pat, off2);
+                    if (b1 == b2) o2 = mp_blk_rank(v, off2);
                     else { s.o1 = o1; next = MK_OCC2; s.ptr = ix.occ + b2; done = false; }
                 } else o1 = s.o1;
                 if (done) {
@@ -716,40 +715,73 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
             }
             // ---- a lane without a seed under way: where does the next one start?  (pre-filter, then the table look-up)
             if (!fin && next == MK_NONE && s.seed_len == 0) {
-                for (;;) {
-                    if (s.len - s.i < P.seed_min_length) { fin = true; break; }        // `break` of the scan loop
-                    const uint32_t wq = (uint32_t)s.i >> 4, sh = 2 * ((uint32_t)s.i & 15);
-                    const uint64_t two = ((uint64_t)sl[wq + 1] << 32) | sl[wq];
-                    if (pf) {
-                        // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe.  A futile
-                        // start (they occur nowhere) costs no look-up: the scan moves on one base.
-                        const uint64_t k17 = (two >> sh) & ((1ull << 34) - 1);
-                        bool futile;
-                        if (ix.kmer15x3) {
-                            const int a = s.i - s.pg;
-                            if (a < 0 || a > 2) { next = MK_PRE; s.ptr = ix.kmer15x3 + ((k17 >> 4) & ((1ull << 30) - 1)); ev.kload++; break; }
-                            const uint32_t bit = a == 0 ? (uint32_t)(k17 & 15) : a == 1 ? 16u + ((uint32_t)(k17 & 3) | ((uint32_t)(k17 >> 32) & 3u) << 2)
-                                                                                       : 32u + (uint32_t)((k17 >> 30) & 15);
-                            futile = ((s.pe >> bit) & 1ull) == 0;
-                        } else {
-                            if (s.pg != s.i) { next = MK_PRE; s.ptr = ix.kmer17 + (k17 >> 5); ev.kload++; break; }
-                            futile = (((uint32_t)s.pe >> (uint32_t)(k17 & 31)) & 1u) == 0;
+                // the scan bases from here on as a 96-bit window: enough for the six positions two pre-filter entries answer and for the
+                // keys of the two entries after them
+                const uint32_t wq0 = (uint32_t)s.i >> 4;
+                const uint32_t w0 = sl[wq0], w1 = sl[wq0 + 1], w2 = sl[wq0 + 2];
+                auto bases_at = [&](int pos) -> uint64_t {                   // scan bases pos .. pos + 16 at least (pos - 16 wq0 <= 24)
+                    const uint32_t off = (uint32_t)pos - 16u * wq0;
+                    const uint64_t win = off < 16 ? (((uint64_t)w1 << 32) | w0) : (((uint64_t)w2 << 32) | w1);
+                    return win >> (2 * (off & 15));
+                };
+                if (kind == MK_PRE) {
+                    // what just arrived, as one bit per position: is the 17-mer that starts there anywhere in the text?
+                    uint32_t nf;
+                    if (ix.kmer15x3) {
+                        const unsigned long long e1 = ((unsigned long long)a1 << 32) | a0, e2 = ((unsigned long long)b1 << 32) | b0;
+                        nf = 0;
+#pragma unroll
+                        for (int q = 0; q < 6; q++) {
+                            const uint64_t k17 = bases_at(s.i + q) & ((1ull << 34) - 1);
+                            const int aa = q % 3;
+                            const uint32_t bit = aa == 0 ? (uint32_t)(k17 & 15) : aa == 1 ? 16u + ((uint32_t)(k17 & 3) | ((uint32_t)(k17 >> 32) & 3u) << 2)
+                                                                                          : 32u + (uint32_t)((k17 >> 30) & 15);
+                            nf |= (uint32_t)(((q < 3 ? e1 : e2) >> bit) & 1ull) << q;
                         }
-                        ev.kmer++;
-                        if (futile) { ++s.i; continue; }          // a seed shorter than seed_min_length: nothing reported, restart one base on
+                    } else nf = (a0 >> (uint32_t)(bases_at(s.i) & 31)) & 1u;
+                    s.nf = nf; s.pg = s.i;
+                }
+                const int lim = s.len - P.seed_min_length;                    // the last position a seed may start at (`break` of the scan loop beyond)
+                if (s.i > lim) fin = true;
+                else {
+                    bool start_here = true;
+                    if (pf) {
+                        // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe.  A futile start
+                        // (they occur nowhere) costs no look-up -- a seed shorter than seed_min_length, nothing reported, restart one base
+                        // on: the scan jumps to the first position that is not futile, or past what the entries answer.
+                        const int span = ix.kmer15x3 ? 6 : 1;
+                        const int a = s.i - s.pg;
+                        if (a >= 0 && a < span) {
+                            const uint32_t bits = s.nf >> a;
+                            const int adv = bits ? __ffs((int)bits) - 1 : span - a;
+                            if (s.i + adv > lim) { ev.kmer += (uint32_t)(lim - s.i + 1); s.i = lim + 1; fin = true; start_here = false; }
+                            else { ev.kmer += (uint32_t)adv + (bits ? 1u : 0u); s.i += adv; start_here = bits != 0; }
+                        } else start_here = false;
+                        if (!fin && !start_here) {
+                            const uint64_t k17 = bases_at(s.i) & ((1ull << 34) - 1);
+                            next = MK_PRE;
+                            if (ix.kmer15x3) {
+                                // two entries at once: this position's and the one three bases on (runs of futile starts are the rule: every
+                                // mismatch of the read costs seventeen of them)
+                                s.ptr = ix.kmer15x3 + ((k17 >> 4) & ((1ull << 30) - 1));
+                                s.aux = (uint32_t)((bases_at(s.i + 3) >> 4) & ((1ull << 30) - 1));
+                                ev.kload += 2;
+                            } else { s.ptr = ix.kmer17 + (k17 >> 5); ev.kload++; }
+                        }
                     }
-                    const uint32_t key16 = (uint32_t)(two >> sh);
-                    if (pf && ix.lkt16 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
-                        // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
-                        // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
-                        // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
-                        if (ix.lkt16u) { next = MK_LKT16U; s.ptr = ix.lkt16u + key16; }
-                        else { next = MK_LKT16; s.ptr = ix.lkt16 + (key16 - 1); }
-                    } else {
-                        const uint32_t key = key16 & (MP_LKT_ENTRIES - 1);
-                        next = MK_LKT13; s.aux = key == 0; s.ptr = ix.lkt + (key ? key - 1 : 0);
+                    if (start_here) {
+                        const uint32_t key16 = (uint32_t)bases_at(s.i);
+                        if (pf && ix.lkt16 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
+                            // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
+                            // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
+                            // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
+                            if (ix.lkt16u) { next = MK_LKT16U; s.ptr = ix.lkt16u + key16; }
+                            else { next = MK_LKT16; s.ptr = ix.lkt16 + (key16 - 1); }
+                        } else {
+                            const uint32_t key = key16 & (MP_LKT_ENTRIES - 1);
+                            next = MK_LKT13; s.aux = key == 0; s.ptr = ix.lkt + (key ? key - 1 : 0);
+                        }
                     }
-                    break;
                 }
             }
             // ---- a lane with a seed under way: its next extension

@@ -8,13 +8,16 @@
 #include "../../include/megapath_hip.h"
 
 // ------------------------------------------------------------------------------------------------ HBM index layout
-// One 64-byte block per 192 BWT symbols: running counts of A,C,G,T before the block, then the symbols themselves,
-// 2 bits each, LSB-first (symbol s of the block at bits 2*(s%16) of word s/16).  One rank query = one aligned 64 B
-// load.  Counts are 32-bit: a text is < 2^32-2 bases (the reference's own per-chunk limit).
+// One 64-byte block per 192 BWT symbols: running counts of A,C,G,T before the block, then the symbols themselves as two bit
+// planes (symbol s of the block: its low bit at bit s%32 of lo[s/32], its high bit at the same place of hi).  One rank query =
+// one aligned 64 B load; with the planes the matches of a symbol are one dense mask per 32 symbols (two logic operations), their
+// running popcounts six more, and a rank is a select and one masked popcount -- a quarter of the instructions the 2-bit-per-symbol
+// packing needs.  Counts are 32-bit: a text is < 2^32-2 bases (the reference's own per-chunk limit).
 #define MP_OCC_SYMS 192u
 struct mp_occ_block {
     uint32_t cnt[4];
-    uint32_t bwt[12];
+    uint32_t lo[6];
+    uint32_t hi[6];
 };
 static_assert(sizeof(mp_occ_block) == 64, "occ block must be one 64-byte sector");
 

@@ -757,26 +757,38 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
                            c->big_slabs.p);
         MP_TRACE(s, "seed_overflow_kernel");
     }
-    if (c->seeds.reserve((size_t)n_hits + 64) || c->hit_row.reserve((size_t)n_hits + 64) || c->hits.reserve((size_t)n_hits + 64) ||
-        c->seedpos.reserve((size_t)n_hits + 64)) return MP_ENOMEM;
+    // With the whole suffix array resident the merge kernel makes its sort keys straight from the seeding kernel's records (a hit is
+    // at most one 4-byte load): no expand / locate launch, no 16-byte hit array.  Otherwise (LF walks to a sampled row): one lane per hit.
+    const bool fused = dix.sa_dense && dix.sa_dense_shift == 0;
+    if (c->seedpos.reserve((size_t)n_hits + 64)) return MP_ENOMEM;
+    if (fused) { if (c->hits.reserve(((size_t)n_hits + 1) / 2 + 64)) return MP_ENOMEM; }
+    else if (c->seeds.reserve((size_t)n_hits + 64) || c->hit_row.reserve((size_t)n_hits + 64) || c->hits.reserve((size_t)n_hits + 64)) return MP_ENOMEM;
     HIPCHK(hipEventRecord(c->ev[9], s));
     HIPCHK(hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(expand_hits_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, c->slabs.p, c->seeds_per_rs.p, c->rs_base.p, n_items,
-                       c->over_slot.p, c->big_slabs.p, c->seeds.p, c->hit_row.p, c->ctr.p, slab_limit);
-    MP_TRACE(s, "expand_hits_kernel");
-    if (n_hits)
-        hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, dix, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
-                           c->ctr.p);
+    if (!fused) {
+        hipLaunchKernelGGL(expand_hits_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, c->slabs.p, c->seeds_per_rs.p, c->rs_base.p, n_items,
+                           c->over_slot.p, c->big_slabs.p, c->seeds.p, c->hit_row.p, c->ctr.p, slab_limit);
+        MP_TRACE(s, "expand_hits_kernel");
+        if (n_hits)
+            hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, dix, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
+                               c->ctr.p);
         MP_TRACE(s, "locate_kernel");
+    }
     HIPCHK(hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_THREADS), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, (int)((c->max_len + 63) / 64), c->seedpos.p, c->n_pos.p,
-                       c->n_neg.p, c->ctr.p);
+    const int cov_words = (int)((c->max_len + 63) / 64);
+    if (fused)
+        hipLaunchKernelGGL(merge_kernel<true>, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_THREADS), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, cov_words,
+                           c->seedpos.p, c->n_pos.p, c->n_neg.p, c->ctr.p, dix, c->slabs.p, c->seeds_per_rs.p, c->over_slot.p, c->big_slabs.p, slab_limit, c->d_lens);
+    else
+        hipLaunchKernelGGL(merge_kernel<false>, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_THREADS), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, cov_words,
+                           c->seedpos.p, c->n_pos.p, c->n_neg.p, c->ctr.p, dix, c->slabs.p, c->seeds_per_rs.p, c->over_slot.p, c->big_slabs.p, slab_limit, c->d_lens);
     MP_TRACE(s, "merge_kernel");
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     mp_seed_stats st{};
     st.n_occ = h.n_occ; st.n_lkt = h.n_lkt;
+    if (fused) h.n_hits = n_hits;                     // (locate_kernel's counter)
     st.n_sa = h.n_sa + (h.n_hits - h.n_located);      // seed_kernel's reads for single-row matches + one per hit locate had to look up
     st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
     st.n_seeds = h.n_seeds; st.n_prefilter = h.n_kmer; st.n_occ_loaded = h.n_occ_loaded;

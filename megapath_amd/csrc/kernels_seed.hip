@@ -1200,9 +1200,57 @@ __device__ __forceinline__ uint32_t merge_read_wave(const uint64_t *k, int n, mp
 // reads are sorted one after the other by all 64 lanes together: a bitonic network over registers and wavefront
 // shuffles, 1 to 8 keys per lane.  The grouping pass is linear and runs one lane per read.  A block whose range does not
 // fit in LDS packs and sorts in place in global memory, lane by lane.
+// The seeds of one (read, strand) as sort keys, one per SA row (what expand_hits_kernel + locate_kernel + hit_key produce), for an index
+// whose whole suffix array is resident: a seed reported by its text position is one key with no look-up, a row is one load.
+__device__ __forceinline__ uint32_t mp_rs_keys(const mp_dev_index &ix, const mp_dev_mmp &P, uint32_t rs, const mp_seed_rec *__restrict__ slabs, const uint32_t *__restrict__ seeds_per_rs,
+                                               const uint32_t *__restrict__ over_slot, const mp_seed_rec *__restrict__ big_slabs, uint32_t slab_limit,
+                                               const uint32_t *__restrict__ lens, uint64_t *dst)
+{
+    const uint32_t ns = seeds_per_rs[rs];
+    if (ns == 0) return 0;
+    const mp_seed_rec *src = slabs + (uint64_t)rs * MP_SEED_SLAB;
+    if (ns > slab_limit) src = big_slabs + (uint64_t)over_slot[rs] * MP_SEED_BIG;
+    const uint32_t len = lens[rs >> 1], strand = rs & 1u;
+    uint32_t w = 0;
+    for (uint32_t j0 = 0; j0 < ns; j0 += 4) {
+        // four records per round: their loads (and the suffix-array reads of single-row seeds, the common kind that was not already
+        // reported by its position) are in flight together
+        mp_seed_rec r4[4];
+        uint32_t sa4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (j0 + u < ns) r4[u] = src[j0 + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) sa4[u] = (j0 + u < ns && r4[u].sa_diff != MP_SEED_LOCATED && r4[u].sa_l != 0) ? ix.sa_dense[r4[u].sa_l] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (j0 + u >= ns) break;
+            const mp_seed_rec rec = r4[u];
+            const bool located = rec.sa_diff == MP_SEED_LOCATED;
+            const uint32_t rows = located ? 1u : rec.sa_diff + 1u;
+            const uint32_t off = rec.query_offset, seedlen = rec.seed_len;
+            mp_seed_hit h;
+            h.length = (uint16_t)seedlen; h.qo = (uint16_t)off; h.strand = (uint16_t)strand;
+            h.mult = (seedlen >= (uint32_t)P.good_seed_len || seedlen >= len / 2 || located) ? (uint16_t)1 : (uint16_t)(rec.sa_diff + 1);
+            for (uint32_t k = 0; k < rows; k++) {
+                const uint32_t row = rec.sa_l + k;
+                // SA[0] is kept as -1 (BWT.c:242,994-996); unsigned 64-bit arithmetic: the projection may wrap exactly as in the reference
+                const uint64_t sav = located ? (uint64_t)rec.sa_l : (row == 0 ? ~0ull : (uint64_t)(k == 0 ? sa4[u] : ix.sa_dense[row]));
+                h.offset = strand == 0 ? sav - off : sav - ((uint64_t)len - seedlen - off);
+                dst[w++] = hit_key(h, P);
+            }
+        }
+    }
+    return ns;
+}
+
+// FUSED (whole suffix array resident): the keys are made here from the seeding kernel's records -- no expand / locate launch, no hit
+// array; `hits` is then only scratch for the blocks that do not fit in LDS (8 bytes per hit).
+template <bool FUSED>
 __global__ void __launch_bounds__(MP_MERGE_THREADS)
 merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P, uint64_t text_len, int cov_words,
-             mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr)
+             mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr,
+             mp_dev_index ix, const mp_seed_rec *__restrict__ slabs, const uint32_t *__restrict__ seeds_per_rs, const uint32_t *__restrict__ over_slot,
+             const mp_seed_rec *__restrict__ big_slabs, uint32_t slab_limit, const uint32_t *__restrict__ lens)
 {
     __shared__ uint64_t s_key[MP_MERGE_CAP];
     __shared__ uint32_t s_base[MP_MERGE_BLOCK + 1];
@@ -1212,26 +1260,46 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_bas
     const bool staged = T <= MP_MERGE_CAP;
     const int lane = threadIdx.x & (MP_WAVE - 1), wave = threadIdx.x / MP_WAVE;
     if (!staged) {
-        // a block whose hits do not fit in LDS: one lane per read, in place in global memory (key i overwrites bytes 8i..8i+7 of the
-        // read's own records, all of them already consumed)
+        // a block whose hits do not fit in LDS: one lane per read, in global memory (not FUSED: in place, key i overwrites bytes
+        // 8i..8i+7 of the read's own records, all of them already consumed)
         const uint32_t r = r0 + threadIdx.x;
         if (threadIdx.x >= MP_MERGE_BLOCK || r >= n_reads) return;
         const uint32_t base = rs_base[2 * r];
         const int n = (int)(rs_base[2 * r + 2] - base);
-        uint64_t *k = reinterpret_cast<uint64_t *>(hits + base);
-        for (int i = 0; i < n; i++) { const mp_seed_hit h = hits[base + i]; k[i] = hit_key(h, P); }
+        uint64_t *k;
+        if (FUSED) {
+            k = reinterpret_cast<uint64_t *>(hits) + base;
+            uint32_t nsd = mp_rs_keys(ix, P, 2 * r, slabs, seeds_per_rs, over_slot, big_slabs, slab_limit, lens, k);
+            nsd += mp_rs_keys(ix, P, 2 * r + 1, slabs, seeds_per_rs, over_slot, big_slabs, slab_limit, lens, k + (rs_base[2 * r + 1] - base));
+            if (nsd) atomicAdd(&ctr->n_seeds, (unsigned long long)nsd);
+        } else {
+            k = reinterpret_cast<uint64_t *>(hits + base);
+            for (int i = 0; i < n; i++) { const mp_seed_hit h = hits[base + i]; k[i] = hit_key(h, P); }
+        }
         sort_keys(k, n);
         merge_read(k, n, seedpos + base, r, P, text_len, cov_words, n_pos, n_neg, ctr);
         return;
     }
     if (threadIdx.x <= MP_MERGE_BLOCK) { const uint32_t r = min(r0 + threadIdx.x, r1); s_base[threadIdx.x] = rs_base[2 * r] - b0; }
-    // four independent 16-byte loads in flight per lane
-    for (uint32_t i0 = 0; i0 < T; i0 += 4 * MP_MERGE_THREADS) {
-        mp_seed_hit h4[4];
+    if (FUSED) {
+        // one lane per (read, strand) writes its keys into the block's LDS range
+        uint32_t nsd = 0;
+        const uint32_t rs = 2 * r0 + threadIdx.x;
+        if (threadIdx.x < 2 * MP_MERGE_BLOCK && rs < 2 * r1)
+            nsd = mp_rs_keys(ix, P, rs, slabs, seeds_per_rs, over_slot, big_slabs, slab_limit, lens, s_key + (rs_base[rs] - b0));
+        if (threadIdx.x < 2 * MP_MERGE_BLOCK) {
+            for (int o = MP_WAVE / 2; o > 0; o >>= 1) nsd += __shfl_down(nsd, o);
+            if (lane == 0 && nsd) atomicAdd(&ctr->n_seeds, (unsigned long long)nsd);
+        }
+    } else {
+        // four independent 16-byte loads in flight per lane
+        for (uint32_t i0 = 0; i0 < T; i0 += 4 * MP_MERGE_THREADS) {
+            mp_seed_hit h4[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_THREADS + threadIdx.x; if (i < T) h4[u] = hits[b0 + i]; }
+            for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_THREADS + threadIdx.x; if (i < T) h4[u] = hits[b0 + i]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_THREADS + threadIdx.x; if (i < T) s_key[i] = hit_key(h4[u], P); }
+            for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * MP_MERGE_THREADS + threadIdx.x; if (i < T) s_key[i] = hit_key(h4[u], P); }
+        }
     }
     __syncthreads();
     // ---- one read after the other, each by a whole wavefront: sort (lane = key), then groups (lane = group); the block's wavefronts

@@ -191,7 +191,7 @@ def run_steps(ctx, wl, params, n_steps, barrier=None):
             add("ms_" + k, v)
         s = st.seed
         for k in ("n_occ", "n_occ_loaded", "n_lkt", "n_lkt16", "n_sa", "n_seedpos", "n_prefilter", "n_prefilter_loads", "n_text_words", "n_steps_skipped",
-                  "n_seeds", "n_hits"):
+                  "n_seeds", "n_hits", "n_sa_seed_kernel"):
             add(k, int(getattr(s, k)))
         add("cand", int(st.n_candidates)); add("pair_hits", int(st.n_pair_hits))
         add("failed", int(rst.n_failed_pairs)); add("stasks", int(rst.n_single_tasks)); add("rtasks", int(rst.n_rescue_tasks))
@@ -202,12 +202,15 @@ def run_steps(ctx, wl, params, n_steps, barrier=None):
     return time.perf_counter() - t0, acc
 
 
-def loaded_bytes(acc, sum_len_per_step, n_steps):
+def loaded_bytes(acc, sum_len_per_step, n_steps, fused=False):
     """Bytes the seed stage's kernels request from memory, by event (each counted by the kernels themselves):
     64 B per rank block loaded, 8 B per look-up in the 13-mer / 16-mer tables (two adjacent 32-bit bounds), 8 B per pre-filter
     entry loaded, 4 B per suffix-array entry, 8 B per 16-base text word compared, 0.25 B per read base (2-bit reads),
-    16 B per kept seed position written."""
-    return (64 * acc["n_occ_loaded"] + 8 * (acc["n_lkt"] + acc["n_lkt16"]) + 8 * acc["n_prefilter_loads"] + 4 * acc["n_sa"] + 8 * acc["n_text_words"]
+    16 B per kept seed position written.  `fused` (whole suffix array resident: no expand / locate launch, the merge kernel reads the
+    one suffix-array entry per hit that is still needed): only the seeding kernel's own suffix-array reads are counted, because only
+    its time is in the denominator."""
+    n_sa = acc["n_sa_seed_kernel"] if fused else acc["n_sa"]
+    return (64 * acc["n_occ_loaded"] + 8 * (acc["n_lkt"] + acc["n_lkt16"]) + 8 * acc["n_prefilter_loads"] + 4 * n_sa + 8 * acc["n_text_words"]
             + 0.25 * sum_len_per_step * n_steps + 16 * acc["n_seedpos"])
 
 
@@ -238,7 +241,7 @@ def pmc_pass(counter, args, tmpdir):
     return per
 
 
-def live_traffic(args, tmpdir):
+def live_traffic(args, tmpdir, kernels=SEED_STAGE_KERNELS):
     if shutil.which("rocprofv3") is None:
         return None
     fetch = pmc_pass("FETCH_SIZE", args, tmpdir)
@@ -247,7 +250,7 @@ def live_traffic(args, tmpdir):
         return None
     per_kernel = {}
     total = 0.0
-    for k in SEED_STAGE_KERNELS:
+    for k in kernels:
         f = fetch.get(k, [0.0])[-1] * 1024.0                       # the counters are in KiB
         w = write.get(k, [0.0])[-1] * 1024.0
         per_kernel[k] = {"fetch_bytes": f, "write_bytes": w}
@@ -481,7 +484,10 @@ def main():
         K = args.steps
         total_pairs = world * K * P
         t_seed_s = (acc["ms_seed"] + acc["ms_locate"]) / 1e3
-        b_loaded = loaded_bytes(acc, wl.sum_len, K)
+        # whole suffix array resident: expand_hits_kernel / locate_kernel are not launched (merge_kernel<true> makes its keys from the seed records)
+        fused = acc["ms_locate"] / K < 0.05
+        roof_kernels = ("seed_kernel", "seed_overflow_kernel") if fused else SEED_STAGE_KERNELS
+        b_loaded = loaded_bytes(acc, wl.sum_len, K, fused)
         achieved = b_loaded / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
         kernel_ms = {k[3:]: acc[k] / K for k in acc if k.startswith("ms_")}
         per_pair = lambda k: acc[k] / (K * P)      # noqa: E731
@@ -503,12 +509,12 @@ def main():
                                    "that as many contexts work on side by side" % (args.read_len, args.genome_mbp, P, n_ctx),
                        "index_replicated_per_gpu": True, "pairs_per_step_per_gpu": P, "genome_mbp": args.genome_mbp,
                        "index_bytes_in_hbm": int(gix.info.device_bytes), "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750},
-            "roofline": {"bound": "hbm", "kernel": "seed_kernel+seed_overflow_kernel+expand_hits_kernel+locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "+".join(roof_kernels), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": b_loaded / K, "bytes_per_pair": b_loaded / (K * P), "launch_ms": (acc["ms_seed"] + acc["ms_locate"]) / K,
-                         "formula": "64*rank_blocks_loaded + 8*(lkt13 + lkt16 look-ups) + 8*prefilter_entries_loaded + 4*sa_reads + 8*text_words_compared + "
-                                    "0.25*read_bases + 16*seed_positions_out; every count is emitted by the kernels (events_per_pair) and only events "
-                                    "that load memory are priced",
+                         "formula": ("64*rank_blocks_loaded + 8*(lkt13 + lkt16 look-ups) + 8*prefilter_entries_loaded + 4*sa_reads%s + 8*text_words_compared + "
+                                     "0.25*read_bases + 16*seed_positions_out; every count is emitted by the kernels (events_per_pair) and only events "
+                                     "that load memory are priced") % (" (the seeding kernel's own, %.2f per pair: the kernels in the denominator)" % (acc["n_sa_seed_kernel"] / (K * P)) if fused else ""),
                          "random64_gather_ceiling_gbs": gather_gbs,
                          "note": "dependent random 4..64-byte gathers: the physical ceiling of this access shape is the measured random-64-B-gather rate, "
                                  "not the streaming peak; traffic_frac / frac_of_gather_ceiling say how close the sectors actually moved come to either"},
@@ -555,7 +561,7 @@ def main():
         try:
             if world == 1 and not args.no_pmc:
                 try:
-                    tr = live_traffic(args, tmpdir)
+                    tr = live_traffic(args, tmpdir, roof_kernels)
                 except Exception as e:  # noqa: BLE001
                     log("[bench] PMC passes failed: %r" % (e,))
                     tr = None

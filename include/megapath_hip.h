@@ -138,6 +138,10 @@ typedef struct {
     uint64_t n_text_words;         /* 16-base text words compared in place of rank queries (single-row matches) */
     uint64_t n_steps_skipped;      /* extension steps never carried out: 3 per 16-mer look-up + 1 per base matched in the text;
                                     * n_occ + 2 * n_steps_skipped = rank queries of the same walk without those short cuts */
+    uint64_t n_sa_seed_kernel;     /* the part of n_sa read by the seeding kernel itself (position of a single-row match); the rest, one per
+                                    * hit that was not already reported by its text position, is read by locate -- or, when the whole suffix
+                                    * array is resident, by the merge kernel, which then makes its keys straight from the seed records
+                                    * (ms_locate = 0: no expand / locate launch) */
 } mp_seed_stats;
 
 int mp_seed_batch(mp_ctx *ctx, const mp_mmp_params *params, mp_seed_stats *out_stats);

@@ -793,6 +793,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     st.n_hits = h.n_hits; st.n_seedpos = h.n_seedpos;
     st.n_seeds = h.n_seeds; st.n_prefilter = h.n_kmer; st.n_occ_loaded = h.n_occ_loaded;
     st.n_lkt16 = h.n_lkt16; st.n_prefilter_loads = h.n_kmer_loads; st.n_text_words = h.n_text_words; st.n_steps_skipped = h.n_steps_skipped;
+    st.n_sa_seed_kernel = h.n_sa;
     float ms_over = 0;
     (void)hipEventElapsedTime(&st.ms_seed, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&ms_over, c->ev[8], c->ev[9]);     // items redone with the full-size slab belong to K1

@@ -208,7 +208,7 @@ __global__ void prep_scan_kernel(const uint32_t *reads, const uint32_t *lens, ui
 // whatever mix of states the 64 lanes are in, which keeps the number of serialised memory waits per trip at two.
 // Seeds go to a fixed slab of MP_SEED_SLAB records per (read, strand) -- no atomics on the hot path; the rare item with
 // more seeds is listed in `overflow_rs` and redone by seed_overflow_kernel with a full-size slab.
-#define MP_SEED_SLAB 32
+#define MP_SEED_SLAB 64
 #define MP_MIN_ALIGNABLE_LEN 30   // = mp_dp_cutoff(len) for every len <= 150: shorter reads cannot reach their cutoff
 #define MP_SEED_CHUNK 64
 

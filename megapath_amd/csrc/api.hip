@@ -1195,9 +1195,12 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     static const bool verbose2 = getenv("MP_DP_BAND_STATS") != nullptr;
     if (verbose2) fprintf(stderr, "[band] tier %d pre-filter: %u narrow, %u whole band, of %u\n", TIER1 ? 1 : 2, n_narrow, n_wide, n);
     HIPCHK(hipEventRecord(c->ev_pool[1], s));
-    // classes by distance from the best cell's diagonal; perfect matches and instances below their cutoff are finished here
+    // classes by distance from the best cell's diagonal; perfect matches, plain diagonal alignments (mismatches only; MP_DP_DIAG=0
+    // sends them through the second pass like the rest: test switch) and instances below their cutoff are finished here
+    const bool diag_shortcut = !(getenv("MP_DP_DIAG") && atoi(getenv("MP_DP_DIAG")) == 0);
     hipLaunchKernelGGL(dp_band_classify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, (const mp_fill_result *)c->band_fill.p, n,
-                       c->near_flag.p, c->far_flag.p, c->band_flag.p, d_res, in_list, TIER1 ? (uint32_t *)nullptr : c->vfar_flag.p, c->mid_flag.p);
+                       c->near_flag.p, c->far_flag.p, c->band_flag.p, d_res, in_list, TIER1 ? (uint32_t *)nullptr : c->vfar_flag.p, c->mid_flag.p,
+                       diag_shortcut ? c->ix->d.text : (const uint32_t *)nullptr, (const uint32_t *)c->d_reads, c->W);
     MP_TRACE(s, "dp_band_classify_kernel");
     int rc = scan(c->near_flag.p, c->near_idx.p); if (rc) return rc;
     rc = scan(c->far_flag.p, c->far_idx.p); if (rc) return rc;

@@ -452,10 +452,63 @@ __global__ void dp_band_select_kernel(const mp_fill_result *__restrict__ fill, u
 #define MP_BAND_MID 9
 #define MP_BAND_GBM 7
 #define MP_BAND_WM (2 * MP_BAND_GBM + 1)
+// Word w (bases 16w .. 16w+15) of a read in alignment orientation, as dp_prefilter_kernel stages it.
+__device__ __forceinline__ uint32_t mp_oriented_word(const uint32_t *__restrict__ rd, int nw, int L, uint32_t strand, int w)
+{
+    if (w >= nw) return 0u;
+    uint32_t v;
+    if (strand == 1) v = rd[w];
+    else {
+        // reverse strand: reverse the 2-bit groups of every word, take the words in reverse order, complement, and shift out the
+        // 16 nw - L pad bases that the reversal brought to the front
+        auto z = [&](int q) -> uint32_t {
+            if (q >= nw) return 0u;
+            const uint32_t x = __brev(rd[nw - 1 - q]);
+            return ~(((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u));
+        };
+        v = (uint32_t)((((uint64_t)z(w + 1) << 32) | z(w)) >> (2u * (uint32_t)(16 * nw - L)));
+    }
+    if (w == nw - 1 && (L & 15)) v &= (1u << (2 * (L & 15))) - 1u;
+    return v;
+}
+
+// Is the alignment the traceback would report for best cell (row, col) with score S simply the diagonal through that cell --
+// read bases 1..col against window rows hit+1..hit+col, hit = row - col, no gap, no left clip?  Sufficient condition, from the read and
+// the window alone: every prefix of the diagonal scores above zero (the k-th mismatch lies right of column 3k) and the whole of it
+// scores S.  Then for every cell c of that diagonal  prefix(c) <= H(c)  (the diagonal from column 0 is one of the paths into it) and
+// H(c) <= S - (score of the rest of the diagonal) = prefix(c)  (continuing along the diagonal reaches the best cell, whose value is S):
+// H equals the diagonal's own prefix score everywhere on it, so the traceback (CPU_DP.cpp:622-786: diagonal first whenever
+// H(r,c) = H(r-1,c-1) + s) takes the diagonal at every step, and its exit test never fires before column 1 -- a predecessor whose value
+// is the clip floor would need H = 0, the prefixes are >= 1.  What dp_trace_kernel writes in that case: col diagonal steps after
+// L - col clipped bases, hit_loc = row - col.
+__device__ __forceinline__ bool mp_diag_alignment(const uint32_t *__restrict__ text, const uint32_t *__restrict__ rd, int L, uint32_t strand, uint64_t win_start, int m,
+                                                  int hit, int col, int S)
+{
+    if (hit < 0 || col < 1 || col > L || hit + col > m) return false;
+    const int nw = (L + 15) / 16, nwc = (col + 15) / 16;
+    int k = 0;
+    for (int w = 0; w < nwc; w++) {
+        const uint64_t p = win_start + (uint64_t)(16 * w + hit);
+        const uint32_t t = (uint32_t)((((uint64_t)text[(p >> 4) + 1] << 32) | text[p >> 4]) >> (2 * (uint32_t)(p & 15)));
+        const uint32_t x = t ^ mp_oriented_word(rd, nw, L, strand, w);
+        uint32_t mm = (x | (x >> 1)) & 0x55555555u;
+        if (16 * w + 16 > col) mm &= (1u << (2 * (col - 16 * w))) - 1u;
+        while (mm) {
+            const int b = __ffs((int)mm) - 1;
+            mm &= mm - 1;
+            k++;
+            if (16 * w + (b >> 1) + 1 <= 3 * k) return false;
+        }
+    }
+    return col - 3 * k == S;
+}
+
 __global__ void dp_band_classify_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, const mp_fill_result *__restrict__ fill,
                                         uint32_t n, uint32_t *__restrict__ flag_near, uint32_t *__restrict__ flag_far, uint32_t *__restrict__ flag_full,
                                         mp_dp_result *__restrict__ res, const uint32_t *__restrict__ list = nullptr,
-                                        uint32_t *__restrict__ flag_vfar = nullptr, uint32_t *__restrict__ flag_mid = nullptr)
+                                        uint32_t *__restrict__ flag_vfar = nullptr, uint32_t *__restrict__ flag_mid = nullptr,
+                                        const uint32_t *__restrict__ text = nullptr /* with reads: finish plain diagonal alignments here */,
+                                        const uint32_t *__restrict__ reads = nullptr, uint32_t Wr = 0)
 {
     // flags are indexed by slot; with a list, slot s stands for instance list[s].  The second tier (scores down to L - 25)
     // has a third class, `flag_vfar`: scores below L - MP_BAND_GB, second pass over 51 diagonals.
@@ -470,6 +523,11 @@ __global__ void dp_band_classify_kernel(const mp_dp_task *__restrict__ tasks, co
     else if (fr.score == 0 || fr.score < mp_dp_cutoff(L)) res[t] = z;              // nothing to align / below the cutoff
     else if (fr.score == L && fr.col == L && fr.row >= L) {
         z.score = L; z.hit_loc = (uint32_t)(fr.row - L); z.max_score_count = fr.count; z.n_ops = (uint32_t)L;
+        res[t] = z;
+    } else if (text && mp_diag_alignment(text, reads + (uint64_t)tasks[t].read_id * Wr, L, tasks[t].strand, tasks[t].win_start, (int)tasks[t].win_len,
+                                         (int)fr.row - (int)fr.col, (int)fr.col, (int)fr.score)) {
+        // mismatches only, on one diagonal, no clip on the left: no second pass, no traceback
+        z.score = fr.score; z.hit_loc = (uint32_t)((int)fr.row - (int)fr.col); z.max_score_count = fr.count; z.n_ops = (uint32_t)L;
         res[t] = z;
     } else if (fr.score >= L - MP_BAND_NEAR) fn = 1;
     else if (flag_mid && fr.score >= L - MP_BAND_MID) fm = 1;

@@ -208,6 +208,38 @@ def test_banded_dp_kernel_changes_nothing(tmp_path, clips, banded, read_len):
     gix.close()
 
 
+@pytest.mark.parametrize("sub,junk", [(0.04, 0.0), (0.02, 0.5)])
+def test_plain_diagonal_alignments_need_no_traceback(monkeypatch, sub, junk):
+    """Deep-DP instances whose reported alignment is the best cell's diagonal (mismatches only, no clip on the left) are finished by
+    dp_band_classify_kernel from the read and the window alone (mp_diag_alignment).  Many substitutions -- also within the first bases,
+    where the prefix condition fails -- and junk read starts: the hit set must equal what the second pass + traceback give
+    (MP_DP_DIAG=0) and what the full-table kernels give, in every field."""
+    genome = synth.random_genome(400000, 911, n_seqs=2, repeat_frac=0.1)
+    arrs = index_builder.build_index_arrays(genome, sa_interval=16)
+    gix = H.Index.from_arrays(0, **arrs)
+    names, r1, r2 = synth.simulate_pairs(genome, 4000, 150, 912, sub=sub, ins=0.0005, dele=0.0005, random_frac=0.02, junk_end_frac=junk, junk_end_max=40)
+    seqs = [x for pr in zip(r1, r2) for x in pr]
+    packed, lens, W = H.pack_reads(seqs, 151)
+
+    def run(band, diag):
+        monkeypatch.setenv("MP_DP_DIAG", "1" if diag else "0")
+        ctx = H.Context(gix)
+        ctx.set_reads(packed, lens)
+        ctx.set_dp_band(band)
+        hits, nh, st = ctx.deep_dp_round(H.AlignParams(1, 750, 130, 130, H.MmpParams.nt2()))
+        got = sorted((h.pair_id, h.left_is_mate, h.algnmt_1, h.algnmt_2, h.score_1, h.score_2, h.start_1, h.start_2, h.dplen_1, h.dplen_2, h.count_1, h.count_2)
+                     for h in hits[:nh])
+        ctx.close()
+        return got, st
+    full, _ = run(False, True)
+    two_pass, _ = run(True, False)
+    short, _ = run(True, True)
+    assert len(full) > 3000
+    assert [h[:10] for h in two_pass] == [h[:10] for h in full]      # (the tie counts are only filled in when asked for: not by the full-table kernels here)
+    assert short == two_pass                                           # every field, tie counts included
+    gix.close()
+
+
 def test_seed_projection_wrapping_below_zero(tmp_path):
     """Reads whose first bases are junk and whose match starts within the first bases of the text: the seed projection
     position - query offset wraps below zero in unsigned arithmetic, exactly as in the reference

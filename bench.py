@@ -384,7 +384,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity sample")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs (roofline.traffic = null)")
     ap.add_argument("--no-legs", action="store_true", help="skip the C3/C4/C5 workload legs, the lean-layout leg and the resident-chunks leg")
-    ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "2")),
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "3")),
                     help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")
     ap.add_argument("--nt-chunks", type=int, default=int(os.environ.get("MP_BENCH_NT_CHUNKS", "4")), help="index chunks of the resident-chunks leg")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -500,7 +500,7 @@ def main():
             "contexts_per_gpu": n_ctx,
             "single_context": {"pairs_per_s": world * K * P / elapsed_single, "ms_per_step": elapsed_single / K * 1e3,
                                "note": "the same %d steps with ONE context doing the whole batch on one stream: the run the per-kernel HIP-event times, "
-                                       "event counts and the roofline below come from (kernels of two contexts would overlap and stretch each other)" % K},
+                                       "event counts and the roofline below come from (kernels of several contexts would overlap and stretch each other)" % K},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "2x%dbp synthetic pairs vs synthetic %.0f Mbp genome in 24 sequences (BASELINE configs[1], human-filter stage; GRCh38 indexes ~2.95 Gbp of "

@@ -1184,7 +1184,7 @@ int main(int argc, char **argv)
     // aligned, every pair is printed as unaligned.  Never a substitute for the device path: it says so on stderr.
     const bool plumbing_only = getenv("MP_PLUMBING_TEST") != nullptr;
     if (plumbing_only) fprintf(stderr, "[soap4-mi355x] MP_PLUMBING_TEST: NO ALIGNMENT IS DONE -- host plumbing test only, every pair is reported unaligned\n");
-    int workers_per_gpu = 2;                   // two contexts per GPU: the latency-bound seeding of one batch overlaps with the VALU-bound DP of another
+    int workers_per_gpu = 3;                   // three contexts per GPU: the memory-bound seeding of one batch overlaps with the VALU-bound DP of the others (bench.py: +4 % over two)
     if (const char *e = getenv("MP_WORKERS_PER_GPU")) workers_per_gpu = std::max(1, atoi(e));
     fill_char_map();
 

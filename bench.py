@@ -428,8 +428,9 @@ def main():
     gix = H.Index.from_arrays(local_rank, **arrs)
     t2 = time.time()
     if rank == 0:
-        log("[bench] genome %.0f Mbp: suffix sort + BWT %.1fs, HBM re-layout + upload %.1fs, index %.2f GB in HBM"
-            % (args.genome_mbp, t1 - t0, t2 - t1, gix.info.device_bytes / 1e9))
+        bi = index_builder.last_build_info or {}
+        log("[bench] genome %.0f Mbp: generated + index built in %.1fs (mp_build_index_arrays: suffix array in %.2f s, %s doubling rounds), HBM re-layout + upload %.1fs, "
+            "index %.2f GB in HBM" % (args.genome_mbp, t1 - t0, bi.get("ms_suffix_sort", 0.0) / 1e3, bi.get("rounds", "?"), t2 - t1, gix.info.device_bytes / 1e9))
     torch.cuda.empty_cache()
     g_ms, g_bytes = gix.bench_gather64()
     gather_gbs = g_bytes / (g_ms * 1e-3) / 1e9

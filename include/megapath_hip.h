@@ -305,6 +305,16 @@ int mp_coverage_spike_intervals(mp_coverage *cov, uint32_t *out_seq_id, uint64_t
 /* per interval the number of its bases that are spike bases (bedtools annotate's numerator) */
 int mp_coverage_spike_bases(mp_coverage *cov, const uint32_t *seq_id_1based, const uint64_t *start0, const uint32_t *ref_span, uint64_t n, uint32_t *out_covered);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Index construction.  Replaces the compute of `2bwt-builder` (2BWT-Builder.c:199-393: BWTConstruct.c builds
+ * the BWT incrementally on one core, then the sampled suffix array by inverse-psi walks): from the n base codes (0..3, host) of the
+ * text, the arrays the reference's files hold -- BWT words with the '$' row left out (16 symbols per word, first in the top bits:
+ * .bwt), that row's number (inverseSa0), cumulative symbol counts, SA[k * sa_interval] for k = 0 .. n / sa_interval (.sa; SA[0] = n),
+ * and the packed text (.pac: 4 bases per byte, first in bits 7-6; (n + 3) / 4 bytes).  Suffix array by prefix doubling in HBM
+ * (33 bytes per base while it runs); n < 2^32 - 3.  out_rounds / out_ms_suffix_sort may be NULL. */
+int mp_build_index_arrays(int device, const uint8_t *codes, uint64_t n, uint32_t sa_interval, uint32_t *out_bwt_words, uint64_t *out_sa_samples,
+                          uint8_t *out_pac, uint64_t *out_inv_sa0, uint64_t *out_cum /* [5] */, uint32_t *out_rounds, float *out_ms_suffix_sort);
+
 /* Library / device probe: fails loudly (MP_ENODEV) when no gfx950 device is usable. */
 int mp_device_check(int device, char *out_name, size_t name_cap);
 const char *mp_strerror(int code);

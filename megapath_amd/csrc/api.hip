@@ -14,6 +14,7 @@
 #include "kernels_dp_band.hip"
 #include "kernels_rescue.hip"
 #include "kernels_cov.hip"
+#include "kernels_build.hip"
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     fprintf(stderr, "[megapath_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MP_ENODEV; } } while (0)
@@ -134,6 +135,98 @@ extern "C" const char *mp_strerror(int code)
         case MP_ERANGE: return "input outside the supported range";
         default: return "unknown error";
     }
+}
+
+// ------------------------------------------------------------------------------------------------ index construction
+extern "C" int mp_build_index_arrays(int device, const uint8_t *codes, uint64_t n, uint32_t sa_interval, uint32_t *out_bwt_words, uint64_t *out_sa_samples,
+                                     uint8_t *out_pac, uint64_t *out_inv_sa0, uint64_t *out_cum, uint32_t *out_rounds, float *out_ms_suffix_sort)
+{
+    if (!codes || !out_bwt_words || !out_sa_samples || !out_pac || !out_inv_sa0 || !out_cum || sa_interval == 0) return MP_EINVAL;
+    if (n < 1 || n + 3 >= (1ull << 32)) return MP_ERANGE;                       // an index chunk holds < 2^32 - 3 bases (the reference's limit)
+    HIPCHK(hipSetDevice(device));
+    const uint64_t m = n + 1;                                                   // suffixes 0 .. n, suffix n = '$'
+    DevBuf<uint8_t> d_codes, d_tmp, d_pac;
+    DevBuf<uint64_t> key_a, key_b;
+    DevBuf<uint32_t> idx_a, idx_b, rank, row_rank, d_words;
+    DevBuf<unsigned long long> d_small, d_samples;
+    struct Free { DevBuf<uint8_t> &a, &b, &c; DevBuf<uint64_t> &d, &e; DevBuf<uint32_t> &f, &g, &h, &i, &j; DevBuf<unsigned long long> &k, &l;
+                  ~Free() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); g.release(); h.release(); i.release(); j.release(); k.release(); l.release(); } }
+        guard{d_codes, d_tmp, d_pac, key_a, key_b, idx_a, idx_b, rank, row_rank, d_words, d_small, d_samples};
+    auto exact = [](auto &buf, size_t count) -> int {                           // no growth margin: these are tens of GB
+        using T = typename std::remove_reference<decltype(*buf.p)>::type;
+        if (hipMalloc((void **)&buf.p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) { buf.p = nullptr; return MP_ENOMEM; }
+        buf.cap = count;
+        return MP_OK;
+    };
+    if (exact(d_codes, n) || exact(key_a, m) || exact(key_b, m) || exact(idx_a, m) || exact(idx_b, m) || exact(rank, m) || exact(row_rank, m) || exact(d_small, 8))
+        return MP_ENOMEM;
+    hipStream_t s = nullptr;
+    HIPCHK(hipMemcpy(d_codes.p, codes, n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(d_small.p, 0, 8 * sizeof(unsigned long long), s));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(build_init_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, (const uint8_t *)d_codes.p, n, key_a.p, idx_a.p);
+    hipcub::DoubleBuffer<uint64_t> keys(key_a.p, key_b.p);
+    hipcub::DoubleBuffer<uint32_t> vals(idx_a.p, idx_b.p);
+    int rank_bits = 1;
+    while ((1ull << rank_bits) <= m) rank_bits++;
+    auto sort_pairs = [&](int end_bit) -> int {
+        size_t bytes = 0;
+        if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, vals, m, 0, end_bit, s) != hipSuccess) return MP_ENODEV;
+        if (bytes > d_tmp.cap) { d_tmp.release(); if (exact(d_tmp, bytes + 256)) return MP_ENOMEM; }
+        if (hipcub::DeviceRadixSort::SortPairs(d_tmp.p, bytes, keys, vals, m, 0, end_bit, s) != hipSuccess) return MP_ENODEV;
+        return MP_OK;
+    };
+    int rc = sort_pairs(3 * MP_BUILD_K);
+    if (rc) return rc;
+    uint32_t rounds = 0;
+    for (uint64_t h = MP_BUILD_K;; h *= 2) {
+        rounds++;
+        hipLaunchKernelGGL(build_flag_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, (const uint64_t *)keys.Current(), m, row_rank.p);
+        {
+            size_t bytes = 0;
+            if (hipcub::DeviceScan::InclusiveSum(nullptr, bytes, row_rank.p, row_rank.p, m, s) != hipSuccess) return MP_ENODEV;
+            if (bytes > d_tmp.cap) { d_tmp.release(); if (exact(d_tmp, bytes + 256)) return MP_ENOMEM; }
+            if (hipcub::DeviceScan::InclusiveSum(d_tmp.p, bytes, row_rank.p, row_rank.p, m, s) != hipSuccess) return MP_ENODEV;
+        }
+        uint32_t top = 0;
+        HIPCHK(hipMemcpyAsync(&top, row_rank.p + (m - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if ((uint64_t)top == m - 1) break;                                      // all ranks differ: vals is the suffix array
+        if (h >= m) return MP_ENODEV;                                             // cannot happen: suffixes differ within n + 1 symbols
+        hipLaunchKernelGGL(build_scatter_rank_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, (const uint32_t *)vals.Current(), (const uint32_t *)row_rank.p, m, rank.p);
+        hipLaunchKernelGGL(build_next_key_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, (const uint32_t *)vals.Current(), (const uint32_t *)row_rank.p,
+                           (const uint32_t *)rank.p, m, h, keys.Current());
+        rc = sort_pairs(32 + rank_bits);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(e1, s));
+    const uint32_t *sa = vals.Current();
+    // ---- what the builder writes: BWT words, '$' row, counts, sampled suffix array, packed text
+    key_a.release(); key_b.release(); rank.release(); row_rank.release();      // (the suffix array lives in one of the idx buffers)
+    const uint64_t n_words = (n + 15) / 16, n_pac = (n + 3) / 4, n_samples = (m + sa_interval - 1) / sa_interval;
+    if (exact(d_words, n_words) || exact(d_pac, n_pac) || exact(d_samples, n_samples)) return MP_ENOMEM;
+    hipLaunchKernelGGL(build_find_row0_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, sa, m, d_small.p + 4);
+    unsigned long long small[8];
+    HIPCHK(hipMemcpyAsync(small, d_small.p, sizeof small, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t inv_sa0 = small[4];
+    hipLaunchKernelGGL(build_bwt_words_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, s, (const uint8_t *)d_codes.p, sa, n, inv_sa0, d_words.p);
+    hipLaunchKernelGGL(build_sa_samples_kernel, dim3(grid_for(n_samples, 256)), dim3(256), 0, s, sa, m, sa_interval, n_samples, d_samples.p);
+    hipLaunchKernelGGL(build_pac_kernel, dim3(grid_for(n_pac, 256)), dim3(256), 0, s, (const uint8_t *)d_codes.p, n, d_pac.p, d_small.p);
+    HIPCHK(hipMemcpyAsync(out_bwt_words, d_words.p, n_words * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_sa_samples, d_samples.p, n_samples * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_pac, d_pac.p, n_pac, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(small, d_small.p, sizeof small, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *out_inv_sa0 = inv_sa0;
+    out_cum[0] = 0;
+    for (int c = 0; c < 4; c++) out_cum[c + 1] = out_cum[c] + small[c];
+    if (out_rounds) *out_rounds = rounds;
+    if (out_ms_suffix_sort) (void)hipEventElapsedTime(out_ms_suffix_sort, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MP_OK;
 }
 
 extern "C" int mp_device_check(int device, char *out_name, size_t name_cap)

@@ -106,7 +106,27 @@ EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
            "mp_test_sort_longer_seed", "mp_coverage_create", "mp_coverage_destroy", "mp_coverage_add", "mp_coverage_finish", "mp_coverage_seq_stats",
-           "mp_coverage_spike_intervals", "mp_coverage_spike_bases"]
+           "mp_coverage_spike_intervals", "mp_coverage_spike_bases", "mp_build_index_arrays"]
+
+
+def build_index_arrays_native(codes, sa_interval: int = 16, device: int = 0):
+    """The compute of the reference's 2bwt-builder on the device (mp_build_index_arrays): from the text's base codes the BWT words
+    (MSB-first, '$' row left out), inverseSa0, cumulative counts, sampled suffix array and .pac bytes -- host numpy arrays in the
+    layouts megapath_amd.index_builder.write_index_files writes.  Returns (dict, info) with info = {rounds, ms_suffix_sort}."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n = int(codes.size)
+    bwt_words = np.zeros((n + 15) // 16, dtype=np.uint32)
+    samples = np.zeros((n + 1 + sa_interval - 1) // sa_interval, dtype=np.uint64)
+    pac = np.zeros((n + 3) // 4, dtype=np.uint8)
+    inv, cum = C.c_uint64(), (C.c_uint64 * 5)()
+    rounds, ms = C.c_uint32(), C.c_float()
+    lib = load_library()
+    lib.mp_build_index_arrays.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+    _chk(lib.mp_build_index_arrays(device, codes.ctypes.data, n, sa_interval, bwt_words.ctypes.data, samples.ctypes.data, pac.ctypes.data, C.byref(inv), cum,
+                                   C.byref(rounds), C.byref(ms)), "mp_build_index_arrays")
+    return (dict(n=n, inv_sa0=int(inv.value), cum=np.array(list(cum), dtype=np.uint64), bwt_words=bwt_words, sa_samples=samples, pac=pac),
+            dict(rounds=int(rounds.value), ms_suffix_sort=float(ms.value)))
 
 
 def build_library(force: bool = False) -> str:

@@ -1,14 +1,16 @@
 """2BWT index construction (the builder side of 2bwt-lib, off the hot path).
 
-Builds, from sequences of base codes, the arrays the reference's `2bwt-builder` writes to disk
-(2BWT-Builder.c:199-393, BWTConstruct.c, file layouts in SURVEY App. A): suffix array by prefix doubling with
-device-wide radix sorts (torch.sort -- plumbing, on the GPU when one is present), BWT with '$' omitted, cumulative
-frequencies, sampled SA, packed text.  The result can be handed to the HIP library directly
-(`mp_index_from_arrays`) or written out as reference-format index files (`write_index_files`), which the reference
-soap4 and this repo's loaders both read.
+Builds, from sequences of base codes or a FASTA parsed the reference's way, the arrays the reference's `2bwt-builder` writes to disk
+(2BWT-Builder.c:199-393, BWTConstruct.c, file layouts in SURVEY App. A): BWT with '$' omitted, inverseSa0, cumulative frequencies,
+sampled SA, packed text -- and writes them as reference-format index files (`write_index_files`: .bwt .fmv .sa .pac .ann .amb .tra
+[.lkt]), byte-identical to the real builder's (tests/golden/g1, tests/golden/nrun), which the reference soap4 and this repo's loaders
+both read; or hands them to the HIP library directly (`mp_index_from_arrays`).
 
-Limits: ACGT only ('N' and other letters map to G/A as the read path does; runs of >= 10 non-ACGT letters are not
-removed as HSPParseFASTAToPacked does, HSP.c:486-527); text length < 3.03e9 (the 63-bit rank-pair key of the doubling).
+The compute is the HIP library's `mp_build_index_arrays` (kernels_build.hip: suffix array by prefix doubling, device-wide radix sorts
+of (64-bit key, suffix) pairs and one streaming kernel per step; texts up to 2^32 - 3 bases) whenever a GPU is there.  `suffix_array`
+below is the same algorithm in torch calls: it runs on the CPU, where the not-gpu tests compare it with the real builder's files, and
+is limited to 3.03e9 bases (63-bit rank-pair key).  FASTA parsing (HSPParseFASTAToPacked, HSP.c:354-567: runs of >= 10 ambiguity
+letters removed and recorded for .tra / .amb, shorter ones replaced) and the file writers are host code.
 """
 from __future__ import annotations
 
@@ -16,6 +18,9 @@ import os
 
 import numpy as np
 import torch
+
+
+last_build_info = None      # {rounds, ms_suffix_sort} of the most recent native build
 
 
 def _device():
@@ -243,10 +248,16 @@ def translate_table(n, starts, ambiguity, first_amb_index):
     return out_grid, rows
 
 
-def build_index_arrays(seqs, sa_interval: int = 16, device=None):
+def build_index_arrays(seqs, sa_interval: int = 16, device=None, native=None):
     """seqs: list of (name, uint8 array of base codes 0..3 or ASCII letters), or the dict parse_fasta_reference_style() returns
     (then runs of >= 10 ambiguity letters are already removed and recorded for .tra).  Returns the keyword arguments of
-    `megapath_amd.hipapi.Index.from_arrays` (host numpy arrays in the reference's file layouts) plus what write_index_files needs."""
+    `megapath_amd.hipapi.Index.from_arrays` (host numpy arrays in the reference's file layouts) plus what write_index_files needs.
+
+    native: True = the HIP builder (mp_build_index_arrays: prefix doubling with device-wide radix sorts and its own kernels), False = the
+    torch restatement below (runs on the CPU too: the not-gpu tests compare it with the real builder's files); None = native when a GPU
+    is there.  Both give identical arrays (tests/test_gpu_parity.py)."""
+    if native is None:
+        native = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
     dev = device or _device()
     parsed = None
     if isinstance(seqs, dict):
@@ -271,6 +282,19 @@ def build_index_arrays(seqs, sa_interval: int = 16, device=None):
         pos += len(a)
     text = np.concatenate(parts)
     n = len(text)
+    if native:
+        from . import hipapi
+        dev_index = torch.device(device).index if device is not None and torch.device(device).index is not None else \
+            (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        core, info = hipapi.build_index_arrays_native(text, sa_interval, dev_index)
+        out = dict(core)
+        out["pac"] = np.concatenate([out["pac"], np.zeros(8, dtype=np.uint8)])
+        out.update(sa_interval=sa_interval, names=names, starts=np.asarray(starts, dtype=np.uint64), lengths=np.asarray(lengths, dtype=np.uint64))
+        if parsed is not None:
+            out["_fasta"] = dict(gi=parsed["gi"], ambiguity=parsed["ambiguity"], first_amb_index=parsed["first_amb_index"], actual=parsed["actual"])
+        global last_build_info
+        last_build_info = info
+        return out
     codes = torch.from_numpy(text).to(dev)
     sa = suffix_array(codes)                            # n+1 entries, sa[0] == n
     inv_sa0 = int(_nonzero(lambda c0, c1: sa[c0:c1] == 0, n + 1, dev)[0].item())
@@ -397,3 +421,47 @@ def write_index_files(prefix: str, arrs, write_lkt: bool = False, lkt_table=None
         with open(prefix + ".lkt", "wb") as f:
             f.write(np.int32(13).tobytes())
             f.write(table.tobytes())
+
+
+def main(argv=None) -> int:
+    """`2bwt-builder <sequence file>` (2BWT-Builder.c:199-393): writes <file>.index.{bwt,fmv,sa,pac,ann,amb,tra,lkt} like the reference's
+    builder -- same parsing of the FASTA (N runs, IUPAC codes, gi| headers), same files (the .ann carries a fixed number where the
+    reference writes a time-based seed).  The suffix array is built on the GPU (mp_build_index_arrays); the 13-mer table comes from the
+    HIP library's own loader of the new index, so the library has read the files' content once before they are written."""
+    import argparse
+    import sys
+    import time
+    ap = argparse.ArgumentParser(prog="2bwt-builder", description="build a 2BWT index (reference-compatible files) on an MI355X")
+    ap.add_argument("fasta")
+    ap.add_argument("--sa-interval", type=int, default=16, help="SaValueFreq of 2bwt-builder.ini (default 16, what soap4 expects)")
+    ap.add_argument("--device", type=int, default=int(os.environ.get("MP_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    ap.add_argument("--no-lkt", action="store_true", help="skip the 512 MiB 13-mer table (this repo's loaders rebuild it; the reference soap4 needs it)")
+    args = ap.parse_args(argv)
+    from . import hipapi
+    t0 = time.time()
+    try:
+        data = open(args.fasta, "rb").read()
+    except OSError as e:
+        print("Cannot open sequence file %s: %s" % (args.fasta, e), file=sys.stderr)
+        return 1
+    parsed = parse_fasta_reference_style(data)
+    if not parsed["names"]:
+        print("No sequence in %s" % args.fasta, file=sys.stderr)
+        return 1
+    arrs = build_index_arrays(parsed, sa_interval=args.sa_interval, device="cuda:%d" % args.device, native=True)
+    t1 = time.time()
+    lkt = None
+    if not args.no_lkt:
+        gix = hipapi.Index.from_arrays(args.device, **index_kwargs(arrs))
+        lkt = gix.lkt_table()
+        gix.close()
+    write_index_files(args.fasta + ".index", arrs, lkt_table=lkt)
+    info = last_build_info or {}
+    print("[2bwt-builder] %d bases in %d sequences, %d removed ambiguity runs: suffix array %.2f s (%s doubling rounds), arrays %.1f s, files %.1f s"
+          % (arrs["n"], len(arrs["names"]), len(parsed["ambiguity"]), info.get("ms_suffix_sort", 0.0) / 1e3, info.get("rounds", "?"), t1 - t0, time.time() - t1),
+          file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -290,3 +290,56 @@ def test_device_longer_seed_sort_is_the_reference_order(golden_dir):
         perm = np.zeros(max(len(lens), 1), dtype=np.int32)
         lib.mpo_sort_longer_seed_perm(np.ascontiguousarray(lens).ctypes.data, len(lens), perm.ctypes.data)
         assert np.array_equal(g.astype(np.int64), perm[:len(lens)].astype(np.int64)), a
+
+
+# ------------------------------------------------------------------------------------------------ native index builder (8f row 1)
+def _fasta_seqs(path):
+    seqs, name, buf = [], None, []
+    for line in open(path, "rb"):
+        line = line.rstrip()
+        if line.startswith(b">"):
+            if name is not None:
+                seqs.append((name, np.frombuffer(b"".join(buf), dtype=np.uint8)))
+            name, buf = line[1:].split()[0].decode(), []
+        else:
+            buf.append(line)
+    seqs.append((name, np.frombuffer(b"".join(buf), dtype=np.uint8)))
+    return seqs
+
+
+def test_native_builder_writes_the_reference_builders_files(golden_dir, tmp_path):
+    """mp_build_index_arrays (prefix doubling on the device) + the host file writers against the files the REAL 2bwt-builder wrote:
+    tests/golden/g1 (three sequences, 8 % copied repeats) and tests/golden/nrun (N runs removed, IUPAC codes) -- .bwt .fmv .sa .pac
+    .tra .amb byte-identical."""
+    from megapath_amd.index_builder import build_index_arrays, parse_fasta_reference_style, write_index_files
+    d = os.path.join(golden_dir, "g1")
+    arrs = build_index_arrays(_fasta_seqs(os.path.join(d, "ref.fa")), sa_interval=16, native=True)
+    prefix = str(tmp_path / "g1.index")
+    write_index_files(prefix, arrs, write_lkt=False)
+    for ext in (".bwt", ".sa", ".pac", ".fmv"):
+        assert open(prefix + ext, "rb").read() == open(os.path.join(d, "ref.fa.index" + ext), "rb").read(), ext
+    d = os.path.join(golden_dir, "nrun")
+    arrs = build_index_arrays(parse_fasta_reference_style(open(os.path.join(d, "n.fa"), "rb").read()), sa_interval=16, native=True)
+    prefix = str(tmp_path / "n.index")
+    write_index_files(prefix, arrs, write_lkt=False)
+    for ext in (".pac", ".bwt", ".fmv", ".sa", ".tra", ".amb"):
+        assert open(prefix + ext, "rb").read() == open(os.path.join(d, "n.fa.index" + ext), "rb").read(), ext
+
+
+@pytest.mark.parametrize("n,repeat,interval", [(1, 0.0, 1), (17, 0.0, 4), (5000, 0.0, 16), (300000, 0.5, 16), (2000003, 0.3, 32)])
+def test_native_builder_equals_the_torch_restatement(n, repeat, interval):
+    """Same arrays from the HIP builder and from the torch prefix doubling (which the not-gpu tests pin on the real builder's files),
+    on texts of awkward lengths, with long copied repeats (many doubling rounds) and a homopolymer tail."""
+    from megapath_amd import index_builder, synth
+    rng = np.random.default_rng(n)
+    genome = synth.random_genome(n, 1000 + n, n_seqs=1, repeat_frac=repeat) if n >= 5000 else [("s", rng.integers(0, 4, n, dtype=np.uint8))]
+    if n >= 5000:
+        genome[0][1][-700:] = ord("G")                            # a run of one letter at the very end: the '$' ordering decides
+    a = index_builder.build_index_arrays(genome, sa_interval=interval, native=True)
+    rounds = index_builder.last_build_info["rounds"]
+    b = index_builder.build_index_arrays(genome, sa_interval=interval, native=False, device="cpu")
+    assert a["n"] == b["n"] and a["inv_sa0"] == b["inv_sa0"]
+    for k in ("cum", "bwt_words", "sa_samples", "pac"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    if repeat > 0:
+        assert rounds >= 5                                        # kilobase repeats need h up to a few thousand

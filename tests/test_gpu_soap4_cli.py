@@ -416,3 +416,23 @@ def test_cli_spike_filter_equals_the_file_pipeline(golden_dir, tmp_path, k, over
     want_names = sorted(S.read_filter(bed, mine, overlap))
     got_names = sorted(open(prefix + ".readFilter").read().split())
     assert got_names == want_names and 0 < len(want_names) < len(bed)
+
+
+def test_builder_cli_then_align(golden_dir, tmp_path):
+    """`bin/2bwt-builder ref.fa` (the reference builder's command line) on the golden genome: the files equal the real builder's, and
+    `bin/soap4` aligning against the freshly built index prints the golden stdout of the real soap4."""
+    import shutil
+    d = os.path.join(golden_dir, "g1")
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(d, "ref.fa"), fa)
+    r = subprocess.run([os.path.join(ROOT, "bin", "2bwt-builder"), fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    for ext in (".bwt", ".fmv", ".sa", ".pac", ".tra", ".amb"):
+        assert open(fa + ".index" + ext, "rb").read() == open(os.path.join(d, "ref.fa.index" + ext), "rb").read(), ext
+    assert os.path.getsize(fa + ".index.lkt") == 4 + 8 * 4 ** 13
+    out = tmp_path / "out.fq"
+    _run_cli(["pair", fa + ".index", os.path.join(d, "reads_a_1.fq"), os.path.join(d, "reads_a_2.fq"), "-o", str(tmp_path / "o"),
+              "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "2", "-u", "750", "-F", "-nc"], out)
+    assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_a.fq"))
+    r = subprocess.run([os.path.join(ROOT, "bin", "2bwt-builder"), str(tmp_path / "missing.fa")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Cannot open" in r.stderr

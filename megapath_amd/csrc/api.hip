@@ -1517,6 +1517,9 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
     const uint32_t nc = (uint32_t)h.n_cand;
     st.n_candidates = nc; st.n_dp_left = nc;
     c->n_pair_hits_host = 0;
+    // pairs with a hit of this round (the rescue round works on the others): set by collect_pair_hits_kernel as it stores a hit
+    if (c->pair_done.reserve((size_t)c->n_reads / 2 + 1)) return MP_ENOMEM;
+    HIPCHK(hipMemsetAsync(c->pair_done.p, 0, ((size_t)c->n_reads / 2 + 1) * 4, s));
     if (nc) {
         if (c->tasks_l.reserve(nc) || c->tasks_r.reserve(nc) || c->res_l.reserve(nc) || c->res_r.reserve(nc) || c->pair_hits.reserve(nc)) return MP_ENOMEM;
         const uint32_t margin2 = 60;
@@ -1537,7 +1540,7 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(c->n_pair_hits.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(collect_pair_hits_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,
-                           c->res_r.p, c->pair_hits.p, c->n_pair_hits.p, (uint32_t)c->pair_hits.cap);
+                           c->res_r.p, c->pair_hits.p, c->n_pair_hits.p, (uint32_t)c->pair_hits.cap, c->pair_done.p);
         MP_TRACE(s, "collect_pair_hits_kernel");
         unsigned long long nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, c->n_pair_hits.p, sizeof nh, hipMemcpyDeviceToHost, s));
@@ -1642,15 +1645,11 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
     HIPCHK(hipSetDevice(c->ix->device));
     if (c->rescue_copy_started) { HIPCHK(hipEventSynchronize(c->ev_rescue_copied)); c->rescue_copy_started = false; }
     hipStream_t s = c->stream;
-    const uint32_t n_reads = c->n_reads, n_pairs = n_reads / 2;
+    const uint32_t n_reads = c->n_reads;
     mp_rescue_stats st{};
     const hipEvent_t t0 = c->ev_round[0], t1 = c->ev_round[1], t2 = c->ev_round[2];
     HIPCHK(hipEventRecord(t0, s));
-    if (c->pair_done.reserve(n_pairs + 1) || c->failed_flag.reserve(n_reads + 2) || c->failed_off.reserve(n_reads + 2)) return MP_ENOMEM;
-    HIPCHK(hipMemsetAsync(c->pair_done.p, 0, (size_t)(n_pairs + 1) * 4, s));
-    if (c->n_pair_hits_host)
-        hipLaunchKernelGGL(mark_done_kernel, dim3(grid_for(c->n_pair_hits_host, 256)), dim3(256), 0, s, c->pair_hits.p, (uint32_t)c->n_pair_hits_host, c->pair_done.p);
-        MP_TRACE(s, "mark_done_kernel");
+    if (c->failed_flag.reserve(n_reads + 2) || c->failed_off.reserve(n_reads + 2) || !c->pair_done.p) return MP_ENOMEM;      // (pair_done: left by the deep-DP round of this batch)
     hipLaunchKernelGGL(failed_flag_kernel, dim3(grid_for(n_reads + 1, 256)), dim3(256), 0, s, c->pair_done.p, n_reads, c->failed_flag.p);
     MP_TRACE(s, "failed_flag_kernel");
     int rc = exclusive_scan_u32(c, c->failed_flag.p, c->failed_off.p, n_reads + 1);

@@ -738,7 +738,7 @@ __global__ void build_right_tasks_kernel(const mp_candidate *__restrict__ cands,
 __global__ void collect_pair_hits_kernel(const mp_candidate *__restrict__ cands, uint32_t n, const uint32_t *__restrict__ lens,
                                          const mp_dp_task *__restrict__ lt, const mp_dp_result *__restrict__ lr,
                                          const mp_dp_task *__restrict__ rt, const mp_dp_result *__restrict__ rr,
-                                         mp_pair_hit *__restrict__ hits, unsigned long long *n_hits, uint32_t cap)
+                                         mp_pair_hit *__restrict__ hits, unsigned long long *n_hits, uint32_t cap, uint32_t *__restrict__ pair_done)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -766,4 +766,5 @@ __global__ void collect_pair_hits_kernel(const mp_candidate *__restrict__ cands,
         h.count_1 = (uint16_t)b.max_score_count; h.count_2 = (uint16_t)a.max_score_count;
     }
     hits[slot] = h;
+    pair_done[h.pair_id] = 1u;
 }

@@ -1,7 +1,6 @@
 // megapath_amd/csrc/kernels_rescue.hip -- product code: task generation for the rescue passes of pairs the deep-DP
 // round left unaligned (reference soap4/alignment.cpp:137-250).  The DP itself is the same dp_fill / dp_trace kernels.
 //
-//   mark_done_kernel          pairs that produced at least one deep-DP hit
 //   list_failed_kernel        compact list of reads belonging to failed pairs
 //   single_cand_kernel        transferSeed + singleMerge: pooled seeds -> <= 200 DP candidates per read
 //                             (DV-DPForSingleReads.cpp:121-215, DV-DPfunctions.cpp:295-342)
@@ -10,12 +9,6 @@
 //                             (DV-SemiDP.cpp:37-44, DV-DPfunctions.cpp:1048-1079) -> HalfEndAlgnBatch::pack windows (:1151-1231)
 #include <hip/hip_runtime.h>
 #include "mp_internal.h"
-
-__global__ void mark_done_kernel(const mp_pair_hit *__restrict__ hits, uint32_t n_hits, uint32_t *__restrict__ pair_done)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_hits) pair_done[hits[t].pair_id] = 1u;
-}
 
 // failed_flag[r] = 1 for both reads of a pair without deep-DP hit; an exclusive scan of it gives the slot of each read
 __global__ void failed_flag_kernel(const uint32_t *__restrict__ pair_done, uint32_t n_reads, uint32_t *__restrict__ failed_flag)

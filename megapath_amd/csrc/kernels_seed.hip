@@ -183,21 +183,25 @@ __global__ void prep_scan_kernel(const uint32_t *reads, const uint32_t *lens, ui
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t total = (uint64_t)n_reads * 2 * W2;
     if (t >= total) return;
-    uint32_t w = (uint32_t)(t % W2);
-    uint32_t rs = (uint32_t)(t / W2);
-    uint32_t r = rs >> 1, strand = rs & 1;
-    uint32_t len = lens[r];
+    const int w = (int)(t % W2);
+    const uint32_t rs = (uint32_t)(t / W2);
+    const uint32_t r = rs >> 1, strand = rs & 1;
+    const int len = (int)lens[r], nw = (len + 15) / 16;
     const uint32_t *src = reads + (uint64_t)r * W;
     uint32_t out = 0;
-#pragma unroll 4
-    for (uint32_t j = 0; j < 16; j++) {
-        uint32_t k = w * 16 + j;
-        if (k < len) {
-            uint32_t p = strand == 0 ? len - 1 - k : k;
-            uint32_t c = (src[p >> 4] >> (2 * (p & 15))) & 3u;
-            if (strand) c = 3u - c;
-            out |= c << (2 * j);
+    if (w < nw) {
+        if (strand) out = ~src[w];                                 // left to right, complemented
+        else {
+            // right to left: the 2-bit groups of every word reversed, the words in reverse order, and the 16 nw - len pad bases that the
+            // reversal brought to the front shifted out
+            auto z = [&](int q) -> uint32_t {
+                if (q >= nw) return 0u;
+                const uint32_t x = __brev(src[nw - 1 - q]);
+                return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+            };
+            out = (uint32_t)((((uint64_t)z(w + 1) << 32) | z(w)) >> (2u * (uint32_t)(16 * nw - len)));
         }
+        if (w == nw - 1 && (len & 15)) out &= (1u << (2 * (len & 15))) - 1u;     // zero padding past the read's end
     }
     scan[t] = out;
 }

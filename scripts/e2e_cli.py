@@ -21,6 +21,8 @@ ap.add_argument("--pairs", type=int, default=1 << 20)
 ap.add_argument("--bam", action="store_true")
 ap.add_argument("--gz", action="store_true")
 ap.add_argument("--threads", type=int, default=2)
+ap.add_argument("--null", action="store_true", help="stdout to /dev/null: the host pipeline without the file system")
+ap.add_argument("--extra", default="", help="extra soap4 flags, e.g. -lsam-noseq")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 tmp = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
@@ -56,11 +58,11 @@ print("reads written in %.1f s" % (time.time() - t0), flush=True)
 del text, codes
 torch.cuda.empty_cache()
 cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix, f1, f2, "-o", os.path.join(tmp, "out"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
-       "-L", "151", "-T", str(args.threads), "-u", "750", "-F", "-nc"] + (["-b"] if args.bam else [])
+       "-L", "151", "-T", str(args.threads), "-u", "750", "-F", "-nc"] + (["-b"] if args.bam else []) + args.extra.split()
 t0 = time.time()
-with open(os.path.join(tmp, "out.fq"), "wb") as fo:
+with open("/dev/null" if args.null else os.path.join(tmp, "out.fq"), "wb") as fo:
     r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, MP_TIMING="1"))
 wall = time.time() - t0
 print(r.stderr.decode()[-1500:])
 print("rc %d, wall %.2f s (index load included) -> %.0f pairs/s over the whole process" % (r.returncode, wall, P / wall))
-print("stdout bytes", os.path.getsize(os.path.join(tmp, "out.fq")), [(f, os.path.getsize(os.path.join(tmp, f))) for f in os.listdir(tmp) if f.startswith("out.")])
+print("stdout bytes", 0 if args.null else os.path.getsize(os.path.join(tmp, "out.fq")), [(f, os.path.getsize(os.path.join(tmp, f))) for f in os.listdir(tmp) if f.startswith("out.")])

@@ -1026,9 +1026,14 @@ void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint3
 {
     if (LPI * C <= 160) {
         // the leaner filter kernel for reads of up to 160 bases: 8 lanes x 20 columns per instance pair (kernels_dp.hip)
+        // (19 columns per lane when no read is longer than 152 bases: 150-base reads then leave 2 idle columns instead of 10)
         const unsigned pairs8 = (n + 1) / 2, groups8 = MP_DP_BLOCK / 8;
-        hipLaunchKernelGGL((dp_score_kernel<8, 20>), dim3(grid_for(pairs8, groups8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                           tasks, n, fill);
+        if (c->max_len <= 8 * 19)
+            hipLaunchKernelGGL((dp_score_kernel<8, 19>), dim3(grid_for(pairs8, groups8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                               tasks, n, fill);
+        else
+            hipLaunchKernelGGL((dp_score_kernel<8, 20>), dim3(grid_for(pairs8, groups8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                               tasks, n, fill);
         MP_TRACE(s, "dp_score_kernel");
         return;
     }

@@ -1235,12 +1235,22 @@ __device__ __forceinline__ uint32_t mp_rs_keys(const mp_dev_index &ix, const mp_
             mp_seed_hit h;
             h.length = (uint16_t)seedlen; h.qo = (uint16_t)off; h.strand = (uint16_t)strand;
             h.mult = (seedlen >= (uint32_t)P.good_seed_len || seedlen >= len / 2 || located) ? (uint16_t)1 : (uint16_t)(rec.sa_diff + 1);
-            for (uint32_t k = 0; k < rows; k++) {
-                const uint32_t row = rec.sa_l + k;
-                // SA[0] is kept as -1 (BWT.c:242,994-996); unsigned 64-bit arithmetic: the projection may wrap exactly as in the reference
-                const uint64_t sav = located ? (uint64_t)rec.sa_l : (row == 0 ? ~0ull : (uint64_t)(k == 0 ? sa4[u] : ix.sa_dense[row]));
+            // SA[0] is kept as -1 (BWT.c:242,994-996); unsigned 64-bit arithmetic: the projection may wrap exactly as in the reference
+            auto emit = [&](uint64_t sav) {
                 h.offset = strand == 0 ? sav - off : sav - ((uint64_t)len - seedlen - off);
                 dst[w++] = hit_key(h, P);
+            };
+            if (located) emit((uint64_t)rec.sa_l);
+            else {
+                emit(rec.sa_l == 0 ? ~0ull : (uint64_t)sa4[u]);
+                // further rows of a seed with several occurrences: consecutive suffix-array entries, eight loads in flight at a time
+                for (uint32_t k0 = 1; k0 < rows; k0 += 8) {
+                    uint32_t v8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v8[q] = k0 + q < rows ? ix.sa_dense[rec.sa_l + k0 + q] : 0u;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) if (k0 + q < rows) emit((uint64_t)v8[q]);
+                }
             }
         }
     }

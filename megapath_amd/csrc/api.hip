@@ -88,7 +88,7 @@ struct mp_ctx {
     DevBuf<mp_dp_result> sel_res;
     DevBuf<uint32_t> band_flag, band_idx;        // instances the band kernel left to the full kernels
     DevBuf<uint32_t> near_flag, near_idx, near_list, far_flag, far_idx, far_list;   // classes of the second band pass
-    DevBuf<uint32_t> pre_cls, narrow_list, wide_list;                               // dp_prefilter_kernel's classes: first band pass over 27 / 87 diagonals
+    DevBuf<uint32_t> pre_cls, narrow_list, wide_list, narrow15_list;                               // dp_prefilter_kernel's classes: first band pass over 27 / 87 diagonals
     DevBuf<uint32_t> mid_flag, mid_idx, mid_list;                                   // scores L-9 .. L-6: second pass over 15 diagonals
     DevBuf<uint32_t> vfar_flag, vfar_idx, vfar_list, und_list[2];                   // second tier; instances still undecided after a tier
     DevBuf<mp_dp_task> band_tasks;
@@ -717,7 +717,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->census.release();
     c->sh_flag.release(); c->sh_slot.release(); c->rh_flag.release(); c->rh_slot.release(); c->d_single_hits.release(); c->d_rescue_hits.release();
     c->band_flag.release(); c->band_idx.release(); c->near_flag.release(); c->near_idx.release(); c->near_list.release(); c->far_flag.release(); c->far_idx.release();
-    c->far_list.release(); c->pre_cls.release(); c->narrow_list.release(); c->wide_list.release(); c->mid_flag.release(); c->mid_idx.release(); c->mid_list.release();
+    c->far_list.release(); c->pre_cls.release(); c->narrow_list.release(); c->wide_list.release(); c->narrow15_list.release(); c->mid_flag.release(); c->mid_idx.release(); c->mid_list.release();
     c->vfar_flag.release(); c->vfar_idx.release(); c->vfar_list.release(); c->und_list[0].release(); c->und_list[1].release(); c->band_tasks.release();
     c->band_res.release(); c->band_fill.release();
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1256,12 +1256,29 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     MP_TRACE(s, "dp_class_flag_kernel");
     hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_WIDE, c->far_flag.p);
     MP_TRACE(s, "dp_class_flag_kernel");
-    { int rc0 = scan(c->near_flag.p, c->near_idx.p); if (rc0) return rc0; rc0 = scan(c->far_flag.p, c->far_idx.p); if (rc0) return rc0; }
-    uint32_t n_narrow = 0, n_wide = 0;
+    if (TIER1) { hipLaunchKernelGGL(dp_class_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t *)c->pre_cls.p, n, MP_PRE_NARROW15, c->mid_flag.p); MP_TRACE(s, "dp_class_flag_kernel"); }
+    { int rc0 = scan(c->near_flag.p, c->near_idx.p); if (rc0) return rc0; rc0 = scan(c->far_flag.p, c->far_idx.p); if (rc0) return rc0;
+      if (TIER1) { rc0 = scan(c->mid_flag.p, c->mid_idx.p); if (rc0) return rc0; } }
+    uint32_t n_narrow = 0, n_wide = 0, n_narrow15 = 0;
     HIPCHK(hipMemcpyAsync(&n_narrow, c->near_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&n_wide, c->far_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    if (TIER1) HIPCHK(hipMemcpyAsync(&n_narrow15, c->mid_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (c->narrow_list.reserve(n_narrow + 130) || c->wide_list.reserve(n_wide + 130)) return MP_ENOMEM;
+    if (c->narrow_list.reserve(n_narrow + 130) || c->wide_list.reserve(n_wide + 130) || c->narrow15_list.reserve(n_narrow15 + 130)) return MP_ENOMEM;
+    if (n_narrow15) {
+        // a diagonal with at most two mismatches is known: 15 diagonals decide the instance (dp_prefilter_kernel)
+        hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->mid_flag.p, c->mid_idx.p, n, c->narrow15_list.p, in_list);
+        MP_TRACE(s, "dp_band_list_kernel");
+        const dim3 g15((n_narrow15 + 127) / 128);
+        census_add(c, CENSUS_BAND_SCORE, d_tasks, c->narrow15_list.p, n_narrow15, MP_BAND_WM);
+        if (small)
+            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_WM, MP_BAND_GBM, 160, 3>), g15, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_narrow15, cl, cr,
+                               (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p, (const uint32_t *)c->narrow15_list.p);
+        else
+            hipLaunchKernelGGL((dp_band_kernel<MP_BAND_WM, MP_BAND_GBM, MP_BAND_MAXL, 3>), g15, dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_narrow15,
+                               cl, cr, (uint32_t *)nullptr, 0u, (const mp_fill_result *)c->band_fill.p, c->band_fill.p, (const uint32_t *)c->narrow15_list.p);
+        MP_TRACE(s, "dp_band_kernel");
+    }
     if (n_narrow) {
         hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->near_flag.p, c->near_idx.p, n, c->narrow_list.p, in_list);
         MP_TRACE(s, "dp_band_list_kernel");
@@ -1291,7 +1308,7 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
         MP_TRACE(s, "dp_band_kernel");
     }
     static const bool verbose2 = getenv("MP_DP_BAND_STATS") != nullptr;
-    if (verbose2) fprintf(stderr, "[band] tier %d pre-filter: %u narrow, %u whole band, of %u\n", TIER1 ? 1 : 2, n_narrow, n_wide, n);
+    if (verbose2) fprintf(stderr, "[band] tier %d pre-filter: %u narrow (15 diagonals), %u narrow, %u whole band, of %u\n", TIER1 ? 1 : 2, n_narrow15, n_narrow, n_wide, n);
     HIPCHK(hipEventRecord(c->ev_pool[1], s));
     // classes by distance from the best cell's diagonal; perfect matches, plain diagonal alignments (mismatches only; MP_DP_DIAG=0
     // sends them through the second pass like the rest: test switch) and instances below their cutoff are finished here

@@ -314,6 +314,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #define MP_BAND_TW ((MP_BAND_MAXL + MP_BAND_DMAX) / 16 + 2)
 #define MP_PRE_MINB 8
 #define MP_PRE_NONE 3u
+#define MP_PRE_NARROW15 4u         // as MP_PRE_NARROW, and a diagonal with at most two mismatches exists: 15 diagonals decide it
 #define MP_PRE_WIDE 2u
 #define MP_PRE_NARROW 1u
 #define MP_PRE_DONE 0u
@@ -401,26 +402,31 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
     if (dhi < dlo) { cls[slot] = MP_PRE_NONE; fill[t] = r; return; }
     if (dhi - dlo > 4) { fill[t] = r; return; }                 // wide
     const int centre = (dlo + dhi) >> 1;                        // floor: dlo + 2 >= centre >= dhi - 2
-    // ---- exact diagonals among the matching ones
-    int first = -1, exact = 0;
+    // ---- exact diagonals among the matching ones; fewest mismatches of the read laid on one of them
+    int first = -1, exact = 0, kmin = 1 << 20;
     const uint32_t tail = (L & 15) ? ((1u << (2 * (L & 15))) - 1u) : 0xFFFFFFFFu;
     for (int dl = max(dlo, 0); dl <= min(dhi, m - L); dl++) {
-        bool same = true;
-        for (int w = 0; w < nw && same; w++) {
+        int kk = 0;
+        for (int w = 0; w < nw; w++) {
             const int at = 16 * w + dl;
             const uint64_t two = ((uint64_t)s_t[(at >> 4) + 1][lane] << 32) | s_t[at >> 4][lane];
             uint32_t x = (uint32_t)(two >> (2 * (at & 15))) ^ s_a[w][lane];
             if (w == nw - 1) x &= tail;
-            same = x == 0;
+            kk += __popc((x | (x >> 1)) & 0x55555555u);
+            if (kk > 2) break;                                  // only 0, 1, 2 matter
         }
-        if (same) { if (first < 0) first = dl; exact++; }
+        if (kk == 0) { if (first < 0) first = dl; exact++; }
+        kmin = kk < kmin ? kk : kmin;
     }
     if (first >= 0) {
         r.score = L; r.row = (uint16_t)(first + L); r.col = (uint16_t)L; r.count = exact > 255 ? 255u : (uint32_t)exact;
         cls[slot] = MP_PRE_DONE;
     } else {
         r.score = -2; r.row = (uint16_t)(centre + 256); r.col = 256; r.count = 0;      // row - col = centre, read by the MODE 3 pass
-        cls[slot] = MP_PRE_NARROW;
+        // At most two mismatches on one of those diagonals: the best score is >= L - 6, and an alignment that loses at most 7 has
+        // at most 5 gap bases (a gap of k bases costs k + 2), i.e. stays within 2 + 5 diagonals of the centre: the first pass over
+        // 15 diagonals (qualifying score L - 7) is certain to decide it.
+        cls[slot] = (GBUD == MP_BAND_GB && kmin <= 2) ? MP_PRE_NARROW15 : MP_PRE_NARROW;
     }
     fill[t] = r;
 }

@@ -9,7 +9,8 @@
 // K4  pair_kernel     one lane per pair: insert-window join of '+' seeds with the mate's '-' seeds
 //                     (pairEndMerge, DV-DPfunctions.cpp:1968-2070).
 // All of it is dependent integer gathers over HBM-resident tables: no LDS tiling applies, the levers are one 64-byte
-// sector per rank query, enough waves in flight to cover ~1 us of HBM latency per step, and no host round trips.
+// sector per rank query, every lane's dependent load of a step in flight at once (one wait per trip of the persistent
+// loop), few instructions per step (bit-plane rank blocks), and no host round trips.
 #include <hip/hip_runtime.h>
 #include "mp_internal.h"
 
@@ -208,8 +209,9 @@ __global__ void prep_scan_kernel(const uint32_t *reads, const uint32_t *lens, ui
 
 // ------------------------------------------------------------------------------------------------ K1
 // Persistent lanes: every lane pulls (read, strand) items from one queue until it is empty, so a wavefront never idles
-// behind its slowest read.  One trip of the loop issues at most one LKT lookup and one pair of rank queries per lane,
-// whatever mix of states the 64 lanes are in, which keeps the number of serialised memory waits per trip at two.
+// behind its slowest read.  seed_kernel (below) issues one load per lane and trip and waits once, whatever mix of states the
+// 64 lanes are in; mp_mmp_trip is the same state machine written as branches that load and use (kept for
+// seed_overflow_kernel: one item per lane, run to completion).
 // Seeds go to a fixed slab of MP_SEED_SLAB records per (read, strand) -- no atomics on the hot path; the rare item with
 // more seeds is listed in `overflow_rs` and redone by seed_overflow_kernel with a full-size slab.
 #define MP_SEED_SLAB 64

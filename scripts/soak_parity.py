@@ -1,0 +1,72 @@
+"""Randomised whole-path parity campaign on the GPU box: bin/soap4-mi355x against the oracle (test infrastructure) on freshly generated
+genomes and read sets with randomly drawn shapes.  python scripts/soak_parity.py [--rounds 40] [--seed 1]; prints every configuration and
+stops with exit code 1 at the first difference (the configuration is then reproducible from its line)."""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from conftest import fastq_records  # noqa: E402
+from megapath_amd import index_builder, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=40)
+ap.add_argument("--seed", type=int, default=1)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+lib = O.oracle()
+for rnd in range(args.rounds):
+    read_len = int(rng.choice([76, 100, 150, 150, 150, 250, 300]))
+    cfg = dict(n_bases=int(rng.integers(100000, 800000)), n_seqs=int(rng.integers(1, 8)), rep=float(rng.choice([0.0, 0.05, 0.2, 0.5])),
+               n_pairs=int(rng.integers(500, 4000)), read_len=read_len, gseed=int(rng.integers(1, 1 << 30)), rseed=int(rng.integers(1, 1 << 30)),
+               mode=int(rng.choice([1, 1, 2])), threads=int(rng.integers(1, 6)),
+               # which optional index tables the run may build (every combination takes another path through the seeding kernels)
+               env={k: str(int(v)) for k, v in (("MP_KMER_FILTER", rng.random() < 0.8), ("MP_KMER15", rng.random() < 0.7), ("MP_LKT16", rng.random() < 0.7),
+                                                ("MP_SA_DENSE", rng.random() < 0.7), ("MP_LKT16U", rng.random() < 0.7), ("MP_SA_DENSE_SPACING", rng.choice([1, 1, 2, 4])),
+                                                ("MP_DP_DIAG", rng.random() < 0.8))},
+               kw=dict(sub=float(rng.choice([0.0, 0.005, 0.01, 0.03, 0.06])), ins=float(rng.choice([0.0, 0.001, 0.004])), dele=float(rng.choice([0.0, 0.001, 0.004])),
+                       random_frac=float(rng.choice([0.0, 0.05, 0.3])), broken_mate_frac=float(rng.choice([0.0, 0.1, 0.3])),
+                       noisy_mate_frac=float(rng.choice([0.0, 0.2])), noisy_sub=0.15, n_frac=float(rng.choice([0.0, 0.002])),
+                       long_indel_frac=float(rng.choice([0.0, 0.2])), long_indel_max=int(rng.integers(4, 27)),
+                       junk_end_frac=float(rng.choice([0.0, 0.3])), junk_end_max=int(rng.integers(5, 60)),
+                       len_range=(max(20, read_len // 3), read_len) if rng.random() < 0.4 else None,
+                       frag_mean=read_len + 200, frag_sd=40, frag_min=read_len + 20, frag_max=min(740, read_len + 420)))
+    print("round %d: %r" % (rnd, cfg), flush=True)
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        genome = synth.random_genome(cfg["n_bases"], cfg["gseed"], n_seqs=cfg["n_seqs"], repeat_frac=cfg["rep"])
+        prefix = os.path.join(tmp, "g.index")
+        index_builder.write_index_files(prefix, index_builder.build_index_arrays(genome, sa_interval=16))
+        names, r1, r2 = synth.simulate_pairs(genome, cfg["n_pairs"], read_len, cfg["rseed"], **cfg["kw"])
+        f1, f2 = os.path.join(tmp, "r_1.fq"), os.path.join(tmp, "r_2.fq")
+        synth.write_fastq_pair(f1, f2, names, r1, r2)
+        L = read_len + 1
+        out = os.path.join(tmp, "out.fq")
+        cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix, f1, f2, "-o", os.path.join(tmp, "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
+               "-L", str(L), "-T", str(cfg["threads"]), "-u", "750", "-F" if cfg["mode"] == 1 else "-P", "-nc"]
+        with open(out, "wb") as fo:
+            r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, MP_BATCH_PAIRS=str(max(64, cfg["n_pairs"] // 3)), **cfg["env"]))
+        if r.returncode != 0:
+            print("FAILED to run:", r.stderr.decode()[-800:])
+            sys.exit(1)
+        ix = lib.mpo_index_open(prefix.encode())
+        p = O.default_params(L=L, mode=cfg["mode"], nc=True)
+        st = O.AlignStats()
+        want = os.path.join(tmp, "want.fq")
+        assert lib.mpo_align_fastq(ix, C.byref(p), f1.encode(), f2.encode(), want.encode(), None, C.byref(st)) == 0
+        lib.mpo_index_close(ix)
+        a, b = fastq_records(out), fastq_records(want)
+        if a != b:
+            bad = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]
+            print("DIFFERENT: %d vs %d records, first differing %s" % (len(a), len(b), bad[:5]))
+            for i in bad[:3]:
+                print(" got ", a[i][:3]); print(" want", b[i][:3])
+            sys.exit(1)
+print("all %d rounds equal" % args.rounds)

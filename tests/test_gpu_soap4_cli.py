@@ -436,3 +436,36 @@ def test_builder_cli_then_align(golden_dir, tmp_path):
     assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_a.fq"))
     r = subprocess.run([os.path.join(ROOT, "bin", "2bwt-builder"), str(tmp_path / "missing.fa")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"Cannot open" in r.stderr
+
+
+SOAK = [  # (seed, genome bases, sequences, repeat fraction, pairs, read length, -L, simulate_pairs keywords)
+    (11, 400000, 3, 0.15, 2500, 150, 151, dict(sub=0.01, ins=0.001, dele=0.001, random_frac=0.05)),
+    (12, 250000, 1, 0.30, 2000, 150, 151, dict(sub=0.03, ins=0.003, dele=0.003, random_frac=0.10, broken_mate_frac=0.1, junk_end_frac=0.2, junk_end_max=40)),
+    (13, 300000, 5, 0.05, 2000, 100, 101, dict(sub=0.02, random_frac=0.05, len_range=(40, 100), noisy_mate_frac=0.2, noisy_sub=0.12)),
+    (14, 500000, 2, 0.10, 1500, 250, 251, dict(sub=0.015, ins=0.002, dele=0.002, random_frac=0.05, long_indel_frac=0.2, long_indel_max=20,
+                                               frag_mean=450, frag_sd=50, frag_min=300, frag_max=700)),
+    (15, 200000, 2, 0.50, 1500, 150, 151, dict(sub=0.005, random_frac=0.3, n_frac=0.002)),
+    (16, 350000, 4, 0.10, 1500, 300, 301, dict(sub=0.02, ins=0.001, dele=0.001, random_frac=0.1, broken_mate_frac=0.3, len_range=(75, 300),
+                                               frag_mean=500, frag_sd=60, frag_min=320, frag_max=740)),
+]
+
+
+@pytest.mark.parametrize("cfg", SOAK, ids=[str(c[0]) for c in SOAK])
+def test_cli_equals_oracle_on_random_workloads(tmp_path, cfg):
+    """Whole path through the executable against the oracle's whole path on freshly generated genomes and read sets of several shapes
+    (repeat-rich, divergent, short / long / mixed lengths, junk ends, long indels, broken and noisy mates, many random pairs): the
+    index is built by bin/2bwt-builder's code path, every optional table is on (the index is small), two batches per worker."""
+    from megapath_amd import index_builder, synth
+    seed, n_bases, n_seqs, rep, n_pairs, read_len, L, kw = cfg
+    genome = synth.random_genome(n_bases, 7000 + seed, n_seqs=n_seqs, repeat_frac=rep)
+    prefix = str(tmp_path / "soak.index")
+    index_builder.write_index_files(prefix, index_builder.build_index_arrays(genome, sa_interval=16))
+    names, r1, r2 = synth.simulate_pairs(genome, n_pairs, read_len, 8000 + seed, **kw)
+    f1, f2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    synth.write_fastq_pair(f1, f2, names, r1, r2)
+    out = tmp_path / "out.fq"
+    _run_cli(["pair", prefix, f1, f2, "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L), "-T", "4", "-u", "750", "-F", "-nc"],
+             out, batch_pairs=max(64, n_pairs // 5))
+    got, want = fastq_records(str(out)), fastq_records(_oracle_stdout(prefix, f1, f2, L, tmp_path))
+    assert len(got) == len(want) == 2 * n_pairs
+    assert got == want

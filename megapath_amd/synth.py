@@ -113,6 +113,7 @@ def simulate_pairs(seqs, n_pairs: int, read_len: int, seed: int, frag_mean: floa
                 k = int(rng.integers(3, junk_end_max + 1))
                 pick_a = rng.random() < 0.5
                 tgt = (a if pick_a else b).copy()
+                k = min(k, len(tgt))
                 if rng.random() < 0.5:
                     tgt[:k] = _BASES[rng.integers(0, 4, size=k)]
                 else:

@@ -27,7 +27,7 @@ for rnd in range(args.rounds):
     read_len = int(rng.choice([76, 100, 150, 150, 150, 250, 300]))
     cfg = dict(n_bases=int(rng.integers(100000, 800000)), n_seqs=int(rng.integers(1, 8)), rep=float(rng.choice([0.0, 0.05, 0.2, 0.5])),
                n_pairs=int(rng.integers(500, 4000)), read_len=read_len, gseed=int(rng.integers(1, 1 << 30)), rseed=int(rng.integers(1, 1 << 30)),
-               mode=int(rng.choice([1, 1, 2])), threads=int(rng.integers(1, 6)),
+               mode=int(rng.choice([1, 1, 2])), threads=int(rng.integers(1, 6)), bam=bool(rng.random() < 0.4 and read_len <= 300),
                # which optional index tables the run may build (every combination takes another path through the seeding kernels)
                env={k: str(int(v)) for k, v in (("MP_KMER_FILTER", rng.random() < 0.8), ("MP_KMER15", rng.random() < 0.7), ("MP_LKT16", rng.random() < 0.7),
                                                 ("MP_SA_DENSE", rng.random() < 0.7), ("MP_LKT16U", rng.random() < 0.7), ("MP_SA_DENSE_SPACING", rng.choice([1, 1, 2, 4])),
@@ -50,7 +50,7 @@ for rnd in range(args.rounds):
         L = read_len + 1
         out = os.path.join(tmp, "out.fq")
         cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix, f1, f2, "-o", os.path.join(tmp, "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
-               "-L", str(L), "-T", str(cfg["threads"]), "-u", "750", "-F" if cfg["mode"] == 1 else "-P", "-nc"]
+               "-L", str(L), "-T", str(cfg["threads"]), "-u", "750", "-F" if cfg["mode"] == 1 else "-P", "-nc"] + (["-b", "-p", "-D", "rg1", "-A", "default"] if cfg["bam"] else [])
         with open(out, "wb") as fo:
             r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, MP_BATCH_PAIRS=str(max(64, cfg["n_pairs"] // 3)), **cfg["env"]))
         if r.returncode != 0:
@@ -60,8 +60,22 @@ for rnd in range(args.rounds):
         p = O.default_params(L=L, mode=cfg["mode"], nc=True)
         st = O.AlignStats()
         want = os.path.join(tmp, "want.fq")
-        assert lib.mpo_align_fastq(ix, C.byref(p), f1.encode(), f2.encode(), want.encode(), None, C.byref(st)) == 0
+        if cfg["bam"]:
+            assert lib.mpo_align_fastq_bam(ix, C.byref(p), f1.encode(), f2.encode(), want.encode(), None, os.path.join(tmp, "obam").encode(), 1, b"rg1", C.byref(st)) == 0
+        else:
+            assert lib.mpo_align_fastq(ix, C.byref(p), f1.encode(), f2.encode(), want.encode(), None, C.byref(st)) == 0
         lib.mpo_index_close(ix)
+        if cfg["bam"]:
+            import bamtext
+            for kind, path in (("dpout", "o.dpout.1"), ("gout", "o.gout.1"), ("unpair", "o.unpair")):
+                got_recs = sorted(bamtext.read_bam(os.path.join(tmp, path))[2])
+                want_recs = sorted(open(os.path.join(tmp, "obam.%s.txt" % kind)).read().splitlines())
+                if got_recs != want_recs:
+                    bad = [i for i in range(min(len(got_recs), len(want_recs))) if got_recs[i] != want_recs[i]]
+                    print("BAM %s DIFFERENT: %d vs %d records" % (kind, len(got_recs), len(want_recs)))
+                    for i in bad[:2]:
+                        print(" got ", got_recs[i][:300]); print(" want", want_recs[i][:300])
+                    sys.exit(1)
         a, b = fastq_records(out), fastq_records(want)
         if a != b:
             bad = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]

@@ -88,7 +88,7 @@ struct mp_ctx {
     DevBuf<mp_dp_result> sel_res;
     DevBuf<uint32_t> band_flag, band_idx;        // instances the band kernel left to the full kernels
     DevBuf<uint32_t> near_flag, near_idx, near_list, far_flag, far_idx, far_list;   // classes of the second band pass
-    DevBuf<uint32_t> pre_cls, narrow_list, wide_list, narrow15_list;                               // dp_prefilter_kernel's classes: first band pass over 27 / 87 diagonals
+    DevBuf<uint32_t> pre_cls, narrow_list, wide_list, narrow15_list, score_list;                               // dp_prefilter_kernel's classes: first band pass over 27 / 87 diagonals
     DevBuf<uint32_t> mid_flag, mid_idx, mid_list;                                   // scores L-9 .. L-6: second pass over 15 diagonals
     DevBuf<uint32_t> vfar_flag, vfar_idx, vfar_list, und_list[2];                   // second tier; instances still undecided after a tier
     DevBuf<mp_dp_task> band_tasks;
@@ -163,8 +163,9 @@ extern "C" int mp_build_index_arrays(int device, const uint8_t *codes, uint64_t 
     hipStream_t s = nullptr;
     HIPCHK(hipMemcpy(d_codes.p, codes, n, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(d_small.p, 0, 8 * sizeof(unsigned long long), s));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;
+    HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     HIPCHK(hipEventRecord(e0, s));
     hipLaunchKernelGGL(build_init_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, (const uint8_t *)d_codes.p, n, key_a.p, idx_a.p);
     hipcub::DoubleBuffer<uint64_t> keys(key_a.p, key_b.p);
@@ -225,7 +226,6 @@ extern "C" int mp_build_index_arrays(int device, const uint8_t *codes, uint64_t 
     for (int c = 0; c < 4; c++) out_cum[c + 1] = out_cum[c] + small[c];
     if (out_rounds) *out_rounds = rounds;
     if (out_ms_suffix_sort) (void)hipEventElapsedTime(out_ms_suffix_sort, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return MP_OK;
 }
 
@@ -717,7 +717,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->census.release();
     c->sh_flag.release(); c->sh_slot.release(); c->rh_flag.release(); c->rh_slot.release(); c->d_single_hits.release(); c->d_rescue_hits.release();
     c->band_flag.release(); c->band_idx.release(); c->near_flag.release(); c->near_idx.release(); c->near_list.release(); c->far_flag.release(); c->far_idx.release();
-    c->far_list.release(); c->pre_cls.release(); c->narrow_list.release(); c->wide_list.release(); c->narrow15_list.release(); c->mid_flag.release(); c->mid_idx.release(); c->mid_list.release();
+    c->far_list.release(); c->pre_cls.release(); c->narrow_list.release(); c->wide_list.release(); c->narrow15_list.release(); c->score_list.release(); c->mid_flag.release(); c->mid_idx.release(); c->mid_list.release();
     c->vfar_flag.release(); c->vfar_idx.release(); c->vfar_list.release(); c->und_list[0].release(); c->und_list[1].release(); c->band_tasks.release();
     c->band_res.release(); c->band_fill.release();
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1024,16 +1024,45 @@ void fill_round(const mp_ctx *c, bool count, uint32_t *out)
 template <int LPI, int C>
 void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, mp_fill_result *fill)
 {
-    if (LPI * C <= 160) {
-        // the leaner filter kernel for reads of up to 160 bases: 8 lanes x 20 columns per instance pair (kernels_dp.hip)
-        // (19 columns per lane when no read is longer than 152 bases: 150-base reads then leave 2 idle columns instead of 10)
-        const unsigned pairs8 = (n + 1) / 2, groups8 = MP_DP_BLOCK / 8;
-        if (c->max_len <= 8 * 19)
-            hipLaunchKernelGGL((dp_score_kernel<8, 19>), dim3(grid_for(pairs8, groups8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                               tasks, n, fill);
-        else
-            hipLaunchKernelGGL((dp_score_kernel<8, 20>), dim3(grid_for(pairs8, groups8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                               tasks, n, fill);
+    if (c->max_len <= 320) {
+        // the leaner filter kernel (kernels_dp.hip): 8 lanes x 19 or 20 columns per instance pair for reads of up to 152 / 160 bases
+        // (150-base reads then leave 2 idle columns instead of 10), 16 lanes x 12 / 16 / 20 columns up to 192 / 256 / 320 bases
+#define MP_SCORE_LAUNCH(L_, C_, TASKS_N, LIST) hipLaunchKernelGGL((dp_score_kernel<L_, C_>), dim3(grid_for(((TASKS_N) + 1) / 2, MP_DP_BLOCK / L_)), dim3(MP_DP_BLOCK), 0, s, \
+                                                   c->ix->d.text, c->d_reads, c->d_lens, c->W, tasks, (TASKS_N), fill, (LIST))
+        const uint32_t *none = nullptr;
+        if (c->max_len <= 8 * 19) MP_SCORE_LAUNCH(8, 19, n, none);
+        else if (c->max_len <= 8 * 20) MP_SCORE_LAUNCH(8, 20, n, none);
+        else {
+            // a batch with longer reads is usually a batch of mixed lengths (trimmed reads): one launch per length class, each with the
+            // kernel of its width, instead of the widest kernel for all
+            mp_ctx *cc = const_cast<mp_ctx *>(c);
+            const uint32_t bounds[5] = {0u, 152u, 192u, 256u, 320u};
+            auto by_class = [&]() -> bool {
+                for (int k = 0; k < 4; k++) {
+                    if (c->max_len <= bounds[k]) break;
+                    if (cc->sel_flag.reserve(n + 2) || cc->sel_idx.reserve(n + 2)) return false;
+                    hipLaunchKernelGGL(dp_len_class_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, tasks, c->d_lens, n, bounds[k], bounds[k + 1], cc->sel_flag.p);
+                    size_t tmp_bytes = 0;
+                    (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, cc->sel_flag.p, cc->sel_idx.p, (int)n, s);
+                    if (cc->cub_tmp.reserve(tmp_bytes + 256)) return false;
+                    (void)hipcub::DeviceScan::InclusiveSum(cc->cub_tmp.p, tmp_bytes, cc->sel_flag.p, cc->sel_idx.p, (int)n, s);
+                    uint32_t n_k = 0;
+                    if (hipMemcpyAsync(&n_k, cc->sel_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
+                    if (n_k == 0) continue;
+                    if (cc->score_list.reserve(n_k + 2)) return false;
+                    hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, cc->sel_flag.p, cc->sel_idx.p, n, cc->score_list.p, none);
+                    const uint32_t *lst = cc->score_list.p;
+                    if (k == 0) MP_SCORE_LAUNCH(8, 19, n_k, lst);
+                    else if (k == 1) MP_SCORE_LAUNCH(16, 12, n_k, lst);
+                    else if (k == 2) MP_SCORE_LAUNCH(16, 16, n_k, lst);
+                    else MP_SCORE_LAUNCH(16, 20, n_k, lst);
+                    if (hipStreamSynchronize(s) != hipSuccess) return false;        // the list buffer is reused by the next class
+                }
+                return true;
+            };
+            if (!by_class()) MP_SCORE_LAUNCH(16, 20, n, none);                       // no memory for the lists: the widest kernel over everything
+        }
+#undef MP_SCORE_LAUNCH
         MP_TRACE(s, "dp_score_kernel");
         return;
     }

@@ -446,7 +446,8 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 template <int LPI, int C>
 __global__ void __launch_bounds__(MP_DP_BLOCK)
 dp_score_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t W,
-                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, mp_fill_result *__restrict__ out)
+                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, mp_fill_result *__restrict__ out,
+                const uint32_t *__restrict__ list = nullptr /* slot s of the launch stands for instance list[s] (a length class of a mixed batch) */)
 {
     constexpr int GROUPS = MP_DP_BLOCK / LPI;
     constexpr int B = MP_DP_BIAS;
@@ -458,10 +459,10 @@ dp_score_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ 
     uint32_t rid[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const uint32_t inst = 2 * pair + q;
+        const uint32_t slot = 2 * pair + q;
         mp_dp_task task; task.read_id = 0; task.strand = 1; task.win_start = 0; task.win_len = 0; task.reserved = 0;
-        const bool live = inst < n_tasks;
-        if (live) task = tasks[inst];
+        const bool live = slot < n_tasks;
+        if (live) task = tasks[list ? list[slot] : slot];
         L[q] = live ? (int)lens[task.read_id] : 0;
         m[q] = (int)task.win_len;
         if (m[q] > MP_DP_MAX_WIN) m[q] = MP_DP_MAX_WIN;
@@ -538,11 +539,11 @@ dp_score_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ 
     for (int q = 0; q < 2; q++) {
         int b = (int)(unsigned short)(q == 0 ? best.x : best.y) - B;
         for (int o = LPI / 2; o > 0; o >>= 1) { const int v = __shfl_xor(b, o, LPI); b = v > b ? v : b; }
-        const uint32_t inst = 2 * pair + q;
-        if (inst < n_tasks && k == 0) {
+        const uint32_t slot = 2 * pair + q;
+        if (slot < n_tasks && k == 0) {
             mp_fill_result r;
             r.score = b; r.row = 0; r.col = 0; r.count = 0;
-            out[inst] = r;
+            out[list ? list[slot] : slot] = r;
         }
     }
 }
@@ -631,6 +632,16 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
     }
     if (valid) { res.score = fr.score; res.hit_loc = (uint32_t)hit; res.n_ops = n; }
     out[inst] = res;
+}
+
+// flag[t] = 1 for the instances whose read has lo < length <= hi (length classes of a mixed batch: the score-only pre-pass
+// runs a kernel of matching width over each class)
+__global__ void dp_len_class_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, uint32_t n, uint32_t lo, uint32_t hi, uint32_t *__restrict__ flag)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t L = lens[tasks[t].read_id];
+    flag[t] = (L > lo && L <= hi) ? 1u : 0u;
 }
 
 // ---- score-only pre-pass bookkeeping: which instances can pass, compaction of their tasks, scatter of their results

@@ -34,7 +34,7 @@
 //                           centred bands (their rows <= 0 must lie under the left clip).
 #pragma once
 
-#define MP_BAND_MAXL 256            // longest read the band kernel is instantiated for (a second instance for <= 160 needs less LDS)
+#define MP_BAND_MAXL 320            // longest read the band kernel is instantiated for (a second instance for <= 160 needs less LDS)
 #define MP_BAND_DMAX 60             // 2 x DP2_MARGIN: widest window surplus of a deep-DP instance
 #define MP_BAND_GB 13               // guard diagonals either side; qualifies scores >= L - 13
 

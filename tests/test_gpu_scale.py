@@ -168,12 +168,12 @@ def test_batch_scale_properties():
 
 
 @pytest.mark.parametrize("clips,banded,read_len", [((130, 130), True, 150), ((40, 13), True, 150), ((13, 60), True, 150), ((12, 130), False, 150),
-                                                  ((130, 130), True, 250), ((130, 130), False, 300),
+                                                  ((130, 130), True, 250), ((130, 130), True, 300), ((130, 130), False, 340),
                                                   ((130, 130), True, 80)])      # reads too short for the block pre-filter: first pass over the whole band
 def test_banded_dp_kernel_changes_nothing(tmp_path, clips, banded, read_len):
     """The deep-DP legs with the banded fill kernel (plus full-table fallback) against the full-table kernels alone, on
     reads with long indels and junk ends: the same hit set (positions, scores, windows) in every field, for several
-    soft-clip limits -- below MP_BAND_GB, or with reads longer than MP_BAND_MAXL, the band path must not engage at all."""
+    soft-clip limits -- below MP_BAND_GB, or with reads longer than MP_BAND_MAXL (320), the band path must not engage at all."""
     genome = synth.random_genome(500000, 611, n_seqs=3, repeat_frac=0.1)
     arrs = index_builder.build_index_arrays(genome, sa_interval=16)
     gix = H.Index.from_arrays(0, **arrs)

@@ -343,3 +343,25 @@ def test_native_builder_equals_the_torch_restatement(n, repeat, interval):
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
     if repeat > 0:
         assert rounds >= 5                                        # kilobase repeats need h up to a few thousand
+
+
+@pytest.mark.parametrize("kind", ["one_letter", "period_2", "period_3_then_random"])
+def test_native_builder_on_degenerate_texts(kind):
+    """The worst cases of prefix doubling -- a single letter, a short period (suffixes differ only at the very end: log2(n) rounds) --
+    against the torch restatement."""
+    from megapath_amd import index_builder
+    n = 70001
+    rng = np.random.default_rng(3)
+    if kind == "one_letter":
+        codes = np.full(n, 3, dtype=np.uint8)
+    elif kind == "period_2":
+        codes = np.tile(np.array([1, 2], dtype=np.uint8), n // 2 + 1)[:n]
+    else:
+        codes = np.concatenate([np.tile(np.array([0, 0, 3], dtype=np.uint8), 20000), rng.integers(0, 4, n - 60000, dtype=np.uint8)])
+    a = index_builder.build_index_arrays([("s", codes)], sa_interval=16, native=True)
+    rounds = index_builder.last_build_info["rounds"]
+    b = index_builder.build_index_arrays([("s", codes)], sa_interval=16, native=False, device="cpu")
+    assert a["inv_sa0"] == b["inv_sa0"]
+    for k in ("cum", "bwt_words", "sa_samples", "pac"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    assert rounds >= 10

@@ -321,14 +321,16 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 // GBUD: what a qualifying alignment may lose against a perfect match (13: the first tier; 25: the second tier, run on the
 // instances the first tier left undecided, with band kernels of 51 diagonals).  With a list, slot s stands for instance
 // list[s]; cls is indexed by slot, fill by instance.
-template <int GBUD, int MINB>
+// MAXL: longest read of the batch the instance is compiled for (160 for the usual short-read batches: half the words to orient and stage)
+template <int GBUD, int MINB, int MAXL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                     const mp_dp_task *__restrict__ tasks, uint32_t n, mp_fill_result *__restrict__ fill, uint32_t *__restrict__ cls,
                     const uint32_t *__restrict__ list = nullptr)
 {
-    __shared__ uint32_t s_a[MP_BAND_RW + 1][64];        // the read in alignment orientation, LSB-first words
-    __shared__ uint32_t s_t[MP_BAND_TW + 1][64];        // the window, word 0 starts at its first base
+    constexpr int RW = MAXL / 16, TW = (MAXL + MP_BAND_DMAX) / 16 + 2;
+    __shared__ uint32_t s_a[RW + 1][64];        // the read in alignment orientation, LSB-first words
+    __shared__ uint32_t s_t[TW + 1][64];        // the window, word 0 starts at its first base
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const uint32_t t = list ? list[slot] : slot;
@@ -337,7 +339,7 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
     const int L = (int)lens[task.read_id], m = (int)task.win_len;
     mp_fill_result r; r.score = -1; r.row = 0; r.col = 0; r.count = 0;
     cls[slot] = MP_PRE_WIDE;
-    if (L < 30 || L > MP_BAND_MAXL || m < 1 || m - L > MP_BAND_DMAX) { fill[t] = r; return; }      // the first pass decides what to do with it
+    if (L < 30 || L > MAXL || m < 1 || m - L > MP_BAND_DMAX) { fill[t] = r; return; }      // the first pass decides what to do with it
     constexpr int RUNS = GBUD / 3 + 1;               // at most GBUD / 3 mismatches and gaps
     const int R = (L - GBUD + RUNS - 1) / RUNS, b = min(16, (R + 1) / 2);
     if (b < MINB) { fill[t] = r; return; }
@@ -346,33 +348,33 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
     // ---- oriented read.  Reverse strand: reverse the 2-bit groups of every word, take the words in reverse order,
     // complement, and shift out the 16 nw - L pad bases that the reversal brought to the front.
     {
-        uint32_t a[MP_BAND_RW + 1];
+        uint32_t a[RW + 1];
 #pragma unroll
-        for (int w = 0; w <= MP_BAND_RW; w++) a[w] = 0;
+        for (int w = 0; w <= RW; w++) a[w] = 0;
         if (task.strand == 1) {
 #pragma unroll
-            for (int w = 0; w < MP_BAND_RW; w++) if (w < nw) a[w] = rd[w];
+            for (int w = 0; w < RW; w++) if (w < nw) a[w] = rd[w];
         } else {
-            uint32_t z[MP_BAND_RW + 1];
+            uint32_t z[RW + 1];
 #pragma unroll
-            for (int w = 0; w <= MP_BAND_RW; w++) {
+            for (int w = 0; w <= RW; w++) {
                 z[w] = 0;
                 if (w < nw) { const uint32_t x = __brev(rd[nw - 1 - w]); z[w] = ~(((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u)); }
             }
             const uint32_t s2 = 2u * (uint32_t)(16 * nw - L);
 #pragma unroll
-            for (int w = 0; w < MP_BAND_RW; w++) a[w] = (uint32_t)((((uint64_t)z[w + 1] << 32) | z[w]) >> s2);
+            for (int w = 0; w < RW; w++) a[w] = (uint32_t)((((uint64_t)z[w + 1] << 32) | z[w]) >> s2);
         }
         const uint32_t tail = (L & 15) ? ((1u << (2 * (L & 15))) - 1u) : 0xFFFFFFFFu;
 #pragma unroll
-        for (int w = 0; w <= MP_BAND_RW; w++) { if (w == nw - 1) a[w] &= tail; if (w >= nw) a[w] = 0; s_a[w][lane] = a[w]; }
+        for (int w = 0; w <= RW; w++) { if (w == nw - 1) a[w] &= tail; if (w >= nw) a[w] = 0; s_a[w][lane] = a[w]; }
     }
     // ---- window words, aligned to the window's first base
     {
         const uint64_t q0 = task.win_start >> 4;
         const uint32_t sh = 2u * (uint32_t)(task.win_start & 15);
         const int tw = (m + 15) / 16;
-        for (int w = 0; w <= MP_BAND_TW; w++) {
+        for (int w = 0; w <= TW; w++) {
             uint32_t v = 0;
             if (w < tw) { const uint64_t two = ((uint64_t)text[q0 + w + 1] << 32) | text[q0 + w]; v = (uint32_t)(two >> sh); }
             s_t[w][lane] = v;
@@ -384,10 +386,6 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
         const uint64_t two = ((uint64_t)s_a[(at >> 4) + 1][lane] << 32) | s_a[at >> 4][lane];
         return (uint32_t)(two >> (2 * (at & 15))) & bmask;
     };
-    auto bases_t = [&](int at) -> uint32_t {
-        const uint64_t two = ((uint64_t)s_t[(at >> 4) + 1][lane] << 32) | s_t[at >> 4][lane];
-        return (uint32_t)(two >> (2 * (at & 15))) & bmask;
-    };
     // ---- every block against every diagonal: window row (0-based) of read base u on diagonal dl is u + dl
     const int nb = L / b;
     int dlo = 1 << 20, dhi = -(1 << 20);
@@ -396,8 +394,19 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
         int lo = -GBUD, hi = m - L + GBUD;
         if (lo < -k * b) lo = -k * b;                           // the block's rows stay inside the window
         if (hi > m - k * b - b) hi = m - k * b - b;
-        for (int dl = lo; dl <= hi; dl++)
-            if (bases_t(k * b + dl) == vb) { dlo = dl < dlo ? dl : dlo; dhi = dl > dhi ? dl : dhi; }
+        // window positions at = k b + dl, one 16-base word of the window at a time: the two words that cover a position's b <= 16 bases
+        // are read once per word, the sixteen positions in it are shifts of that pair, their matches one bit each
+        const int at_lo = k * b + lo, at_hi = k * b + hi;
+        for (int w = at_lo >> 4; w <= (at_hi >> 4); w++) {
+            const uint64_t two = ((uint64_t)s_t[w + 1][lane] << 32) | s_t[w][lane];
+            const int j0 = at_lo > 16 * w ? at_lo - 16 * w : 0, j1 = at_hi < 16 * w + 15 ? at_hi - 16 * w : 15;
+            uint32_t mbits = 0;
+            for (int j = j0; j <= j1; j++) mbits |= ((((uint32_t)(two >> (2 * j))) & bmask) == vb ? 1u : 0u) << j;
+            if (mbits) {
+                const int d_first = 16 * w + (__ffs((int)mbits) - 1) - k * b, d_last = 16 * w + (31 - __clz((int)mbits)) - k * b;
+                dlo = d_first < dlo ? d_first : dlo; dhi = d_last > dhi ? d_last : dhi;
+            }
+        }
     }
     if (dhi < dlo) { cls[slot] = MP_PRE_NONE; fill[t] = r; return; }
     if (dhi - dlo > 4) { fill[t] = r; return; }                 // wide

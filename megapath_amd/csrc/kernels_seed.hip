@@ -1266,14 +1266,15 @@ __global__ void __launch_bounds__(MP_MERGE_THREADS)
 merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_base, uint32_t n_reads, mp_dev_mmp P, uint64_t text_len, int cov_words,
              mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr,
              mp_dev_index ix, const mp_seed_rec *__restrict__ slabs, const uint32_t *__restrict__ seeds_per_rs, const uint32_t *__restrict__ over_slot,
-             const mp_seed_rec *__restrict__ big_slabs, uint32_t slab_limit, const uint32_t *__restrict__ lens)
+             const mp_seed_rec *__restrict__ big_slabs, uint32_t slab_limit, const uint32_t *__restrict__ lens,
+             uint32_t stage_cap /* <= MP_MERGE_CAP; smaller only to exercise the path of blocks that do not fit in LDS */)
 {
     __shared__ uint64_t s_key[MP_MERGE_CAP];
     __shared__ uint32_t s_base[MP_MERGE_BLOCK + 1];
     const uint32_t r0 = blockIdx.x * MP_MERGE_BLOCK;
     const uint32_t r1 = min(r0 + MP_MERGE_BLOCK, n_reads);
     const uint32_t b0 = rs_base[2 * r0], T = rs_base[2 * r1] - b0;
-    const bool staged = T <= MP_MERGE_CAP;
+    const bool staged = T <= stage_cap;
     const int lane = threadIdx.x & (MP_WAVE - 1), wave = threadIdx.x / MP_WAVE;
     if (!staged) {
         // a block whose hits do not fit in LDS: one lane per read, in global memory (not FUSED: in place, key i overwrites bytes

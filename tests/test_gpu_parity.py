@@ -190,6 +190,31 @@ def test_seed_stage_matches_oracle(gidx, oidx, golden_dir, tag, mmp, monkeypatch
     ctx.close()
 
 
+@pytest.mark.parametrize("dense", [False, True])
+def test_merge_kernel_paths_that_do_not_stage_in_lds(golden_dir, oidx, monkeypatch, dense):
+    """merge_kernel handles a block of 64 reads whose hits do not fit in its 32 KB of LDS one lane per read in global memory.  Forced for every
+    block (MP_MERGE_STAGE_CAP=0), with the keys made from the seed records (whole suffix array resident) and from the located hits:
+    the kept seeds must equal the oracle's."""
+    monkeypatch.setenv("MP_MERGE_STAGE_CAP", "0")
+    monkeypatch.setenv("MP_SA_DENSE", "1" if dense else "0")
+    for k in ("MP_KMER_FILTER", "MP_KMER15", "MP_LKT16", "MP_LKT16U"):
+        monkeypatch.setenv(k, "1" if dense else "0")
+    d = os.path.join(golden_dir, "g1")
+    gix = H.Index(os.path.join(d, "ref.fa.index"), 0)
+    seqs = read_fastq_pairs(os.path.join(d, "reads_a_1.fq"), os.path.join(d, "reads_a_2.fq"))
+    packed, lens, W = H.pack_reads(seqs, 151)
+    ctx = H.Context(gix)
+    ctx.set_reads(packed, lens)
+    mmp = H.MmpParams.nt2()
+    ctx.seed_batch(mmp)
+    arr, off = ctx.get_seeds()
+    want, _ = oracle_seeds(oidx, seqs, 151, to_oracle_mmp(mmp))
+    got = [[(arr[i].pos, arr[i].strand_read_id, arr[i].paired_seed_length) for i in range(int(off[r]), int(off[r + 1]))] for r in range(len(seqs))]
+    assert got == want
+    ctx.close()
+    gix.close()
+
+
 def test_dp_matches_reference_vectors(golden_dir, tmp_path):
     """callDP golden vectors: build a throw-away index whose text is the concatenation of the windows."""
     v = np.load(os.path.join(golden_dir, "dp_vectors.npz"))

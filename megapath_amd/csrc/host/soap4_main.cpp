@@ -881,7 +881,8 @@ void for_chunks(size_t n_items, int threads, BamState *bam, Pass1 *pass1, F &&bo
 }
 
 // `carry`: not the last resident chunk -- the records keep their new header comments for the next chunk instead of being printed.
-void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b, BamState *bam, int threads, Stats &st, bool carry, Pass1 *pass1)
+void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b, BamState *bam, int threads, Stats &st, bool carry, Pass1 *pass1,
+                  bool keep_unchanged = false /* carry mode, second chunk on: a read without a hit in this chunk keeps the comment the chunk before left */)
 {
     const uint32_t n_pairs = bt.n_reads / 2;
     double t0 = now_s();
@@ -1010,6 +1011,9 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
                     if (bam) { s.cigar = b.scig[ci++].c_str(); s.editdist = mpbam::edit_dist(s.cigar, (int)bt.lens[r], h.score, nullptr); }
                     lst[k].push_back(s);
                 }
+                // Resident chunks: the comment this run's previous chunk wrote is a fixed point of the merge when the chunk adds nothing (its
+                // entries already passed the threshold of the best score it carries), so it is left alone -- with many chunks most reads hit few
+                if (keep_unchanged && bt.rec(r).has_comment && (lst[k].empty() || p.mode == 2)) continue;
                 if (p.mode) w.single(bt.rec(r), bt.lens[r], lst[k]);
             }
             if (!bam) continue;
@@ -1272,6 +1276,7 @@ int main(int argc, char **argv)
         }
         filled_q.close();
     });
+    const bool carry_rewrite = getenv("MP_CARRY_REWRITE") != nullptr;     // test switch: merge every comment again in every chunk, also where the chunk adds nothing
     std::thread printer([&]() {
         for (uint64_t seq = 0;; seq++) {
             Batch *b = aligned_q.pop_seq(seq);
@@ -1279,7 +1284,7 @@ int main(int argc, char **argv)
             // the chunks in database order: each one's per-reference hits join the header comments the earlier ones left
             for (size_t c = 0; c < n_chunks; c++) {
                 const bool last = c + 1 == n_chunks;
-                output_stage(devices[0].chunks[c], p, *b, b->ch[c], last ? bam : nullptr, threads, st_printer, !last, p.tax ? &pass1_total : nullptr);
+                output_stage(devices[0].chunks[c], p, *b, b->ch[c], last ? bam : nullptr, threads, st_printer, !last, p.tax ? &pass1_total : nullptr, !last && c > 0 && !carry_rewrite);
             }
             free_q.push(b);
         }

@@ -332,6 +332,30 @@ def test_cli_resident_chunks_equal_reference_chain(golden_dir, tmp_path, tag, L)
     assert b"3 index chunk(s)" in err
 
 
+@pytest.mark.parametrize("mode", ["-F", "-P"])
+def test_cli_many_resident_chunks_leave_untouched_comments_alone(golden_dir, tmp_path, mode):
+    """With many chunks most reads hit few of them: from the second chunk on, a read without a hit in a chunk keeps the comment the
+    chunk before left (it is a fixed point of the merge).  Seven resident chunks, against the same run with MP_CARRY_REWRITE=1
+    (every comment merged again in every chunk) -- and the three-chunk prefix of it is pinned on the real chain by the test above."""
+    g1, g3 = os.path.join(golden_dir, "g1"), os.path.join(golden_dir, "g3")
+    order = [0, 1, 2, 1, 0, 2, 1]
+    prefixes = ",".join(os.path.join(g3, "c%d.fa.index" % k) for k in order)
+    outs = []
+    for rewrite in (False, True):
+        out = tmp_path / ("out_%d.fq" % rewrite)
+        cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefixes, os.path.join(g1, "reads_a_1.fq"), os.path.join(g1, "reads_a_2.fq"), "-o", str(tmp_path / "o"),
+               "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "3", "-u", "750", mode, "-nc", "-top", "95"]
+        env = dict(os.environ, MP_BATCH_PAIRS="60")
+        if rewrite:
+            env["MP_CARRY_REWRITE"] = "1"
+        with open(out, "wb") as fo:
+            r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+        assert b"7 index chunk(s)" in r.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 100000
+
+
 def test_cli_same_chunk_twice_equals_chained_golden_e(golden_dir, tmp_path):
     """The chained two-run golden of g1 (set e: run 2 reads run 1's stdout with its comments) from ONE process holding the index twice."""
     d = os.path.join(golden_dir, "g1")

@@ -271,9 +271,11 @@ bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out, int threa
     out.W = (uint32_t)(p.max_read_length + 15) / 16;
     size_t nb = 0;
     const int per_file = std::max(1, threads / 4);          // the output stage of the previous batch runs at the same time
+    const double t0 = now_s();
     std::thread second([&]() { nb = parse_file(b, p, out, 1, bp, per_file); });
     const size_t na = parse_file(a, p, out, 0, bp, per_file);
     second.join();
+    const double t1 = now_s();
     if (na != nb) fatal("Error: number of sequences of pair-end files not matched.\n");
     out.n_reads = (uint32_t)(2 * na);
     out.last = na < bp;
@@ -284,7 +286,9 @@ bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out, int threa
             memcpy(out.packed.data() + (2 * q + k) * (size_t)W, out.packed_m[k].data() + q * (size_t)W, (size_t)W * 4);
             out.lens[2 * q + k] = out.lens_m[k][q];
         }
+    const double t2 = now_s();
     for (auto &c : out.ch) c.clear();
+    if (getenv("MP_TIMING")) fprintf(stderr, "[Main] reader: both files %.3f s, interleave %.3f s, clear %.3f s\n", t1 - t0, t2 - t1, now_s() - t2);
     return na > 0;
 }
 
@@ -826,9 +830,11 @@ void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, boo
         fprintf(stderr, "[Main] batch %llu: %llu seed positions, %llu candidates, %llu pair hits, %u of %u pairs done, %zu single hits, %zu rescues (insert %d..%d)\n",
                 (unsigned long long)bt.seq, (unsigned long long)rs.seed.n_seedpos, (unsigned long long)rs.n_candidates, (unsigned long long)nh, n_done, n_pairs,
                 b.singles.size(), b.resc.size(), ap.insert_low, ap.insert_high);
+    // ordering and de-duplicating the hit lists is done here, by the worker that owns the batch (several workers side by side), not by
+    // the one printer thread every batch has to pass through in input order
+    prepare_lists(bt, b, threads);
+    st.t_sort += now_s() - t0; t0 = now_s();
     if (bam) {
-        prepare_lists(bt, b, threads);
-        st.t_sort += now_s() - t0; t0 = now_s();
         std::vector<mp_dp_task> tasks;
         tasks.reserve(2 * b.hits.size());
         for (const mp_pair_hit &h : b.hits) {

@@ -103,8 +103,9 @@ struct mp_ctx {
     // rescue passes
     DevBuf<uint32_t> pair_done, failed_flag, failed_off, failed_reads, n_scand, s_off, rsrc;
     DevBuf<mp_single_cand> scand;
-    DevBuf<mp_dp_task> stasks, rtasks;
-    DevBuf<mp_dp_result> sres, rres;
+    DevBuf<mp_dp_task> stasks, rtasks, rtasks_c;     // rtasks_c / rres_c / rlist: the filled mate-rescue slots, gathered
+    DevBuf<mp_dp_result> sres, rres, rres_c;
+    DevBuf<uint32_t> rlist;
     uint32_t n_failed_reads = 0, n_stasks = 0;
     bool rescued = false;
     bool census_on = false;                      // mp_ctx_set_dp_census: count the cells each DP kernel family computes
@@ -728,7 +729,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->ops.release(); c->pair_hits.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
     if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
     c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
-    c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release();
+    c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release(); c->rtasks_c.release(); c->rres_c.release(); c->rlist.release();
     delete c;
     return MP_OK;
 }
@@ -1748,9 +1749,33 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
             const uint32_t rwin = (uint32_t)(ap->insert_high - ap->insert_low) + c->max_len + 1;   // HalfEnd maxDNALength (DV-DPfunctions.cpp:1340)
             if (rwin > MP_DP_MAX_WIN) return MP_ERANGE;
             census_add(c, CENSUS_FULL_EQUIV, c->rtasks.p, nullptr, 4 * nf, 0);
-            rc = run_dp_filtered(c, c->rtasks.p, 4 * nf, rwin, ap->clip_left, ap->clip_right, c->rres.p, &st.ms_dp_fill, &st.ms_dp_trace,
-                                 ap->want_tie_counts != 0);
-            if (rc) return rc;
+            // four slots per read, most of them empty (a read without a passing single-end hit has none to rescue its mate from): the DP
+            // runs over the filled slots only, gathered in slot order; the empty ones keep an all-zero result
+            {
+                const uint32_t n_slots = 4 * nf;
+                if (c->sel_flag.reserve(n_slots + 2) || c->sel_idx.reserve(n_slots + 2)) return MP_ENOMEM;
+                HIPCHK(hipMemsetAsync(c->rres.p, 0, (size_t)n_slots * sizeof(mp_dp_result), s));
+                hipLaunchKernelGGL(dp_nonempty_flag_kernel, dim3(grid_for(n_slots, 256)), dim3(256), 0, s, (const mp_dp_task *)c->rtasks.p, n_slots, c->sel_flag.p);
+                MP_TRACE(s, "dp_nonempty_flag_kernel");
+                size_t tmp_bytes = 0;
+                (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, c->sel_flag.p, c->sel_idx.p, (int)n_slots, s);
+                if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+                (void)hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, c->sel_flag.p, c->sel_idx.p, (int)n_slots, s);
+                uint32_t n_filled = 0;
+                HIPCHK(hipMemcpyAsync(&n_filled, c->sel_idx.p + (n_slots - 1), 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (n_filled) {
+                    if (c->rlist.reserve(n_filled + 2) || c->rtasks_c.reserve(n_filled + 2) || c->rres_c.reserve(n_filled + 2)) return MP_ENOMEM;
+                    hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n_slots, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, n_slots, c->rlist.p, (const uint32_t *)nullptr);
+                    hipLaunchKernelGGL(dp_gather_tasks_kernel, dim3(grid_for(n_filled, 256)), dim3(256), 0, s, (const mp_dp_task *)c->rtasks.p, (const uint32_t *)c->rlist.p, n_filled, c->rtasks_c.p);
+                    MP_TRACE(s, "dp_gather_tasks_kernel");
+                    rc = run_dp_filtered(c, c->rtasks_c.p, n_filled, rwin, ap->clip_left, ap->clip_right, c->rres_c.p, &st.ms_dp_fill, &st.ms_dp_trace,
+                                         ap->want_tie_counts != 0);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(dp_scatter_list_kernel, dim3(grid_for(n_filled, 256)), dim3(256), 0, s, (const mp_dp_result *)c->rres_c.p, (const uint32_t *)c->rlist.p, n_filled, c->rres.p);
+                    MP_TRACE(s, "dp_scatter_list_kernel");
+                }
+            }
             n_rt = 4 * nf;
             st.n_rescue_tasks = n_rt;
         }

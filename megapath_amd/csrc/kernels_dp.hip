@@ -644,6 +644,13 @@ __global__ void dp_len_class_kernel(const mp_dp_task *__restrict__ tasks, const 
     flag[t] = (L > lo && L <= hi) ? 1u : 0u;
 }
 
+// flag[t] = 1 for the task slots that hold an instance (mate rescue reserves four slots per read and fills those it has a hit for)
+__global__ void dp_nonempty_flag_kernel(const mp_dp_task *__restrict__ tasks, uint32_t n, uint32_t *__restrict__ flag)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) flag[t] = tasks[t].win_len != 0 ? 1u : 0u;
+}
+
 // ---- score-only pre-pass bookkeeping: which instances can pass, compaction of their tasks, scatter of their results
 __global__ void dp_select_kernel(const mp_dp_task *__restrict__ tasks, const mp_fill_result *__restrict__ fill, const uint32_t *__restrict__ lens,
                                  uint32_t n, uint32_t *__restrict__ flag, mp_dp_result *__restrict__ res)

@@ -1125,9 +1125,10 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 8ull << 30;
         c->slab_budget = std::min<size_t>(24ull << 30, std::max<size_t>(2ull << 30, (free_b + c->flags.cap) / 4));
     }
-    uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 2 * std::max<uint64_t>(512, c->slab_budget / per_pair));   // even
-    chunk &= ~1u;
-    if (chunk < 2) chunk = 2;
+    // instances per launch: everything when the slab holds it (an odd n must not be cut into n - 1 and 1: the second launch would
+    // cost a whole table's latency for one instance), else an even number (two instances share a lane group)
+    uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 2 * std::max<uint64_t>(512, c->slab_budget / per_pair));
+    if (chunk < n) { chunk &= ~1u; if (chunk < 2) chunk = 2; }
     uint32_t round = 0;
     MP_DP_DISPATCH(fill_round, c, count, &round);
     if (round >= 2 && chunk > round && chunk < n) chunk = chunk / round * round;      // whole rounds of resident blocks per launch

@@ -435,8 +435,7 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         "v_sub_u32 %[fo], %[Hl], %[k3]\n\t"                       /* open an insertion: H - 3 (same row) */ \
         "v_sub_u32 %[Fl], %[Fl], %[k1]\n\t" \
         "v_pk_max_u16 %[Fl], %[fo], %[Fl]\n\t" \
-        "v_xor_b32 %[t1], %[base], %[rb]\n\t" \
-        "v_pk_min_u16 %[t1], %[t1], %[k3]\n\t" \
+        "v_perm_b32 %[t1], %[tb], %[ta], %[base]\n\t"             /* mismatch penalty of both instances: one byte look-up each */ \
         "v_sub_u32 %[dg], %[diag], %[t1]\n\t"                     /* the row term swallows the +1 of a match */ \
         "v_pk_max_u16 %[t1], %[dg], %[Eup]\n\t" \
         "v_pk_max_u16 %[t1], %[t1], %[Fl]\n\t" \
@@ -476,24 +475,26 @@ dp_score_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ 
             s_win[g][q][w] = (uint32_t)(two >> sh);
         }
     }
-    v2s rb[C], Hup[C], Eup[C];
+    // ta / tb[cc]: per column the penalty (0 match, 3 mismatch) of instance 0 / 1 for each of the four window bases, one byte each:
+    // v_perm_b32 picks both with the row's selector (byte 0: base of instance 0, byte 2: 4 + base of instance 1, 0x0D = pad row: 255)
+    uint32_t ta[C], tb[C];
+    v2s Hup[C], Eup[C];
 #pragma unroll
     for (int cc = 0; cc < C; cc++) {
         const int j = k * C + cc + 1;
-        short b2[2];
+        uint32_t tab[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            int b = 9 + q;
+            tab[q] = 0x03030303u;                              // a column past the read's end matches nothing
             if (j <= L[q]) {
                 const uint32_t *rd = reads + (uint64_t)rid[q] * W;
                 int p = strand[q] == 1 ? j - 1 : L[q] - j;
-                b = (int)((rd[p >> 4] >> (2 * (p & 15))) & 3u);
+                int b = (int)((rd[p >> 4] >> (2 * (p & 15))) & 3u);
                 if (strand[q] != 1) b = 3 - b;
-                b = MP_DP_CODE(b);
+                tab[q] &= ~(0xFFu << (8 * b));
             }
-            b2[q] = (short)b;
         }
-        rb[cc] = pk(b2[0], b2[1]); Hup[cc] = pk1((short)B); Eup[cc] = pk1(MP_DP_SENT);
+        ta[cc] = tab[0]; tb[cc] = tab[1]; Hup[cc] = pk1((short)B); Eup[cc] = pk1(MP_DP_SENT);
     }
     v2s diag_carry = pk1((short)B);
     __syncthreads();
@@ -510,10 +511,10 @@ dp_score_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ 
         int inFi = wave_shr1(as_int(outF));
         int inB = wave_shr1(outB);
         if (((t - 1) & 15) == 0) { wq0 = s_win[g][0][(t - 1) >> 4]; wq1 = s_win[g][1][(t - 1) >> 4]; }
-        const int r0 = t <= m[0] ? MP_DP_CODE(wq0 & 3u) : 12, r1 = t <= m[1] ? MP_DP_CODE(wq1 & 3u) : 15;   // pads match nothing
+        const int r0 = t <= m[0] ? (int)(wq0 & 3u) : 0x0D, r1 = t <= m[1] ? 4 + (int)(wq1 & 3u) : 0x0D;   // pad rows: penalty 255
         wq0 >>= 2; wq1 >>= 2;
         const int i = t - k;                           // row handled now
-        if (k == 0) { inHi = as_int(pk1((short)(B - i))); inFi = as_int(pk1(MP_DP_SENT)); inB = r0 | (r1 << 16); }   // column 0: H = 0
+        if (k == 0) { inHi = as_int(pk1((short)(B - i))); inFi = as_int(pk1(MP_DP_SENT)); inB = r0 | (r1 << 16) | 0x0C000C00; }   // column 0: H = 0
         if (i >= 1 && i <= mmax) {
             const v2s base = as_v2s(inB);
             const v2s floorr = pk1((short)(B - i));    // score 0 in this row's frame
@@ -524,7 +525,7 @@ dp_score_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ 
                 asm(MP_DP_SCORE_CELL
                     : [eo] "=&v"(eo), [fo] "=&v"(fo), [dg] "=&v"(dg), [t1] "=&v"(t1), [dn] "=&v"(dnext), [Hup] "+&v"(Hup[cc]), [Eup] "+&v"(Eup[cc]),
                       [Fl] "+&v"(Fl), [rowmax] "+&v"(rowmax)
-                    : [Hl] "v"(Hl), [diag] "v"(diag), [base] "v"(base), [rb] "v"(rb[cc]), [floorr] "v"(floorr), [k1] "v"(k1), [k2] "v"(k2),
+                    : [Hl] "v"(Hl), [diag] "v"(diag), [base] "v"(base), [ta] "v"(ta[cc]), [tb] "v"(tb[cc]), [floorr] "v"(floorr), [k1] "v"(k1), [k2] "v"(k2),
                       [k3] "v"(k3), [k4] "v"(k4));
                 diag = dnext;
                 Hl = Hup[cc];

@@ -422,8 +422,11 @@ dp_fill_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 // and decided exactly).  That freedom buys a leaner kernel than dp_fill_kernel<.., 2>:
 //  * cell values are held relative to the ROW (x + MP_DP_BIAS - i) instead of the column: the same cancellation of the
 //    match bonus along the diagonal, but now every cell of a row shares the frame, so the left-clip floor is one
-//    register per row and the maximum is one running register -- no per-column arrays, which lets a lane own 20 columns
-//    (8 lanes per instance pair) at five waves per SIMD and halves the per-row work per cell;
+//    register per row and the maximum is one running register -- no per-column floor / eligibility arrays, which lets a lane
+//    own 19 or 20 columns (8 lanes per instance pair) and halves the per-row work per cell;
+//  * the mismatch penalty of both packed instances is ONE v_perm_b32: per column a 4-byte table per instance (penalty for each of
+//    the four window bases), the row's selector (byte 0: base of instance 0, byte 2: 4 + base of instance 1, travelling from lane
+//    to lane with the row) picks both -- instead of an XOR of base codes and a packed min (13 instructions per two cells);
 //  * the floor is applied in every column and row 0 is all zeros (as if the whole read could be clipped on the left),
 //    rows past the shorter window of a pair and columns that cannot end an alignment are not excluded: all of these can
 //    only raise scores.

@@ -604,11 +604,18 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
         emit('S', L - c);
         enum { NORMAL, I_EXT, D_EXT } state = NORMAL;
         bool ended = false, sm_exit = false;
+        // the cell looked at for the exit test of a diagonal step is the cell the next step starts from: it is kept (one flag word
+        // per step instead of two -- the walk is a chain of dependent loads)
+        uint32_t kept = 0;
+        bool have_kept = false;
         while (c > 0 && r > 0) {
-            const uint32_t b = cell(r, c);
+            const uint32_t b = have_kept ? kept : cell(r, c);
+            have_kept = false;
             if (state == NORMAL) {
-                if ((b & TB_D) && c != 1 && (cell(r - 1, c - 1) & TB_Z)) { sm_exit = true; break; }   // DP_BT_SM_EXIT
-                else if (b & TB_D) { emit('X', 1); r--; c--; }
+                uint32_t pred = 0;
+                if ((b & TB_D) && c != 1) pred = cell(r - 1, c - 1);
+                if ((b & TB_D) && c != 1 && (pred & TB_Z)) { sm_exit = true; break; }   // DP_BT_SM_EXIT
+                else if (b & TB_D) { emit('X', 1); r--; c--; if (c >= 1) { kept = pred; have_kept = true; } }
                 else if (b & TB_E) { emit('D', 1); r--; if (!(b & TB_EO)) state = D_EXT; }
                 else { emit('I', 1); c--; if (!(b & TB_FO)) state = I_EXT; }
             } else if (state == D_EXT) {

@@ -398,10 +398,17 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
         // are read once per word, the sixteen positions in it are shifts of that pair, their matches one bit each
         const int at_lo = k * b + lo, at_hi = k * b + hi;
         for (int w = at_lo >> 4; w <= (at_hi >> 4); w++) {
-            const uint64_t two = ((uint64_t)s_t[w + 1][lane] << 32) | s_t[w][lane];
+            const uint32_t w_lo = s_t[w][lane], w_hi = s_t[w + 1][lane];
             const int j0 = at_lo > 16 * w ? at_lo - 16 * w : 0, j1 = at_hi < 16 * w + 15 ? at_hi - 16 * w : 15;
+            // all sixteen positions of the word, shifts known at compile time (v_alignbit_b32), no loop control; the positions outside
+            // at_lo .. at_hi are masked off afterwards
             uint32_t mbits = 0;
-            for (int j = j0; j <= j1; j++) mbits |= ((((uint32_t)(two >> (2 * j))) & bmask) == vb ? 1u : 0u) << j;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t v = j == 0 ? w_lo : __builtin_amdgcn_alignbit(w_hi, w_lo, 2 * j);
+                mbits |= (v & bmask) == vb ? 1u << j : 0u;
+            }
+            mbits &= ((2u << j1) - 1u) & ~((1u << j0) - 1u);
             if (mbits) {
                 const int d_first = 16 * w + (__ffs((int)mbits) - 1) - k * b, d_last = 16 * w + (31 - __clz((int)mbits)) - k * b;
                 dlo = d_first < dlo ? d_first : dlo; dhi = d_last > dhi ? d_last : dhi;

@@ -87,6 +87,26 @@
 MP_PKOP2(pk_maxu, "v_pk_max_u16")
 __device__ __forceinline__ v2s pk_subsat(v2s a, v2s b) { v2s r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// Word w (bases 16w .. 16w+15) of a read in alignment orientation, as dp_prefilter_kernel stages it.
+__device__ __forceinline__ uint32_t mp_oriented_word(const uint32_t *__restrict__ rd, int nw, int L, uint32_t strand, int w)
+{
+    if (w >= nw) return 0u;
+    uint32_t v;
+    if (strand == 1) v = rd[w];
+    else {
+        // reverse strand: reverse the 2-bit groups of every word, take the words in reverse order, complement, and shift out the
+        // 16 nw - L pad bases that the reversal brought to the front
+        auto z = [&](int q) -> uint32_t {
+            if (q >= nw) return 0u;
+            const uint32_t x = __brev(rd[nw - 1 - q]);
+            return ~(((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u));
+        };
+        v = (uint32_t)((((uint64_t)z(w + 1) << 32) | z(w)) >> (2u * (uint32_t)(16 * nw - L)));
+    }
+    if (w == nw - 1 && (L & 15)) v &= (1u << (2 * (L & 15))) - 1u;
+    return v;
+}
+
 // MODE 0: one pass -- band of W = MP_BAND_W diagonals fixed to the window, traceback bits and best cell.
 // MODE 1: the same band, scores only (best cell, ties): first pass of the two-pass scheme.
 // MODE 3: as MODE 1, over the W = 2 GB + 1 diagonals around a centre found by dp_prefilter_kernel (instances for which it
@@ -108,6 +128,7 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     constexpr int R = MAXL + W + 1;        // LDS rows: row i of the window sits at index i + GB
     constexpr int B = MP_DP_BIAS;
     __shared__ uint8_t s_code[R][64];                 // code of instance 0 | code of instance 1 << 4
+    __shared__ uint32_t s_rd[MAXL / 16][2][64];       // both reads in alignment orientation, 16 bases per word: a column's base is a shift
     const int lane = threadIdx.x;
     const uint32_t pair = blockIdx.x * 64 + lane;
     // per-instance state, packed to keep the register budget for the band: L | m << 9 | forward << 18 | fit << 19 |
@@ -144,6 +165,11 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         info[q] = (uint32_t)L | ((uint32_t)m << 9) | (task.strand == 1 ? 1u << 18 : 0u) | (fit ? 1u << 19 : 0u) | (empty ? 1u << 20 : 0u);
         if (q == 0)
             for (int r = 0; r < R; r++) s_code[r][lane] = (uint8_t)(12 | (15 << 4));      // pads: match nothing
+        {
+            const uint32_t *rd = reads + (uint64_t)task.read_id * Wr;
+            const int nw = (L + 15) / 16;
+            for (int w = 0; w < MAXL / 16; w++) s_rd[w][q][lane] = w < nw ? mp_oriented_word(rd, nw, L, task.strand, w) : 0u;
+        }
         for (int w = 0; w * 16 < m; w++) {
             uint64_t p = task.win_start + 16ull * (uint64_t)w;
             uint32_t sh = 2 * (uint32_t)(p & 15);
@@ -178,21 +204,15 @@ dp_band_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 
     for (int j = 1; j <= Lw; j++) {
         short b2[2], fl2[2], th2[2], el2[2];
+        if (((j - 1) & 15) == 0) { rw[0] = s_rd[(j - 1) >> 4][0][lane]; rw[1] = s_rd[(j - 1) >> 4][1][lane]; }
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             // read base of column j in alignment orientation (packRead, DV-DPfunctions.cpp:3009-3040)
             const int L = (int)(info[q] & 511u);
             const bool fwd = (info[q] >> 18) & 1u;
             const int clipL = fwd ? clip_left : clip_right, clipR = fwd ? clip_right : clip_left;
-            const int p = fwd ? j - 1 : L - j;
             int b = 9 + q;
-            if (j <= L) {
-                const uint32_t *rd = reads + (uint64_t)rid[q] * Wr;
-                if (j == 1 || (fwd ? (p & 15) == 0 : (p & 15) == 15)) rw[q] = rd[p >> 4];
-                b = (int)((rw[q] >> (2 * (p & 15))) & 3u);
-                if (!fwd) b = 3 - b;
-                b = MP_DP_CODE(b);
-            }
+            if (j <= L) b = MP_DP_CODE((rw[q] >> (2 * ((j - 1) & 15))) & 3u);     // (rw: this column's word of the oriented read, below)
             b2[q] = (short)b;
             fl2[q] = (short)(j <= clipL ? B - j : 0);
             th2[q] = (short)(L - GB - 1 + B - j);             // score L - GB - 1 in this column's frame
@@ -474,26 +494,6 @@ __global__ void dp_band_select_kernel(const mp_fill_result *__restrict__ fill, u
 #define MP_BAND_MID 9
 #define MP_BAND_GBM 7
 #define MP_BAND_WM (2 * MP_BAND_GBM + 1)
-// Word w (bases 16w .. 16w+15) of a read in alignment orientation, as dp_prefilter_kernel stages it.
-__device__ __forceinline__ uint32_t mp_oriented_word(const uint32_t *__restrict__ rd, int nw, int L, uint32_t strand, int w)
-{
-    if (w >= nw) return 0u;
-    uint32_t v;
-    if (strand == 1) v = rd[w];
-    else {
-        // reverse strand: reverse the 2-bit groups of every word, take the words in reverse order, complement, and shift out the
-        // 16 nw - L pad bases that the reversal brought to the front
-        auto z = [&](int q) -> uint32_t {
-            if (q >= nw) return 0u;
-            const uint32_t x = __brev(rd[nw - 1 - q]);
-            return ~(((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u));
-        };
-        v = (uint32_t)((((uint64_t)z(w + 1) << 32) | z(w)) >> (2u * (uint32_t)(16 * nw - L)));
-    }
-    if (w == nw - 1 && (L & 15)) v &= (1u << (2 * (L & 15))) - 1u;
-    return v;
-}
-
 // Is the alignment the traceback would report for best cell (row, col) with score S simply the diagonal through that cell --
 // read bases 1..col against window rows hit+1..hit+col, hit = row - col, no gap, no left clip?  Sufficient condition, from the read and
 // the window alone: every prefix of the diagonal scores above zero (the k-th mismatch lies right of column 3k) and the whole of it

@@ -64,7 +64,8 @@ MP_PKOP2(pk_minu, "v_pk_min_u16")
 __device__ __forceinline__ v2s pk_mad(v2s a, v2s b, v2s c) { v2s r; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ v2s pk_xor(v2s a, v2s b) { return a ^ b; }
 // lane k receives lane k-1's value (wavefront shift right by one; the first lane of each 32-lane group is overridden by the caller)
-__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+// (lane 0, which has no source, keeps its own value: it is a first lane, overridden anyway -- no zero to materialise per call)
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
 
 // Number representation inside dp_fill_kernel.  A cell value x of read column j is held as the unsigned 16-bit number
 //   x + MP_DP_BIAS - j

@@ -371,6 +371,43 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
     return cb, parity
 
 
+# ------------------------------------------------------------------------------------------------ N ranks from one command line
+def launch_ranks(n, argv, script=None, extra_env=None):
+    """`python bench.py --gpus N` started without a launcher (no RANK in the environment): start N fresh child processes of
+    this script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set
+    them), wait for all of them and return the worst exit code.  Rank 0 inherits stdout, so its ONE JSON line is this process's
+    JSON line; the other ranks' stdout goes to stderr.  The parent never touches the GPU and never execs: the children are
+    ordinary subprocesses.  A rank that dies takes the others down (they would wait in the barrier forever)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": env.get("MASTER_PORT", str(port)),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                log("[bench] rank %d exited with code %d" % (r, code))
+                rc = rc or (code if code > 0 else 1)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -392,6 +429,10 @@ def main():
     if args.pmc_child:
         args.no_cpu_baseline = args.no_pmc = args.no_legs = True
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: be the launcher (nothing here has touched the GPU yet)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -410,6 +451,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()                 # what the process group really spans: this is what n_gpus reports
+        if world != args.gpus:
+            log("[bench] --gpus %d but the process group has %d ranks; reporting %d" % (args.gpus, world, world))
     barrier = dist.barrier if world > 1 else None
 
     from megapath_amd import hipapi as H
@@ -527,7 +571,8 @@ def main():
                                 "seed_positions_out": per_pair("n_seedpos"), "candidates": per_pair("cand"), "pair_hits": per_pair("pair_hits"),
                                 "failed_pairs": per_pair("failed"), "single_dp_tasks": per_pair("stasks"), "rescue_dp_slots": per_pair("rtasks"),
                                 "single_hits": per_pair("single_hits"), "rescue_hits": per_pair("rescue_hits")},
-            "hit_count_allreduce": {"references": int(len(ref_counts)), "pair_hits_counted": int(ref_counts.sum()), "ranks": world},
+            "hit_count_allreduce": {"references": int(len(ref_counts)), "pair_hits_counted": int(ref_counts.sum()), "ranks": world,
+                                    "backend": (backend if world > 1 else None)},
         }
         # ---- what the short cuts stand for (NOT in frac): the same walk priced as if every step had issued its rank queries,
         # and the reference algorithm's own look-ups (SURVEY 8d formula, reference layouts: 64 B/occ, 16 B/lkt, 8 B/sa)

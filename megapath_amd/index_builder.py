@@ -15,6 +15,7 @@ letters removed and recorded for .tra / .amb, shorter ones replaced) and the fil
 from __future__ import annotations
 
 import os
+import re
 
 import numpy as np
 import torch
@@ -132,6 +133,7 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
 
 
 # ---- FASTA parsing as the reference builder does it (HSPParseFASTAToPacked, 2bwt-lib/HSP.c:354-567)
+_WS = re.compile(rb"[ \t\n\v\f\r]")
 _DNA_CHAR = b"ACGTMRSVWYHKDBN"        # dnaChar[0..14] (HSP.h:154); 'L' = nonMatchDnaCharIndex and everything else is skipped
 
 
@@ -140,25 +142,30 @@ def parse_fasta_reference_style(data: bytes):
     actual [(startPos, length) per sequence incl. removed runs]).  Rules (HSP.c:441-547): the name is the header up to the first
     white space; letters outside IUPAC are skipped (so is 'U'); lower case counts as upper case; a run of ambiguity letters
     (anything but ACGT, white space inside it ignored) shorter than 10 becomes that many 'G', a run of 10 or more is REMOVED from
-    the packed text and recorded; any '>' starts the next record."""
+    the packed text and recorded; a '>' in the sequence body starts the next record, a '>' inside a header line does not."""
     kind = np.zeros(256, dtype=np.uint8)                 # 0 skip, 1..4 = A C G T (code + 1), 5 = ambiguity letter
     for i, ch in enumerate(_DNA_CHAR):
         v = i + 1 if i < 4 else 5
         kind[ch] = v
         kind[ch + 32] = v
     buf = np.frombuffer(data, dtype=np.uint8)
-    gt = np.flatnonzero(buf == ord(">"))
     if len(buf) == 0 or buf[0] != ord(">"):
         raise ValueError("FASTA file does not begin with '>'")
     names, gis, seqs, ambiguity, first_amb, actual = [], [], [], [], [], []
     total, discarded = 0, 0
-    for r, h0 in enumerate(gt):
-        rec_end = int(gt[r + 1]) if r + 1 < len(gt) else len(buf)
-        nl = data.find(b"\n", int(h0), rec_end)
+    h0 = 0
+    while h0 < len(buf):
+        # the header runs to the end of its line whatever it contains ("3'->5' exonuclease"); only then does a '>' start the next
+        # record (HSP.c:441-449 reads to '\n', :476 scans the body for '>')
+        nl = data.find(b"\n", h0)
         if nl < 0:
-            nl = rec_end
-        header = data[int(h0) + 1:nl]
-        name = header.split()[0] if header.split() else b""
+            nl = len(buf)                                 # header without a newline: a record with an empty sequence
+        rec_end = data.find(b">", nl + 1) if nl + 1 < len(buf) else -1
+        if rec_end < 0:
+            rec_end = len(buf)
+        header = data[h0 + 1:nl]
+        m = _WS.search(header)                            # the name ends at the first white-space byte (a header that begins
+        name = header[:m.start()] if m else header        # with one has an empty name, HSP.c:442-445)
         name = name[:255]                                 # MAX_SEQ_NAME_LENGTH
         gi = 0
         if len(name) > 3 and name[:3] == b"gi|":
@@ -196,6 +203,7 @@ def parse_fasta_reference_style(data: bytes):
         total += len(codes)
         first_amb.append(len(ambiguity))
         actual.append((start_actual, total + discarded - start_actual))
+        h0 = rec_end
     return dict(names=names, gi=gis, seqs=seqs, ambiguity=ambiguity, first_amb_index=first_amb, actual=actual)
 
 

@@ -99,3 +99,24 @@ def test_builder_removes_long_n_runs_like_the_reference(golden_dir, tmp_path):
     for ext in (".pac", ".bwt", ".fmv", ".sa", ".tra", ".amb"):
         assert open(prefix + ext, "rb").read() == open(os.path.join(d, "n.fa.index" + ext), "rb").read(), ext
     assert open(prefix + ".ann").read().split()[3:] == open(os.path.join(d, "n.fa.index.ann")).read().split()[3:]
+
+
+def test_builder_reads_headers_like_the_reference(golden_dir, tmp_path):
+    """tests/golden/hdr (files written by the REAL 2bwt-builder): a '>' inside a header line does not start a record (NT titles such as
+    "3'->5' exonuclease"; HSP.c:441-449 reads the header to its newline), a header that begins with white space has an empty name, a
+    last header without a newline is a record of length 0."""
+    from megapath_amd.index_builder import parse_fasta_reference_style
+    d = os.path.join(golden_dir, "hdr")
+    parsed = parse_fasta_reference_style(open(os.path.join(d, "h.fa"), "rb").read())
+    assert parsed["names"] == ["AB000001.1", "CD000002.2", "", "EF000003.1", "last_header_without_newline"]
+    assert [len(s) for s in parsed["seqs"]] == [1500, 900, 700, 1100, 0]
+    arrs = build_index_arrays(parsed, sa_interval=16)
+    prefix = str(tmp_path / "mine.index")
+    write_index_files(prefix, arrs, write_lkt=False)
+    for ext in (".pac", ".bwt", ".fmv", ".sa", ".tra", ".amb"):
+        assert open(prefix + ext, "rb").read() == open(os.path.join(d, "h.fa.index" + ext), "rb").read(), ext
+    mine, ref = open(prefix + ".ann").read().split("\n"), open(os.path.join(d, "h.fa.index.ann")).read().split("\n")
+    assert mine[1:] == ref[1:] and mine[0].split()[:2] == ref[0].split()[:2]
+    # the advisor's example
+    r = parse_fasta_reference_style(b">AB1.1 exo 3->5 domain\nACGTACGT\n>CD2.1 x\nGGGG\n")
+    assert r["names"] == ["AB1.1", "CD2.1"] and [len(s) for s in r["seqs"]] == [8, 4]

@@ -101,6 +101,15 @@ mmpShortSeedRatio=0.5
 """
 
 
+HG_INI = NT2_INI.replace("mmpSeedMinLength=17", "mmpSeedMinLength=22").replace("mmpReseedLen=18", "mmpReseedLen=23")   # soap4.ini
+INIS = {"soap4.ini": HG_INI, "soap4-nt2.ini": NT2_INI}
+
+
+def mmp_of(ini_name):
+    from megapath_amd import hipapi as H
+    return H.MmpParams.human() if ini_name == "soap4.ini" else H.MmpParams.nt2()
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 class Workload:
     """A batch of synthetic pairs in pinned host memory (what a reader thread hands to the device stage)."""
@@ -108,11 +117,14 @@ class Workload:
     def __init__(self, text, n_pairs, seed, read_len=150, L=None, **sim):
         from megapath_amd import simulate
         codes, lens = simulate.paired_reads(text, n_pairs, read_len, seed=seed, **sim)
-        self.max_len = int(codes.shape[1])
-        self.L = L if L is not None else self.max_len + 1             # the -L value: maxReadLength, reads are cut to L - 1
+        self.L = L if L is not None else int(codes.shape[1]) + 1      # the -L value: maxReadLength, reads are cut to L - 1 (QueryParser.cpp:188)
         self.W = (self.L + 15) // 16
+        self.codes = codes                                            # untruncated: what the FASTQ files of the parity sample hold
+        if codes.shape[1] > self.L - 1:
+            codes = codes[:, :self.L - 1].contiguous()
+            lens = lens.clamp(max=self.L - 1)
+        self.max_len = int(codes.shape[1])                            # longest read as the aligner sees it
         packed = simulate.pack_codes(codes, self.W)
-        self.codes = codes
         self.n_pairs = n_pairs
         self.sum_len = int(lens.sum().item())
         self.packed_h = packed.cpu().pin_memory()
@@ -222,7 +234,7 @@ def pmc_pass(counter, args, tmpdir):
     out_dir = os.path.join(tmpdir, "pmc_" + counter)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-include-regex", PMC_REGEX, "--output-format", "csv", "-d", out_dir, "--",
            sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "0", "--genome-mbp", str(args.genome_mbp),
-           "--pairs-per-step", str(args.pairs_per_step), "--read-len", str(args.read_len)]
+           "--pairs-per-step", str(args.pairs_per_step), "--read-len", str(args.read_len), "--ini", args.ini] + (["--L", str(args.L)] if args.L is not None else [])
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -296,9 +308,9 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
     use_ref = os.path.exists(ref_bin)
     index_builder.write_index_files(prefix, arrs, write_lkt=use_ref, lkt_table=lkt_table if use_ref else None)
     cores = os.cpu_count() or 1
-    ini = os.path.join(tmpdir, "soap4-nt2.ini")
+    ini = os.path.join(tmpdir, args.ini)
     with open(ini, "w") as f:
-        f.write(NT2_INI)
+        f.write(INIS[args.ini])
     cb, parity = None, None
     ref_out = os.path.join(tmpdir, "ref.out")
     if use_ref:
@@ -332,6 +344,7 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
         lib = O.oracle()
         ix = lib.mpo_index_open(prefix.encode())
         p = O.default_params(L=read_L)
+        p.mmp.seed_min_length, p.mmp.reseed_len = (22, 23) if args.ini == "soap4.ini" else (17, 18)
         st = O.AlignStats()
         few = min(n_pairs, 4000)
         f1s, f2s = os.path.join(tmpdir, "few_1.fq"), os.path.join(tmpdir, "few_2.fq")
@@ -366,8 +379,8 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
             aligned = sum(1 for v in want.values() if b"SCORE:0;" not in v[0])
             parity = {"pairs": n_pairs, "records": len(want), "records_equal": not diff, "records_differing": len(diff), "first_diff": first,
                       "reference_records_with_a_hit": aligned, "against": cb["kind"] if cb else None,
-                      "how": "bin/soap4-mi355x pair <same index files> <same FASTQ> -L %d -u 750 -F -nc (whole-process %.0f s), stdout compared with the "
-                             "CPU run's, record by record, order-insensitive" % (read_L, time.time() - t0)}
+                      "how": "bin/soap4-mi355x pair <same index files> <same FASTQ> -C %s -L %d -u 750 -F -nc (whole-process %.0f s), stdout compared with the "
+                             "CPU run's, record by record, order-insensitive" % (args.ini, read_L, time.time() - t0)}
     return cb, parity
 
 
@@ -417,6 +430,9 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MP_BENCH_GENOME_MBP", "2950")))
     ap.add_argument("--pairs-per-step", type=int, default=int(os.environ.get("MP_BENCH_PAIRS", str(1 << 20))))
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--ini", choices=sorted(INIS), default=os.environ.get("MP_BENCH_INI", "soap4.ini"),
+                    help="soap4.ini + -L <read-len> is how runMegaPath.sh:136 runs the human-filter stage (configs[1]); soap4-nt2.ini + -L <read-len + 1> is the NT stage's")
+    ap.add_argument("--L", type=int, default=None, help="-L value (maxReadLength; reads are cut to L - 1); default: read-len for soap4.ini, read-len + 1 for soap4-nt2.ini")
     ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MP_BENCH_CPU_PAIRS", "100000")))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity sample")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs (roofline.traffic = null)")
@@ -482,9 +498,11 @@ def main():
         log("[bench] random 64-B gather ceiling over the rank blocks: %.0f GB/s" % gather_gbs)
 
     P = args.pairs_per_step
-    wl = Workload(text, P, seed=1000 + rank, read_len=args.read_len)
+    read_L = args.L if args.L is not None else (args.read_len if args.ini == "soap4.ini" else args.read_len + 1)
+    wl = Workload(text, P, seed=1000 + rank, read_len=args.read_len, L=read_L)
     ctx = H.Context(gix)
-    params = H.AlignParams(args.read_len, 750, 130, 130, H.MmpParams.nt2())
+    # insert_low = the longest read of the first batch (SOAP4.cpp:465-474), as the executable settles it
+    params = H.AlignParams(wl.max_len, 750, 130, 130, mmp_of(args.ini))
 
     for _ in range(max(args.warmup, 0 if args.pmc_child else 1)):
         step(ctx, wl, params)
@@ -553,7 +571,8 @@ def main():
                                    "rescue round (single-end DP, mate rescue) + all three hit lists back in pinned host memory; the batch is cut into %d contiguous blocks "
                                    "that as many contexts work on side by side" % (args.read_len, args.genome_mbp, P, n_ctx),
                        "index_replicated_per_gpu": True, "pairs_per_step_per_gpu": P, "genome_mbp": args.genome_mbp,
-                       "index_bytes_in_hbm": int(gix.info.device_bytes), "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750},
+                       "index_bytes_in_hbm": int(gix.info.device_bytes), "ini": args.ini, "L": read_L, "u": 750,
+                       "command_line": "soap4 pair <index> r1.fq r2.fq -C %s -L %d -u 750 -F -nc (runMegaPath.sh:136)" % (args.ini, read_L)},
             "roofline": {"bound": "hbm", "kernel": "+".join(roof_kernels), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": b_loaded / K, "bytes_per_pair": b_loaded / (K * P), "launch_ms": (acc["ms_seed"] + acc["ms_locate"]) / K,
@@ -623,7 +642,7 @@ def main():
             cb = parity = None
             if world == 1 and not args.no_cpu_baseline:
                 try:
-                    cb, parity = cpu_baseline_and_parity(args, arrs, wl.codes[: 2 * min(args.cpu_sample_pairs, P)], tmpdir, gix.lkt_table(), local_rank, args.read_len + 1)
+                    cb, parity = cpu_baseline_and_parity(args, arrs, wl.codes[: 2 * min(args.cpu_sample_pairs, P)], tmpdir, gix.lkt_table(), local_rank, read_L)
                 except Exception as e:  # noqa: BLE001 -- the baseline is auxiliary; report its absence, never hide the GPU number
                     log("[bench] cpu baseline / parity sample failed: %r" % (e,))
             out["cpu_baseline"] = cb
@@ -639,6 +658,22 @@ def main():
                 ("C5_mixed_rescue", "lengths uniform 75-300 (-L 301), 30 % of pairs with one mate random: rescue stress", dict(
                     read_len=300, len_range=(75, 300), broken_mate_frac=0.3, frag_mean=450.0, frag_sd=50.0, frag_max=700)),
             ]
+            # every leg below is an NT-stage shape: soap4-nt2.ini (17-base seeds), -L = read length + 1 (runMegaPath.sh:206)
+            nt_L = args.read_len + 1
+            nt_wl = wl if (args.ini == "soap4-nt2.ini" and read_L == nt_L) else Workload(text, max(P // 4, 1 << 16), seed=1000 + rank, read_len=args.read_len, L=nt_L)
+            nt_params = H.AlignParams(nt_wl.max_len, 750, 130, 130, H.MmpParams.nt2())
+            try:
+                lp = nt_wl.n_pairs
+                lctx = H.Context(gix)
+                step(lctx, nt_wl, nt_params)
+                el, la = run_steps(lctx, nt_wl, nt_params, 2)
+                legs["nt2_ini_same_reads"] = {"workload": "the default read mix with the NT stage's parameters (-C soap4-nt2.ini -L %d: 17-base seeds, reads of %d bases) against the same "
+                                                          "index, one context: the configuration rounds 1 and 2 quoted" % (nt_L, nt_wl.max_len),
+                                              "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3,
+                                              "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")}}
+                lctx.close()
+            except Exception as e:  # noqa: BLE001
+                legs["nt2_ini_same_reads"] = {"error": repr(e)}
             for name, desc, sim in specs:
                 try:
                     lp = max(P // 4, 1 << 16)
@@ -674,7 +709,8 @@ def main():
                         os.environ[k] = v
                 lean_bytes = sum(int(x.info.device_bytes) for x in lean)
                 lp = max(P // 4, 1 << 16)
-                lw = WorkloadSlice(wl, 0, lp)
+                lw = WorkloadSlice(nt_wl, 0, min(lp, nt_wl.n_pairs))
+                params_default, params = params, nt_params                       # (the chunk loop below uses `params`)
                 lctx = H.Context(lean[0])
                 step(lctx, lw, params)
                 el, la = run_steps(lctx, lw, params, 2)

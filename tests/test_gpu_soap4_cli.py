@@ -493,3 +493,18 @@ def test_cli_equals_oracle_on_random_workloads(tmp_path, cfg):
     got, want = fastq_records(str(out)), fastq_records(_oracle_stdout(prefix, f1, f2, L, tmp_path))
     assert len(got) == len(want) == 2 * n_pairs
     assert got == want
+
+
+@pytest.mark.parametrize("driver", ["cxx", "py"])
+@pytest.mark.parametrize("tag,ini,flags", [("h", "soap4.ini", ["-F", "-nc"]), ("r", "soap4.ini", ["-F", "-P", "-nc", "-top", "100"]),
+                                           ("n", "soap4-nt2.ini", ["-F", "-nc"])])
+def test_cli_soap4_ini_stages_equal_reference(golden_dir, tmp_path, tag, ini, flags, driver):
+    """The host-filter and 16S command lines of runMegaPath.sh:136,162 (`-C soap4.ini`: seeds of >= 22 bases, `-L 150`; 16S: `-F -P -nc
+    -top 100`) against the real soap4's stdout (tests/golden/g5, make_golden_ini.py)."""
+    d = os.path.join(golden_dir, "g5")
+    out = tmp_path / "out.fq"
+    _run_cli(["pair", os.path.join(golden_dir, "g1", "ref.fa.index"), os.path.join(d, "reads_1.fq"), os.path.join(d, "reads_2.fq"),
+              "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", ini), "-L", "150", "-T", "2", "-u", "750"] + flags, out, driver=driver,
+             batch_pairs=90 if driver == "cxx" else None)
+    got, want = fastq_records(str(out)), fastq_records(os.path.join(d, "expected_%s.fq" % tag))
+    assert len(got) == len(want) and got == want

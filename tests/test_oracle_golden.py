@@ -166,3 +166,25 @@ def test_three_chained_chunks_match_reference_chain(golden_dir, tmp_path, tag, L
     got, want = fastq_records(out), fastq_records(os.path.join(g3, "expected_chain_%s.fq" % tag))
     assert got == want
     assert sum(1 for r in want if r[2].count(",") >= 2) > 0 or tag == "c"      # some reads do carry hits from more than one chunk
+
+
+# (tag, MegaPath mode, -top, seed_min_length, reseed_len): tests/golden/g5, the stages that run with soap4.ini (runMegaPath.sh:136,162)
+G5_SETS = {"h": (1, 95, 22, 23), "r": (2, 100, 22, 23), "n": (1, 95, 17, 18)}
+
+
+@pytest.mark.parametrize("tag", sorted(G5_SETS))
+def test_soap4_ini_stage_goldens(g1, golden_dir, tmp_path, tag):
+    """Host filter (`-C soap4.ini -L 150 -F -nc`) and 16S filter (`-C soap4.ini -L 150 -F -P -nc -top 100`) as the pipeline runs them:
+    mmpSeedMinLength 22 / mmpReseedLen 23 instead of the NT stage's 17 / 18.  Expected = stdout of the real soap4
+    (tests/golden/make_golden_ini.py); "n" is the same read set with soap4-nt2.ini and differs from "h" in ten records."""
+    lib = O.oracle()
+    d = os.path.join(golden_dir, "g5")
+    mode, top, smin, rlen = G5_SETS[tag]
+    p = O.default_params(L=150, insert_high=750, mode=mode, top=top, nc=True)
+    p.mmp.seed_min_length, p.mmp.reseed_len = smin, rlen
+    st = O.AlignStats()
+    out = tmp_path / "out.fq"
+    assert lib.mpo_align_fastq(g1, C.byref(p), os.path.join(d, "reads_1.fq").encode(), os.path.join(d, "reads_2.fq").encode(), str(out).encode(), None, C.byref(st)) == 0
+    got, want = fastq_records(str(out)), fastq_records(os.path.join(d, "expected_%s.fq" % tag))
+    assert len(got) == len(want) == 2 * st.n_pairs and got == want
+    assert fastq_records(os.path.join(d, "expected_h.fq")) != fastq_records(os.path.join(d, "expected_n.fq"))

@@ -403,8 +403,19 @@ def launch_ranks(n, argv, script=None, extra_env=None):
                     "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc = 0
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # rank 0's stdout is relayed line by line: JSON lines go to stdout, anything else a library prints there (gloo's connection
+    # banner) goes to stderr, so that stdout stays ONE JSON line
+    import threading
+
+    def relay(pipe):
+        for raw in iter(pipe.readline, b""):
+            line = raw.decode(errors="replace")
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush(); sys.stderr.flush()
+    pump = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    pump.start()
+    codes = {}
     live = set(range(n))
     while live:
         for r in sorted(live):
@@ -412,13 +423,15 @@ def launch_ranks(n, argv, script=None, extra_env=None):
             if code is None:
                 continue
             live.discard(r)
+            codes[r] = code
             if code != 0:
                 log("[bench] rank %d exited with code %d" % (r, code))
-                rc = rc or (code if code > 0 else 1)
                 for o in live:
                     procs[o].terminate()
         time.sleep(0.05)
-    return rc
+    pump.join(timeout=10)
+    bad = [c for c in codes.values() if c != 0]
+    return 0 if not bad else max([c for c in bad if c > 0] or [1])       # the worst exit code; a rank killed by a signal counts as 1
 
 
 # ------------------------------------------------------------------------------------------------ main

@@ -59,7 +59,7 @@ public:
     ~Bgzf() { close(); }
 
 private:
-    static const size_t kBlock = 0xff00, kGroup = 16, kOut = 0x10000 + 64;
+    static constexpr size_t kBlock = 0xff00, kGroup = 16, kOut = 0x10000 + 64;   // constexpr: std::min takes them by reference (ODR use)
     // one BGZF block: 18-byte header with the BC extra field, raw deflate data, CRC32 and input size
     static size_t deflate_block(const uint8_t *in, size_t n, uint8_t *out, int level)
     {

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Sanitizer runs of the host code (CPU only; GPU ASan is not available on this pool): builds host/soap4_main.cpp with
+# -fsanitize=thread and with -fsanitize=address,undefined and drives the reader -> workers -> printer plumbing (MP_PLUMBING_TEST:
+# no device, nothing aligned) with several fake GPUs, jittered batch times, tiny batches, two chunks, gz input and a corrupt gz.
+# Usage: bash scripts/sanitize_host.sh        (exit code 0 = both clean)
+set -u
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+B="$ROOT/build/sanitize"; mkdir -p "$B"
+G1="$ROOT/tests/golden/g1"
+SRC="$ROOT/megapath_amd/csrc/host/soap4_main.cpp"
+fail=0
+gzip -c "$G1/reads_a_1.fq" > "$B/a_1.fq.gz"; gzip -c "$G1/reads_a_2.fq" > "$B/a_2.fq.gz"
+head -c 6000 "$B/a_1.fq.gz" > "$B/bad_1.fq.gz"
+for kind in thread address,undefined; do
+    exe="$B/soap4-$(echo $kind | tr , -)"
+    g++ -O1 -g -std=c++17 -Wall -pthread -fno-omit-frame-pointer -fsanitize=$kind -o "$exe" "$SRC" -L"$ROOT/megapath_amd" -lmegapath_hip -lz -Wl,-rpath,"$ROOT/megapath_amd" || { echo "build ($kind) failed"; exit 2; }
+    export TSAN_OPTIONS="halt_on_error=0 exitcode=66 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=1 exitcode=66" UBSAN_OPTIONS="print_stacktrace=1 halt_on_error=0 exitcode=66"
+    run() {   # name, expected rc, args...
+        local name="$1" want="$2"; shift 2
+        MP_PLUMBING_TEST=1 "$@" > "$B/$name.$kind.out" 2> "$B/$name.$kind.err"; local rc=$?
+        if grep -q "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error:\|ERROR: LeakSanitizer" "$B/$name.$kind.err"; then echo "[$kind] $name: SANITIZER REPORT (see $B/$name.$kind.err)"; fail=1;
+        elif [ $rc -ne $want ]; then echo "[$kind] $name: exit code $rc, expected $want"; tail -5 "$B/$name.$kind.err"; fail=1;
+        else echo "[$kind] $name: clean (rc $rc, $(grep -c '^@' "$B/$name.$kind.out") records)"; fi
+    }
+    common=(-o "$B/o" -C "$ROOT/tests/soap4-nt2.ini" -L 151 -u 750)
+    MP_PLUMBING_JITTER_US=4000 MP_BATCH_PAIRS=7 run order 0 "$exe" pair x,y "$G1/reads_a_1.fq" "$G1/reads_a_2.fq" "${common[@]}" -T 3 -F -nc -c 0,1,2
+    MP_PLUMBING_JITTER_US=500 MP_BATCH_PAIRS=3 MP_WORKERS_PER_GPU=4 run tiny 0 "$exe" pair x "$B/a_1.fq.gz" "$B/a_2.fq.gz" "${common[@]}" -T 8 -F -c 0,1
+    MP_BATCH_PAIRS=1000 run onebatch 0 "$exe" pair x,y,z "$G1/reads_d_1.fq" "$G1/reads_d_2.fq" "${common[@]}" -T 2 -P
+    MP_BATCH_PAIRS=50 run lsam 0 "$exe" pair x "$G1/reads_e_1.fq" "$G1/reads_e_2.fq" "${common[@]}" -T 4 -F -top 95 -lsam
+    # fatal() leaves through _exit() from whichever thread met the error, on purpose (no atexit handlers while other stages write):
+    # the threads it leaves behind are not a leak to report
+    TSAN_OPTIONS="$TSAN_OPTIONS report_thread_leaks=0" ASAN_OPTIONS="$ASAN_OPTIONS detect_leaks=0" MP_BATCH_PAIRS=20 run corrupt 1 "$exe" pair x "$B/bad_1.fq.gz" "$G1/reads_a_2.fq" "${common[@]}" -T 2 -F -nc
+done
+[ $fail -eq 0 ] && echo "sanitizers: all clean" || echo "sanitizers: REPORTS ABOVE"
+exit $fail

@@ -508,3 +508,14 @@ def test_cli_soap4_ini_stages_equal_reference(golden_dir, tmp_path, tag, ini, fl
              batch_pairs=90 if driver == "cxx" else None)
     got, want = fastq_records(str(out)), fastq_records(os.path.join(d, "expected_%s.fq" % tag))
     assert len(got) == len(want) and got == want
+
+
+def test_cli_two_worker_pools_on_one_device(golden_dir, tmp_path):
+    """`-c 0,0`: the multi-device code path of the executable (one worker pool, one index replica and one set of contexts per listed
+    device, a single ordered output) on real hardware -- both 'devices' are GPU 0 here.  Output = the real soap4's for golden a."""
+    d = os.path.join(golden_dir, "g1")
+    out = tmp_path / "out.fq"
+    err = _run_cli(["pair", os.path.join(d, "ref.fa.index"), os.path.join(d, "reads_a_1.fq"), os.path.join(d, "reads_a_2.fq"), "-o", str(tmp_path / "o"),
+                    "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "2", "-u", "750", "-F", "-nc", "-c", "0,0"], out, batch_pairs=17)
+    assert fastq_records(str(out)) == fastq_records(os.path.join(d, "expected_a.fq"))
+    assert b"2 GPU(s)" in err

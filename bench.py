@@ -384,6 +384,96 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
     return cb, parity
 
 
+# ------------------------------------------------------------------------------------------------ through the boundary
+def write_fastq_fast(codes_dev, path1, path2, first_id=0):
+    """2P x L base codes on the device -> two FASTQ files with fixed-width names, formatted as one byte matrix per file on the
+    device (a Python loop over millions of records would take longer than the run it feeds)."""
+    n2, L = codes_dev.shape
+    dev = codes_dev.device
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    ids = torch.arange(first_id, first_id + n2 // 2, device=dev, dtype=torch.int64)
+    digits = torch.stack([(ids // (10 ** k)) % 10 for k in range(8, -1, -1)], dim=1).to(torch.uint8) + 48       # 9 digits
+    for m, path in ((0, path1), (1, path2)):
+        P = n2 // 2
+        rec = torch.empty(P, 2 + 9 + 3 + L + 3 + L + 1, dtype=torch.uint8, device=dev)
+        rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 2:11] = digits
+        rec[:, 11] = ord("/"); rec[:, 12] = ord("1") + m; rec[:, 13] = 10
+        rec[:, 14:14 + L] = lut[codes_dev[m::2].long()]
+        o = 14 + L
+        rec[:, o] = 10; rec[:, o + 1] = ord("+"); rec[:, o + 2] = 10
+        rec[:, o + 3:o + 3 + L] = ord("I")
+        rec[:, o + 3 + L] = 10
+        with open(path, "ab") as f:
+            f.write(rec.cpu().numpy().tobytes())
+        del rec
+
+
+def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=12, gz_pairs=1 << 20):
+    """FASTQ files in, annotated FASTQ out, through bin/soap4-mi355x (the boundary a pipeline maintainer sees): pairs/s of the
+    executable's alignment loop (index load excluded, as for the CPU soap4), stdout to /dev/null; plain input and gzip'ed input."""
+    from megapath_amd import simulate
+    exe = os.path.join(ROOT, "bin", "soap4-mi355x")
+    if not os.path.exists(exe) or not os.path.exists(prefix + ".bwt"):
+        return {"error": "executable or index files missing"}
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tmpdir
+    d = tempfile.mkdtemp(prefix="mpe2e_", dir=shm)
+    res = {}
+    try:
+        P = args.pairs_per_step
+        f1, f2 = os.path.join(d, "r_1.fq"), os.path.join(d, "r_2.fq")
+        t0 = time.time()
+        for b in range(n_batches):
+            codes, _ = simulate.paired_reads(text, P, args.read_len, seed=7000 + b)
+            write_fastq_fast(codes, f1, f2, first_id=b * P)
+            del codes
+        torch.cuda.empty_cache()
+        t_gen = time.time() - t0
+        threads = min(os.cpu_count() or 16, int(os.environ.get("MP_BENCH_E2E_THREADS", "16")))
+
+        def run(a, b, n_pairs, extra_env=None):
+            env = dict(os.environ, MP_TIMING="1", MP_DEVICE=str(device))
+            env.update(extra_env or {})
+            env.pop("LOCAL_RANK", None)
+            cmd = [exe, "pair", prefix, a, b, "-o", os.path.join(d, "o"), "-C", ini_path, "-L", str(read_L), "-T", str(threads), "-u", "750", "-F", "-nc"]
+            t0 = time.time()
+            with open(os.devnull, "wb") as fo:
+                r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
+            wall = time.time() - t0
+            err = r.stderr.decode(errors="replace")
+            loop_s = None
+            for line in err.splitlines():
+                if "alignment loop" in line:
+                    loop_s = float(line.split("alignment loop")[1].split()[0])
+            out = {"rc": r.returncode, "pairs": n_pairs, "process_s": wall, "alignment_loop_s": loop_s, "pairs_per_s": (n_pairs / loop_s) if loop_s else None,
+                   "threads": threads, "stage_seconds": next((l.split("seconds:")[1].strip() for l in err.splitlines() if "seconds:" in l), None)}
+            if r.returncode != 0:
+                out["stderr_tail"] = err[-400:]
+            return out
+        res["plain"] = run(f1, f2, n_batches * P)
+        # tuning aid: MP_BENCH_E2E_VARIANTS="name:ENV=val,ENV=val;name2:..." runs the plain input again under each environment
+        for spec in filter(None, os.environ.get("MP_BENCH_E2E_VARIANTS", "").split(";")):
+            nm, _, kv = spec.partition(":")
+            res["plain_" + nm] = run(f1, f2, n_batches * P, dict(x.split("=", 1) for x in kv.split(",") if "=" in x))
+        res["plain"]["input"] = "%d pairs, 2 x %.2f GB of FASTQ in %s (generated in %.0f s)" % (n_batches * P, os.path.getsize(f1) / 1e9, shm, t_gen)
+        # gzip'ed input (what runMegaPath.sh:136 feeds): one zlib stream per file inflates at a few hundred MB/s
+        g1, g2 = os.path.join(d, "g_1.fq"), os.path.join(d, "g_2.fq")
+        rec_bytes = os.path.getsize(f1) // (n_batches * P)
+        for src, dst in ((f1, g1), (f2, g2)):
+            with open(src, "rb") as fi, open(dst, "wb") as fo:
+                fo.write(fi.read(rec_bytes * gz_pairs))
+        t0 = time.time()
+        procs = [subprocess.Popen(["gzip", "-1", g]) for g in (g1, g2)]
+        for pr in procs:
+            pr.wait()
+        res["gz"] = run(g1 + ".gz", g2 + ".gz", gz_pairs)
+        res["gz"]["input"] = "%d pairs, gzip -1 (%.2f GB per file, compressed in %.0f s)" % (gz_pairs, os.path.getsize(g1 + ".gz") / 1e9, time.time() - t0)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    res["note"] = ("pairs/s of the executable's alignment loop: reading, packing, device stage, grouping, formatting and writing (to /dev/null) of every "
+                   "record; the index load is outside, as it is for the CPU soap4's 'Overall alignment time'")
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ N ranks from one command line
 def launch_ranks(n, argv, script=None, extra_env=None):
     """`python bench.py --gpus N` started without a launcher (no RANK in the environment): start N fresh child processes of
@@ -453,8 +543,16 @@ def main():
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "3")),
                     help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")
     ap.add_argument("--nt-chunks", type=int, default=int(os.environ.get("MP_BENCH_NT_CHUNKS", "4")), help="index chunks of the resident-chunks leg")
+    ap.add_argument("--legs", default=os.environ.get("MP_BENCH_LEGS", "all"), help="comma-separated legs to run (e2e_cli, nt2_ini_same_reads, C3_divergent, C4_2x250, "
+                    "C5_mixed_rescue, lean_layout, nt_replica) or 'all'")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the leg through the executable (FASTQ files in, annotated FASTQ out)")
+    ap.add_argument("--e2e-batches", type=int, default=int(os.environ.get("MP_BENCH_E2E_BATCHES", "24")), help="batches of --pairs-per-step pairs in the e2e leg's input files")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    leg_set = None if args.legs == "all" else set(x for x in args.legs.split(",") if x)
+
+    def want_leg(name):
+        return leg_set is None or name in leg_set
     if args.pmc_child:
         args.no_cpu_baseline = args.no_pmc = args.no_legs = True
 
@@ -660,6 +758,19 @@ def main():
                     log("[bench] cpu baseline / parity sample failed: %r" % (e,))
             out["cpu_baseline"] = cb
             out["parity_sample"] = parity
+            if world == 1 and not args.no_legs and not args.no_e2e and want_leg("e2e_cli"):
+                try:
+                    from megapath_amd import index_builder as _ib
+                    prefix = os.path.join(tmpdir, "ref.index")
+                    if not os.path.exists(prefix + ".bwt"):
+                        _ib.write_index_files(prefix, arrs, write_lkt=False)
+                    ini_path = os.path.join(tmpdir, args.ini)
+                    with open(ini_path, "w") as f:
+                        f.write(INIS[args.ini])
+                    out["e2e_cli"] = e2e_cli_leg(args, text, prefix, ini_path, read_L, local_rank, tmpdir, n_batches=args.e2e_batches)
+                except Exception as e:  # noqa: BLE001
+                    out["e2e_cli"] = {"error": repr(e)}
+                    log("[bench] e2e leg failed: %r" % (e,))
         finally:
             shutil.rmtree(tmpdir, ignore_errors=True)
         # ---- workload legs: the other configs' read shapes against the same index (sensitivity of the fast paths)
@@ -676,6 +787,8 @@ def main():
             nt_wl = wl if (args.ini == "soap4-nt2.ini" and read_L == nt_L) else Workload(text, max(P // 4, 1 << 16), seed=1000 + rank, read_len=args.read_len, L=nt_L)
             nt_params = H.AlignParams(nt_wl.max_len, 750, 130, 130, H.MmpParams.nt2())
             try:
+                if not want_leg("nt2_ini_same_reads"):
+                    raise KeyError("skipped")
                 lp = nt_wl.n_pairs
                 lctx = H.Context(gix)
                 step(lctx, nt_wl, nt_params)
@@ -685,9 +798,13 @@ def main():
                                               "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3,
                                               "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")}}
                 lctx.close()
+            except KeyError:
+                pass
             except Exception as e:  # noqa: BLE001
                 legs["nt2_ini_same_reads"] = {"error": repr(e)}
             for name, desc, sim in specs:
+                if not want_leg(name):
+                    continue
                 try:
                     lp = max(P // 4, 1 << 16)
                     lw = Workload(text, lp, seed=2000 + len(legs), **sim)
@@ -707,6 +824,8 @@ def main():
             # ---- lean layout: what a chunk of a 250 GB NT replica gets -- rank blocks, 13-mer table, the file's SA samples, text
             # (1.09 B/base), none of the optional tables -- and N such chunks resident at once, every batch aligned against each
             try:
+                if not (want_leg("lean_layout") or want_leg("resident_chunks")):
+                    raise KeyError("skipped")
                 knobs = {"MP_KMER_FILTER": "0", "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}
                 saved = {k: os.environ.get(k) for k in knobs}
                 os.environ.update(knobs)
@@ -761,9 +880,13 @@ def main():
                 lctx.close()
                 for x in lean:
                     x.close()
+            except KeyError:
+                pass
             except Exception as e:  # noqa: BLE001
                 legs["resident_chunks"] = {"error": repr(e)}
                 log("[bench] lean / resident-chunks leg failed: %r" % (e,))
+            if "e2e_cli" in out:
+                legs["e2e_cli"] = out.pop("e2e_cli")
             out["legs"] = legs
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -227,6 +227,7 @@ typedef struct {
 } mp_dp_census;
 int mp_ctx_set_dp_census(mp_ctx *ctx, int on);
 int mp_ctx_get_dp_census(mp_ctx *ctx, mp_dp_census *out);
+/* The hit list is grouped by pair, pairs in ascending order (the hits of one pair in no particular order). */
 int mp_get_pair_hits(mp_ctx *ctx, mp_pair_hit *out_hits, uint64_t cap);
 /* Same without a pageable copy: the hits land in a pinned buffer owned by the context (valid until the next round).  The
  * transfer is started by mp_deep_dp_round itself on a copy stream; this call waits for it, so a mp_rescue_round issued in

@@ -96,6 +96,7 @@ struct mp_ctx {
     DevBuf<mp_fill_result> band_fill;
     uint64_t n_band = 0, n_band_full = 0;        // instances run through the band kernel / re-run by the full kernels
     DevBuf<mp_pair_hit> pair_hits;
+    DevBuf<uint32_t> pair_cnt, pair_off;   // hits per pair and where each pair's group starts in pair_hits
     DevBuf<unsigned long long> n_pair_hits;
     uint64_t n_pair_hits_host = 0;
     mp_pair_hit *h_pair_hits = nullptr;    // pinned staging for mp_get_pair_hits_view
@@ -726,7 +727,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->seedpos.release(); c->hit_row.release(); c->seeds_per_rs.release(); c->hits_per_rs.release(); c->rs_base.release(); c->overflow_rs.release(); c->over_slot.release();
     c->queue.release(); c->n_pos.release(); c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
     c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
-    c->ops.release(); c->pair_hits.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
+    c->ops.release(); c->pair_hits.release(); c->pair_cnt.release(); c->pair_off.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
     if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
     c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
     c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release(); c->rtasks_c.release(); c->rres_c.release(); c->rlist.release();
@@ -1540,6 +1541,7 @@ extern "C" int mp_sgdp_batch(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int
 
 // ------------------------------------------------------------------------------------------------ deep-DP round
 static int start_hits_copy(mp_ctx *c);
+static int exclusive_scan_u32(mp_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n);
 
 extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *out_n_hits, mp_round_stats *out_stats)
 {
@@ -1597,12 +1599,20 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         rc = use_band ? run_dp_band(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0)
                       : run_dp(c, c->tasks_r.p, nc, max_win, ap->clip_left, ap->clip_right, c->res_r.p, nullptr, 0, &st.ms_dp_fill, &st.ms_dp_trace, ap->want_tie_counts != 0);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(c->n_pair_hits.p, 0, sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(collect_pair_hits_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,
-                           c->res_r.p, c->pair_hits.p, c->n_pair_hits.p, (uint32_t)c->pair_hits.cap, c->pair_done.p);
+        // the hits leave grouped by pair, pairs ascending: count per pair, scan, store at the group's offset
+        const uint32_t np1 = n_pairs + 1;
+        if (c->pair_cnt.reserve(np1) || c->pair_off.reserve(np1)) return MP_ENOMEM;
+        HIPCHK(hipMemsetAsync(c->pair_cnt.p, 0, (size_t)np1 * 4, s));
+        hipLaunchKernelGGL(collect_pair_hits_kernel<true>, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,
+                           c->res_r.p, c->pair_hits.p, c->pair_cnt.p, (const uint32_t *)c->pair_off.p, (uint32_t)c->pair_hits.cap, c->pair_done.p);
+        rc = exclusive_scan_u32(c, c->pair_cnt.p, c->pair_off.p, np1);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(c->pair_cnt.p, 0, (size_t)np1 * 4, s));
+        hipLaunchKernelGGL(collect_pair_hits_kernel<false>, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,
+                           c->res_r.p, c->pair_hits.p, c->pair_cnt.p, (const uint32_t *)c->pair_off.p, (uint32_t)c->pair_hits.cap, c->pair_done.p);
         MP_TRACE(s, "collect_pair_hits_kernel");
-        unsigned long long nh = 0;
-        HIPCHK(hipMemcpyAsync(&nh, c->n_pair_hits.p, sizeof nh, hipMemcpyDeviceToHost, s));
+        uint32_t nh = 0;
+        HIPCHK(hipMemcpyAsync(&nh, c->pair_off.p + n_pairs, sizeof nh, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         c->n_pair_hits_host = nh;
     }

@@ -125,7 +125,7 @@ struct PairAln { Side m[2]; long long insert = 0; };
 // what bedtools bamtobed would print for a mapped record of the merged BAM (runMegaPath.sh:212-215): the spike filter's input
 struct CovRec { uint32_t seq_id; uint64_t start0; uint32_t span; uint8_t mate; std::string name; };
 
-struct ReadView { const char *name; const char *seq; const char *qual; uint32_t len; };   // seq = "ACGT" text, qual = raw ASCII
+struct ReadView { const char *name; uint32_t name_len; const char *seq; const char *qual; uint32_t len; };   // views, not NUL-terminated; seq = "ACGT" text, qual = raw ASCII
 
 struct Options {
     std::string read_group, sample_name = "default", rg_option;   // -D / -A / -R (SOAP4.cpp:297-306)
@@ -261,7 +261,7 @@ public:
             if (cov && r[k].mapped && chr[k]) {
                 uint32_t num = 0, span = 0;                     // reference span of the BAM CIGAR: M and D
                 for (char ch : r[k].cigar) { if (ch >= '0' && ch <= '9') { num = num * 10 + (uint32_t)(ch - '0'); continue; } if (ch == 'M' || ch == 'D') span += num; num = 0; }
-                cov->push_back(CovRec{chr[k], tp[k] - 1, span, (uint8_t)(k + 1), rd[k].name});
+                cov->push_back(CovRec{chr[k], tp[k] - 1, span, (uint8_t)(k + 1), std::string(rd[k].name, rd[k].name_len)});
             }
         }
     }
@@ -549,7 +549,7 @@ private:
                 if (num > 0) { const uint32_t op = ch == 'M' ? 0 : ch == 'I' ? 1 : ch == 'D' ? 2 : 4; put32(cig, num << 4 | op); n_cig++; num = 0; }
             }
         }
-        const uint32_t l_name = (uint32_t)strlen(rd.name) + 1, L = rd.len;
+        const uint32_t l_name = rd.name_len + 1, L = rd.len;
         const uint32_t mapq = r.mapped ? (uint32_t)(r.mapq & 0xFF) : 0u;
         const size_t at = rec_.size();                          // records are appended to the caller's buffer (one per file kind)
         put32(rec_, 0);                                         // block_size, patched below
@@ -557,7 +557,7 @@ private:
         put32(rec_, 0u << 16 | mapq << 8 | l_name);             // bin = bam_reg2bin(0, 0) = 0 for every record (BGS-IO.cpp:438)
         put32(rec_, (uint32_t)flag << 16 | n_cig);
         put32(rec_, L); put32(rec_, (uint32_t)mtid); put32(rec_, (uint32_t)mpos); put32(rec_, (uint32_t)(int32_t)isize);
-        rec_.append(rd.name, l_name);
+        rec_.append(rd.name, rd.name_len); rec_ += '\0';
         rec_ += cig;
         const bool neg = r.strand == 2;
         auto nt16 = [&](uint32_t i) -> uint8_t {                // bam_nt16_table of A C G T

@@ -16,6 +16,9 @@
 #include <zlib.h>
 #include <stdarg.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <atomic>
 #include <stdint.h>
 #include <stdio.h>
@@ -31,6 +34,7 @@
 #include <unordered_set>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <vector>
 #include <memory>
@@ -57,24 +61,41 @@ struct Params {
     size_t batch_pairs = 1u << 20;                                   // SOAP4.cpp:206
 };
 
+// One read as the stages see it.  Name, comment, sequence and qualities are VIEWS into the batch's text -- the mapped input file,
+// or the batch's own buffer of inflated bytes -- nothing is copied; only what cannot be used as it stands is owned (RecOwned).
+struct RecOwned {
+    std::string seq, qual;      // the decoded 2-bit read when the text has anything but upper-case ACGT (the reference echoes the decoded
+                                // read: N -> G), and the joined lines of a wrapped record
+    std::string comment;        // resident chunks: the comment the chunk before left in place of the record's own (Writer::carry)
+};
 struct Rec {
-    std::string name, comment, seq, qual;   // seq = decoded 2-bit codes (what the reference echoes: N -> G, truncated)
-    bool has_comment = false;
+    const char *name = nullptr, *seq = nullptr, *qual = nullptr, *comment = nullptr;
+    uint32_t name_len = 0, seq_len = 0, qual_len = 0, comment_len = 0;   // seq / qual after the -L cut (QueryParser.cpp:188)
+    bool has_comment = false;   // the rest of the header line (kseq), unless -nc
+    std::unique_ptr<RecOwned> own;
+    std::string_view name_v() const { return std::string_view(name, name_len); }
+    std::string_view seq_v() const { return std::string_view(seq, seq_len); }
+    std::string_view qual_v() const { return std::string_view(qual, qual_len); }
+    std::string_view comment_v() const { return std::string_view(comment, comment_len); }
+    bool ignore() const { return has_comment && comment_len == 6 && memcmp(comment, "IGNORE", 6) == 0; }
+    RecOwned &owned() { if (!own) own.reset(new RecOwned()); return *own; }
 };
 
 struct RescueRow { uint32_t pair; uint64_t a1, a2; int s1, s2; uint32_t src; };
 
 // One batch on its way through the three stages: reader threads fill the inputs, the GPU stage the hit lists, the output
-// stage prints.  The objects are recycled, so the strings keep their capacity.
+// stage prints.  The objects are recycled, so the vectors keep their capacity.
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-struct RawRec { size_t h, hn, s, sn, q, qn; bool fasta; };
+// where a record's lines sit in its block of text (offsets from the block's base); sn/qn of a wrapped record span several lines
+struct RawRec { uint64_t h; uint32_t hn; uint64_t s; uint32_t sn; uint64_t q; uint32_t qn; bool fasta, wrapped; };
 
 struct Batch {
     // ---- stage 1: parsed and packed reads (2 per pair)
     std::vector<Rec> recs[2];               // per mate file, grown on demand
-    std::vector<RawRec> raw[2];             // where each record's lines sit in the reader's buffer (parse_file)
-    std::vector<uint32_t> packed_m[2], lens_m[2];
+    std::vector<RawRec> raw[2];
+    std::vector<char> text[2];              // gz input: the inflated bytes of this batch's records (plain files are mapped instead)
+    std::vector<uint32_t> nl[2];            // scratch of the splitter: where the lines of the block end
     std::vector<uint32_t> packed, lens;     // interleaved 2q / 2q+1 as the device wants them
     uint32_t W = 0, n_reads = 0;
     bool last = false;
@@ -96,7 +117,7 @@ struct Batch {
     uint64_t seq = 0;                       // position of the batch in the input: the printer writes batches in this order
 };
 
-unsigned char g_code[256];
+unsigned char g_code[256], g_unclean[256];
 void fill_char_map()
 {
     memset(g_code, 0, sizeof g_code);                         // INDEXFillCharMap: everything is 'A' unless listed
@@ -104,6 +125,8 @@ void fill_char_map()
     for (int i = 0; i < 4; i++) { g_code[(int)b[i]] = (unsigned char)i; g_code[(int)b[i] + 32] = (unsigned char)i; }
     g_code['U'] = g_code['u'] = 3;
     g_code['N'] = g_code['n'] = 2;
+    memset(g_unclean, 1, sizeof g_unclean);                   // the text can be echoed as it stands only where it is upper-case ACGT
+    for (int i = 0; i < 4; i++) g_unclean[(int)b[i]] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ ini
@@ -146,149 +169,451 @@ double ini_dbl(const Ini &ini, const char *key, double dflt) { auto it = ini.fin
     _exit(1);
 }
 
-// ------------------------------------------------------------------------------------------------ FASTQ (plain or gz)
-// Four-line FASTQ or two-line FASTA records through zlib (as the reference's kseq does), read in 4 MiB gulps.
-struct FqReader {
-    gzFile f = nullptr;
-    std::string path;
-    std::vector<char> buf;
-    size_t pos = 0, end = 0;
-    bool eof = false;
-    bool open(const char *file) { path = file; f = gzopen(file, "rb"); if (f) gzbuffer(f, 1 << 20); buf.resize(1 << 24); return f != nullptr; }
-    // Drops what earlier batches consumed.  Within a batch the buffer only grows, so offsets handed out by line() stay
-    // valid until the next begin_batch() (the buffer may be reallocated: use data() + offset, never a kept pointer).
-    void begin_batch()
+// A few threads that live as long as their owner (one pool per read file for the splitter, one for the printer): run(n, body) calls
+// body(0 .. n-1), the caller being one of the runners, and returns when all are done.  Thread creation per batch slice was a
+// measurable part of the host pipeline.
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    int n_jobs = 0, next = 0, running = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+    explicit Pool(int helpers)
     {
-        if (pos) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
+        for (int i = 0; i < helpers; i++)
+            th.emplace_back([this]() {
+                uint64_t seen = 0;
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    cv.wait(lk, [&] { return stop || (gen != seen && next < n_jobs); });
+                    if (stop) return;
+                    const uint64_t g = gen;
+                    while (gen == g && next < n_jobs) {
+                        const int t = next++;
+                        running++;
+                        const std::function<void(int)> *fn = job;
+                        lk.unlock();
+                        (*fn)(t);
+                        lk.lock();
+                        running--;
+                    }
+                    seen = g;
+                    if (running == 0 && next >= n_jobs) cv_done.notify_all();
+                }
+            });
     }
-    const char *data() const { return buf.data(); }
-    // next line without its terminator, as offset + length
-    bool line(size_t &off, size_t &n)
+    ~Pool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+    void run(int n, const std::function<void(int)> &body)
     {
-        for (;;) {
-            const char *nl = end > pos ? (const char *)memchr(buf.data() + pos, '\n', end - pos) : nullptr;
-            if (nl) { off = pos; n = (size_t)(nl - buf.data()) - pos; pos = (size_t)(nl - buf.data()) + 1; break; }
-            if (eof) { if (pos >= end) return false; off = pos; n = end - pos; pos = end; break; }
-            if (end + (1u << 22) > buf.size()) buf.resize(buf.size() * 2);
-            const int got = gzread(f, buf.data() + end, (unsigned)std::min(buf.size() - end, (size_t)1 << 28));
-            if (got < 0) {
-                // a corrupt or truncated .gz must not pass for a shorter input
-                int errnum = 0;
-                const char *msg = gzerror(f, &errnum);
-                fatal("[soap4-mi355x] error while reading %s: %s\n", path.c_str(), errnum == Z_ERRNO ? strerror(errno) : (msg ? msg : "zlib error"));
-            }
-            if (got == 0) {
-                int errnum = 0;
-                (void)gzerror(f, &errnum);
-                if (errnum != Z_OK && errnum != Z_STREAM_END) fatal("[soap4-mi355x] error while reading %s: %s\n", path.c_str(), gzerror(f, &errnum));
-                eof = true;
-            } else end += (size_t)got;
+        if (n <= 0) return;
+        if (n == 1 || th.empty()) { for (int t = 0; t < n; t++) body(t); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        job = &body; n_jobs = n; next = 0; gen++;
+        cv.notify_all();
+        while (next < n_jobs) {
+            const int t = next++;
+            running++;
+            lk.unlock();
+            body(t);
+            lk.lock();
+            running--;
         }
-        const char *p = buf.data() + off;
-        while (n && (p[n - 1] == '\r' || p[n - 1] == '\n')) n--;
-        return true;
+        cv_done.wait(lk, [&] { return running == 0; });
+        job = nullptr; n_jobs = 0;
     }
-    ~FqReader() { if (f) gzclose(f); }
 };
 
-// Parses up to max_pairs records of one file into the slots of mate k and packs them as appendToQueryArrays does
-// (QueryParser.cpp:184-234): length capped to maxReadLength-1, N/other -> G/A through the character map, 2 bits per base
-// LSB-first, words contiguous per read.  The name loses a trailing /1 /2 (QueryParser.cpp:177); the comment is the rest
-// of the header line (kseq).  Returns the number of records read.
-// Two phases: one thread splits the text into records (memchr speed), then `threads` threads copy and pack them.
-size_t parse_file(FqReader &rd, const Params &p, Batch &out, int k, size_t max_pairs, int threads)
+// runs body(t) for t = 0 .. n-1 on n threads (the caller is one of them): on the pool when there is one
+template <typename F>
+void fan_out(int n, F &&body, Pool *pool = nullptr)
+{
+    if (pool) { const std::function<void(int)> fn = [&body](int t) { body(t); }; pool->run(n, fn); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n; t++) th.emplace_back([&body, t]() { body(t); });
+    body(0);
+    for (auto &x : th) x.join();
+}
+
+// ------------------------------------------------------------------------------------------------ FASTQ / FASTA input (plain or gz)
+// The reference reads its inputs through kseq on ONE IO thread (aio_thread.cpp:247,665; QueryParser.cpp:184-262).  Here a read file is
+// either MAPPED (plain text: no copy at all, the records of a batch are views into the mapping) or inflated by zlib into the
+// batch's own buffer (one gzip stream inflates at a few hundred MB/s: that, not the aligner, is what a .gz input runs at).
+// A batch's block of text is cut into lines by several threads, each over its own byte range (the line number of a byte follows
+// from the newline counts of the ranges before it), then the same threads build the records and pack the reads.  That fast path
+// takes the block to be strictly four (FASTQ) or two (FASTA) lines per record and CHECKS it record by record; anything else
+// (blank lines, wrapped sequences, mixed files) goes through the careful sequential splitter below, which reads records the way
+// kseq does: sequence lines up to the '+' line (or the next header), then quality lines until they are as long as the sequence.
+struct Source {
+    std::string path;
+    bool gz = false;
+    const char *map = nullptr;                // plain file
+    size_t map_len = 0, pos = 0;
+    gzFile f = nullptr;                       // gz file
+    std::vector<char> carry;                  // inflated bytes behind the last batch's records
+    bool eof = false;
+    bool careful = false;                     // once the strict shape failed the file stays on the careful splitter
+    double bytes_per_rec = 0;                 // estimate for the next window
+    std::unique_ptr<Pool> pool;               // the threads that cut this file's blocks into lines and pack its reads
+    std::thread toucher;                      // plain file: maps the pages of the NEXT block while this one is worked on
+    void touch_ahead(size_t from, size_t bytes)
+    {
+        if (toucher.joinable()) toucher.join();
+        static const bool on = getenv("MP_TOUCH_AHEAD") && atoi(getenv("MP_TOUCH_AHEAD")) != 0;      // off by default: measured slower (it competes with the splitters' own faults)
+        if (!on || !map || from >= map_len) return;
+        const size_t a = from & ~(size_t)4095, n = std::min(bytes + 4096, map_len - a);
+        const char *base = map;
+        toucher = std::thread([base, a, n]() {
+#ifdef MADV_POPULATE_READ
+            if (madvise((void *)(base + a), n, MADV_POPULATE_READ) == 0) return;
+#endif
+            volatile char sink = 0;
+            for (size_t i = 0; i < n; i += 4096) sink = (char)(sink + base[a + i]);
+            (void)sink;
+        });
+    }
+
+    bool open(const char *file)
+    {
+        path = file;
+        const int fd = ::open(file, O_RDONLY);
+        if (fd < 0) return false;
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got = pread(fd, magic, 2, 0);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); return false; }
+        gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (gz || !S_ISREG(st.st_mode)) {
+            close(fd);
+            gz = true;                                            // (a pipe or device is read through zlib too: gzread passes plain bytes through)
+            f = gzopen(file, "rb");
+            if (f) gzbuffer(f, 1 << 20);
+            return f != nullptr;
+        }
+        map_len = (size_t)st.st_size;
+        if (map_len) {
+            void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); return false; }
+            (void)madvise(m, map_len, MADV_SEQUENTIAL);
+            (void)madvise(m, map_len, MADV_WILLNEED);
+            map = (const char *)m;
+        }
+        close(fd);
+        return true;
+    }
+    ~Source() { if (toucher.joinable()) toucher.join(); if (f) gzclose(f); if (map) munmap((void *)map, map_len); }
+
+    // gz: appends up to `want` more inflated bytes to buf; false at the end of the stream
+    bool inflate_more(std::vector<char> &buf, size_t &end, size_t want)
+    {
+        if (eof) return false;
+        if (end + want > buf.size()) buf.resize(std::max(buf.size() * 2, end + want));
+        const int got = gzread(f, buf.data() + end, (unsigned)std::min(want, (size_t)1 << 28));
+        if (got < 0) {
+            // a corrupt or truncated .gz must not pass for a shorter input
+            int errnum = 0;
+            const char *msg = gzerror(f, &errnum);
+            fatal("[soap4-mi355x] error while reading %s: %s\n", path.c_str(), errnum == Z_ERRNO ? strerror(errno) : (msg ? msg : "zlib error"));
+        }
+        if (got == 0) {
+            int errnum = 0;
+            (void)gzerror(f, &errnum);
+            if (errnum != Z_OK && errnum != Z_STREAM_END) fatal("[soap4-mi355x] error while reading %s: %s\n", path.c_str(), gzerror(f, &errnum));
+            eof = true;
+            return false;
+        }
+        end += (size_t)got;
+        return true;
+    }
+};
+
+// the careful splitter: records as kseq reads them, one after the other.  `avail(need)` makes sure text[0 .. need) is there if the
+// input has that much (gz: inflates more) and returns the bytes now available; returns the bytes the records used.
+template <typename Avail, typename Base>
+size_t split_careful(Base &&base, Avail &&avail, size_t max_recs, std::vector<RawRec> &raw, const std::string &path)
+{
+    size_t pos = 0, have = avail(1);
+    auto line = [&](size_t &off, size_t &n) -> bool {           // next line without its terminator
+        for (;;) {
+            const char *b = base();
+            const char *nlp = have > pos ? (const char *)memchr(b + pos, '\n', have - pos) : nullptr;
+            if (nlp) { off = pos; n = (size_t)(nlp - b) - pos; pos = (size_t)(nlp - b) + 1; break; }
+            const size_t more = avail(have + (1u << 22));
+            if (more == have) { if (pos >= have) return false; off = pos; n = have - pos; pos = have; break; }
+            have = more;
+        }
+        const char *b = base();
+        while (n && (b[off + n - 1] == '\r' || b[off + n - 1] == '\n')) n--;
+        return true;
+    };
+    size_t pend_off = 0, pend_n = 0;
+    bool pending = false;                                       // a header line already read while looking for the end of a FASTA record
+    while (raw.size() < max_recs) {
+        RawRec r{};
+        size_t o, n;
+        if (pending) { o = pend_off; n = pend_n; pending = false; }
+        else do { if (!line(o, n)) return pos; } while (n == 0);
+        const char c0 = base()[o];
+        if (c0 != '@' && c0 != '>') fatal("[soap4-mi355x] %s: a record does not begin with '@' or '>' (\"%.20s\")\n", path.c_str(), std::string(base() + o, std::min(n, (size_t)20)).c_str());
+        r.h = o; r.hn = (uint32_t)n; r.fasta = c0 == '>';
+        // sequence lines up to '+', the next header or the end (kseq: ks_getuntil ... until c is '>', '+' or '@')
+        size_t s0 = 0, s1 = 0, lines = 0;
+        bool plus = false;
+        for (;;) {
+            const size_t before = pos;
+            if (!line(o, n)) break;
+            if (n == 0) continue;
+            const char c = base()[o];
+            if (c == '+') { plus = true; break; }
+            if (c == '>' || c == '@') { pend_off = o; pend_n = n; pending = true; (void)before; break; }
+            if (lines == 0) s0 = o;
+            s1 = o + n; lines++;
+        }
+        if (lines == 0 && !plus && !pending && r.fasta == false) fatal("[soap4-mi355x] %s ends inside a record (header without sequence)\n", path.c_str());
+        r.s = s0; r.sn = (uint32_t)(s1 - s0); r.wrapped = lines > 1;
+        if (plus) {
+            // quality lines until they hold as many characters as the sequence (kseq)
+            size_t seq_chars = 0;
+            if (r.wrapped) { const char *b = base(); for (size_t i = s0; i < s1; i++) seq_chars += b[i] != '\n' && b[i] != '\r'; } else seq_chars = r.sn;
+            size_t q0 = 0, q1 = 0, ql = 0, got = 0;
+            while (got < seq_chars) {
+                if (!line(o, n)) break;
+                if (ql == 0) q0 = o;
+                q1 = o + n; ql++; got += n;
+            }
+            if (got < seq_chars && ql == 0) fatal("[soap4-mi355x] %s ends inside a FASTQ record\n", path.c_str());
+            r.q = q0; r.qn = (uint32_t)(q1 - q0);
+            if (ql > 1) r.wrapped = true;
+            r.fasta = false;
+        } else { r.q = 0; r.qn = 0; r.fasta = true; }
+        raw.push_back(r);
+    }
+    return pending ? pend_off : pos;
+}
+
+// Fast path.  nl[] receives the offsets of the first `want_lines` newlines of text[0 .. len) (a missing newline at the very end of
+// the input counts as one when at_eof), found by `threads` threads over byte ranges; returns how many were found (<= want_lines).
+size_t find_newlines(const char *text, size_t len, bool at_eof, size_t want_lines, std::vector<uint32_t> &nl, int threads, Pool *pool)
+{
+    const int T = std::max(1, std::min(threads, (int)(len >> 22) + 1));
+    std::vector<std::vector<uint32_t>> part((size_t)T);
+    fan_out(T, [&](int t) {
+        const size_t a = len * (size_t)t / (size_t)T, b = len * (size_t)(t + 1) / (size_t)T;
+        std::vector<uint32_t> &v = part[(size_t)t];
+        v.reserve((b - a) / 64 + 16);
+        const char *p = text + a, *e = text + b;
+        while (p < e) {
+            const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+            if (!q) break;
+            v.push_back((uint32_t)(q - text));
+            p = q + 1;
+        }
+    }, pool);
+    size_t total = 0;
+    for (auto &v : part) total += v.size();
+    const bool virt = at_eof && len > 0 && text[len - 1] != '\n';
+    const size_t n = std::min(want_lines, total + (virt ? 1 : 0));
+    nl.resize(n);
+    size_t o = 0;
+    for (auto &v : part) { const size_t c = std::min(v.size(), n - o); if (c) memcpy(nl.data() + o, v.data(), c * 4); o += c; if (o == n) break; }
+    if (o < n) nl[o++] = (uint32_t)len;
+    return n;
+}
+
+// Reads the next block of at most max_recs records of mate file k: decides where the block's text is, cuts it into records
+// (out.raw[k]) and returns the base pointer of the offsets in them.
+const char *next_block(Source &src, Batch &out, int k, size_t max_recs, int threads, size_t &n_recs)
+{
+    std::vector<RawRec> &raw = out.raw[k];
+    std::vector<uint32_t> &nl = out.nl[k];
+    raw.clear();
+    n_recs = 0;
+    if (!src.gz && src.pos >= src.map_len) return src.map;
+    std::vector<char> &buf = out.text[k];
+    size_t end = 0;                                             // gz: bytes of buf in use
+    if (src.gz) {
+        if (buf.size() < (1u << 22)) buf.resize(1u << 22);
+        if (!src.carry.empty()) { if (buf.size() < src.carry.size() + (1u << 22)) buf.resize(src.carry.size() + (1u << 22)); memcpy(buf.data(), src.carry.data(), src.carry.size()); end = src.carry.size(); src.carry.clear(); }
+        if (end == 0 && !src.inflate_more(buf, end, 1u << 22) && end == 0) return buf.data();
+    }
+    auto text0 = [&]() -> const char * { return src.gz ? buf.data() : src.map + src.pos; };
+    while (!src.careful) {
+        const char first = *text0();
+        if (first != '@' && first != '>') { src.careful = true; break; }          // blank lines in front, or not a read file: let the careful splitter say so
+        const size_t lpr = first == '@' ? 4 : 2, want = lpr * max_recs;
+        // how much text to look at: an estimate from the last block, grown until it holds the lines (gz: inflated until it does)
+        size_t n_lines = 0, win = 0;
+        double est = src.bytes_per_rec > 0 ? src.bytes_per_rec * 1.03 * (double)max_recs + 4096 : 512.0 * (double)max_recs + (1u << 20);
+        for (;;) {
+            if (src.gz) {
+                while (end < (size_t)est && src.inflate_more(buf, end, 1u << 24)) {}
+                win = end;
+            } else win = std::min(src.map_len - src.pos, (size_t)est);
+            if (win >= ((size_t)1 << 32) - 16) fatal("[soap4-mi355x] %s: a batch of %zu records is larger than 4 GiB of text; lower MP_BATCH_PAIRS\n", src.path.c_str(), max_recs);
+            const bool at_eof = src.gz ? src.eof : win == src.map_len - src.pos;
+            n_lines = find_newlines(text0(), win, at_eof, want, nl, threads, src.pool.get());
+            if (n_lines == want || at_eof) break;
+            est *= 1.5;
+        }
+        const char *t = text0();
+        if (n_lines % lpr) {
+            // the text ends inside a record: either the file is cut short or this is not the strict shape
+            src.careful = true;
+            break;
+        }
+        const size_t n = n_lines / lpr;
+        raw.resize(n);
+        std::atomic<bool> ok{true};
+        const int T = std::max(1, std::min(threads, (int)(n / 8192) + 1));
+        fan_out(T, [&](int th) {
+            const size_t q0 = n * (size_t)th / (size_t)T, q1 = n * (size_t)(th + 1) / (size_t)T;
+            bool good = true;
+            for (size_t q = q0; q < q1 && good; q++) {
+                RawRec &r = raw[q];
+                const size_t l0 = lpr * q;
+                r.h = l0 ? (size_t)nl[l0 - 1] + 1 : 0;
+                size_t he = nl[l0];
+                r.s = he + 1;
+                size_t se = nl[l0 + 1];
+                r.fasta = lpr == 2; r.wrapped = false;
+                if (t[r.h] != first) { good = false; break; }
+                if (lpr == 4) {
+                    const size_t pl = se + 1, pe = nl[l0 + 2];
+                    if (pe <= pl || t[pl] != '+') { good = false; break; }
+                    r.q = pe + 1;
+                    size_t qe = nl[l0 + 3];
+                    while (qe > r.q && t[qe - 1] == '\r') qe--;
+                    r.qn = (uint32_t)(qe - r.q);
+                } else { r.q = 0; r.qn = 0; }
+                while (he > r.h && t[he - 1] == '\r') he--;
+                while (se > r.s && t[se - 1] == '\r') se--;
+                r.hn = (uint32_t)(he - r.h); r.sn = (uint32_t)(se - r.s);
+                if (r.sn == 0 || r.hn == 0) { good = false; break; }                 // blank lines: not the strict shape
+                const char c = t[r.s];
+                if (c == '@' || c == '>' || c == '+') { good = false; break; }
+            }
+            if (!good) ok = false;
+        }, src.pool.get());
+        if (!ok) { src.careful = true; raw.clear(); break; }
+        const size_t used = n_lines ? std::min((size_t)nl[n_lines - 1] + 1, win) : 0;
+        if (n) src.bytes_per_rec = (double)used / (double)n;
+        if (src.gz) { src.carry.assign(buf.data() + used, buf.data() + end); }
+        else { src.pos += used; src.touch_ahead(src.pos, (size_t)(src.bytes_per_rec * 1.03 * (double)max_recs) + 4096); }
+        n_recs = n;
+        return t;
+    }
+    // ---- careful splitter (sequential)
+    const char *t;
+    size_t used;
+    if (src.gz) {
+        used = split_careful([&]() { return (const char *)buf.data(); }, [&](size_t need) { while (end < need && src.inflate_more(buf, end, 1u << 22)) {} return end; }, max_recs, raw, src.path);
+        src.carry.assign(buf.data() + used, buf.data() + end);
+        t = buf.data();
+    } else {
+        t = src.map + src.pos;
+        const size_t left = src.map_len - src.pos;
+        used = split_careful([&]() { return t; }, [&](size_t) { return left; }, max_recs, raw, src.path);
+        src.pos += used;
+    }
+    n_recs = raw.size();
+    return t;
+}
+
+// Builds the records of mate k from the block's lines and packs the reads as appendToQueryArrays does (QueryParser.cpp:184-234):
+// length capped to maxReadLength-1, N/other -> G/A through the character map, 2 bits per base LSB-first, words contiguous per
+// read, straight into the interleaved arrays the device takes (read 2q+k).  The name loses a trailing /1 /2
+// (QueryParser.cpp:177); the comment is the rest of the header line (kseq).
+void build_records(const char *base, const Params &p, Batch &out, int k, size_t n, int threads, Pool *pool)
 {
     const uint32_t W = out.W;
     const size_t cap = (size_t)p.max_read_length - 1;
-    std::vector<RawRec> &raw = out.raw[k];
-    raw.clear();
-    const double t_begin = now_s();
-    rd.begin_batch();
-    while (raw.size() < max_pairs) {
-        RawRec r;
-        do { if (!rd.line(r.h, r.hn)) goto scanned; } while (r.hn == 0);
-        r.fasta = rd.data()[r.h] == '>';
-        if (!rd.line(r.s, r.sn)) fatal("[soap4-mi355x] %s ends inside a record (header without sequence)\n", rd.path.c_str());
-        r.q = 0; r.qn = 0;
-        if (!r.fasta) {
-            size_t po, pn;
-            if (!rd.line(po, pn) || !rd.line(r.q, r.qn)) fatal("[soap4-mi355x] %s ends inside a FASTQ record\n", rd.path.c_str());
-        }
-        raw.push_back(r);
-    }
-scanned:
-    const size_t n = raw.size();
-    const double t_scan = now_s();
     std::vector<Rec> &recs = out.recs[k];
-    std::vector<uint32_t> &packed = out.packed_m[k], &lens = out.lens_m[k];
+    const std::vector<RawRec> &raw = out.raw[k];
     if (recs.size() < n) recs.resize(n);
-    if (packed.size() < n * (size_t)W) packed.resize(n * (size_t)W);
-    if (lens.size() < n) lens.resize(n);
-    const char *base = rd.data();
     auto work = [&](size_t q0, size_t q1) {
+        std::string joined_s, joined_q;
         for (size_t q = q0; q < q1; q++) {
             const RawRec &rr = raw[q];
             const char *h = base + rr.h, *sq = base + rr.s, *ql = base + rr.q;
-            const size_t hn = rr.hn, sn = rr.sn, qn = rr.qn;
+            size_t hn = rr.hn, sn = rr.sn, qn = rr.qn;
             Rec &r = recs[q];
+            if (rr.wrapped) {
+                // a wrapped record: the lines joined, as kseq hands them over
+                joined_s.clear(); joined_q.clear();
+                for (size_t i = 0; i < sn; i++) if (sq[i] != '\n' && sq[i] != '\r') joined_s += sq[i];
+                for (size_t i = 0; i < qn; i++) if (ql[i] != '\n' && ql[i] != '\r') joined_q += ql[i];
+                sn = joined_s.size(); qn = joined_q.size();
+                sq = joined_s.data(); ql = joined_q.data();
+            }
             size_t cut = 1;
             while (cut < hn && h[cut] != ' ' && h[cut] != '\t') cut++;
             size_t nl = cut - 1;
             if (nl > 2 && h[cut - 2] == '/' && h[cut - 1] >= '0' && h[cut - 1] <= '9') nl -= 2;
-            r.name.assign(h + 1, nl);
+            r.name = h + 1; r.name_len = (uint32_t)nl;
             r.has_comment = !p.ignore_comments && cut + 1 < hn;
-            if (r.has_comment) r.comment.assign(h + cut + 1, hn - cut - 1); else r.comment.clear();
+            r.comment = r.has_comment ? h + cut + 1 : nullptr; r.comment_len = r.has_comment ? (uint32_t)(hn - cut - 1) : 0u;
             const size_t keep = std::min(sn, cap);                                          // QueryParser.cpp:188
-            r.seq.resize(keep);
-            uint32_t *dst = packed.data() + q * (size_t)W;
+            uint32_t *dst = out.packed.data() + (2 * q + (size_t)k) * (size_t)W;
+            unsigned unclean = 0;
             for (uint32_t w = 0; w < W; w++) {
                 uint32_t v = 0;
                 const size_t lo = (size_t)w * 16, hi = std::min(keep, lo + 16);
                 for (size_t i = lo; i < hi; i++) {
-                    const unsigned c = g_code[(unsigned char)sq[i]];
-                    v |= c << (2 * (i - lo));
-                    r.seq[i] = "ACGT"[c];
+                    const unsigned char ch = (unsigned char)sq[i];
+                    v |= (uint32_t)g_code[ch] << (2 * (i - lo));
+                    unclean |= g_unclean[ch];
                 }
                 dst[w] = v;
             }
-            lens[q] = (uint32_t)keep;
-            if (rr.fasta) r.qual.clear(); else r.qual.assign(ql, std::min(qn, keep));
+            out.lens[2 * q + (size_t)k] = (uint32_t)keep;
+            if (unclean || rr.wrapped) {
+                std::string &o = r.owned().seq;
+                o.resize(keep);
+                for (size_t i = 0; i < keep; i++) o[i] = "ACGT"[g_code[(unsigned char)sq[i]]];
+                r.seq = o.data();
+            } else r.seq = sq;
+            r.seq_len = (uint32_t)keep;
+            const size_t qkeep = rr.fasta ? 0 : std::min(qn, keep);
+            if (rr.wrapped && qkeep) { std::string &o = r.owned().qual; o.assign(ql, qkeep); r.qual = o.data(); } else r.qual = ql;
+            r.qual_len = (uint32_t)qkeep;
         }
     };
     const int T = std::max(1, std::min(threads, (int)(n / 4096) + 1));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; t++) pool.emplace_back(work, n * (size_t)t / T, n * (size_t)(t + 1) / T);
-    work(0, n / (size_t)T);
-    for (auto &th : pool) th.join();
-    if (k == 0 && getenv("MP_TIMING")) fprintf(stderr, "[Main] reader: %zu records split in %.3f s, copied and packed in %.3f s by %d threads\n", n, t_scan - t_begin, now_s() - t_scan, T);
-    return n;
+    fan_out(T, [&](int t) { work(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T); }, pool);
 }
 
-// reads the next batch: the two files are parsed side by side
-bool fill_batch(FqReader &a, FqReader &b, const Params &p, Batch &out, int threads)
+// reads the next batch: the two files are cut into records side by side, then packed side by side
+bool fill_batch(Source &a, Source &b, const Params &p, Batch &out, int threads)
 {
     const size_t bp = p.batch_pairs;
     out.W = (uint32_t)(p.max_read_length + 15) / 16;
-    size_t nb = 0;
-    const int per_file = std::max(1, threads / 4);          // the output stage of the previous batch runs at the same time
+    size_t na = 0, nb = 0;
+    const char *base[2] = {nullptr, nullptr};
+    // -T is the budget of the whole host side: the two files' splitters take a quarter each, the printer's formatters half
+    // (MP_READER_THREADS / MP_PRINTER_THREADS override)
+    static const int reader_threads = getenv("MP_READER_THREADS") ? std::max(1, atoi(getenv("MP_READER_THREADS"))) : std::max(1, threads / 4);
+    const int per_file = reader_threads;
+    if (!a.pool) a.pool.reset(new Pool(per_file - 1));
+    if (!b.pool) b.pool.reset(new Pool(per_file - 1));
     const double t0 = now_s();
-    std::thread second([&]() { nb = parse_file(b, p, out, 1, bp, per_file); });
-    const size_t na = parse_file(a, p, out, 0, bp, per_file);
-    second.join();
+    {
+        std::thread second([&]() { base[1] = next_block(b, out, 1, bp, per_file, nb); });
+        base[0] = next_block(a, out, 0, bp, per_file, na);
+        second.join();
+    }
     const double t1 = now_s();
     if (na != nb) fatal("Error: number of sequences of pair-end files not matched.\n");
     out.n_reads = (uint32_t)(2 * na);
     out.last = na < bp;
-    const uint32_t W = out.W;
-    out.packed.resize(2 * na * (size_t)W); out.lens.resize(2 * na);
-    for (size_t q = 0; q < na; q++)
-        for (int k = 0; k < 2; k++) {
-            memcpy(out.packed.data() + (2 * q + k) * (size_t)W, out.packed_m[k].data() + q * (size_t)W, (size_t)W * 4);
-            out.lens[2 * q + k] = out.lens_m[k][q];
-        }
-    const double t2 = now_s();
+    out.packed.resize(2 * na * (size_t)out.W); out.lens.resize(2 * na);
+    {
+        std::thread second([&]() { build_records(base[1], p, out, 1, nb, per_file, b.pool.get()); });
+        build_records(base[0], p, out, 0, na, per_file, a.pool.get());
+        second.join();
+    }
     for (auto &c : out.ch) c.clear();
-    if (getenv("MP_TIMING")) fprintf(stderr, "[Main] reader: both files %.3f s, interleave %.3f s, clear %.3f s\n", t1 - t0, t2 - t1, now_s() - t2);
+    if (getenv("MP_TIMING")) fprintf(stderr, "[Main] reader: %zu pairs: lines found in %.3f s, records built and packed in %.3f s (%d threads per file)\n", na, t1 - t0, now_s() - t1, per_file);
     return na > 0;
 }
 
@@ -423,24 +748,36 @@ struct Pass1 {
 
 // ------------------------------------------------------------------------------------------------ output
 struct ChrHit { int chr, neg; bool operator<(const ChrHit &o) const { return chr != o.chr ? chr < o.chr : neg < o.neg; } };
-struct HdrMap { int score; std::string text; };
+struct HdrMap { int score; std::string_view text; };
 
-// getMappingFromHeader (BGS-IO.cpp:1348-1371), quirks included (the record filter tests the header's best score)
+// atoi over a view (leading white space, optional sign, digits)
+int view_atoi(const char *c, const char *e)
+{
+    while (c < e && (*c == ' ' || (*c >= '\t' && *c <= '\r'))) c++;
+    bool neg = false;
+    if (c < e && (*c == '-' || *c == '+')) { neg = *c == '-'; c++; }
+    long v = 0;
+    while (c < e && *c >= '0' && *c <= '9') { v = v * 10 + (*c - '0'); if (v > 0x7fffffffL) { v = 0x7fffffffL; } c++; }
+    return (int)(neg ? -v : v);
+}
+
+// getMappingFromHeader (BGS-IO.cpp:1348-1371), quirks included (the record filter tests the header's best score); the texts of the
+// kept entries are views into the comment
 int mapping_from_header(const Rec &r, std::vector<HdrMap> &v, double top, double scoreT)
 {
     v.clear();
-    if (!r.has_comment || r.comment == "IGNORE") return 0;
-    const char *c = r.comment.c_str();
-    if (r.comment.size() < 6) return 0;
-    int score = atoi(c + 6);
+    if (!r.has_comment || r.ignore()) return 0;
+    const char *c = r.comment, *e = c + r.comment_len;
+    if (r.comment_len < 6) return 0;
+    int score = view_atoi(c + 6, e);
     if (score < scoreT) return score;
     else if (scoreT < score * top) scoreT = score * top;
-    const char *p = strchr(c + 6, ';');
-    while (p && *(p + 1) != '\0') {
+    const char *p = (const char *)memchr(c + 6, ';', (size_t)(e - (c + 6)));
+    while (p && p + 1 < e) {
         const char *s = p + 1;
-        const char *q = strchr(s, ';');
+        const char *q = (const char *)memchr(s, ';', (size_t)(e - s));
         if (!q) break;
-        if (score >= scoreT) v.push_back(HdrMap{atoi(s), std::string(s, q)});
+        if (score >= scoreT) v.push_back(HdrMap{view_atoi(s, q), std::string_view(s, (size_t)(q - s))});
         p = q;
     }
     return score;
@@ -449,14 +786,14 @@ int mapping_from_header(const Rec &r, std::vector<HdrMap> &v, double top, double
 struct Writer {
     const mp_index *ix;
     const Params &p;
-    std::string out;
+    std::string &out;           // the caller's buffer (kept between calls: its capacity is the steady state's)
     // carry = true: this is not the last resident index chunk.  Instead of printing a record, its new header comment
     // ("SCORE:..." or "IGNORE") replaces the record's own: exactly what the next run of the chained NT loop would read back
     // from this run's stdout (runMegaPath.sh:191-227, getMappingFromHeader BGS-IO.cpp:1348-1371), without the file round trip.
     bool carry;
-    Writer(const mp_index *i, const Params &pp, bool carry_ = false) : ix(i), p(pp), carry(carry_) {}
+    Writer(const mp_index *i, const Params &pp, std::string &out_, bool carry_ = false) : ix(i), p(pp), out(out_), carry(carry_) {}
     // -lsam: the line cc/fastq2lsam would print for a record (print_lsam_line, cc/fastq2lsam.cpp:28-78)
-    void lsam_line(const std::string &name, const std::string &comm, const std::string &seq, const std::string &qual, int which_end)
+    void lsam_line(std::string_view name, const std::string &comm, std::string_view seq, std::string_view qual, int which_end)
     {
         char tmp[32];
         out += name;
@@ -531,19 +868,19 @@ struct Writer {
     void lsam_record(const Rec &r, const std::string &comm)
     {
         if (held_) {
-            if (held_->name == r.name) { lsam_line(held_->name, held_comm_, held_->seq, held_->qual, 1); lsam_line(r.name, comm, r.seq, r.qual, 2); held_ = nullptr; return; }
-            lsam_line(held_->name, held_comm_, held_->seq, held_->qual, 0);
+            if (held_->name_v() == r.name_v()) { lsam_line(held_->name_v(), held_comm_, held_->seq_v(), held_->qual_v(), 1); lsam_line(r.name_v(), comm, r.seq_v(), r.qual_v(), 2); held_ = nullptr; return; }
+            lsam_line(held_->name_v(), held_comm_, held_->seq_v(), held_->qual_v(), 0);
         }
         held_ = &r; held_comm_ = comm;
     }
-    void finish() { if (held_) { lsam_line(held_->name, held_comm_, held_->seq, held_->qual, 0); held_ = nullptr; } }
+    void finish() { if (held_) { lsam_line(held_->name_v(), held_comm_, held_->seq_v(), held_->qual_v(), 0); held_ = nullptr; } }
     // one output record: the annotated FASTQ header + sequence + qualities, or its LSAM line
     void record(const Rec &r, int best, const std::vector<ChrHit> &hits, const std::vector<HdrMap> &v)
     {
         const bool to_comment = p.lsam || carry;
         std::string &o = to_comment ? comm_ : out;
-        if (to_comment) comm_.clear(); else { out += '@'; out += r.name; out += '\t'; }
-        if (r.has_comment && r.comment == "IGNORE") o += "IGNORE";
+        if (to_comment) comm_.clear(); else { out += '@'; out.append(r.name, r.name_len); out += '\t'; }
+        if (r.ignore()) o += "IGNORE";
         else {
             char tmp[64];
             snprintf(tmp, sizeof tmp, "SCORE:%d;", best); o += tmp;
@@ -559,14 +896,17 @@ struct Writer {
             for (const HdrMap &m : v) if (m.score >= best * p.top) { o += m.text; o += ';'; }
         }
         if (carry) {
-            // the record is this thread's alone (pairs are split between the formatting threads); v points into the old comment
+            // the record is this thread's alone (pairs are split between the formatting threads); v points into the old comment,
+            // which is only let go of now
             Rec &w = const_cast<Rec &>(r);
-            w.comment.swap(comm_);
+            std::string &own = w.owned().comment;
+            own.swap(comm_);
+            w.comment = own.data(); w.comment_len = (uint32_t)own.size();
             w.has_comment = true;
             return;
         }
         if (p.lsam) { lsam_record(r, comm_); return; }
-        out += '\n'; out += r.seq; out += "\n+\n"; out += r.qual; out += '\n';
+        out += '\n'; out.append(r.seq, r.seq_len); out += "\n+\n"; out.append(r.qual, r.qual_len); out += '\n';
     }
     const Rec *held_ = nullptr;
     std::string held_comm_, comm_;
@@ -606,7 +946,7 @@ struct Writer {
     // unproperlypairDPOutputFastqAPI (BGS-IO.cpp:1384-1446); in -F mode hits that span a sequence boundary are un-aligned in place
     void single(const Rec &r, uint32_t len, std::vector<Side> &hits)
     {
-        if (r.has_comment && r.comment == "IGNORE") { h1_.clear(); record(r, 0, h1_, std::vector<HdrMap>()); return; }
+        if (r.ignore()) { h1_.clear(); record(r, 0, h1_, std::vector<HdrMap>()); return; }
         int best = 0;
         h1_.clear();
         if (p.mode != 2)
@@ -677,7 +1017,9 @@ struct BamState {
     int stage_rescue = 2, stage_unpaired = 3;                // hspaux->dpStageId (alignment.cpp:93,228,308)
 };
 
-mpbam::ReadView view_of(const Rec &r, uint32_t len) { return mpbam::ReadView{r.name.c_str(), r.seq.c_str(), r.qual.c_str(), len}; }
+// (a read without qualities -- FASTA input -- gets blanks: the BAM record then carries 0xff, "no quality")
+const std::string g_blank_qual(1024, ' ');
+mpbam::ReadView view_of(const Rec &r, uint32_t len) { return mpbam::ReadView{r.name, r.name_len, r.seq, r.qual_len >= len || len > g_blank_qual.size() ? r.qual : g_blank_qual.data(), len}; }
 
 // MD text of the best alignments of one pair (-p only): one small device gather per pair
 struct PairText {
@@ -710,10 +1052,11 @@ void prepare_lists(Batch &bt, Batch::ChunkHits &b, int threads)
         if (x.score_1 != y.score_1) return x.score_1 < y.score_1;
         return x.score_2 < y.score_2;
     };
-    // the device hands the hits over in slot order (arbitrary between wavefronts): bucket them by pair with one counting
-    // pass, then order the few hits of each pair, slices of the list side by side
+    // order the few hits of each pair, slices of the list side by side (a list that is not grouped by pair is bucketed first)
     const uint32_t n_pairs = bt.n_reads / 2;
-    {
+    bool grouped_by_pair = true;                    // the library hands the list over grouped by pair, pairs ascending (megapath_hip.h)
+    for (size_t i = 1; i < hits.size() && grouped_by_pair; i++) grouped_by_pair = hits[i].pair_id >= hits[i - 1].pair_id;
+    if (!grouped_by_pair) {
         std::vector<uint32_t> start((size_t)n_pairs + 2, 0u);
         for (const mp_pair_hit &h : hits) start[(size_t)h.pair_id + 2]++;
         for (size_t q = 2; q < start.size(); q++) start[q] += start[q - 1];          // start[q+1] = first slot of pair q
@@ -832,7 +1175,7 @@ void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, boo
                 b.singles.size(), b.resc.size(), ap.insert_low, ap.insert_high);
     // ordering and de-duplicating the hit lists is done here, by the worker that owns the batch (several workers side by side), not by
     // the one printer thread every batch has to pass through in input order
-    prepare_lists(bt, b, threads);
+    prepare_lists(bt, b, std::max(1, threads / 4));         // (several workers do this side by side)
     st.t_sort += now_s() - t0; t0 = now_s();
     if (bam) {
         std::vector<mp_dp_task> tasks;
@@ -863,20 +1206,30 @@ void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, boo
 // buffers go out in chunk order.
 struct Sink { std::string text, bam[3]; uint64_t n = 0; Pass1 pass1; std::vector<mpbam::CovRec> cov; };
 
+// the printer's threads and their buffers: both live as long as the run (the buffers keep the capacity of the steady state --
+// fresh strings cost a page fault per 4 KiB of output)
+struct Formatters {
+    Pool pool;
+    std::vector<Sink> sinks;
+    explicit Formatters(int threads) : pool(std::max(1, threads) - 1), sinks((size_t)std::max(1, threads)) {}
+};
+
 template <typename F>
-void for_chunks(size_t n_items, int threads, BamState *bam, Pass1 *pass1, F &&body)
+void for_chunks(size_t n_items, Formatters &fm, BamState *bam, Pass1 *pass1, F &&body)
 {
     const size_t chunk = 4096;
     const size_t n_chunks = (n_items + chunk - 1) / chunk;
-    const size_t wave = (size_t)std::max(1, threads);
-    std::vector<Sink> sinks(wave);
+    const size_t wave = fm.sinks.size();
+    std::vector<Sink> &sinks = fm.sinks;
     for (size_t c0 = 0; c0 < n_chunks; c0 += wave) {
         const size_t nc = std::min(wave, n_chunks - c0);
-        auto run = [&](size_t t) { Sink &s = sinks[t]; s.text.clear(); s.pass1 = Pass1(); s.cov.clear(); for (auto &x : s.bam) x.clear(); body((c0 + t) * chunk, std::min(n_items, (c0 + t + 1) * chunk), s); };
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nc; t++) pool.emplace_back(run, t);
-        run(0);
-        for (auto &th : pool) th.join();
+        const std::function<void(int)> run = [&](int t) {
+            Sink &s = sinks[(size_t)t];
+            s.text.clear(); s.pass1 = Pass1(); s.cov.clear();
+            for (auto &x : s.bam) x.clear();
+            body((c0 + (size_t)t) * chunk, std::min(n_items, (c0 + (size_t)t + 1) * chunk), s);
+        };
+        fm.pool.run((int)nc, run);
         for (size_t t = 0; t < nc; t++) {
             fwrite(sinks[t].text.data(), 1, sinks[t].text.size(), stdout);
             if (bam) for (int k = 0; k < 3; k++) bam->w->append(k, sinks[t].bam[k]);
@@ -887,7 +1240,7 @@ void for_chunks(size_t n_items, int threads, BamState *bam, Pass1 *pass1, F &&bo
 }
 
 // `carry`: not the last resident chunk -- the records keep their new header comments for the next chunk instead of being printed.
-void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b, BamState *bam, int threads, Stats &st, bool carry, Pass1 *pass1,
+void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b, BamState *bam, int threads, Formatters &fm, Stats &st, bool carry, Pass1 *pass1,
                   bool keep_unchanged = false /* carry mode, second chunk on: a read without a hit in this chunk keeps the comment the chunk before left */)
 {
     const uint32_t n_pairs = bt.n_reads / 2;
@@ -915,8 +1268,8 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
     std::vector<size_t> grp;
     for (size_t i = 0; i < hits.size(); i++) if (i == 0 || hits[i].pair_id != hits[i - 1].pair_id) grp.push_back(i);
     grp.push_back(hits.size());
-    for_chunks(grp.size() - 1, threads, bam, pass1, [&](size_t g0, size_t g1, Sink &sink) {
-        Writer w(ix, p, carry);
+    for_chunks(grp.size() - 1, fm, bam, pass1, [&](size_t g0, size_t g1, Sink &sink) {
+        Writer w(ix, p, sink.text, carry);
         PairText text;
         std::vector<PairAln> res;
         for (size_t g = g0; g < g1; g++) {
@@ -944,7 +1297,6 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
             emit_pair(w, sink, text, res, q, mpbam::Writer::FILE_DPOUT, 1);
         }
         w.finish();
-        sink.text.swap(w.out);
         sink.pass1.add(w.pass1);
     });
     if (!carry) st.deep += grp.size() - 1;
@@ -954,8 +1306,8 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
     grp.clear();
     for (size_t i = 0; i < rows.size(); i++) if (i == 0 || rows[i].pair != rows[i - 1].pair) grp.push_back(i);
     grp.push_back(rows.size());
-    for_chunks(grp.size() - 1, threads, bam, pass1, [&](size_t g0, size_t g1, Sink &sink) {
-        Writer w(ix, p, carry);
+    for_chunks(grp.size() - 1, fm, bam, pass1, [&](size_t g0, size_t g1, Sink &sink) {
+        Writer w(ix, p, sink.text, carry);
         PairText text;
         std::vector<PairAln> res;
         for (size_t g = g0; g < g1; g++) {
@@ -982,7 +1334,6 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
             emit_pair(w, sink, text, res, q, mpbam::Writer::FILE_GOUT, bam ? bam->stage_rescue : 0);
         }
         w.finish();
-        sink.text.swap(w.out);
         sink.pass1.add(w.pass1);
     });
     if (!carry) st.rescued += grp.size() - 1;
@@ -999,8 +1350,8 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
             si = e;
         }
     }
-    for_chunks(rest.size(), threads, bam, pass1, [&](size_t i0, size_t i1, Sink &sink) {
-        Writer w(ix, p, carry);
+    for_chunks(rest.size(), fm, bam, pass1, [&](size_t i0, size_t i1, Sink &sink) {
+        Writer w(ix, p, sink.text, carry);
         std::vector<Side> lst[2];
         std::vector<mpbam::Writer::RefText> ref_of[2];
         std::vector<uint8_t> tbuf[2];
@@ -1043,7 +1394,6 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
             bam->w->unpaired(sink.bam[mpbam::Writer::FILE_UNPAIR], bam->stage_unpaired, rd, lst, rp);
         }
         w.finish();
-        sink.text.swap(w.out);
         sink.pass1.add(w.pass1);
     });
     if (!carry) st.unpaired += rest.size();
@@ -1238,7 +1588,7 @@ int main(int argc, char **argv)
         if (p.lsam == 0) p.lsam = 1;
     } else if (!pass1_path.empty()) { fprintf(stderr, "[soap4-mi355x] -pass1 counts taxids: it needs -lsamid\n"); return 1; }
     Pass1 pass1_total;
-    FqReader ra, rb;
+    Source ra, rb;
     if (!ra.open(fq1) || !rb.open(fq2)) { fprintf(stderr, "[soap4-mi355x] cannot open read files\n"); return 1; }
     BamState bam_state, *bam = nullptr;
     if (p.want_bam && !plumbing_only) {
@@ -1284,13 +1634,14 @@ int main(int argc, char **argv)
     });
     const bool carry_rewrite = getenv("MP_CARRY_REWRITE") != nullptr;     // test switch: merge every comment again in every chunk, also where the chunk adds nothing
     std::thread printer([&]() {
+        Formatters fm(getenv("MP_PRINTER_THREADS") ? std::max(1, atoi(getenv("MP_PRINTER_THREADS"))) : std::max(1, threads / 2));
         for (uint64_t seq = 0;; seq++) {
             Batch *b = aligned_q.pop_seq(seq);
             if (!b) break;
             // the chunks in database order: each one's per-reference hits join the header comments the earlier ones left
             for (size_t c = 0; c < n_chunks; c++) {
                 const bool last = c + 1 == n_chunks;
-                output_stage(devices[0].chunks[c], p, *b, b->ch[c], last ? bam : nullptr, threads, st_printer, !last, p.tax ? &pass1_total : nullptr, !last && c > 0 && !carry_rewrite);
+                output_stage(devices[0].chunks[c], p, *b, b->ch[c], last ? bam : nullptr, threads, fm, st_printer, !last, p.tax ? &pass1_total : nullptr, !last && c > 0 && !carry_rewrite);
             }
             free_q.push(b);
         }

@@ -764,11 +764,16 @@ __global__ void build_right_tasks_kernel(const mp_candidate *__restrict__ cands,
     tasks[t] = k;
 }
 
-// DP2CPUAlgnThread result assembly (DV-DPfunctions.cpp:3432-3530), positions and scores only
+// DP2CPUAlgnThread result assembly (DV-DPfunctions.cpp:3432-3530), positions and scores only.  Two passes over the candidates so
+// that the hit list leaves the device GROUPED BY PAIR in ascending pair order (the host then only orders the few hits inside a
+// group): COUNT adds up each pair's hits, an exclusive scan turns the counts into group offsets, the second pass stores every hit
+// at its group's offset plus a per-pair cursor.
+template <bool COUNT>
 __global__ void collect_pair_hits_kernel(const mp_candidate *__restrict__ cands, uint32_t n, const uint32_t *__restrict__ lens,
                                          const mp_dp_task *__restrict__ lt, const mp_dp_result *__restrict__ lr,
                                          const mp_dp_task *__restrict__ rt, const mp_dp_result *__restrict__ rr,
-                                         mp_pair_hit *__restrict__ hits, unsigned long long *n_hits, uint32_t cap, uint32_t *__restrict__ pair_done)
+                                         mp_pair_hit *__restrict__ hits, uint32_t *__restrict__ pair_cnt, const uint32_t *__restrict__ pair_off, uint32_t cap,
+                                         uint32_t *__restrict__ pair_done)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -777,7 +782,8 @@ __global__ void collect_pair_hits_kernel(const mp_candidate *__restrict__ cands,
     const mp_dp_result a = lr[t], b = rr[t];
     if (a.score <= 0 || b.score <= 0) return;
     if (a.score < mp_dp_cutoff((int)lens[left]) || b.score < mp_dp_cutoff((int)lens[right])) return;
-    uint32_t slot = (uint32_t)atomicAdd(n_hits, 1ull);
+    if (COUNT) { atomicAdd(&pair_cnt[left >> 1], 1u); return; }
+    const uint32_t slot = pair_off[left >> 1] + atomicAdd(&pair_cnt[left >> 1], 1u);
     if (slot >= cap) return;
     const int read_side = (int)(left & 1u);          // 0: the read (even id) is the left leg
     mp_pair_hit h;

@@ -11,6 +11,20 @@ SRC="$ROOT/megapath_amd/csrc/host/soap4_main.cpp"
 fail=0
 gzip -c "$G1/reads_a_1.fq" > "$B/a_1.fq.gz"; gzip -c "$G1/reads_a_2.fq" > "$B/a_2.fq.gz"
 head -c 6000 "$B/a_1.fq.gz" > "$B/bad_1.fq.gz"
+# shapes that leave the strict fast path of the reader: wrapped FASTA, blank lines + CRLF + lower case / N
+python3 - "$G1" "$B" <<'PY'
+import sys
+g1, b = sys.argv[1], sys.argv[2]
+for m in (1, 2):
+    lines = open("%s/reads_a_%d.fq" % (g1, m)).read().split("\n")
+    fa, odd = [], []
+    for i in range(0, len(lines) - 3, 4):
+        seq = lines[i + 1]
+        fa.append(">" + lines[i][1:] + "\n" + "\n".join(seq[j:j + 60] for j in range(0, len(seq), 60)) + "\n")
+        odd.append(lines[i] + "\r\n" + seq.lower().replace("a", "N", 1) + "\r\n+\r\n" + lines[i + 3] + "\r\n" + ("\r\n" if (i // 4) % 5 == 0 else ""))
+    open("%s/w_%d.fa" % (b, m), "w").write("".join(fa))
+    open("%s/odd_%d.fq" % (b, m), "w", newline="").write("".join(odd))
+PY
 for kind in thread address,undefined; do
     exe="$B/soap4-$(echo $kind | tr , -)"
     g++ -O1 -g -std=c++17 -Wall -pthread -fno-omit-frame-pointer -fsanitize=$kind -o "$exe" "$SRC" -L"$ROOT/megapath_amd" -lmegapath_hip -lz -Wl,-rpath,"$ROOT/megapath_amd" || { echo "build ($kind) failed"; exit 2; }
@@ -26,6 +40,8 @@ for kind in thread address,undefined; do
     MP_PLUMBING_JITTER_US=4000 MP_BATCH_PAIRS=7 run order 0 "$exe" pair x,y "$G1/reads_a_1.fq" "$G1/reads_a_2.fq" "${common[@]}" -T 3 -F -nc -c 0,1,2
     MP_PLUMBING_JITTER_US=500 MP_BATCH_PAIRS=3 MP_WORKERS_PER_GPU=4 run tiny 0 "$exe" pair x "$B/a_1.fq.gz" "$B/a_2.fq.gz" "${common[@]}" -T 8 -F -c 0,1
     MP_BATCH_PAIRS=1000 run onebatch 0 "$exe" pair x,y,z "$G1/reads_d_1.fq" "$G1/reads_d_2.fq" "${common[@]}" -T 2 -P
+    MP_BATCH_PAIRS=11 run wrapped_fasta 0 "$exe" pair x "$B/w_1.fa" "$B/w_2.fa" "${common[@]}" -T 4 -F -nc
+    MP_BATCH_PAIRS=13 run odd_shapes 0 "$exe" pair x "$B/odd_1.fq" "$B/odd_2.fq" "${common[@]}" -T 4 -F -nc
     MP_BATCH_PAIRS=50 run lsam 0 "$exe" pair x "$G1/reads_e_1.fq" "$G1/reads_e_2.fq" "${common[@]}" -T 4 -F -top 95 -lsam
     # fatal() leaves through _exit() from whichever thread met the error, on purpose (no atexit handlers while other stages write):
     # the threads it leaves behind are not a leak to report

@@ -332,6 +332,26 @@ def test_cli_resident_chunks_equal_reference_chain(golden_dir, tmp_path, tag, L)
     assert b"3 index chunk(s)" in err
 
 
+@pytest.mark.parametrize("rewrite", [False, True])
+def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, rewrite):
+    """g6: nine index chunks resident in one process (homologous sequences at 0-7 % divergence in several of them) against the last
+    stdout of NINE chained runs of the real soap4; with the untouched comments left alone from the second chunk on (the default) and
+    with every comment merged again in every chunk (MP_CARRY_REWRITE=1)."""
+    g6 = os.path.join(golden_dir, "g6")
+    out = tmp_path / "out.fq"
+    prefixes = ",".join(os.path.join(g6, "c%d.fa.index" % k) for k in range(9))
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefixes, os.path.join(g6, "reads_1.fq"), os.path.join(g6, "reads_2.fq"), "-o", str(tmp_path / "o"),
+           "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "3", "-u", "750", "-F", "-nc", "-top", "95"]
+    env = dict(os.environ, MP_BATCH_PAIRS="64")
+    if rewrite:
+        env["MP_CARRY_REWRITE"] = "1"
+    with open(out, "wb") as fo:
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"9 index chunk(s)" in r.stderr
+    assert fastq_records(str(out)) == fastq_records(os.path.join(g6, "expected_chain.fq"))
+
+
 @pytest.mark.parametrize("mode", ["-F", "-P"])
 def test_cli_many_resident_chunks_leave_untouched_comments_alone(golden_dir, tmp_path, mode):
     """With many chunks most reads hit few of them: from the second chunk on, a read without a hit in a chunk keeps the comment the

@@ -222,3 +222,124 @@ def test_bench_gpus_n_launches_n_ranks_by_itself(tmp_path):
     # and bench.py itself takes that road before anything touches the GPU (here: no GPU at all, every rank says so and fails)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and r.stderr.count("bench.py needs an MI355X") == 2, r.stderr[-600:]
+
+
+def _plumb(tmp_path, f1, f2, extra_env=None, L=151, threads=4, flags=("-F", "-nc")):
+    exe = os.path.join(ROOT, "bin", "soap4-mi355x")
+    env = dict(os.environ, MP_PLUMBING_TEST="1", **(extra_env or {}))
+    r = subprocess.run([exe, "pair", "x", str(f1), str(f2), "-o", str(tmp_path / "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L), "-T", str(threads),
+                        "-u", "750", *flags], env=env, capture_output=True)
+    return r
+
+
+def _kseq_records(data: bytes):
+    """kseq's reading of a FASTA/FASTQ text (klib kseq.h: sequence lines up to '+' or the next header, then quality lines until they
+    are as long as the sequence) -> [(name, comment or None, seq, qual)]"""
+    lines = data.replace(b"\r", b"").split(b"\n")
+    i, out = 0, []
+    while i < len(lines):
+        if not lines[i]:
+            i += 1
+            continue
+        assert lines[i][:1] in (b"@", b">")
+        hdr = lines[i][1:]
+        i += 1
+        cut = len(hdr)
+        for j, ch in enumerate(hdr):
+            if ch in b" \t":
+                cut = j
+                break
+        name, comment = hdr[:cut], (hdr[cut + 1:] if cut + 1 < len(hdr) else None)
+        seq = b""
+        while i < len(lines) and lines[i][:1] not in (b"+", b">", b"@"):
+            seq += lines[i]
+            i += 1
+        qual = b""
+        if i < len(lines) and lines[i][:1] == b"+":
+            i += 1
+            while i < len(lines) and len(qual) < len(seq):
+                qual += lines[i]
+                i += 1
+        out.append((name, comment, seq, qual))
+    return out
+
+
+def _expected_plumbing(recs1, recs2, L):
+    code = {c: "ACGT"[k] for k, c in enumerate("ACGT")}
+    code.update({c.lower(): v for c, v in list(code.items())})
+    code.update({"N": "G", "n": "G", "U": "T", "u": "T"})
+    out = []
+    for a, b in zip(recs1, recs2):
+        for name, _, seq, qual in (a, b):
+            nm = name.decode()
+            if len(nm) > 2 and nm[-2] == "/" and nm[-1].isdigit():
+                nm = nm[:-2]
+            s = "".join(code.get(chr(c), "A") for c in seq[:L - 1])
+            out.append("@%s\tSCORE:0;\n%s\n+\n%s\n" % (nm, s, qual[:len(s)].decode()))
+    return "".join(out)
+
+
+@pytest.mark.parametrize("shape", ["strict", "no_final_newline", "crlf", "blank_lines", "wrapped_fastq", "fasta", "wrapped_fasta", "lowercase_n", "gz", "gz_wrapped"])
+@pytest.mark.parametrize("batch", [5, 1000])
+def test_reader_shapes_equal_kseq_reading(tmp_path, shape, batch):
+    """The ingest of the executable (mapped plain files cut into lines by several threads, gz inflated into the batch; strict fast
+    path with a per-record check, careful kseq-style splitter otherwise) must hand over exactly the records kseq would
+    (QueryParser.cpp:184-262): names without /1 /2, reads cut to L-1, N -> G, wrapped sequence / quality lines joined."""
+    import gzip
+    import random
+    rng = random.Random(sum(map(ord, shape)))
+    n = 37
+    recs = [[], []]
+    for k in range(2):
+        for i in range(n):
+            ln = rng.choice([30, 75, 150, 151, 160])
+            alpha = "ACGT" if shape != "lowercase_n" else "ACGTNacgtnRY"
+            seq = "".join(rng.choice(alpha) for _ in range(ln))
+            qual = "".join(chr(rng.randrange(34, 74)) for _ in range(ln))
+            if i % 5 == 0:
+                qual = "@" + qual[1:]                     # a quality line that begins with '@'
+            recs[k].append(("r%d/%d" % (i, k + 1), seq, qual))
+    files = []
+    for k in range(2):
+        t = ""
+        for i, (nm, seq, qual) in enumerate(recs[k]):
+            fasta = shape in ("fasta", "wrapped_fasta")
+            wrap = 60 if shape in ("wrapped_fastq", "wrapped_fasta", "gz_wrapped") else 10 ** 9
+            body = "\n".join(seq[j:j + wrap] for j in range(0, len(seq), wrap))
+            if fasta:
+                t += ">%s\n%s\n" % (nm, body)
+            else:
+                qb = "\n".join(qual[j:j + wrap] for j in range(0, len(qual), wrap))
+                t += "@%s\n%s\n+\n%s\n" % (nm, body, qb)
+            if shape == "blank_lines" and i % 7 == 3:
+                t += "\n"
+        if shape == "no_final_newline":
+            t = t[:-1]
+        if shape == "crlf":
+            t = t.replace("\n", "\r\n")
+        data = t.encode()
+        path = tmp_path / ("in_%d.fq" % (k + 1))
+        if shape.startswith("gz"):
+            path = tmp_path / ("in_%d.fq.gz" % (k + 1))
+            path.write_bytes(gzip.compress(data))
+        else:
+            path.write_bytes(data)
+        files.append((path, data))
+    r = _plumb(tmp_path, files[0][0], files[1][0], {"MP_BATCH_PAIRS": str(batch)})
+    assert r.returncode == 0, r.stderr.decode()
+    want = _expected_plumbing(_kseq_records(files[0][1]), _kseq_records(files[1][1]), 151)
+    assert r.stdout.decode() == want
+
+
+def test_reader_rejects_garbage_and_mate_count_mismatch(tmp_path):
+    a = tmp_path / "a.fq"; b = tmp_path / "b.fq"
+    a.write_bytes(b"@r0/1\nACGT\n+\nIIII\n@r1/1\nACGT\n+\nIIII\n")
+    b.write_bytes(b"@r0/2\nACGT\n+\nIIII\n")
+    r = _plumb(tmp_path, a, b)
+    assert r.returncode == 1 and b"not matched" in r.stderr
+    b.write_bytes(b"@r0/2\nACGT\n+\nIIII\nACGT\nACGT\n")                 # a line that is neither header nor part of a record
+    r = _plumb(tmp_path, a, b)
+    assert r.returncode == 1 and b"does not begin with" in r.stderr
+    b.write_bytes(b"@r0/2\nACGT\n+\nIIII\n@r1/2\nACGT\n+\n")               # cut short inside a record
+    r = _plumb(tmp_path, a, b)
+    assert r.returncode == 1 and b"ends inside" in r.stderr

@@ -168,6 +168,32 @@ def test_three_chained_chunks_match_reference_chain(golden_dir, tmp_path, tag, L
     assert sum(1 for r in want if r[2].count(",") >= 2) > 0 or tag == "c"      # some reads do carry hits from more than one chunk
 
 
+def test_nine_chained_chunks_match_reference_chain(golden_dir, tmp_path):
+    """g6: nine index chunks with homologous sequences at 0-7 % divergence in several of them; nine chained runs of the real soap4
+    (tests/golden/make_golden_g6.py).  The oracle chained the same way must end with the same records: the -top 95 rule decides chunk
+    after chunk which per-reference scores stay in the header."""
+    lib = O.oracle()
+    g6 = os.path.join(golden_dir, "g6")
+    in1, in2 = os.path.join(g6, "reads_1.fq"), os.path.join(g6, "reads_2.fq")
+    out = None
+    for k in range(9):
+        ix = lib.mpo_index_open(os.path.join(g6, "c%d.fa.index" % k).encode())
+        p = O.default_params(L=151, insert_high=750, mode=1, top=95, nc=(k == 0))
+        st = O.AlignStats()
+        out = str(tmp_path / ("chain_%d.fq" % k))
+        assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), out.encode(), None, C.byref(st)) == 0
+        lib.mpo_index_close(ix)
+        lines = open(out, "rb").read().split(b"\n")
+        in1, in2 = out + ".1", out + ".2"
+        with open(in1, "wb") as a, open(in2, "wb") as b:
+            for i in range(0, len(lines) - 7, 8):
+                a.write(b"\n".join(lines[i:i + 4]) + b"\n")
+                b.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
+    got, want = fastq_records(out), fastq_records(os.path.join(g6, "expected_chain.fq"))
+    assert got == want
+    assert sum(1 for r in want if r[2].count(",c") >= 2) > 50
+
+
 # (tag, MegaPath mode, -top, seed_min_length, reseed_len): tests/golden/g5, the stages that run with soap4.ini (runMegaPath.sh:136,162)
 G5_SETS = {"h": (1, 95, 22, 23), "r": (2, 100, 22, 23), "n": (1, 95, 17, 18)}
 

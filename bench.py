@@ -384,6 +384,147 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
     return cb, parity
 
 
+# ------------------------------------------------------------------------------------------------ the metric's configuration
+def nt_replica_leg(args, H, index_builder, simulate, arrs_a, text_a, dev, device, n_bases):
+    """BASELINE configs[2] on one GPU: an NT-sized replica of the database resident in HBM in the lean layout (0.92 B/base + a 13-mer
+    table per chunk), every batch aligned against every chunk in turn (runMegaPath.sh:191-227 in one process).  Chunk 0 is the genome
+    the reads come from; every other chunk is a DIFFERENT genome -- one unrelated synthetic genome of the same size, indexed once and
+    copied device-to-device into its own arrays (mp_index_clone) -- so that, as with the real database, a read has its true
+    alignment in one chunk and only chance matches in the others.  Read mix of SURVEY 8d C3: 60 % drawn from chunk 0 at 0-8 %
+    divergence, 40 % random."""
+    knobs = {"MP_KMER_FILTER": "0", "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}
+    saved = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    chunks = []
+    try:
+        t0 = time.time()
+        torch.cuda.empty_cache()
+        chunks.append(H.Index.from_arrays(device, **arrs_a))
+        text_b = simulate.genome(n_bases, seed=4, device=dev)
+        tb = text_b.cpu().numpy()
+        del text_b
+        bounds = np.linspace(0, n_bases, 25).astype(np.int64)
+        arrs_b = index_builder.build_index_arrays([("ntB%d" % (i + 1), tb[bounds[i]:bounds[i + 1]]) for i in range(24)], sa_interval=16, device=dev)
+        del tb
+        torch.cuda.empty_cache()
+        chunks.append(H.Index.from_arrays(device, **arrs_b))
+        # the real soap4 beside it: the same read mix against ONE of the other chunks (its files written here), on the host cores; a database
+        # of n chunks costs it n such runs (runMegaPath.sh:191-227), so its rate for the replica is that of one run / n
+        cpu_nt = None
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "soap4")
+        if os.path.exists(ref_bin) and not args.no_cpu_baseline:
+            td = tempfile.mkdtemp(prefix="mpnt_")
+            try:
+                prefix = os.path.join(td, "ntB.index")
+                index_builder.write_index_files(prefix, arrs_b, write_lkt=True, lkt_table=chunks[1].lkt_table())
+                n_cpu = int(os.environ.get("MP_BENCH_NT_CPU_PAIRS", "20000"))
+                cw = Workload(text_a, n_cpu, seed=4242, read_len=args.read_len, L=args.read_len + 1, sub_max=0.08, random_frac=0.4)
+                f1, f2 = os.path.join(td, "n_1.fq"), os.path.join(td, "n_2.fq")
+                write_fastq(cw.codes.cpu().numpy(), n_cpu, f1, f2)
+                ini = os.path.join(td, "soap4-nt2.ini")
+                with open(ini, "w") as f:
+                    f.write(NT2_INI)
+                T = min(os.cpu_count() or 1, 32)
+                with open(os.devnull, "wb") as fo, open(os.path.join(td, "err"), "wb") as fe:
+                    rc = subprocess.call([ref_bin, "pair", prefix, f1, f2, "-o", os.path.join(td, "o"), "-C", ini, "-L", str(args.read_len + 1), "-T", str(T), "-u", "750", "-F", "-nc"],
+                                         stdout=fo, stderr=fe)
+                al = None
+                for line in open(os.path.join(td, "err"), errors="replace"):
+                    if "Overall alignment time" in line:
+                        al = float(line.split(":")[1].split()[0])
+                if rc == 0 and al:
+                    cpu_nt = {"kind": "reference", "threads": T, "pairs": n_cpu, "alignment_s_one_chunk": al, "pairs_per_s_one_chunk": n_cpu / al}
+            except Exception as e:  # noqa: BLE001
+                log("[bench] NT cpu baseline failed: %r" % (e,))
+            finally:
+                shutil.rmtree(td, ignore_errors=True)
+        del arrs_b
+        per_chunk = int(chunks[0].info.device_bytes)
+        free_b, total_b = torch.cuda.mem_get_info()
+        want = int(args.nt_replica_gb * 1e9 // per_chunk) + 1
+        fit = 2 + max(0, int((free_b - (20 << 30)) // per_chunk))           # 20 GiB stay free for the batch buffers and traceback slabs
+        n_chunks = max(2, min(want, fit))
+        t1 = time.time()
+        while len(chunks) < n_chunks:
+            chunks.append(chunks[1].clone())
+        torch.cuda.synchronize()
+        t2 = time.time()
+        index_bytes = sum(int(x.info.device_bytes) for x in chunks)
+        log("[bench] NT replica: %d chunks of %.0f Mbp, %.1f GB of index in HBM (two genomes built in %.1f s, %d device-to-device copies in %.1f s)"
+            % (n_chunks, n_bases / 1e6, index_bytes / 1e9, t1 - t0, n_chunks - 2, t2 - t1))
+        lp = args.nt_pairs
+        wl = Workload(text_a, lp, seed=4242, read_len=args.read_len, L=args.read_len + 1, sub_max=0.08, random_frac=0.4)
+        params = H.AlignParams(wl.max_len, 750, 130, 130, H.MmpParams.nt2())
+        ctx = H.Context(chunks[0])
+        keys = ("seed", "locate", "merge", "pair", "fill", "trace", "rescue_tasks", "rescue_fill", "rescue_trace")
+
+        def one_step(acc):
+            ctx.set_reads(wl.packed_np, wl.lens_np)
+            for ci, ix in enumerate(chunks):
+                ctx.set_index(ix)
+                _, nh, st = ctx.deep_dp_round(params, fetch=False)
+                _, _, rst = ctx.rescue_round(params, False, fetch=False)
+                ctx.pair_hits_view(); ctx.single_hits_view(); ctx.rescue_hits_view()
+                if acc is None:
+                    continue
+                grp = acc["source_chunk" if ci == 0 else "other_chunks"]
+                vals = (st.seed.ms_seed, st.seed.ms_locate, st.seed.ms_merge, st.ms_pair, st.ms_dp_fill, st.ms_dp_trace, rst.ms_tasks, rst.ms_dp_fill, rst.ms_dp_trace)
+                for k, v in zip(keys, vals):
+                    grp[k] = grp.get(k, 0.0) + float(v)
+                for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seedpos", "n_seeds", "n_hits"):
+                    grp[k] = grp.get(k, 0) + int(getattr(st.seed, k))
+                grp["pair_hits"] = grp.get("pair_hits", 0) + int(nh)
+                grp["single_dp_tasks"] = grp.get("single_dp_tasks", 0) + int(rst.n_single_tasks)
+                grp["single_hits"] = grp.get("single_hits", 0) + int(rst.n_single_hits)
+                grp["chunks"] = grp.get("chunks", 0) + 1
+        one_step(None)                                            # first touch of the batch buffers
+        torch.cuda.synchronize()
+        acc = {"source_chunk": {}, "other_chunks": {}}
+        t3 = time.perf_counter()
+        one_step(acc)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t3
+        ctx.close()
+        o = acc["other_chunks"]
+        n_o = max(1, o.get("chunks", 1))
+        per_chunk_ms = {k: o.get(k, 0.0) / n_o for k in keys}
+        t_seed_s = sum(g.get("seed", 0.0) + g.get("locate", 0.0) for g in acc.values()) / 1e3
+        ev = {k: sum(g.get(k, 0) for g in acc.values()) for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seedpos")}
+        seed_bytes = 64 * ev["n_occ_loaded"] + 8 * ev["n_lkt"] + 4 * ev["n_sa"] + 0.25 * wl.sum_len * n_chunks + 16 * ev["n_seedpos"]
+        achieved = seed_bytes / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
+        return {
+            "workload": "%d index chunks of %.0f Mbp resident at once in the lean layout = %.1f Gbp, %.1f GB of HBM (BASELINE configs[2] on one GPU): chunk 0 is the genome "
+                        "the reads come from, the other %d hold an unrelated synthetic genome (indexed once, copied device-to-device into separate arrays), so a read "
+                        "finds its true alignment in one chunk and chance matches elsewhere, as in the real database; 2x%d bp, 60 %% of the pairs from chunk 0 at 0-8 %% "
+                        "divergence, 40 %% random (SURVEY 8d C3); soap4-nt2.ini, -L %d; every batch aligned against each chunk in turn by one context, all three hit "
+                        "lists of every chunk fetched" % (n_chunks, n_bases / 1e6, n_chunks * n_bases / 1e9, index_bytes / 1e9, n_chunks - 1, args.read_len, args.read_len + 1),
+            "chunks": n_chunks, "bases_resident": n_chunks * n_bases, "index_bytes_in_hbm": index_bytes, "bytes_per_base": index_bytes / (n_chunks * n_bases),
+            "hbm_total_bytes": int(total_b), "load_s": t2 - t0, "pairs_per_step": lp, "ms_per_step": el * 1e3, "pairs_per_s": lp / el,
+            "chunk_pair_alignments_per_s": lp * n_chunks / el,
+            "cpu_baseline": (dict(cpu_nt, value=cpu_nt["pairs_per_s_one_chunk"] / n_chunks, unit="pairs/s",
+                                  sample="%d pairs of the same read mix, real soap4 (oracle/_ref) -T %d against ONE chunk (the unrelated genome); the replica's %d "
+                                         "chunks are %d such runs for it, so value = that rate / %d" % (cpu_nt["pairs"], cpu_nt["threads"], n_chunks, n_chunks, n_chunks))
+                             if cpu_nt else None),
+            "kernel_ms_per_chunk_other_chunks": per_chunk_ms, "kernel_ms_source_chunk": {k: acc["source_chunk"].get(k, 0.0) for k in keys},
+            "per_pair_per_other_chunk": {k: o.get(k, 0) / (n_o * lp) for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seeds", "n_hits", "n_seedpos", "single_dp_tasks", "single_hits", "pair_hits")},
+            "roofline": {"bound": "hbm", "kernel": "seed_kernel+seed_overflow_kernel+expand_hits_kernel+locate_kernel (lean layout, all chunks of the step)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "bytes_per_pair_per_chunk": seed_bytes / (lp * n_chunks), "launch_ms_per_chunk": t_seed_s * 1e3 / n_chunks,
+                         "formula": "64*rank_blocks_loaded + 8*lkt13_lookups + 4*sa_reads + 0.25*read_bases + 16*seed_positions_out over the seed-stage kernels' time"},
+        }
+    finally:
+        for x in chunks:
+            try:
+                x.close()
+            except Exception:  # noqa: BLE001
+                pass
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 # ------------------------------------------------------------------------------------------------ through the boundary
 def write_fastq_fast(codes_dev, path1, path2, first_id=0):
     """2P x L base codes on the device -> two FASTQ files with fixed-width names, formatted as one byte matrix per file on the
@@ -444,11 +585,15 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
             for line in err.splitlines():
                 if "alignment loop" in line:
                     loop_s = float(line.split("alignment loop")[1].split()[0])
+            rd = [l for l in err.splitlines() if "reader:" in l and " 0 pairs" not in l]
+            rd_t = [(float(l.split("lines found in")[1].split()[0]), float(l.split("packed in")[1].split()[0])) for l in rd[len(rd) // 2:]]     # second half: steady state
             out = {"rc": r.returncode, "pairs": n_pairs, "process_s": wall, "alignment_loop_s": loop_s, "pairs_per_s": (n_pairs / loop_s) if loop_s else None,
-                   "threads": threads, "stage_seconds": next((l.split("seconds:")[1].strip() for l in err.splitlines() if "seconds:" in l), None)}
+                   "threads": threads, "stage_seconds": next((l.split("seconds:")[1].strip() for l in err.splitlines() if "seconds:" in l), None),
+                   "reader_ms_per_batch_steady": {"lines": 1e3 * sum(a for a, _ in rd_t) / len(rd_t), "records_and_packing": 1e3 * sum(b for _, b in rd_t) / len(rd_t)} if rd_t else None}
             if r.returncode != 0:
                 out["stderr_tail"] = err[-400:]
             return out
+        res["plain_first_run"] = run(f1, f2, n_batches * P)       # the first process after the files were written runs slower (cold pages, clocks): listed, not quoted
         res["plain"] = run(f1, f2, n_batches * P)
         # tuning aid: MP_BENCH_E2E_VARIANTS="name:ENV=val,ENV=val;name2:..." runs the plain input again under each environment
         for spec in filter(None, os.environ.get("MP_BENCH_E2E_VARIANTS", "").split(";")):
@@ -542,7 +687,9 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the C3/C4/C5 workload legs, the lean-layout leg and the resident-chunks leg")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "3")),
                     help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")
-    ap.add_argument("--nt-chunks", type=int, default=int(os.environ.get("MP_BENCH_NT_CHUNKS", "4")), help="index chunks of the resident-chunks leg")
+    ap.add_argument("--nt-replica-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_GB", "242")),
+                    help="HBM bytes (GB) of index the nt_replica leg makes resident (as many lean chunks of --genome-mbp as that takes; 0 = skip the leg)")
+    ap.add_argument("--nt-pairs", type=int, default=int(os.environ.get("MP_BENCH_NT_PAIRS", "65536")), help="pairs per step of the nt_replica leg")
     ap.add_argument("--legs", default=os.environ.get("MP_BENCH_LEGS", "all"), help="comma-separated legs to run (e2e_cli, nt2_ini_same_reads, C3_divergent, C4_2x250, "
                     "C5_mixed_rescue, lean_layout, nt_replica) or 'all'")
     ap.add_argument("--no-e2e", action="store_true", help="skip the leg through the executable (FASTQ files in, annotated FASTQ out)")
@@ -824,16 +971,12 @@ def main():
             # ---- lean layout: what a chunk of a 250 GB NT replica gets -- rank blocks, 13-mer table, the file's SA samples, text
             # (1.09 B/base), none of the optional tables -- and N such chunks resident at once, every batch aligned against each
             try:
-                if not (want_leg("lean_layout") or want_leg("resident_chunks")):
+                if not want_leg("lean_layout"):
                     raise KeyError("skipped")
                 knobs = {"MP_KMER_FILTER": "0", "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}
                 saved = {k: os.environ.get(k) for k in knobs}
                 os.environ.update(knobs)
-                nchunks = max(1, args.nt_chunks)
-                lean = []
-                t0 = time.time()
-                for _ in range(nchunks):
-                    lean.append(H.Index.from_arrays(local_rank, **arrs))
+                lean = [H.Index.from_arrays(local_rank, **arrs)]
                 for k, v in saved.items():
                     if v is None:
                         os.environ.pop(k, None)
@@ -852,45 +995,31 @@ def main():
                                        "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")},
                                        "per_pair": {"rank_blocks_loaded": la["n_occ_loaded"] / (2 * lp), "lkt13_lookups": la["n_lkt"] / (2 * lp), "sa_reads": la["n_sa"] / (2 * lp)}}
 
-                def chunk_step():
-                    lctx.set_reads(lw.packed_np, lw.lens_np)
-                    tot = 0
-                    for ix in lean:
-                        lctx.set_index(ix)
-                        _, nh, _ = lctx.deep_dp_round(params, fetch=False)
-                        lctx.rescue_round(params, False, fetch=False)
-                        lctx.pair_hits_view(); lctx.single_hits_view(); lctx.rescue_hits_view()
-                        tot += nh
-                    return tot
-                chunk_step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                hits_all = chunk_step()
-                torch.cuda.synchronize()
-                el = time.perf_counter() - t1
-                legs["resident_chunks"] = {"workload": "%d index chunks of %.0f Mbp each resident at once in the lean layout (%.1f Gbp, %.1f GB of HBM; the same synthetic genome "
-                                                       "loaded %d times -- every chunk finds the same hits, the work per chunk is what a distinct chunk of that size costs), every batch "
-                                                       "aligned against each chunk in turn by one context (mp_ctx_set_index), hit lists of every chunk fetched" % (
-                                                           nchunks, args.genome_mbp, nchunks * args.genome_mbp / 1e3, lean_bytes / 1e9, nchunks),
-                                           "chunks": nchunks, "bases_resident": nchunks * n_bases, "index_bytes_in_hbm": lean_bytes, "bytes_per_base": lean_bytes / (nchunks * n_bases),
-                                           "load_s": time.time() - t0, "pairs_per_step": lp, "ms_per_step": el * 1e3, "pairs_per_s": lp / el,
-                                           "chunk_pair_alignments_per_s": lp * nchunks / el, "pair_hits_over_all_chunks": int(hits_all),
-                                           "extrapolation": "a 250 GB replica at this layout holds %.0f Gbp; one batch against all of it costs (bases / %.2f Gbp) x %.1f ms at this "
-                                                            "rate" % (250e9 / (lean_bytes / (nchunks * n_bases)) / 1e9, args.genome_mbp / 1e3, el * 1e3 / nchunks)}
                 lctx.close()
                 for x in lean:
                     x.close()
             except KeyError:
                 pass
             except Exception as e:  # noqa: BLE001
-                legs["resident_chunks"] = {"error": repr(e)}
-                log("[bench] lean / resident-chunks leg failed: %r" % (e,))
+                legs["lean_layout"] = {"error": repr(e)}
+                log("[bench] lean-layout leg failed: %r" % (e,))
+            # ---- the metric's own configuration: a full-size NT replica resident in this GPU's HBM (BASELINE configs[2])
+            if want_leg("nt_replica") and args.nt_replica_gb > 0:
+                try:
+                    ctx.close(); gix.close()                       # the 111 GB every-table layout of the human index makes room
+                    ctx = gix = None
+                    legs["nt_replica"] = nt_replica_leg(args, H, index_builder, simulate, arrs, text, dev, local_rank, n_bases)
+                except Exception as e:  # noqa: BLE001
+                    legs["nt_replica"] = {"error": repr(e)}
+                    log("[bench] NT replica leg failed: %r" % (e,))
             if "e2e_cli" in out:
                 legs["e2e_cli"] = out.pop("e2e_cli")
             out["legs"] = legs
         print(json.dumps(out), flush=True)
-    ctx.close()
-    gix.close()
+    if ctx is not None:
+        ctx.close()
+    if gix is not None:
+        gix.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -42,6 +42,9 @@ int mp_index_from_arrays(int device, uint64_t text_length, uint64_t inverse_sa0,
                          const uint8_t *pac_bytes, const uint64_t *lkt,
                          uint32_t num_seq, const char *const *seq_names, const uint64_t *seq_starts, const uint64_t *seq_lengths,
                          mp_index **out);
+/* A second copy of a resident index in the same GPU's HBM (device-to-device copies of every array; the annotation is duplicated):
+ * how the benchmark fills the HBM with as many index chunks as the full NT database has (runMegaPath.sh:191-227 loops over them). */
+int mp_index_clone(const mp_index *src, mp_index **out);
 int mp_index_close(mp_index *ix);
 
 typedef struct {
@@ -60,6 +63,9 @@ int mp_index_chr_and_pos_batch(const mp_index *ix, const uint64_t *amb_pos, uint
 /* Same, also returning getChrAndPos's own return value: the last packed position of the translate segment
  * (BGS-IO.cpp:186-187), which BoundaryCheckDP (BGS-IO.cpp:219) trims BAM records against. */
 int mp_index_chr_pos_segment(const mp_index *ix, uint64_t amb_pos, uint64_t *out_pos, uint32_t *out_seq_id, uint64_t *out_segment_end);
+/* decideTargetChr (BGS-IO.cpp:1312-1341): the 1-based sequence an alignment of `len` bases at amb_pos lies in; 0 when its first and last
+ * base belong to different sequences (such an alignment is dropped by the annotated-FASTQ writers, BGS-IO.cpp:1406-1411, 1993-2001). */
+int mp_index_target_chr(const mp_index *ix, uint64_t amb_pos, uint32_t len, uint32_t *out_seq_id);
 /* HSP seqOffset[i].startPos / packed length (.ann) and seqActualOffset length (.tra tail = the BAM header's LN, SAM.cpp:117) */
 int mp_index_seq_info(const mp_index *ix, uint32_t seq_id_1based, uint64_t *out_start, uint64_t *out_packed_len, uint64_t *out_actual_len);
 /* Text bases (codes 0..3) of n_ranges ranges, gathered on the device from the resident .pac: range r lands in

@@ -218,6 +218,7 @@ extern "C" int mp_build_index_arrays(int device, const uint8_t *codes, uint64_t 
     hipLaunchKernelGGL(build_bwt_words_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, s, (const uint8_t *)d_codes.p, sa, n, inv_sa0, d_words.p);
     hipLaunchKernelGGL(build_sa_samples_kernel, dim3(grid_for(n_samples, 256)), dim3(256), 0, s, sa, m, sa_interval, n_samples, d_samples.p);
     hipLaunchKernelGGL(build_pac_kernel, dim3(grid_for(n_pac, 256)), dim3(256), 0, s, (const uint8_t *)d_codes.p, n, d_pac.p, d_small.p);
+    HIPCHK(hipGetLastError());                                                  // a launch that failed (configuration, resources) must not pass for an index
     HIPCHK(hipMemcpyAsync(out_bwt_words, d_words.p, n_words * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_sa_samples, d_samples.p, n_samples * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_pac, d_pac.p, n_pac, hipMemcpyDeviceToHost, s));
@@ -268,6 +269,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
     if (hipMalloc(&ix->d_occ, occ_bytes) != hipSuccess || hipMalloc(&ix->d_lkt, lkt_bytes) != hipSuccess || hipMalloc(&ix->d_sa, sa_bytes) != hipSuccess ||
         hipMalloc(&ix->d_text, text_bytes) != hipSuccess) return fail(MP_ENOMEM);
     ix->device_bytes = occ_bytes + lkt_bytes + sa_bytes + text_bytes;
+    ix->bytes_occ = occ_bytes; ix->bytes_lkt = lkt_bytes; ix->bytes_sa = sa_bytes; ix->bytes_text = text_bytes;
     const size_t bwt_in = ((size_t)n_blocks * 12 + 16) * 4, pac_in = (size_t)text_words * 4 + 16;
     if (hipMalloc(&d_bwt, bwt_in) != hipSuccess || hipMalloc(&d_pac, pac_in) != hipSuccess || hipMalloc(&d_cnt, (size_t)n_blocks * 16) != hipSuccess ||
         hipMalloc(&d_run, (size_t)n_blocks * 16) != hipSuccess) return fail(MP_ENOMEM);
@@ -312,7 +314,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
             if (hipMemset(ix->d_kmer, 0, kb) != hipSuccess) return fail(MP_ENODEV);
             hipLaunchKernelGGL(kmer17_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, (uint32_t *)ix->d_kmer);
             if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
-            ix->device_bytes += kb;
+            ix->device_bytes += kb; ix->bytes_kmer = kb;
         }
     }
     if (ix->d_kmer) {
@@ -328,7 +330,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
             if (hipMemset(ix->d_kmer15, 0, bytes) != hipSuccess) return fail(MP_ENODEV);
             hipLaunchKernelGGL(kmer15x3_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, (unsigned long long *)ix->d_kmer15);
             if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
-            ix->device_bytes += bytes;
+            ix->device_bytes += bytes; ix->bytes_kmer15 = bytes;
         }
     }
     if (ix->d_kmer) {
@@ -360,7 +362,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
             }
             (void)hipFree(tmp16);
             if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
-            ix->device_bytes += bytes;
+            ix->device_bytes += bytes; ix->bytes_lkt16 = bytes;
         }
     }
     ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt; ix->d.lkt16 = (const uint32_t *)ix->d_lkt16;
@@ -390,7 +392,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
             hipLaunchKernelGGL(sa_dense_build_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, 0, ix->d, rows, shift, (uint32_t *)ix->d_sa_dense);
             if (hipDeviceSynchronize() != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
             ix->d.sa_dense = (const uint32_t *)ix->d_sa_dense;
-            ix->device_bytes += (size_t)rows * 4;
+            ix->device_bytes += (size_t)rows * 4; ix->bytes_sa_dense = (size_t)rows * 4;
         }
     }
     if (ix->d_lkt16 && ix->d_sa_dense && ix->d.sa_dense_shift == 0) {
@@ -409,7 +411,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
                                (const uint32_t *)ix->d_lkt16, (uint4 *)ix->d_lkt16u);
             if (hipDeviceSynchronize() != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
             ix->d.lkt16u = (const uint4 *)ix->d_lkt16u;
-            ix->device_bytes += bytes;
+            ix->device_bytes += bytes; ix->bytes_lkt16u = bytes;
         }
     }
     *out = ix;
@@ -442,6 +444,34 @@ extern "C" int mp_index_from_arrays(int device, uint64_t text_length, uint64_t i
                                    num_seq, seq_names, seq_starts, seq_lengths, h, err);
     if (rc) { fprintf(stderr, "[megapath_hip] %s\n", err.c_str()); return rc; }
     return upload_index(device, h, out);
+}
+
+// A second copy of a resident index in the same HBM: every array copied device-to-device (milliseconds per GB instead of the
+// host parse + upload + re-layout of mp_index_open), the host-side annotation duplicated.  What a benchmark uses to fill the HBM
+// with as many index chunks as a full database has; the copies are ordinary indexes (mp_index_close frees them).
+extern "C" int mp_index_clone(const mp_index *src, mp_index **out)
+{
+    if (!src || !out) return MP_EINVAL;
+    HIPCHK(hipSetDevice(src->device));
+    mp_index *ix = new (std::nothrow) mp_index(*src);                 // annotation, sizes and the kernel view (pointers fixed below)
+    if (!ix) return MP_ENOMEM;
+    ix->d_occ = ix->d_lkt = ix->d_sa = ix->d_text = ix->d_kmer = ix->d_sa_dense = ix->d_lkt16 = ix->d_kmer15 = ix->d_lkt16u = nullptr;
+    ix->host_text = std::make_shared<mp_index::HostText>();
+    struct Arr { void *const *from; void **to; size_t bytes; };
+    const Arr arrs[] = {{&src->d_occ, &ix->d_occ, src->bytes_occ}, {&src->d_lkt, &ix->d_lkt, src->bytes_lkt}, {&src->d_sa, &ix->d_sa, src->bytes_sa},
+                        {&src->d_text, &ix->d_text, src->bytes_text}, {&src->d_kmer, &ix->d_kmer, src->bytes_kmer}, {&src->d_sa_dense, &ix->d_sa_dense, src->bytes_sa_dense},
+                        {&src->d_lkt16, &ix->d_lkt16, src->bytes_lkt16}, {&src->d_kmer15, &ix->d_kmer15, src->bytes_kmer15}, {&src->d_lkt16u, &ix->d_lkt16u, src->bytes_lkt16u}};
+    for (const Arr &a : arrs) {
+        if (!*a.from || a.bytes == 0) continue;
+        if (hipMalloc(a.to, a.bytes) != hipSuccess) { mp_index_close(ix); return MP_ENOMEM; }
+        if (hipMemcpy(*a.to, *a.from, a.bytes, hipMemcpyDeviceToDevice) != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
+    ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt; ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text;
+    ix->d.kmer17 = (const uint32_t *)ix->d_kmer; ix->d.sa_dense = (const uint32_t *)ix->d_sa_dense; ix->d.lkt16 = (const uint32_t *)ix->d_lkt16;
+    ix->d.kmer15x3 = (const unsigned long long *)ix->d_kmer15; ix->d.lkt16u = (const uint4 *)ix->d_lkt16u;
+    *out = ix;
+    return MP_OK;
 }
 
 extern "C" int mp_index_close(mp_index *ix)
@@ -490,6 +520,29 @@ extern "C" int mp_index_chr_and_pos(const mp_index *ix, uint64_t amb_pos, uint64
     return MP_OK;
 }
 
+// decideTargetChr (BGS-IO.cpp:1312-1341): the sequence an alignment of `len` bases at amb_pos lies in, 0 when its two ends fall
+// into different sequences.  One table walk when both ends share a row of the translation table (nearly always).
+extern "C" int mp_index_target_chr(const mp_index *ix, uint64_t amb_pos, uint32_t len, uint32_t *out_seq)
+{
+    if (!ix || !out_seq || ix->grid.empty()) return MP_EINVAL;
+    uint64_t g = amb_pos >> 18;
+    if (g >= ix->grid.size()) g = ix->grid.size() - 1;
+    uint32_t v = ix->grid[g];
+    while (v > 0 && ix->translate[v].start > amb_pos) v--;
+    const uint32_t c1 = ix->translate[v].chr;
+    const uint64_t last = amb_pos + len - 1;
+    uint32_t c2 = c1;
+    if ((size_t)v + 1 < ix->translate.size() && ix->translate[v + 1].start <= last) {
+        uint64_t g2 = last >> 18;
+        if (g2 >= ix->grid.size()) g2 = ix->grid.size() - 1;
+        uint32_t w = ix->grid[g2];
+        while (w > 0 && ix->translate[w].start > last) w--;
+        c2 = ix->translate[w].chr;
+    }
+    *out_seq = c1 == c2 ? c1 : 0u;
+    return MP_OK;
+}
+
 // getChrAndPos with its return value (BGS-IO.cpp:163-188).  The reference evaluates `row < numOfRemovedSegment - 1` in
 // unsigned 64-bit arithmetic, so with no removed segment every row takes the "next row" branch; for the last row that
 // is a read past its array, for which the text length is returned here.
@@ -516,36 +569,35 @@ extern "C" int mp_index_seq_info(const mp_index *ix, uint32_t seq_id_1based, uin
     return MP_OK;
 }
 
-__global__ void fetch_text_kernel(const uint32_t *__restrict__ text, uint64_t n, const uint64_t *__restrict__ pos, const uint32_t *__restrict__ len,
-                                  uint32_t n_ranges, uint8_t *__restrict__ out, uint32_t stride)
-{
-    const uint32_t r = blockIdx.x;
-    if (r >= n_ranges) return;
-    const uint64_t p0 = pos[r];
-    const uint32_t L = len[r] < stride ? len[r] : stride;
-    for (uint32_t i = threadIdx.x; i < L; i += blockDim.x) {
-        const uint64_t p = p0 + i;
-        out[(size_t)r * stride + i] = p < n ? (uint8_t)((text[p >> 4] >> (2 * (p & 15))) & 3u) : (uint8_t)0;
-    }
-}
-
+// Reference bases for the MD / NM tags of the BAM writer (-b -p).  Served from a host mirror of the packed text, copied back from
+// the device once: the callers are the printer's formatting threads, thousands of small requests per batch, and a device round
+// trip for each (allocation, two copies, a launch on the null stream) stalled every context of the GPU.
 extern "C" int mp_index_fetch_text(const mp_index *ix, const uint64_t *pos, const uint32_t *len, uint32_t n_ranges, uint8_t *out, uint32_t stride)
 {
     if (!ix || !pos || !len || !out || stride == 0) return MP_EINVAL;
     if (n_ranges == 0) return MP_OK;
-    HIPCHK(hipSetDevice(ix->device));
-    uint64_t *d_pos = nullptr; uint32_t *d_len = nullptr; uint8_t *d_out = nullptr;
-    int rc = MP_OK;
-    if (hipMalloc((void **)&d_pos, (size_t)n_ranges * 8) != hipSuccess || hipMalloc((void **)&d_len, (size_t)n_ranges * 4) != hipSuccess ||
-        hipMalloc((void **)&d_out, (size_t)n_ranges * stride) != hipSuccess) rc = MP_ENOMEM;
-    if (!rc && (hipMemcpy(d_pos, pos, (size_t)n_ranges * 8, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(d_len, len, (size_t)n_ranges * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = MP_ENODEV;
-    if (!rc) {
-        hipLaunchKernelGGL(fetch_text_kernel, dim3(n_ranges), dim3(64), 0, 0, ix->d.text, ix->n, d_pos, d_len, n_ranges, d_out, stride);
-        if (hipMemcpy(out, d_out, (size_t)n_ranges * stride, hipMemcpyDeviceToHost) != hipSuccess) rc = MP_ENODEV;
+    mp_index::HostText &ht = *ix->host_text;
+    {
+        std::lock_guard<std::mutex> lk(ht.mu);
+        if (!ht.ready) {
+            HIPCHK(hipSetDevice(ix->device));
+            ht.words.resize(ix->bytes_text / 4);
+            HIPCHK(hipMemcpy(ht.words.data(), ix->d_text, ix->bytes_text, hipMemcpyDeviceToHost));
+            ht.ready = true;
+        }
     }
-    (void)hipFree(d_pos); (void)hipFree(d_len); (void)hipFree(d_out);
-    return rc;
+    const uint32_t *text = ht.words.data();
+    const uint64_t n = ix->n;
+    for (uint32_t r = 0; r < n_ranges; r++) {
+        const uint64_t p0 = pos[r];
+        const uint32_t L = len[r] < stride ? len[r] : stride;
+        uint8_t *o = out + (size_t)r * stride;
+        for (uint32_t i = 0; i < L; i++) {
+            const uint64_t p = p0 + i;
+            o[i] = p < n ? (uint8_t)((text[p >> 4] >> (2 * (p & 15))) & 3u) : (uint8_t)0;
+        }
+    }
+    return MP_OK;
 }
 
 extern "C" int mp_index_chr_and_pos_batch(const mp_index *ix, const uint64_t *amb_pos, uint64_t n, uint64_t *out_pos, uint32_t *out_seq)
@@ -689,14 +741,14 @@ extern "C" int mp_ctx_create(mp_index *ix, mp_ctx **out)
     mp_ctx *c = new (std::nothrow) mp_ctx();
     if (!c) return MP_ENOMEM;
     c->ix = ix;
-    HIPCHK(hipStreamCreate(&c->stream));
-    HIPCHK(hipStreamCreate(&c->copy_stream));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_hits_ready, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_hits_copied, hipEventDisableTiming));
-    for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
-    for (auto &e : c->ev_round) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_rescue_ready, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_rescue_copied, hipEventDisableTiming));
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipStreamCreate(&c->copy_stream) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_hits_ready, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_hits_copied, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_rescue_ready, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_rescue_copied, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    for (auto &e : c->ev_round) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) { fprintf(stderr, "[megapath_hip] mp_ctx_create: stream / event creation failed: %s\n", hipGetErrorString(hipGetLastError())); mp_ctx_destroy(c); return MP_ENODEV; }
     if (c->ctr.reserve(1) || c->n_pair_hits.reserve(1)) { mp_ctx_destroy(c); return MP_ENOMEM; }
     *out = c;
     return MP_OK;
@@ -1947,12 +1999,12 @@ static int scan_u32_inplace(uint32_t *d, uint64_t n)
     uint32_t carry = 0;
     for (uint64_t lo = 0; lo < n; lo += part) {
         const uint64_t cnt = std::min<uint64_t>(part, n - lo);
-        (void)hipcub::DeviceScan::InclusiveSum(tmp, tb, d + lo, d + lo, (int)cnt, 0);
+        if (hipcub::DeviceScan::InclusiveSum(tmp, tb, d + lo, d + lo, (int)cnt, 0) != hipSuccess) { (void)hipFree(tmp); return MP_ENODEV; }
         if (carry) hipLaunchKernelGGL(add_offset_kernel, dim3(grid_for(cnt, 256)), dim3(256), 0, 0, d + lo, cnt, carry);
         if (hipMemcpy(&carry, d + lo + cnt - 1, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(tmp); return MP_ENODEV; }
     }
     (void)hipFree(tmp);
-    return hipDeviceSynchronize() == hipSuccess ? MP_OK : MP_ENODEV;
+    return hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess ? MP_OK : MP_ENODEV;
 }
 
 extern "C" int mp_coverage_create(const mp_index *ix, mp_coverage **out)
@@ -2018,7 +2070,7 @@ extern "C" int mp_coverage_add(mp_coverage *c, const uint32_t *seq_id_1based, co
     c->n_added += n;
     return with_intervals(c, seq_id_1based, start0, len, n, [&](const uint32_t *d_seq, const uint64_t *d_st, const uint32_t *d_l) {
         hipLaunchKernelGGL(cov_add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d_seq, d_st, d_l, n, c->d_off, c->d_len, c->d_depth);
-        return hipDeviceSynchronize() == hipSuccess ? MP_OK : MP_ENODEV;
+        return hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess ? MP_OK : MP_ENODEV;
     });
 }
 
@@ -2034,7 +2086,8 @@ extern "C" int mp_coverage_finish(mp_coverage *c, double stdev_k)
     const uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4096, (c->total / c->n_seq) / 65536 + 1));
     hipLaunchKernelGGL(cov_moments_kernel, dim3(c->n_seq * slices), dim3(256), 0, 0, c->d_depth, c->d_off, c->d_len, c->n_seq, slices, d_sums);
     std::vector<unsigned long long> sums((size_t)c->n_seq * 2);
-    hipError_t e = hipMemcpy(sums.data(), d_sums, sums.size() * 8, hipMemcpyDeviceToHost);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(sums.data(), d_sums, sums.size() * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d_sums);
     if (e != hipSuccess) return MP_ENODEV;
     c->mean.resize(c->n_seq); c->var.resize(c->n_seq); c->max_depth.resize(c->n_seq);
@@ -2051,7 +2104,7 @@ extern "C" int mp_coverage_finish(mp_coverage *c, double stdev_k)
     HIPCHK(hipMemcpy(c->d_max, c->max_depth.data(), (size_t)c->n_seq * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void **)&c->d_mask, c->total * 4));
     hipLaunchKernelGGL(cov_mask_kernel, dim3(grid_for(c->total, 256)), dim3(256), 0, 0, c->d_depth, c->d_off, c->d_len, c->d_max, c->n_seq, c->total, c->d_mask);
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
     c->finished = true;
     return MP_OK;
 }
@@ -2078,7 +2131,8 @@ extern "C" int mp_coverage_spike_intervals(mp_coverage *c, uint32_t *out_seq_id,
     if (hipMalloc((void **)&d_m, c->total * 4) != hipSuccess) { (void)hipFree(d_edges); (void)hipFree(d_n); return MP_ENOMEM; }
     hipLaunchKernelGGL(cov_mask_kernel, dim3(grid_for(c->total, 256)), dim3(256), 0, 0, c->d_depth, c->d_off, c->d_len, c->d_max, c->n_seq, c->total, d_m);
     hipLaunchKernelGGL(cov_edges_kernel, dim3(grid_for(c->total, 256)), dim3(256), 0, 0, d_m, c->total, d_edges, edge_cap, d_n);
-    hipError_t e = hipMemcpy(&n_e, d_n, 4, hipMemcpyDeviceToHost);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(&n_e, d_n, 4, hipMemcpyDeviceToHost);
     std::vector<unsigned long long> edges(std::min<uint32_t>(n_e, edge_cap));
     if (e == hipSuccess && !edges.empty()) e = hipMemcpy(edges.data(), d_edges, edges.size() * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d_edges); (void)hipFree(d_n); (void)hipFree(d_m);
@@ -2114,6 +2168,7 @@ extern "C" int mp_coverage_spike_bases(mp_coverage *c, const uint32_t *seq_id_1b
     HIPCHK(hipMalloc((void **)&d_out, n * 4));
     int rc = with_intervals(c, seq_id_1based, start0, len, n, [&](const uint32_t *d_seq, const uint64_t *d_st, const uint32_t *d_l) {
         hipLaunchKernelGGL(cov_query_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d_seq, d_st, d_l, n, c->d_off, c->d_len, c->d_mask, d_out);
+        if (hipGetLastError() != hipSuccess) return MP_ENODEV;
         return hipMemcpy(out_covered, d_out, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? MP_OK : MP_ENODEV;
     });
     (void)hipFree(d_out);

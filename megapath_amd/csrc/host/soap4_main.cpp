@@ -556,16 +556,45 @@ void build_records(const char *base, const Params &p, Batch &out, int k, size_t 
             const size_t keep = std::min(sn, cap);                                          // QueryParser.cpp:188
             uint32_t *dst = out.packed.data() + (2 * q + (size_t)k) * (size_t)W;
             unsigned unclean = 0;
-            for (uint32_t w = 0; w < W; w++) {
-                uint32_t v = 0;
-                const size_t lo = (size_t)w * 16, hi = std::min(keep, lo + 16);
-                for (size_t i = lo; i < hi; i++) {
-                    const unsigned char ch = (unsigned char)sq[i];
-                    v |= (uint32_t)g_code[ch] << (2 * (i - lo));
-                    unclean |= g_unclean[ch];
+            {
+                // eight bases at a time: for upper-case ACGT the code is ((c >> 1) ^ (c >> 2)) & 3 (A 0, C 1, G 2, T 3); the letters are
+                // rebuilt from the codes and compared, so anything else (N, lower case, IUPAC) sends the read to the table loop below
+                uint64_t bad = 0;
+                for (uint32_t w = 0; w < W; w++) {
+                    const size_t lo = (size_t)w * 16;
+                    uint32_t v = 0;
+                    if (lo + 16 <= keep) {
+                        for (int half = 0; half < 2; half++) {
+                            uint64_t x;
+                            memcpy(&x, sq + lo + 8 * (size_t)half, 8);
+                            const uint64_t c = ((x >> 1) ^ (x >> 2)) & 0x0303030303030303ull;
+                            const uint64_t hi1 = (c >> 1) & 0x0101010101010101ull, both = c & hi1;
+                            const uint64_t back = 0x4141414141414141ull + 2 * c + 2 * hi1 + 11 * both;
+                            bad |= back ^ x;
+                            uint64_t y = (c | (c >> 6)) & 0x000F000F000F000Full;
+                            y = (y | (y >> 12)) & 0x000000FF000000FFull;
+                            y = (y | (y >> 24)) & 0xFFFFull;
+                            v |= (uint32_t)y << (16 * half);
+                        }
+                    } else {
+                        const size_t hi = std::min(keep, lo + 16);
+                        for (size_t i = lo; i < hi; i++) {
+                            const unsigned char ch = (unsigned char)sq[i];
+                            v |= (uint32_t)g_code[ch] << (2 * (i - lo));
+                            unclean |= g_unclean[ch];
+                        }
+                    }
+                    dst[w] = v;
                 }
-                dst[w] = v;
+                if (bad) unclean = 1;
             }
+            if (unclean)
+                for (uint32_t w = 0; w < W; w++) {
+                    uint32_t v = 0;
+                    const size_t lo = (size_t)w * 16, hi = std::min(keep, lo + 16);
+                    for (size_t i = lo; i < hi; i++) v |= (uint32_t)g_code[(unsigned char)sq[i]] << (2 * (i - lo));
+                    dst[w] = v;
+                }
             out.lens[2 * q + (size_t)k] = (uint32_t)keep;
             if (unclean || rr.wrapped) {
                 std::string &o = r.owned().seq;
@@ -783,6 +812,17 @@ int mapping_from_header(const Rec &r, std::vector<HdrMap> &v, double top, double
     return score;
 }
 
+// "%d" without the formatting machinery (the printer writes millions of these per second)
+inline void append_int(std::string &o, int v)
+{
+    char buf[12];
+    int n = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) buf[n++] = '-';
+    while (n) o += buf[--n];
+}
+
 struct Writer {
     const mp_index *ix;
     const Params &p;
@@ -882,13 +922,12 @@ struct Writer {
         if (to_comment) comm_.clear(); else { out += '@'; out.append(r.name, r.name_len); out += '\t'; }
         if (r.ignore()) o += "IGNORE";
         else {
-            char tmp[64];
-            snprintf(tmp, sizeof tmp, "SCORE:%d;", best); o += tmp;
+            o += "SCORE:"; append_int(o, best); o += ';';
             if (best > 0) {
                 for (size_t i = 0; i < hits.size(); i++) {
                     if (i > 0 && hits[i].chr == hits[i - 1].chr) continue;
                     if (-hits[i].neg > 0 && -hits[i].neg >= best * p.top) {
-                        snprintf(tmp, sizeof tmp, "%d,", -hits[i].neg); o += tmp;
+                        append_int(o, -hits[i].neg); o += ',';
                         o += mp_index_seq_name(ix, (uint32_t)hits[i].chr); o += ';';
                     }
                 }
@@ -914,10 +953,9 @@ struct Writer {
     // decideTargetChr (BGS-IO.cpp:1312-1341)
     int target_chr(uint64_t pos, uint32_t len) const
     {
-        uint64_t tp; uint32_t c1, c2;
-        mp_index_chr_and_pos(ix, pos, &tp, &c1);
-        mp_index_chr_and_pos(ix, pos + len - 1, &tp, &c2);
-        return c1 == c2 ? (int)c1 : -1;
+        uint32_t c = 0;
+        mp_index_target_chr(ix, pos, len, &c);
+        return c ? (int)c : -1;
     }
     // pairDeepDPOutputFastqAPI (BGS-IO.cpp:1966-2091).  Like the reference it rewrites the results in place (boundary
     // spanning mates become unaligned, scores are normalised): the BAM writer that runs next sees those values.
@@ -937,16 +975,15 @@ struct Writer {
             if (c2 != -1) h2_.push_back(ChrHit{c2, -s2});
         }
         std::sort(h1_.begin(), h1_.end()); std::sort(h2_.begin(), h2_.end());
-        std::vector<HdrMap> v1, v2;
-        int p1 = mapping_from_header(r1, v1, p.top, best1 * p.top), p2 = mapping_from_header(r2, v2, p.top, best2 * p.top);
+        int p1 = mapping_from_header(r1, v1_, p.top, best1 * p.top), p2 = mapping_from_header(r2, v2_, p.top, best2 * p.top);
         best1 = std::max(best1, p1); best2 = std::max(best2, p2);
-        record(r1, best1, h1_, v1);
-        record(r2, best2, h2_, v2);
+        record(r1, best1, h1_, v1_);
+        record(r2, best2, h2_, v2_);
     }
     // unproperlypairDPOutputFastqAPI (BGS-IO.cpp:1384-1446); in -F mode hits that span a sequence boundary are un-aligned in place
     void single(const Rec &r, uint32_t len, std::vector<Side> &hits)
     {
-        if (r.ignore()) { h1_.clear(); record(r, 0, h1_, std::vector<HdrMap>()); return; }
+        if (r.ignore()) { h1_.clear(); v1_.clear(); record(r, 0, h1_, v1_); return; }
         int best = 0;
         h1_.clear();
         if (p.mode != 2)
@@ -956,12 +993,12 @@ struct Writer {
                 best = std::max(best, hs.score);
             }
         std::sort(h1_.begin(), h1_.end());
-        std::vector<HdrMap> v;
-        int prev = mapping_from_header(r, v, p.top, best * p.top);
+        int prev = mapping_from_header(r, v1_, p.top, best * p.top);
         best = std::max(best, prev);
-        record(r, best, h1_, v);
+        record(r, best, h1_, v1_);
     }
     std::vector<ChrHit> h1_, h2_;
+    std::vector<HdrMap> v1_, v2_;
 };
 
 void die(int rc, const char *what) { if (rc) fatal("[soap4-mi355x] %s failed: %s (%d)\n", what, mp_strerror(rc), rc); }

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <memory>
 #include "../../include/megapath_hip.h"
 
 // ------------------------------------------------------------------------------------------------ HBM index layout
@@ -52,6 +54,7 @@ struct mp_index {
     mp_dev_index d{};
     void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr, *d_kmer = nullptr, *d_sa_dense = nullptr, *d_lkt16 = nullptr, *d_kmer15 = nullptr, *d_lkt16u = nullptr;
     uint64_t device_bytes = 0;
+    size_t bytes_occ = 0, bytes_lkt = 0, bytes_sa = 0, bytes_text = 0, bytes_kmer = 0, bytes_sa_dense = 0, bytes_lkt16 = 0, bytes_kmer15 = 0, bytes_lkt16u = 0;   // per array (mp_index_clone)
     uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};
     uint32_t sa_interval = 0;
     std::vector<std::string> seq_names;
@@ -60,6 +63,10 @@ struct mp_index {
     uint64_t n_removed = 0;                 // .tra header: numOfRemovedSegment
     std::vector<uint32_t> grid;
     std::vector<mp_translate_row> translate;
+    // host mirror of the 2-bit text, copied back from the device once, the first time somebody asks for reference bases
+    // (mp_index_fetch_text: MD / NM tags of -b -p); shared_ptr so that the struct stays copyable (mp_index_clone)
+    struct HostText { std::mutex mu; std::vector<uint32_t> words; bool ready = false; };
+    std::shared_ptr<HostText> host_text = std::make_shared<HostText>();
 };
 
 // host-side staging of an index before upload

@@ -101,8 +101,8 @@ class IndexInfo(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
-EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
-           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy", "mp_ctx_set_index",
+EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_clone", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
+           "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_target_chr", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy", "mp_ctx_set_index",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
            "mp_test_sort_longer_seed", "mp_coverage_create", "mp_coverage_destroy", "mp_coverage_add", "mp_coverage_finish", "mp_coverage_seq_stats",
@@ -153,6 +153,7 @@ def load_library():
     lib.mp_index_from_arrays.argtypes = [C.c_int, C.c_uint64, C.c_uint64, u64p, vp, vp, C.c_uint32, vp, vp, C.c_uint32,
                                          C.POINTER(C.c_char_p), vp, vp, C.POINTER(vp)]
     lib.mp_index_close.argtypes = [vp]
+    lib.mp_index_clone.argtypes = [vp, C.POINTER(vp)]
     lib.mp_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     lib.mp_index_seq_name.restype = C.c_char_p
     lib.mp_index_seq_name.argtypes = [vp, C.c_uint32]
@@ -164,6 +165,7 @@ def load_library():
     lib.mp_index_prefilter.argtypes = [vp, vp, C.c_uint64, vp]
     lib.mp_index_copy_lkt.argtypes = [vp, vp]
     lib.mp_index_chr_pos_segment.argtypes = [vp, C.c_uint64, u64p, u32p, u64p]
+    lib.mp_index_target_chr.argtypes = [vp, C.c_uint64, C.c_uint32, u32p]
     lib.mp_index_seq_info.argtypes = [vp, C.c_uint32, u64p, u64p, u64p]
     lib.mp_index_fetch_text.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.mp_index_check_lkt16.argtypes = [vp, C.c_uint64, u64p, u64p]
@@ -271,6 +273,16 @@ class Index:
         self.info = IndexInfo()
         _chk(lib.mp_index_get_info(self._h, C.byref(self.info)), "mp_index_get_info")
         return self
+
+    def clone(self):
+        """A second copy of this index in the same GPU's HBM (mp_index_clone: device-to-device copies)."""
+        lib = load_library()
+        other = type(self).__new__(type(self))
+        other._h = C.c_void_p()
+        _chk(lib.mp_index_clone(self._h, C.byref(other._h)), "mp_index_clone")
+        other.info = IndexInfo()
+        _chk(lib.mp_index_get_info(other._h, C.byref(other.info)), "mp_index_get_info")
+        return other
 
     def close(self):
         if self._h:

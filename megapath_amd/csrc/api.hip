@@ -872,10 +872,12 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
     const size_t seed_lds = (size_t)256 * (mp_scan_stride(W) | 1u) * sizeof(uint32_t);
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, seed_kernel, 256, seed_lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    static const int seed_occ = getenv("MP_SEED_OCC") ? atoi(getenv("MP_SEED_OCC")) : 0;      // experiment switch: 6 = the 80-register build
+    auto kern = seed_occ == 6 ? seed_kernel<6> : seed_kernel<1>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, seed_lds) != hipSuccess || per_cu < 1) per_cu = 4;
     const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * (unsigned)per_cu);
     HIPCHK(hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(seed_kernel, dim3(blocks), dim3(256), seed_lds, s, dix, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), seed_lds, s, dix, c->scan.p, c->d_lens, n_items, W, P, c->slabs.p, c->seeds_per_rs.p,
                        c->hits_per_rs.p, c->overflow_rs.p, c->over_slot.p, overflow_cap, c->queue.p, c->ctr.p, slab_limit);
     MP_TRACE(s, "seed_kernel");
     HIPCHK(hipEventRecord(c->ev[1], s));

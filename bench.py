@@ -637,6 +637,35 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
             nm, _, kv = spec.partition(":")
             res["plain_" + nm] = run(f1, f2, n_batches * P, dict(x.split("=", 1) for x in kv.split(",") if "=" in x))
         res["plain"]["input"] = "%d pairs, 2 x %.2f GB of FASTQ in %s (generated in %.0f s)" % (n_batches * P, os.path.getsize(f1) / 1e9, shm, t_gen)
+        # the NT loop in one process (review item 7: is the per-chunk merge of the header comments on the host in the way?): the same index
+        # given eight times in the lean layout, NT read mix; the printer merges every batch's comments chunk after chunk
+        try:
+            n1, n2 = os.path.join(d, "nt_1.fq"), os.path.join(d, "nt_2.fq")
+            ntp = min(P, 1 << 19)
+            codes, _ = simulate.paired_reads(text, ntp, args.read_len, seed=7100, sub_max=0.08, random_frac=0.4)
+            write_fastq_fast(codes, n1, n2)
+            del codes
+            nt_ini = os.path.join(d, "soap4-nt2.ini")
+            with open(nt_ini, "w") as f:
+                f.write(NT2_INI)
+            env = dict(os.environ, MP_TIMING="1", MP_DEVICE=str(device), MP_KMER_FILTER="0", MP_KMER15="0", MP_LKT16="0", MP_SA_DENSE="0")
+            env.pop("LOCAL_RANK", None)
+            rc8 = {}
+            for k in (2, 8):
+                for label, extra in (("device_reduce", {}), ("host_merge", {"MP_HOST_MERGE": "1"})):
+                    cmd = [exe, "pair", ",".join([prefix] * k), n1, n2, "-o", os.path.join(d, "o"), "-C", nt_ini, "-L", str(args.read_len + 1), "-T", str(threads), "-u", "750", "-F", "-nc", "-top", "95"]
+                    with open(os.devnull, "wb") as fo:
+                        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(env, **extra))
+                    err = r.stderr.decode(errors="replace")
+                    loop_s = next((float(l.split("alignment loop")[1].split()[0]) for l in err.splitlines() if "alignment loop" in l), None)
+                    rc8["%d_chunks_%s" % (k, label)] = {"rc": r.returncode, "alignment_loop_s": loop_s, "pairs_per_s": ntp / loop_s if loop_s else None,
+                                                        "stage_seconds": next((l.split("seconds:")[1].strip() for l in err.splitlines() if "seconds:" in l), None)}
+            rc8["input"] = ("%d pairs of the NT read mix (60 %% at 0-8 %% divergence, 40 %% random) against the same lean index given 2 and 8 times; device_reduce = the "
+                            "per-reference scores reduced on the device over all chunks, ONE printer pass per batch (mp_reduce_*); host_merge = hit lists to the host, header "
+                            "comments merged chunk after chunk (MP_HOST_MERGE=1, the path -b takes).  'output of ...' in stage_seconds is the printer's time" % ntp)
+            res["resident_chunks"] = rc8
+        except Exception as e:  # noqa: BLE001
+            res["resident_chunks"] = {"error": repr(e)}
         # gzip'ed input (what runMegaPath.sh:136 feeds): one zlib stream per file inflates at a few hundred MB/s
         g1, g2 = os.path.join(d, "g_1.fq"), os.path.join(d, "g_2.fq")
         rec_bytes = os.path.getsize(f1) // (n_batches * P)

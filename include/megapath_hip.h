@@ -299,6 +299,28 @@ int mp_bench_gather64(const mp_index *ix, uint32_t lanes, uint32_t per_lane, uin
  * samtools merge/sort | bedtools genomecov -bga | cc/genomeCovFilter (mean + k * stdev of the depth per sequence,
  * cc/genomeCovFilter.cpp:58-92) | bedtools bamtobed + annotate (fraction of each alignment on spike bases).  Intervals are
  * what the BAM side files hold: 1-based sequence id, 0-based start in the sequence's own coordinates, reference span. */
+/* ---------------------------------------------------------------------------------------------------------------
+ * Per-reference best scores of a batch, reduced on the device over every index chunk the batch is aligned against
+ * (SURVEY 8f-2).  What the annotated-FASTQ writers keep of the hit lists is one score per mate and reference sequence
+ * (pairDeepDPOutputFastqAPI BGS-IO.cpp:1966-2091, unproperlypairDPOutputFastqAPI :1384-1446, decideTargetChr :1312-1341,
+ * normalizeScore :1943-1961), and the chained runs of the NT loop merge those per chunk through the header comments
+ * (getMappingFromHeader :1348-1371, runMegaPath.sh:191-227).  Instead of three hit lists per chunk, the host gets ONE sorted
+ * list per batch: a 64-bit key per (read, chunk, sequence),
+ *     read id << 42 | (n_chunks - 1 - chunk) << 32 | 1-based sequence id << 10 | (1023 - score)
+ * so that a read's entries come in the order the final comment lists them (last chunk first, sequences ascending).
+ *   mp_reduce_begin(ctx, n_chunks)     after mp_set_reads
+ *   per chunk: mp_ctx_set_index, mp_deep_dp_round, mp_rescue_round (when pairs are left), mp_reduce_chunk(ctx, mode, chunk)
+ *   mp_reduce_finish(ctx, &keys, &n)   keys in a pinned buffer of the context, valid until the next mp_reduce_begin
+ * megapath_mode: 1 = -F, 2 = -P (IniParam.cpp:879-884).  Limits: 2^22 reads per batch, 1024 chunks, 2^22 - 1 sequences per chunk,
+ * scores < 1024 (MP_ERANGE otherwise: use the hit lists). */
+typedef struct { uint64_t n_deep_pairs, n_rescued_pairs, n_unpaired_pairs, n_entries; } mp_reduce_stats;
+int mp_ctx_set_hit_copies(mp_ctx *ctx, int on);     /* 0: the rounds leave their hit lists on the device (only the reduced list is wanted) */
+int mp_reduce_begin(mp_ctx *ctx, uint32_t n_chunks);
+/* out_pair_class (may be NULL): per pair of the batch how THIS chunk aligned it -- 0 deep-DP round, 1 mate rescue, 2 neither: the order
+ * the reference writes a batch in (alignment.cpp:105-330); the caller's array of n_reads / 2 bytes is filled when the call returns. */
+int mp_reduce_chunk(mp_ctx *ctx, int megapath_mode, uint32_t chunk_index, mp_reduce_stats *out_stats, uint8_t *out_pair_class);
+int mp_reduce_finish(mp_ctx *ctx, const uint64_t **out_keys, uint64_t *out_n);
+
 typedef struct mp_coverage mp_coverage;
 int mp_coverage_create(const mp_index *ix, mp_coverage **out);
 int mp_coverage_destroy(mp_coverage *cov);

@@ -14,6 +14,7 @@
 #include "kernels_dp_band.hip"
 #include "kernels_rescue.hip"
 #include "kernels_cov.hip"
+#include "kernels_reduce.hip"
 #include "kernels_build.hip"
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -123,6 +124,16 @@ struct mp_ctx {
     uint64_t n_single_hits_host = 0, n_rescue_hits_host = 0;
     hipEvent_t ev_rescue_ready = nullptr, ev_rescue_copied = nullptr;
     bool rescue_copy_started = false;
+    // per-reference best scores of the batch, accumulated over the chunks it is aligned against (mp_reduce_*)
+    unsigned long long *red_keys = nullptr, *red_sorted = nullptr, *red_out = nullptr;
+    size_t red_cap = 0, red_sorted_cap = 0, red_out_cap = 0, red_n = 0;
+    DevBuf<uint32_t> resc_done, red_flag, red_slot;
+    DevBuf<uint8_t> red_cls;
+    DevBuf<unsigned long long> red_counts;
+    unsigned long long *h_red = nullptr;       // pinned
+    size_t h_red_cap = 0;
+    uint32_t red_chunks = 0;
+    bool copy_hits = true;                     // mp_ctx_set_hit_copies: the rounds send their hit lists to pinned host memory
 };
 
 // ------------------------------------------------------------------------------------------------ misc
@@ -457,6 +468,7 @@ extern "C" int mp_index_clone(const mp_index *src, mp_index **out)
     if (!ix) return MP_ENOMEM;
     ix->d_occ = ix->d_lkt = ix->d_sa = ix->d_text = ix->d_kmer = ix->d_sa_dense = ix->d_lkt16 = ix->d_kmer15 = ix->d_lkt16u = nullptr;
     ix->host_text = std::make_shared<mp_index::HostText>();
+    ix->d_tr_grid = ix->d_tr_start = ix->d_tr_chr = nullptr;          // uploaded again on first use
     struct Arr { void *const *from; void **to; size_t bytes; };
     const Arr arrs[] = {{&src->d_occ, &ix->d_occ, src->bytes_occ}, {&src->d_lkt, &ix->d_lkt, src->bytes_lkt}, {&src->d_sa, &ix->d_sa, src->bytes_sa},
                         {&src->d_text, &ix->d_text, src->bytes_text}, {&src->d_kmer, &ix->d_kmer, src->bytes_kmer}, {&src->d_sa_dense, &ix->d_sa_dense, src->bytes_sa_dense},
@@ -487,6 +499,9 @@ extern "C" int mp_index_close(mp_index *ix)
     if (ix->d_kmer15) (void)hipFree(ix->d_kmer15);
     if (ix->d_sa_dense) (void)hipFree(ix->d_sa_dense);
     if (ix->d_lkt16u) (void)hipFree(ix->d_lkt16u);
+    if (ix->d_tr_grid) (void)hipFree(ix->d_tr_grid);
+    if (ix->d_tr_start) (void)hipFree(ix->d_tr_start);
+    if (ix->d_tr_chr) (void)hipFree(ix->d_tr_chr);
     delete ix;
     return MP_OK;
 }
@@ -781,6 +796,11 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
     c->ops.release(); c->pair_hits.release(); c->pair_cnt.release(); c->pair_off.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
     if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
+    if (c->red_keys) (void)hipFree(c->red_keys);
+    if (c->red_sorted) (void)hipFree(c->red_sorted);
+    if (c->red_out) (void)hipFree(c->red_out);
+    if (c->h_red) (void)hipHostFree(c->h_red);
+    c->resc_done.release(); c->red_flag.release(); c->red_slot.release(); c->red_counts.release(); c->red_cls.release();
     c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
     c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release(); c->rtasks_c.release(); c->rres_c.release(); c->rlist.release();
     delete c;
@@ -1709,7 +1729,7 @@ static int start_hits_copy(mp_ctx *c)
 {
     c->hits_copy_started = false;
     const size_t n = c->n_pair_hits_host;
-    if (n == 0) return MP_OK;
+    if (n == 0 || !c->copy_hits) return MP_OK;
     int rc = reserve_pinned_hits(c, n);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_hits_ready, c->stream));
@@ -1863,14 +1883,14 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
             HIPCHK(hipMemcpyAsync(&n_rh, c->rh_slot.p + n_rt, 4, hipMemcpyDeviceToHost, s));
         }
         HIPCHK(hipStreamSynchronize(s));
-        if (c->d_single_hits.reserve(n_sh + 1) || c->d_rescue_hits.reserve(n_rh + 1) || reserve_pinned(c->h_single_hits, c->h_single_cap, n_sh) ||
-            reserve_pinned(c->h_rescue_hits, c->h_rescue_cap, n_rh)) return MP_ENOMEM;
+        if (c->d_single_hits.reserve(n_sh + 1) || c->d_rescue_hits.reserve(n_rh + 1)) return MP_ENOMEM;
+        if (c->copy_hits && (reserve_pinned(c->h_single_hits, c->h_single_cap, n_sh) || reserve_pinned(c->h_rescue_hits, c->h_rescue_cap, n_rh))) return MP_ENOMEM;
         if (n_sh) hipLaunchKernelGGL(single_hit_emit_kernel, dim3(grid_for(nst, 256)), dim3(256), 0, s, c->stasks.p, c->sres.p, c->sh_flag.p, c->sh_slot.p, nst, c->d_single_hits.p);
         if (n_rh) hipLaunchKernelGGL(rescue_hit_emit_kernel, dim3(grid_for(n_rt, 256)), dim3(256), 0, s, c->stasks.p, c->sres.p, c->rtasks.p, c->rres.p, c->rsrc.p,
                                      c->rh_flag.p, c->rh_slot.p, n_rt, c->d_rescue_hits.p);
         c->n_single_hits_host = n_sh; c->n_rescue_hits_host = n_rh;
         st.n_single_hits = n_sh; st.n_rescue_hits = n_rh;
-        if (n_sh || n_rh) {
+        if ((n_sh || n_rh) && c->copy_hits) {
             HIPCHK(hipEventRecord(c->ev_rescue_ready, s));
             HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_rescue_ready, 0));
             if (n_sh) HIPCHK(hipMemcpyAsync(c->h_single_hits, c->d_single_hits.p, (size_t)n_sh * sizeof(mp_single_hit), hipMemcpyDeviceToHost, c->copy_stream));
@@ -1895,7 +1915,7 @@ static int wait_rescue_copy(mp_ctx *c)
 
 extern "C" int mp_get_single_hits_view(mp_ctx *c, const mp_single_hit **out_hits, uint64_t *out_n)
 {
-    if (!c || !c->rescued || !out_hits || !out_n) return MP_EINVAL;
+    if (!c || !c->rescued || !out_hits || !out_n || !c->copy_hits) return MP_EINVAL;
     HIPCHK(hipSetDevice(c->ix->device));
     int rc = wait_rescue_copy(c);
     if (rc) return rc;
@@ -1905,7 +1925,7 @@ extern "C" int mp_get_single_hits_view(mp_ctx *c, const mp_single_hit **out_hits
 
 extern "C" int mp_get_rescue_hits_view(mp_ctx *c, const mp_rescue_hit **out_hits, uint64_t *out_n)
 {
-    if (!c || !c->rescued || !out_hits || !out_n) return MP_EINVAL;
+    if (!c || !c->rescued || !out_hits || !out_n || !c->copy_hits) return MP_EINVAL;
     HIPCHK(hipSetDevice(c->ix->device));
     int rc = wait_rescue_copy(c);
     if (rc) return rc;
@@ -1974,6 +1994,135 @@ extern "C" int mp_test_sort_longer_seed(int device, const uint32_t *seed_len, co
     return MP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ per-reference reduction over chunks
+static std::mutex g_tr_mu;
+static int ensure_translate(mp_index *ix)
+{
+    std::lock_guard<std::mutex> lk(g_tr_mu);
+    if (ix->d_tr_grid) return MP_OK;
+    if (ix->grid.empty() || ix->translate.empty()) return MP_EINVAL;
+    const size_t ng = ix->grid.size(), nr = ix->translate.size();
+    std::vector<uint64_t> st(nr);
+    std::vector<uint32_t> ch(nr);
+    for (size_t i = 0; i < nr; i++) { st[i] = ix->translate[i].start; ch[i] = ix->translate[i].chr; }
+    void *g = nullptr, *a = nullptr, *b = nullptr;
+    if (hipMalloc(&g, ng * 4) != hipSuccess || hipMalloc(&a, nr * 8) != hipSuccess || hipMalloc(&b, nr * 4) != hipSuccess ||
+        hipMemcpy(g, ix->grid.data(), ng * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(a, st.data(), nr * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b, ch.data(), nr * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g); (void)hipFree(a); (void)hipFree(b); return MP_ENOMEM; }
+    ix->d_tr_start = a; ix->d_tr_chr = b; ix->d_tr_grid = g;
+    return MP_OK;
+}
+
+// grows a raw device array, keeping its first `keep` elements
+static int grow_keys(unsigned long long *&p, size_t &cap, size_t need, size_t keep, hipStream_t s)
+{
+    if (need <= cap) return MP_OK;
+    const size_t want = need + need / 2 + 4096;
+    unsigned long long *q = nullptr;
+    if (hipMalloc((void **)&q, want * 8) != hipSuccess) return MP_ENOMEM;
+    if (p && keep) { if (hipMemcpyAsync(q, p, keep * 8, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(q); return MP_ENODEV; } }
+    if (p) (void)hipFree(p);
+    p = q; cap = want;
+    return MP_OK;
+}
+
+// 0: the rounds keep their hit lists on the device (a caller that only wants the reduced list saves the transfers and the pinned
+// buffers; the *_view calls then fail); 1 (default): they travel to the host as soon as a round is done.
+extern "C" int mp_ctx_set_hit_copies(mp_ctx *c, int on)
+{
+    if (!c) return MP_EINVAL;
+    c->copy_hits = on != 0;
+    return MP_OK;
+}
+
+extern "C" int mp_reduce_begin(mp_ctx *c, uint32_t n_chunks)
+{
+    if (!c || n_chunks == 0 || n_chunks > MP_RED_MAX_CHUNKS) return MP_EINVAL;
+    if (c->n_reads > (1u << 22)) return MP_ERANGE;                      // 22 bits of read id in a key
+    c->red_n = 0; c->red_chunks = n_chunks;
+    return MP_OK;
+}
+
+// After mp_deep_dp_round and mp_rescue_round of the batch against the bound index chunk: adds the chunk's per-mate (sequence, score)
+// entries to the batch's accumulator.  chunk_index counts from 0 in database order.
+extern "C" int mp_reduce_chunk(mp_ctx *c, int megapath_mode, uint32_t chunk_index, mp_reduce_stats *out_stats, uint8_t *out_pair_class)
+{
+    if (!c || !c->deep_done || c->red_chunks == 0 || chunk_index >= c->red_chunks) return MP_EINVAL;
+    mp_index *ix = c->ix;
+    if (ix->seq_names.size() > MP_RED_MAX_SEQ) return MP_ERANGE;        // 22 bits of sequence id in a key
+    HIPCHK(hipSetDevice(ix->device));
+    int rc = ensure_translate(ix);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    // the hit lists of the round are on their way to the host on the copy stream: they stay valid on the device meanwhile
+    const uint32_t n_pairs = c->n_reads / 2;
+    const size_t n_ph = c->n_pair_hits_host, n_rh = c->rescued ? c->n_rescue_hits_host : 0, n_sh = c->rescued ? c->n_single_hits_host : 0;
+    const size_t add = 2 * n_ph + 2 * n_rh + n_sh;
+    rc = grow_keys(c->red_keys, c->red_cap, c->red_n + add, c->red_n, s);
+    if (rc) return rc;
+    if (c->resc_done.reserve(n_pairs + 1) || c->red_counts.reserve(2)) return MP_ENOMEM;
+    HIPCHK(hipMemsetAsync(c->resc_done.p, 0, ((size_t)n_pairs + 1) * 4, s));
+    HIPCHK(hipMemsetAsync(c->red_counts.p, 0, 2 * sizeof(unsigned long long), s));
+    const mp_dev_translate tr{(const uint32_t *)ix->d_tr_grid, (const uint64_t *)ix->d_tr_start, (const uint32_t *)ix->d_tr_chr, (uint32_t)ix->grid.size(), (uint32_t)ix->translate.size()};
+    const uint32_t inv = c->red_chunks - 1 - chunk_index;
+    unsigned long long *k = c->red_keys + c->red_n;
+    if (n_ph) hipLaunchKernelGGL(reduce_pairs_kernel<false>, dim3(grid_for(n_ph, 256)), dim3(256), 0, s, (const void *)c->pair_hits.p, (uint32_t)n_ph, c->d_lens, tr, megapath_mode, inv, k, c->resc_done.p);
+    if (n_rh) hipLaunchKernelGGL(reduce_pairs_kernel<true>, dim3(grid_for(n_rh, 256)), dim3(256), 0, s, (const void *)c->d_rescue_hits.p, (uint32_t)n_rh, c->d_lens, tr, megapath_mode, inv, k + 2 * n_ph, c->resc_done.p);
+    if (n_sh) hipLaunchKernelGGL(reduce_singles_kernel, dim3(grid_for(n_sh, 256)), dim3(256), 0, s, (const mp_single_hit *)c->d_single_hits.p, (uint32_t)n_sh, c->d_lens, tr, megapath_mode, inv,
+                                 (const uint32_t *)c->pair_done.p, (const uint32_t *)c->resc_done.p, k + 2 * n_ph + 2 * n_rh);
+    if (out_pair_class && c->red_cls.reserve(n_pairs + 4)) return MP_ENOMEM;
+    hipLaunchKernelGGL(reduce_count_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, s, (const uint32_t *)c->pair_done.p, (const uint32_t *)c->resc_done.p, n_pairs, c->red_counts.p,
+                       out_pair_class ? c->red_cls.p : (uint8_t *)nullptr);
+    if (out_pair_class && n_pairs) HIPCHK(hipMemcpyAsync(out_pair_class, c->red_cls.p, n_pairs, hipMemcpyDeviceToHost, s));
+    MP_TRACE(s, "reduce kernels");
+    HIPCHK(hipGetLastError());
+    c->red_n += add;
+    unsigned long long cnt[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(cnt, c->red_counts.p, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (out_stats) { out_stats->n_deep_pairs = cnt[0]; out_stats->n_rescued_pairs = cnt[1]; out_stats->n_unpaired_pairs = n_pairs - cnt[0] - cnt[1]; out_stats->n_entries = add; }
+    return MP_OK;
+}
+
+// After the last chunk: the batch's entries, one 64-bit key each (read << 42 | chunks after the entry's << 32 | sequence id << 10 | 1023 - score),
+// sorted, one per (read, chunk, sequence) -- the best score --, in a pinned buffer owned by the context (valid until the next mp_reduce_begin).
+extern "C" int mp_reduce_finish(mp_ctx *c, const uint64_t **out_keys, uint64_t *out_n)
+{
+    if (!c || !out_keys || !out_n || c->red_chunks == 0) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    hipStream_t s = c->stream;
+    *out_keys = nullptr; *out_n = 0;
+    const size_t n = c->red_n;
+    if (n == 0) return MP_OK;
+    if (n >= (1ull << 31)) return MP_ERANGE;
+    int rc = grow_keys(c->red_sorted, c->red_sorted_cap, n, 0, s);
+    if (rc) return rc;
+    size_t tb = 0;
+    if (hipcub::DeviceRadixSort::SortKeys(nullptr, tb, c->red_keys, c->red_sorted, (int)n, 0, 64, s) != hipSuccess) return MP_ENODEV;
+    if (c->cub_tmp.reserve(tb + 256)) return MP_ENOMEM;
+    if (hipcub::DeviceRadixSort::SortKeys(c->cub_tmp.p, tb, c->red_keys, c->red_sorted, (int)n, 0, 64, s) != hipSuccess) return MP_ENODEV;
+    if (c->red_flag.reserve(n + 2) || c->red_slot.reserve(n + 2)) return MP_ENOMEM;
+    hipLaunchKernelGGL(reduce_first_flag_kernel, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, (const unsigned long long *)c->red_sorted, (uint64_t)n, c->red_flag.p);
+    rc = exclusive_scan_u32(c, c->red_flag.p, c->red_slot.p, (uint32_t)n + 1);
+    if (rc) return rc;
+    uint32_t n_out = 0;
+    HIPCHK(hipMemcpyAsync(&n_out, c->red_slot.p + n, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (n_out) {
+        rc = grow_keys(c->red_out, c->red_out_cap, n_out, 0, s);
+        if (rc) return rc;
+        rc = reserve_pinned(c->h_red, c->h_red_cap, n_out);
+        if (rc) return rc;
+        hipLaunchKernelGGL(reduce_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const unsigned long long *)c->red_sorted, (const uint32_t *)c->red_flag.p,
+                           (const uint32_t *)c->red_slot.p, (uint64_t)n, c->red_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->h_red, c->red_out, (size_t)n_out * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    *out_keys = (const uint64_t *)c->h_red; *out_n = n_out;
+    return MP_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ coverage / spike filter
 struct mp_coverage {

@@ -114,6 +114,14 @@ struct Batch {
         void clear() { hits.clear(); singles.clear(); resc.clear(); rows.clear(); cig.clear(); rcig.clear(); scig.clear(); lists_ready = false; dp_instances = 0; }
     };
     std::vector<ChunkHits> ch;
+    // ---- stage 2, reduced on the device (no -b): one sorted list of (read, chunk, sequence, best score) keys for the whole batch and all
+    // chunks (mp_reduce_finish), and where each read's keys start
+    bool reduced = false;
+    std::vector<uint64_t> red;
+    std::vector<uint32_t> red_off;
+    std::vector<uint8_t> red_class;         // per pair: how the LAST chunk aligned it (0 deep-DP round, 1 mate rescue, 2 neither): the sections of the output
+    mp_reduce_stats red_last{};             // how the last chunk's pairs were aligned (the closing line counts that chunk, as the last run of a chain would)
+    uint64_t red_dp_instances = 0;
     uint64_t seq = 0;                       // position of the batch in the input: the printer writes batches in this order
 };
 
@@ -947,6 +955,36 @@ struct Writer {
         if (p.lsam) { lsam_record(r, comm_); return; }
         out += '\n'; out.append(r.seq, r.seq_len); out += "\n+\n"; out.append(r.qual, r.qual_len); out += '\n';
     }
+    // One output record from the device's reduced list (mp_reduce_finish): k[0..n) are the read's keys -- last chunk first, sequences
+    // ascending, one per (chunk, sequence) with its best score.  What the chain of per-chunk merges leaves in the header
+    // (pairDeepDPOutputFastqAPI / unproperlypairDPOutputFastqAPI + getMappingFromHeader, chunk after chunk): the best score over all
+    // chunks and the record's own comment, then every entry that reaches top% of it.
+    void reduced(const Rec &r, const uint64_t *k, size_t n, mp_index *const *chunks, uint32_t n_chunks)
+    {
+        int best = 0;
+        for (size_t i = 0; i < n; i++) best = std::max(best, 1023 - (int)(k[i] & 1023u));
+        const int prev = mapping_from_header(r, v1_, p.top, best * p.top);
+        best = std::max(best, prev);
+        const bool to_comment = p.lsam != 0;
+        std::string &o = to_comment ? comm_ : out;
+        if (to_comment) comm_.clear(); else { out += '@'; out.append(r.name, r.name_len); out += '\t'; }
+        if (r.ignore()) o += "IGNORE";
+        else {
+            o += "SCORE:"; append_int(o, best); o += ';';
+            if (best > 0)
+                for (size_t i = 0; i < n; i++) {
+                    const int sc = 1023 - (int)(k[i] & 1023u);
+                    if (sc > 0 && sc >= best * p.top) {
+                        const uint32_t chunk = n_chunks - 1 - (uint32_t)((k[i] >> 32) & 1023u), sq = (uint32_t)((k[i] >> 10) & 0x3FFFFFu);
+                        append_int(o, sc); o += ',';
+                        o += mp_index_seq_name(chunks[chunk], sq); o += ';';
+                    }
+                }
+            for (const HdrMap &m : v1_) if (m.score >= best * p.top) { o += m.text; o += ';'; }
+        }
+        if (p.lsam) { lsam_record(r, comm_); return; }
+        out += '\n'; out.append(r.seq, r.seq_len); out += "\n+\n"; out.append(r.qual, r.qual_len); out += '\n';
+    }
     const Rec *held_ = nullptr;
     std::string held_comm_, comm_;
     Pass1 pass1;                  // counters of the lines this writer printed (-lsamid)
@@ -1437,6 +1475,80 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
     st.t_emit_rest += now_s() - t0;
 }
 
+// ---- the same two stages when nothing but the annotated FASTQ (or LSAM) is wanted: the device reduces the hit lists of every chunk to
+// one (sequence, best score) entry per mate, chunk and reference, and the printer makes one pass over the batch whatever the number of
+// chunks.  (-b needs the alignments themselves: it keeps the hit-list path above.)
+mp_align_params align_params_of(const Params &p, bool bam)
+{
+    mp_align_params ap;
+    ap.insert_low = p.insert_low; ap.insert_high = p.insert_high; ap.clip_left = p.clip_left; ap.clip_right = p.clip_right; ap.mmp = p.mmp;
+    ap.want_tie_counts = bam ? 1 : 0; ap.reserved = 0;          // num_sameScore only feeds the BAM MAPQ / X0 / X1
+    return ap;
+}
+
+void gpu_stage_reduced(mp_ctx *ctx, const Params &p, Batch &bt, uint32_t chunk, bool last, Stats &st)
+{
+    double t0 = now_s();
+    const mp_align_params ap = align_params_of(p, false);
+    uint64_t nh = 0;
+    mp_round_stats rs;
+    die(mp_deep_dp_round(ctx, &ap, &nh, &rs), "mp_deep_dp_round");
+    st.t_deep += now_s() - t0; t0 = now_s();
+    mp_rescue_stats rst{};
+    die(mp_rescue_round(ctx, &ap, p.skip_default_dp ? 1 : 0, &rst), "mp_rescue_round");
+    st.t_rescue += now_s() - t0; t0 = now_s();
+    mp_reduce_stats red{};
+    if (last) bt.red_class.resize(bt.n_reads / 2 + 1);
+    die(mp_reduce_chunk(ctx, p.mode, chunk, &red, last ? bt.red_class.data() : nullptr), "mp_reduce_chunk");
+    bt.red_dp_instances += 2 * rs.n_candidates + rst.n_single_tasks + rst.n_rescue_tasks;
+    if (last) bt.red_last = red;
+    if (getenv("MP_TIMING"))
+        fprintf(stderr, "[Main] batch %llu chunk %u: %llu seed positions, %llu candidates, %llu pair hits, %llu + %llu + %llu pairs deep / rescued / left, %llu entries (insert %d..%d)\n",
+                (unsigned long long)bt.seq, chunk, (unsigned long long)rs.seed.n_seedpos, (unsigned long long)rs.n_candidates, (unsigned long long)nh,
+                (unsigned long long)red.n_deep_pairs, (unsigned long long)red.n_rescued_pairs, (unsigned long long)red.n_unpaired_pairs, (unsigned long long)red.n_entries, ap.insert_low, ap.insert_high);
+    st.t_sort += now_s() - t0;
+}
+
+void finish_reduced(mp_ctx *ctx, Batch &bt, Stats &st)
+{
+    const double t0 = now_s();
+    const uint64_t *keys = nullptr;
+    uint64_t n = 0;
+    die(mp_reduce_finish(ctx, &keys, &n), "mp_reduce_finish");
+    bt.red.assign(keys, keys + n);
+    // where each read's keys start (the keys are sorted by read)
+    bt.red_off.assign((size_t)bt.n_reads + 1, 0u);
+    for (uint64_t i = 0; i < n; i++) bt.red_off[(size_t)(keys[i] >> 42) + 1]++;
+    for (size_t r = 0; r < bt.n_reads; r++) bt.red_off[r + 1] += bt.red_off[r];
+    bt.reduced = true;
+    st.t_sort += now_s() - t0;
+}
+
+void output_reduced(mp_index *const *chunks, uint32_t n_chunks, const Params &p, Batch &bt, Formatters &fm, Stats &st, Pass1 *pass1)
+{
+    const double t0 = now_s();
+    const uint32_t n_pairs = bt.n_reads / 2;
+    st.pairs += n_pairs; st.dp += bt.red_dp_instances;
+    st.deep += bt.red_last.n_deep_pairs; st.rescued += bt.red_last.n_rescued_pairs; st.unpaired += bt.red_last.n_unpaired_pairs;
+    // the batch in the reference's order (alignment.cpp:105-330): the pairs of the deep-DP round, the rescued pairs, the rest -- as the last chunk saw them
+    std::vector<uint32_t> order[3];
+    for (uint32_t q = 0; q < n_pairs; q++) order[bt.red_class[q] < 3 ? bt.red_class[q] : 2].push_back(q);
+    for (int sec = 0; sec < 3; sec++) {
+        const std::vector<uint32_t> &ord = order[sec];
+        for_chunks(ord.size(), fm, nullptr, pass1, [&](size_t i0, size_t i1, Sink &sink) {
+            Writer w(chunks[n_chunks - 1], p, sink.text, false);
+            for (size_t i = i0; i < i1; i++)
+                for (uint32_t k = 0; k < 2; k++) {
+                    const uint32_t r = 2 * ord[i] + k;
+                    w.reduced(bt.rec(r), bt.red.data() + bt.red_off[r], bt.red_off[r + 1] - bt.red_off[r], chunks, n_chunks);
+                }
+            w.finish();
+            sink.pass1.add(w.pass1);
+        });
+    }
+    st.t_emit_deep += now_s() - t0;
+}
+
 // hand-over of batches between the stages
 struct BatchQueue {
     std::mutex mu; std::condition_variable cv;
@@ -1669,12 +1781,25 @@ int main(int argc, char **argv)
         }
         filled_q.close();
     });
-    const bool carry_rewrite = getenv("MP_CARRY_REWRITE") != nullptr;     // test switch: merge every comment again in every chunk, also where the chunk adds nothing
+    // Without -b only the per-reference best scores are needed: they are reduced on the device over all chunks (mp_reduce_*), the printer
+    // makes one pass per batch.  MP_HOST_MERGE=1 (and -b, and databases beyond the key's limits) keeps the hit lists and the per-chunk merge
+    // of the header comments on the host: the reference's chain, step by step.
+    bool reduce_on_device = !plumbing_only && bam == nullptr && p.mode != 0 && !getenv("MP_HOST_MERGE") && n_chunks <= 1024;
+    if (reduce_on_device)
+        for (mp_index *ix : devices[0].chunks) { mp_index_info info; mp_index_get_info(ix, &info); if (info.num_seq >= (1u << 22)) reduce_on_device = false; }
+    if (p.max_read_length > 512 || p.batch_pairs > (1u << 21)) reduce_on_device = false;       // scores must stay below 1024, read ids below 2^22
+    const bool carry_rewrite = getenv("MP_CARRY_REWRITE") != nullptr;     // test switch: merge every comment again in every chunk, also where the chunk adds nothing     // test switch: merge every comment again in every chunk, also where the chunk adds nothing
     std::thread printer([&]() {
         Formatters fm(getenv("MP_PRINTER_THREADS") ? std::max(1, atoi(getenv("MP_PRINTER_THREADS"))) : std::max(1, threads / 2));
         for (uint64_t seq = 0;; seq++) {
             Batch *b = aligned_q.pop_seq(seq);
             if (!b) break;
+            if (b->reduced) {
+                output_reduced(devices[0].chunks.data(), (uint32_t)n_chunks, p, *b, fm, st_printer, p.tax ? &pass1_total : nullptr);
+                b->reduced = false;
+                free_q.push(b);
+                continue;
+            }
             // the chunks in database order: each one's per-reference hits join the header comments the earlier ones left
             for (size_t c = 0; c < n_chunks; c++) {
                 const bool last = c + 1 == n_chunks;
@@ -1691,12 +1816,22 @@ int main(int argc, char **argv)
             Stats &st = st_worker[w];
             mp_ctx *ctx = nullptr;
             if (!plumbing_only) die(mp_ctx_create(dev.chunks[0], &ctx), "mp_ctx_create");
+            if (ctx && reduce_on_device) die(mp_ctx_set_hit_copies(ctx, 0), "mp_ctx_set_hit_copies");
             for (;;) {
                 Batch *b = filled_q.pop();
                 if (!b) break;
                 const double tb = now_s();
                 pairs_seen += b->n_reads / 2;
-                if (!plumbing_only) {
+                if (!plumbing_only && reduce_on_device) {
+                    upload_reads(ctx, *b, st);
+                    die(mp_reduce_begin(ctx, (uint32_t)n_chunks), "mp_reduce_begin");
+                    b->red_dp_instances = 0;
+                    for (size_t c = 0; c < n_chunks; c++) {
+                        if (n_chunks > 1 || c > 0) die(mp_ctx_set_index(ctx, dev.chunks[c]), "mp_ctx_set_index");
+                        gpu_stage_reduced(ctx, p, *b, (uint32_t)c, c + 1 == n_chunks, st);
+                    }
+                    finish_reduced(ctx, *b, st);
+                } else if (!plumbing_only) {
                     upload_reads(ctx, *b, st);
                     for (size_t c = 0; c < n_chunks; c++) {
                         if (n_chunks > 1 || c > 0) die(mp_ctx_set_index(ctx, dev.chunks[c]), "mp_ctx_set_index");
@@ -1761,8 +1896,8 @@ int main(int argc, char **argv)
     for (const Stats &w : st_worker) { st.t_upload += w.t_upload; st.t_deep += w.t_deep; st.t_rescue += w.t_rescue; st.t_sort += w.t_sort; st.t_cigar += w.t_cigar; }
     fprintf(stderr, "[Main] %llu pairs: %llu aligned by deep DP, %llu by mate rescue, %llu unpaired; %llu DP instances\n", (unsigned long long)st.pairs,
             (unsigned long long)st.deep, (unsigned long long)st.rescued, (unsigned long long)st.unpaired, (unsigned long long)st.dp);
-    fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped; %zu GPU(s) x %d worker(s), %zu index chunk(s))\n", t_loop,
-            st.pairs / std::max(t_loop, 1e-9), devices.size(), workers_per_gpu, n_chunks);
+    fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped; %zu GPU(s) x %d worker(s), %zu index chunk(s)%s)\n", t_loop,
+            st.pairs / std::max(t_loop, 1e-9), devices.size(), workers_per_gpu, n_chunks, reduce_on_device ? ", per-reference scores reduced on the device" : "");
     if (getenv("MP_TIMING"))
         fprintf(stderr, "[Main] seconds: reading and packing %.2f (own threads), upload %.2f, deep-DP round %.2f, sort %.2f, BAM CIGARs %.2f, output of deep pairs %.2f, rescue round %.2f, output of the rest %.2f\n",
                 st.t_read, st.t_upload, st.t_deep, st.t_sort, st.t_cigar, st.t_emit_deep, st.t_rescue, st.t_emit_rest);

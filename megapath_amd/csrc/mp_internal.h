@@ -53,6 +53,7 @@ struct mp_index {
     int device = 0;
     mp_dev_index d{};
     void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr, *d_kmer = nullptr, *d_sa_dense = nullptr, *d_lkt16 = nullptr, *d_kmer15 = nullptr, *d_lkt16u = nullptr;
+    void *d_tr_grid = nullptr, *d_tr_start = nullptr, *d_tr_chr = nullptr;      // the .tra table on the device (kernels_reduce.hip), uploaded on first use
     uint64_t device_bytes = 0;
     size_t bytes_occ = 0, bytes_lkt = 0, bytes_sa = 0, bytes_text = 0, bytes_kmer = 0, bytes_sa_dense = 0, bytes_lkt16 = 0, bytes_kmer15 = 0, bytes_lkt16u = 0;   // per array (mp_index_clone)
     uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};

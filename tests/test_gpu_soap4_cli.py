@@ -332,7 +332,31 @@ def test_cli_resident_chunks_equal_reference_chain(golden_dir, tmp_path, tag, L)
     assert b"3 index chunk(s)" in err
 
 
-@pytest.mark.parametrize("rewrite", [False, True])
+@pytest.mark.parametrize("tag,L", [("a", 151), ("c", 301)])
+def test_cli_host_merge_path_equals_reference(golden_dir, tmp_path, tag, L):
+    """MP_HOST_MERGE=1: the hit lists travel to the host and the header comments are merged there chunk after chunk (the path -b always takes);
+    the default without -b reduces the per-reference scores on the device (mp_reduce_*).  Both must print the real soap4's records: one chunk
+    (g1) and the three chained chunks of g3."""
+    g1, g3 = os.path.join(golden_dir, "g1"), os.path.join(golden_dir, "g3")
+    for prefixes, want, extra in ((os.path.join(g1, "ref.fa.index"), os.path.join(g1, "expected_%s.fq" % tag), []),
+                                  (",".join(os.path.join(g3, "c%d.fa.index" % k) for k in range(3)), os.path.join(g3, "expected_chain_%s.fq" % tag), ["-top", "95"])):
+        outs = []
+        for host in (True, False):
+            out = tmp_path / ("out_%d.fq" % host)
+            cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefixes, os.path.join(g1, "reads_%s_1.fq" % tag), os.path.join(g1, "reads_%s_2.fq" % tag), "-o", str(tmp_path / "o"),
+                   "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", str(L), "-T", "2", "-u", "750", "-F", "-nc"] + extra
+            env = dict(os.environ, MP_BATCH_PAIRS="50")
+            if host:
+                env["MP_HOST_MERGE"] = "1"
+            with open(out, "wb") as fo:
+                r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
+            assert r.returncode == 0, r.stderr.decode()
+            assert (b"reduced on the device" in r.stderr) == (not host)
+            outs.append(fastq_records(str(out)))
+        assert outs[0] == outs[1] == fastq_records(want)
+
+
+@pytest.mark.parametrize("rewrite", [False, True, "device"])
 def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, rewrite):
     """g6: nine index chunks resident in one process (homologous sequences at 0-7 % divergence in several of them) against the last
     stdout of NINE chained runs of the real soap4; with the untouched comments left alone from the second chunk on (the default) and
@@ -343,12 +367,16 @@ def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, re
     cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefixes, os.path.join(g6, "reads_1.fq"), os.path.join(g6, "reads_2.fq"), "-o", str(tmp_path / "o"),
            "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "3", "-u", "750", "-F", "-nc", "-top", "95"]
     env = dict(os.environ, MP_BATCH_PAIRS="64")
-    if rewrite:
-        env["MP_CARRY_REWRITE"] = "1"
+    if rewrite == "device":
+        pass                                             # the default: per-reference scores reduced on the device over the nine chunks
+    else:
+        env["MP_HOST_MERGE"] = "1"                       # hit lists to the host, comments merged chunk after chunk
+        if rewrite:
+            env["MP_CARRY_REWRITE"] = "1"
     with open(out, "wb") as fo:
         r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
     assert r.returncode == 0, r.stderr.decode()
-    assert b"9 index chunk(s)" in r.stderr
+    assert b"9 index chunk(s)" in r.stderr and (b"reduced on the device" in r.stderr) == (rewrite == "device")
     assert fastq_records(str(out)) == fastq_records(os.path.join(g6, "expected_chain.fq"))
 
 
@@ -365,7 +393,7 @@ def test_cli_many_resident_chunks_leave_untouched_comments_alone(golden_dir, tmp
         out = tmp_path / ("out_%d.fq" % rewrite)
         cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefixes, os.path.join(g1, "reads_a_1.fq"), os.path.join(g1, "reads_a_2.fq"), "-o", str(tmp_path / "o"),
                "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "3", "-u", "750", mode, "-nc", "-top", "95"]
-        env = dict(os.environ, MP_BATCH_PAIRS="60")
+        env = dict(os.environ, MP_BATCH_PAIRS="60", MP_HOST_MERGE="1")
         if rewrite:
             env["MP_CARRY_REWRITE"] = "1"
         with open(out, "wb") as fo:

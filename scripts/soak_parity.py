@@ -28,6 +28,9 @@ for rnd in range(args.rounds):
     cfg = dict(n_bases=int(rng.integers(100000, 800000)), n_seqs=int(rng.integers(1, 8)), rep=float(rng.choice([0.0, 0.05, 0.2, 0.5])),
                n_pairs=int(rng.integers(500, 4000)), read_len=read_len, gseed=int(rng.integers(1, 1 << 30)), rseed=int(rng.integers(1, 1 << 30)),
                mode=int(rng.choice([1, 1, 2])), threads=int(rng.integers(1, 6)), bam=bool(rng.random() < 0.4 and read_len <= 300),
+               # the database cut into 1-4 index chunks resident at once (the NT loop in one process): the oracle is chained chunk after chunk,
+               # each run reading the previous run's stdout (runMegaPath.sh:191-227); 0 = one index, no chain
+               chunks=int(rng.choice([0, 0, 2, 3, 4])), host_merge=bool(rng.random() < 0.3),
                # which optional index tables the run may build (every combination takes another path through the seeding kernels)
                env={k: str(int(v)) for k, v in (("MP_KMER_FILTER", rng.random() < 0.8), ("MP_KMER15", rng.random() < 0.7), ("MP_LKT16", rng.random() < 0.7),
                                                 ("MP_SA_DENSE", rng.random() < 0.7), ("MP_LKT16U", rng.random() < 0.7), ("MP_SA_DENSE_SPACING", rng.choice([1, 1, 2, 4])),
@@ -41,9 +44,20 @@ for rnd in range(args.rounds):
                        frag_mean=read_len + 200, frag_sd=40, frag_min=read_len + 20, frag_max=min(740, read_len + 420)))
     print("round %d: %r" % (rnd, cfg), flush=True)
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
-        genome = synth.random_genome(cfg["n_bases"], cfg["gseed"], n_seqs=cfg["n_seqs"], repeat_frac=cfg["rep"])
+        n_chunks = cfg["chunks"] if not cfg["bam"] else 0
+        genome = synth.random_genome(cfg["n_bases"], cfg["gseed"], n_seqs=max(cfg["n_seqs"], n_chunks), repeat_frac=cfg["rep"])
         prefix = os.path.join(tmp, "g.index")
-        index_builder.write_index_files(prefix, index_builder.build_index_arrays(genome, sa_interval=16))
+        if n_chunks:
+            # sequences dealt round-robin to the chunks (copied repeats then cross chunk borders: one read, hits in several chunks)
+            parts = [[genome[i] for i in range(len(genome)) if i % n_chunks == c] for c in range(n_chunks)]
+            prefixes = []
+            for c, part in enumerate(parts):
+                pc = os.path.join(tmp, "c%d.index" % c)
+                index_builder.write_index_files(pc, index_builder.build_index_arrays(part, sa_interval=16))
+                prefixes.append(pc)
+            prefix = ",".join(prefixes)
+        else:
+            index_builder.write_index_files(prefix, index_builder.build_index_arrays(genome, sa_interval=16))
         names, r1, r2 = synth.simulate_pairs(genome, cfg["n_pairs"], read_len, cfg["rseed"], **cfg["kw"])
         f1, f2 = os.path.join(tmp, "r_1.fq"), os.path.join(tmp, "r_2.fq")
         synth.write_fastq_pair(f1, f2, names, r1, r2)
@@ -51,20 +65,43 @@ for rnd in range(args.rounds):
         out = os.path.join(tmp, "out.fq")
         cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix, f1, f2, "-o", os.path.join(tmp, "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
                "-L", str(L), "-T", str(cfg["threads"]), "-u", "750", "-F" if cfg["mode"] == 1 else "-P", "-nc"] + (["-b", "-p", "-D", "rg1", "-A", "default"] if cfg["bam"] else [])
+        env = dict(os.environ, MP_BATCH_PAIRS=str(max(64, cfg["n_pairs"] // 3)), **cfg["env"])
+        if cfg["host_merge"]:
+            env["MP_HOST_MERGE"] = "1"
         with open(out, "wb") as fo:
-            r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, MP_BATCH_PAIRS=str(max(64, cfg["n_pairs"] // 3)), **cfg["env"]))
+            r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
         if r.returncode != 0:
             print("FAILED to run:", r.stderr.decode()[-800:])
             sys.exit(1)
-        ix = lib.mpo_index_open(prefix.encode())
-        p = O.default_params(L=L, mode=cfg["mode"], nc=True)
-        st = O.AlignStats()
         want = os.path.join(tmp, "want.fq")
-        if cfg["bam"]:
+        if n_chunks:
+            in1, in2 = f1, f2
+            for c, pc in enumerate(prefixes):
+                ix = lib.mpo_index_open(pc.encode())
+                p = O.default_params(L=L, mode=cfg["mode"], nc=(c == 0))
+                st = O.AlignStats()
+                assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), want.encode(), None, C.byref(st)) == 0
+                lib.mpo_index_close(ix)
+                if c + 1 < n_chunks:
+                    lines = open(want, "rb").read().split(b"\n")
+                    in1, in2 = os.path.join(tmp, "chain_%d_1.fq" % c), os.path.join(tmp, "chain_%d_2.fq" % c)
+                    with open(in1, "wb") as fa, open(in2, "wb") as fb:
+                        for i in range(0, len(lines) - 7, 8):
+                            fa.write(b"\n".join(lines[i:i + 4]) + b"\n")
+                            fb.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
+            ix = None
+        else:
+            ix = lib.mpo_index_open(prefix.encode())
+            p = O.default_params(L=L, mode=cfg["mode"], nc=True)
+            st = O.AlignStats()
+        if n_chunks:
+            pass
+        elif cfg["bam"]:
             assert lib.mpo_align_fastq_bam(ix, C.byref(p), f1.encode(), f2.encode(), want.encode(), None, os.path.join(tmp, "obam").encode(), 1, b"rg1", C.byref(st)) == 0
         else:
             assert lib.mpo_align_fastq(ix, C.byref(p), f1.encode(), f2.encode(), want.encode(), None, C.byref(st)) == 0
-        lib.mpo_index_close(ix)
+        if ix is not None:
+            lib.mpo_index_close(ix)
         if cfg["bam"]:
             import bamtext
             for kind, path in (("dpout", "o.dpout.1"), ("gout", "o.gout.1"), ("unpair", "o.unpair")):

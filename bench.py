@@ -586,7 +586,7 @@ def write_fastq_fast(codes_dev, path1, path2, first_id=0):
         del rec
 
 
-def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=12, gz_pairs=1 << 20):
+def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=12, gz_pairs=1 << 22):
     """FASTQ files in, annotated FASTQ out, through bin/soap4-mi355x (the boundary a pipeline maintainer sees): pairs/s of the
     executable's alignment loop (index load excluded, as for the CPU soap4), stdout to /dev/null; plain input and gzip'ed input."""
     from megapath_amd import simulate
@@ -677,6 +677,7 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
         for pr in procs:
             pr.wait()
         res["gz"] = run(g1 + ".gz", g2 + ".gz", gz_pairs)
+        res["gz_zlib"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_INFLATE": "zlib"})        # the same files through zlib's gzread, as the reference reads them
         res["gz"]["input"] = "%d pairs, gzip -1 (%.2f GB per file, compressed in %.0f s)" % (gz_pairs, os.path.getsize(g1 + ".gz") / 1e9, time.time() - t0)
     finally:
         shutil.rmtree(d, ignore_errors=True)

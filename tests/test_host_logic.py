@@ -343,3 +343,60 @@ def test_reader_rejects_garbage_and_mate_count_mismatch(tmp_path):
     b.write_bytes(b"@r0/2\nACGT\n+\nIIII\n@r1/2\nACGT\n+\n")               # cut short inside a record
     r = _plumb(tmp_path, a, b)
     assert r.returncode == 1 and b"ends inside" in r.stderr
+
+
+@pytest.mark.parametrize("inflate", ["fast", "zlib"])
+def test_reader_gzip_members_levels_and_corruption(tmp_path, inflate):
+    """The executable's own gzip decoder (host/fast_inflate.h; MP_INFLATE=zlib keeps zlib's gzread): concatenated members (bgzip, `cat a.gz b.gz`),
+    an empty member, stored blocks (level 0), fixed-Huffman blocks, levels 1-9 -- the records must be what kseq reads from the plain text; a flipped
+    bit or a truncated file must end the run with an error, never with different or fewer records."""
+    import gzip
+    import random
+    import zlib
+    rng = random.Random(77)
+    texts = []
+    for k in range(2):
+        t = "".join("@r%d/%d\n%s\n+\n%s\n" % (i, k + 1, "".join(rng.choice("ACGT") for _ in range(150)), "".join(chr(rng.randrange(35, 74)) for _ in range(150))) for i in range(3000))
+        texts.append(t.encode())
+    env = {"MP_BATCH_PAIRS": "700"}
+    if inflate == "zlib":
+        env["MP_INFLATE"] = "zlib"
+    want = _expected_plumbing(_kseq_records(texts[0]), _kseq_records(texts[1]), 151)
+
+    def members(data, k):
+        cuts = sorted(rng.sample(range(1, len(data)), 5))
+        parts = [data[a:b] for a, b in zip([0] + cuts, cuts + [len(data)])]
+        out = b""
+        for i, part in enumerate(parts):
+            if i == 2:
+                out += gzip.compress(b"")                                     # an empty member in between
+            if i == 3:
+                c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)   # fixed Huffman codes
+                out += c.compress(part) + c.flush()
+            else:
+                out += gzip.compress(part, [0, 1, 6, 9, 3, 0][(i + k) % 6])
+        return out
+    files = []
+    for k in range(2):
+        f = tmp_path / ("m_%d.fq.gz" % (k + 1))
+        f.write_bytes(members(texts[k], k))
+        files.append(f)
+    r = _plumb(tmp_path, files[0], files[1], env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == want
+    # one flipped bit somewhere in the compressed data of file 1: error (CRC at the latest)
+    raw = bytearray(files[0].read_bytes())
+    for trial in range(6):
+        bad = bytearray(raw)
+        i = rng.randrange(40, len(bad) - 40)
+        bad[i] ^= 1 << rng.randrange(8)
+        b1 = tmp_path / "bad_1.fq.gz"
+        b1.write_bytes(bytes(bad))
+        r = _plumb(tmp_path, b1, files[1], env)
+        assert r.returncode == 1 and b"error while reading" in r.stderr, (trial, i, r.returncode, r.stderr[-300:])
+    # truncated in the middle and inside the trailer
+    for cut in (len(raw) // 3, len(raw) - 5):
+        b1 = tmp_path / "cut_1.fq.gz"
+        b1.write_bytes(bytes(raw[:cut]))
+        r = _plumb(tmp_path, b1, files[1], env)
+        assert r.returncode == 1 and (b"error while reading" in r.stderr or b"ends inside" in r.stderr or b"not matched" in r.stderr), r.stderr[-300:]

@@ -221,7 +221,8 @@ def test_bench_gpus_n_launches_n_ranks_by_itself(tmp_path):
     assert r.returncode == 7, (r.returncode, r.stderr)
     # and bench.py itself takes that road before anything touches the GPU (here: no GPU at all, every rank says so and fails)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and r.stderr.count("bench.py needs an MI355X") == 2, r.stderr[-600:]
+    # (the first rank to fail takes the other down: one or both say so)
+    assert r.returncode != 0 and r.stderr.count("bench.py needs an MI355X") >= 1 and "rank" in r.stderr, r.stderr[-600:]
 
 
 def _plumb(tmp_path, f1, f2, extra_env=None, L=151, threads=4, flags=("-F", "-nc")):

@@ -579,7 +579,13 @@ def write_fastq_fast(codes_dev, path1, path2, first_id=0):
         rec[:, 14:14 + L] = lut[codes_dev[m::2].long()]
         o = 14 + L
         rec[:, o] = 10; rec[:, o + 1] = ord("+"); rec[:, o + 2] = 10
-        rec[:, o + 3:o + 3 + L] = ord("I")
+        # qualities as a current sequencer writes them: four bins (F : , #), mostly the top one -- a constant quality string would make the
+        # gzip'ed variant of the files compress (and inflate) unrealistically well
+        u = torch.rand(P, L, device=dev)
+        q = torch.full((P, L), ord("F"), dtype=torch.uint8, device=dev)
+        q[u > 0.90] = ord(":"); q[u > 0.96] = ord(","); q[u > 0.99] = ord("#")
+        rec[:, o + 3:o + 3 + L] = q
+        del u, q
         rec[:, o + 3 + L] = 10
         with open(path, "ab") as f:
             f.write(rec.cpu().numpy().tobytes())

@@ -297,7 +297,7 @@ def fastq_records(path):
     return out
 
 
-def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device, read_L):
+def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device, read_L, ini_name=None, threads_list=None):
     """Real soap4 (oracle/_ref, built by oracle/Makefile.ref and shipped with the snapshot) on a bounded sample of the bench
     workload, on all host cores; then the same sample through the product executable, compared record by record."""
     from megapath_amd import index_builder
@@ -307,18 +307,20 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
     prefix = os.path.join(tmpdir, "ref.index")
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "soap4")
     use_ref = os.path.exists(ref_bin)
-    index_builder.write_index_files(prefix, arrs, write_lkt=use_ref, lkt_table=lkt_table if use_ref else None)
+    if not os.path.exists(prefix + ".bwt") or (use_ref and not os.path.exists(prefix + ".lkt")):
+        index_builder.write_index_files(prefix, arrs, write_lkt=use_ref, lkt_table=lkt_table if use_ref else None)
     cores = os.cpu_count() or 1
-    ini = os.path.join(tmpdir, args.ini)
+    ini_name = ini_name or args.ini
+    ini = os.path.join(tmpdir, ini_name)
     with open(ini, "w") as f:
-        f.write(INIS[args.ini])
+        f.write(INIS[ini_name])
     cb, parity = None, None
     ref_out = os.path.join(tmpdir, "ref.out")
     if use_ref:
         # all host cores, as the north star asks, and a second run at 32 threads (soap4's own thread scaling flattens long before
         # the 256 hardware threads of such a node); the faster one is the baseline, both are listed
         runs = []
-        for T in sorted({cores, min(cores, 32)}, reverse=True):
+        for T in (threads_list or sorted({cores, min(cores, 32)}, reverse=True)):
             cmd = [ref_bin, "pair", prefix, fq1, fq2, "-o", os.path.join(tmpdir, "out"), "-C", ini, "-L", str(read_L), "-T", str(T), "-u", "750", "-F", "-nc"]
             t0 = time.time()
             with open(ref_out + ".T%d" % T, "wb") as fo, open(os.path.join(tmpdir, "ref.err"), "wb") as fe:
@@ -345,7 +347,7 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
         lib = O.oracle()
         ix = lib.mpo_index_open(prefix.encode())
         p = O.default_params(L=read_L)
-        p.mmp.seed_min_length, p.mmp.reseed_len = (22, 23) if args.ini == "soap4.ini" else (17, 18)
+        p.mmp.seed_min_length, p.mmp.reseed_len = (22, 23) if ini_name == "soap4.ini" else (17, 18)
         st = O.AlignStats()
         few = min(n_pairs, 4000)
         f1s, f2s = os.path.join(tmpdir, "few_1.fq"), os.path.join(tmpdir, "few_2.fq")
@@ -381,7 +383,7 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
             parity = {"pairs": n_pairs, "records": len(want), "records_equal": not diff, "records_differing": len(diff), "first_diff": first,
                       "reference_records_with_a_hit": aligned, "against": cb["kind"] if cb else None,
                       "how": "bin/soap4-mi355x pair <same index files> <same FASTQ> -C %s -L %d -u 750 -F -nc (whole-process %.0f s), stdout compared with the "
-                             "CPU run's, record by record, order-insensitive" % (args.ini, read_L, time.time() - t0)}
+                             "CPU run's, record by record, order-insensitive" % (ini_name, read_L, time.time() - t0)}
     return cb, parity
 
 
@@ -485,6 +487,24 @@ def nt_replica_leg(args, H, index_builder, simulate, arrs_a, text_a, dev, device
         one_step(acc)
         torch.cuda.synchronize()
         el_single = time.perf_counter() - t3
+        # how many reads have NO seed of >= 17 bases in a chunk that is not theirs (what a per-chunk pre-screen could skip): the kept seed
+        # positions of the batch against chunk 1, per read
+        seedless = None
+        try:
+            ctx.set_reads(wl.packed_np, wl.lens_np)
+            ctx.set_index(chunks[1])
+            ctx.seed_batch(H.MmpParams.nt2())
+            lib = H.load_library()
+            off = np.zeros(2 * lp + 1, dtype=np.uint64)
+            H._chk(lib.mp_get_seeds(ctx._h, None, 0, off.ctypes.data), "mp_get_seeds")
+            per_read = np.diff(off.astype(np.int64))
+            per_pair = per_read[0::2] + per_read[1::2]
+            seedless = {"reads_without_a_kept_seed_position": float((per_read == 0).mean()), "pairs_without_one": float((per_pair == 0).mean()),
+                        "kept_seed_positions_per_read_mean": float(per_read.mean()), "chunk": 1,
+                        "note": "seed positions that survive the merge / uniqueness / coverage rules (DV-DPfunctions.cpp:2499-2553) of the batch against a chunk none of "
+                                "the reads comes from: a pair without any is the only kind of (pair, chunk) work a pre-screen could skip"}
+        except Exception as e:  # noqa: BLE001
+            log("[bench] seedless census failed: %r" % (e,))
         ctx.close()
         # the configuration the executable runs in: the batch cut into contiguous blocks, one context (own streams, own host thread) per
         # block, each taking its block through every chunk -- the memory-bound seeding of one overlaps with the VALU-bound DP of the others
@@ -543,6 +563,7 @@ def nt_replica_leg(args, H, index_builder, simulate, arrs_a, text_a, dev, device
                                          "chunks are %d such runs for it, so value = that rate / %d" % (cpu_nt["pairs"], cpu_nt["threads"], n_chunks, n_chunks, n_chunks))
                              if cpu_nt else None),
             "kernel_ms_per_chunk_other_chunks": per_chunk_ms, "kernel_ms_source_chunk": {k: acc["source_chunk"].get(k, 0.0) for k in keys},
+            "foreign_chunk_seed_census": seedless,
             "per_pair_per_other_chunk": {k: o.get(k, 0) / (n_o * lp) for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seeds", "n_hits", "n_seedpos", "single_dp_tasks", "single_hits", "pair_hits")},
             "roofline": {"bound": "hbm", "kernel": "seed_kernel+seed_overflow_kernel+expand_hits_kernel+locate_kernel (lean layout, all chunks of the step)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -978,6 +999,16 @@ def main():
                     log("[bench] cpu baseline / parity sample failed: %r" % (e,))
             out["cpu_baseline"] = cb
             out["parity_sample"] = parity
+            if world == 1 and not args.no_cpu_baseline and args.ini != "soap4-nt2.ini" and cb and cb.get("kind") == "reference":
+                # the NT stage's parameters on the same index (17-base seeds: the single-end rescue over chance seeds is exercised): a second sample
+                try:
+                    os.remove(os.path.join(tmpdir, "ref.out")) if os.path.exists(os.path.join(tmpdir, "ref.out")) else None
+                    nt_sample = Workload(text, min(args.cpu_sample_pairs, P) // 2, seed=1000 + rank, read_len=args.read_len, L=args.read_len + 1)
+                    cb2, parity2 = cpu_baseline_and_parity(args, arrs, nt_sample.codes, tmpdir, None, local_rank, args.read_len + 1, ini_name="soap4-nt2.ini", threads_list=[min(os.cpu_count() or 1, 32)])
+                    out["parity_sample_nt2_ini"] = dict(parity2 or {}, cpu_pairs_per_s=(cb2 or {}).get("value"))
+                    del nt_sample
+                except Exception as e:  # noqa: BLE001
+                    log("[bench] nt2 parity sample failed: %r" % (e,))
             if world == 1 and not args.no_legs and not args.no_e2e and want_leg("e2e_cli"):
                 try:
                     from megapath_amd import index_builder as _ib

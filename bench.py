@@ -613,6 +613,29 @@ def write_fastq_fast(codes_dev, path1, path2, first_id=0):
         del rec
 
 
+def _bgzf_block(raw):
+    import struct
+    import zlib
+    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+    comp = c.compress(raw) + c.flush()
+    return b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(raw), len(raw))
+
+
+def write_bgzf(plain_path, dst, n_bytes, block=65280):
+    """The first n_bytes of a file as BGZF: 64 KiB members with the 'BC' extra field and the empty end-of-file member, compressed by a pool of processes."""
+    import multiprocessing as mp
+    left = n_bytes
+    with open(plain_path, "rb") as f, open(dst, "wb") as fo, mp.Pool(min(16, os.cpu_count() or 4)) as pool:
+        while left > 0:
+            data = f.read(min(block * 512, left))
+            if not data:
+                break
+            left -= len(data)
+            for blk in pool.imap(_bgzf_block, [data[i:i + block] for i in range(0, len(data), block)], chunksize=16):
+                fo.write(blk)
+        fo.write(_bgzf_block(b""))
+
+
 def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=12, gz_pairs=1 << 22):
     """FASTQ files in, annotated FASTQ out, through bin/soap4-mi355x (the boundary a pipeline maintainer sees): pairs/s of the
     executable's alignment loop (index load excluded, as for the CPU soap4), stdout to /dev/null; plain input and gzip'ed input."""
@@ -705,6 +728,16 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
             pr.wait()
         res["gz"] = run(g1 + ".gz", g2 + ".gz", gz_pairs)
         res["gz_zlib"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_INFLATE": "zlib"})        # the same files through zlib's gzread, as the reference reads them
+        # the same reads as BGZF (bgzip; what BBTools writes when bgzip is installed): independent members, inflated by several threads per file
+        try:
+            t0 = time.time()
+            b1, b2 = os.path.join(d, "b_1.fq.gz"), os.path.join(d, "b_2.fq.gz")
+            write_bgzf(f1, b1, rec_bytes * gz_pairs)
+            write_bgzf(f2, b2, rec_bytes * gz_pairs)
+            res["bgzf"] = run(b1, b2, gz_pairs)
+            res["bgzf"]["input"] = "%d pairs as BGZF (%.2f GB per file, written in %.0f s)" % (gz_pairs, os.path.getsize(b1) / 1e9, time.time() - t0)
+        except Exception as e:  # noqa: BLE001
+            res["bgzf"] = {"error": repr(e)}
         res["gz"]["input"] = "%d pairs, gzip -1 (%.2f GB per file, compressed in %.0f s)" % (gz_pairs, os.path.getsize(g1 + ".gz") / 1e9, time.time() - t0)
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -261,26 +261,97 @@ void fan_out(int n, F &&body, Pool *pool = nullptr)
 // the bytes into the batch's buffer, computing each member's CRC-32 on the way and comparing it with the trailer's.
 struct GzProducer {
     struct MemberEnd { size_t pos; uint32_t crc, isize; };
-    struct Chunk { std::vector<uint8_t> buf; size_t begin = 0, end = 0; std::vector<MemberEnd> ends; bool eof = false; std::string err; };
+    struct Chunk { std::vector<uint8_t> buf; size_t begin = 0, end = 0; std::vector<MemberEnd> ends; bool eof = false, verified = false; std::string err; };
     static constexpr size_t H = 32768, C = (size_t)8 << 20;
     mpz::Inflater z;
-    std::thread th;
+    std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Chunk *> ready, free_;
     std::vector<std::unique_ptr<Chunk>> all;
     bool stop = false;
-    void start(const uint8_t *data, size_t len, int n_chunks)
+    // BGZF (htslib's blocked gzip -- bgzip, and what BBTools writes when bgzip is installed): every member carries its own compressed size in
+    // a 'BC' extra field and refers to nothing outside itself, so groups of members are inflated side by side and handed over in file order
+    struct Group { size_t a, b; };                  // compressed bytes [a, b) of consecutive members, <= C bytes inflated
+    std::vector<Group> groups;
+    size_t next_group = 0, deliver = 0;
+    std::map<size_t, Chunk *> done;
+    const uint8_t *data_ = nullptr;
+
+    // the members of a BGZF file as groups; false when the file is not BGZF from its first to its last byte
+    static bool scan_bgzf(const uint8_t *d, size_t len, std::vector<Group> &out)
     {
-        z.init(data, len);
+        size_t off = 0, ga = 0, inflated = 0;
+        while (off < len) {
+            if (len - off < 26 || d[off] != 0x1f || d[off + 1] != 0x8b || d[off + 2] != 8 || !(d[off + 3] & 4)) return false;
+            const size_t xlen = d[off + 10] | (size_t)d[off + 11] << 8;
+            if (off + 12 + xlen > len) return false;
+            size_t bsize = 0;
+            for (size_t x = off + 12; x + 4 <= off + 12 + xlen;) {
+                const size_t sl = d[x + 2] | (size_t)d[x + 3] << 8;
+                if (d[x] == 'B' && d[x + 1] == 'C' && sl == 2 && x + 6 <= off + 12 + xlen) bsize = (d[x + 4] | (size_t)d[x + 5] << 8) + 1;
+                x += 4 + sl;
+            }
+            if (bsize < 26 || off + bsize > len) return false;
+            const uint8_t *t = d + off + bsize - 4;
+            const size_t isize = t[0] | (size_t)t[1] << 8 | (size_t)t[2] << 16 | (size_t)t[3] << 24;
+            if (isize > 65536) return false;
+            if (inflated + isize > C && off > ga) { out.push_back(Group{ga, off}); ga = off; inflated = 0; }
+            inflated += isize;
+            off += bsize;
+        }
+        if (off > ga) out.push_back(Group{ga, off});
+        return !out.empty();
+    }
+    void start(const uint8_t *data, size_t len, int n_chunks, int bgzf_threads)
+    {
+        data_ = data;
         for (int i = 0; i < n_chunks; i++) { all.emplace_back(new Chunk()); free_.push_back(all.back().get()); }      // (a chunk's buffer is allocated when it is first used)
-        th = std::thread([this]() {
+        if (bgzf_threads > 0 && scan_bgzf(data, len, groups)) {
+            for (int w = 0; w < bgzf_threads; w++)
+                th.emplace_back([this]() {
+                    mpz::Inflater zz;
+                    for (;;) {
+                        Chunk *c = nullptr;
+                        size_t g = 0;
+                        {   // a group and the chunk for it are taken together, in file order: the group to deliver next always has its chunk
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&] { return stop || next_group >= groups.size() || !free_.empty(); });
+                            if (stop || next_group >= groups.size()) return;
+                            g = next_group++; c = free_.front(); free_.pop_front();
+                        }
+                        c->ends.clear(); c->err.clear(); c->eof = g + 1 == groups.size(); c->verified = true;
+                        if (c->buf.empty()) c->buf.resize(H + C + 512);
+                        zz.init(data_ + groups[g].a, groups[g].b - groups[g].a);
+                        size_t pos = 0, mstart = 0;
+                        for (;;) {
+                            const int rc = zz.run(c->buf.data(), pos, H + C);
+                            if (rc == mpz::MEMBER_END) {
+                                if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), c->buf.data() + mstart, (uInt)(pos - mstart)) != zz.member_crc() || (uint32_t)(pos - mstart) != zz.member_isize())
+                                    { c->err = "incorrect data check (gzip CRC-32 or length)"; break; }
+                                mstart = pos;
+                                continue;
+                            }
+                            if (rc == mpz::ERR) c->err = zz.error();
+                            else if (rc == mpz::NEED_OUTPUT) c->err = "BGZF member larger than its header says";
+                            break;
+                        }
+                        c->begin = 0; c->end = pos;
+                        { std::lock_guard<std::mutex> lk(mu); done[g] = c; }
+                        cv.notify_all();
+                    }
+                });
+            return;
+        }
+        groups.clear();
+        z.init(data, len);
+        th.emplace_back([this]() {
             std::vector<uint8_t> hist(H);
             size_t hist_n = 0;
             for (;;) {
                 Chunk *c = nullptr;
                 { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !free_.empty(); }); if (stop) return; c = free_.front(); free_.pop_front(); }
-                c->ends.clear(); c->err.clear(); c->eof = false;
+                c->ends.clear(); c->err.clear(); c->eof = false; c->verified = false;
                 if (c->buf.empty()) c->buf.resize(H + C + 512);
                 memcpy(c->buf.data(), hist.data(), hist_n);
                 size_t pos = hist_n;
@@ -305,12 +376,18 @@ struct GzProducer {
     Chunk *pop()
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (!groups.empty()) {
+            cv.wait(lk, [&] { return done.count(deliver) != 0; });
+            Chunk *c = done[deliver];
+            done.erase(deliver++);
+            return c;
+        }
         cv.wait(lk, [&] { return !ready.empty(); });
         Chunk *c = ready.front(); ready.pop_front();
         return c;
     }
     void give_back(Chunk *c) { { std::lock_guard<std::mutex> lk(mu); free_.push_back(c); } cv.notify_all(); }
-    ~GzProducer() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+    ~GzProducer() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : th) if (t.joinable()) t.join(); }
 };
 
 struct Source {
@@ -366,7 +443,8 @@ struct Source {
             map = (const char *)m;
             m_crc = (uint32_t)crc32(0L, Z_NULL, 0);
             fast.reset(new GzProducer());
-            fast->start((const uint8_t *)map, map_len, 48);                  // up to 384 MiB inflated ahead of the splitter: about one batch
+            const int bg = getenv("MP_INFLATE_THREADS") ? atoi(getenv("MP_INFLATE_THREADS")) : 3;          // BGZF only: members inflate side by side
+            fast->start((const uint8_t *)map, map_len, 48, bg);             // up to 384 MiB inflated ahead of the splitter: about one batch
             return true;
         }
         if (gz || !S_ISREG(st.st_mode)) {
@@ -402,7 +480,7 @@ struct Source {
                 const size_t n = std::min(want, lim - cur_pos);
                 if (n) {
                     memcpy(buf.data() + end, cur->buf.data() + cur_pos, n);
-                    m_crc = (uint32_t)crc32(m_crc, (const Bytef *)cur->buf.data() + cur_pos, (uInt)n);
+                    if (!cur->verified) m_crc = (uint32_t)crc32(m_crc, (const Bytef *)cur->buf.data() + cur_pos, (uInt)n);      // (BGZF members are checked by the thread that inflates them)
                     m_size += (uint32_t)n; end += n; cur_pos += n; want -= n; got = true;
                 }
                 if (cur_pos < lim) continue;

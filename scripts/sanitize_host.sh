@@ -24,6 +24,15 @@ for m in (1, 2):
         odd.append(lines[i] + "\r\n" + seq.lower().replace("a", "N", 1) + "\r\n+\r\n" + lines[i + 3] + "\r\n" + ("\r\n" if (i // 4) % 5 == 0 else ""))
     open("%s/w_%d.fa" % (b, m), "w").write("".join(fa))
     open("%s/odd_%d.fq" % (b, m), "w", newline="").write("".join(odd))
+    # BGZF: members inflated by several threads, handed over in file order
+    import struct, zlib
+    data = open("%s/reads_a_%d.fq" % (g1, m), "rb").read()
+    out = b""
+    for i in list(range(0, len(data), 3000)) + [None]:
+        raw = b"" if i is None else data[i:i + 3000]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15); comp = c.compress(raw) + c.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(raw), len(raw))
+    open("%s/bg_%d.fq.gz" % (b, m), "wb").write(out)
 PY
 for kind in thread address,undefined; do
     exe="$B/soap4-$(echo $kind | tr , -)"
@@ -42,6 +51,7 @@ for kind in thread address,undefined; do
     MP_BATCH_PAIRS=1000 run onebatch 0 "$exe" pair x,y,z "$G1/reads_d_1.fq" "$G1/reads_d_2.fq" "${common[@]}" -T 2 -P
     MP_BATCH_PAIRS=11 run wrapped_fasta 0 "$exe" pair x "$B/w_1.fa" "$B/w_2.fa" "${common[@]}" -T 4 -F -nc
     MP_BATCH_PAIRS=13 run odd_shapes 0 "$exe" pair x "$B/odd_1.fq" "$B/odd_2.fq" "${common[@]}" -T 4 -F -nc
+    MP_BATCH_PAIRS=9 MP_INFLATE_THREADS=4 run bgzf 0 "$exe" pair x "$B/bg_1.fq.gz" "$B/bg_2.fq.gz" "${common[@]}" -T 4 -F -nc
     MP_BATCH_PAIRS=50 run lsam 0 "$exe" pair x "$G1/reads_e_1.fq" "$G1/reads_e_2.fq" "${common[@]}" -T 4 -F -top 95 -lsam
     # fatal() leaves through _exit() from whichever thread met the error, on purpose (no atexit handlers while other stages write):
     # the threads it leaves behind are not a leak to report

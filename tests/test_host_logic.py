@@ -401,3 +401,47 @@ def test_reader_gzip_members_levels_and_corruption(tmp_path, inflate):
         b1.write_bytes(bytes(raw[:cut]))
         r = _plumb(tmp_path, b1, files[1], env)
         assert r.returncode == 1 and (b"error while reading" in r.stderr or b"ends inside" in r.stderr or b"not matched" in r.stderr), r.stderr[-300:]
+
+
+def _bgzf(data: bytes, block: int = 60000) -> bytes:
+    """htslib's blocked gzip: every member has the 'BC' extra field with its own size; an empty member marks the end."""
+    import struct
+    import zlib
+    out = b""
+    for i in list(range(0, len(data), block)) + [None]:
+        raw = b"" if i is None else data[i:i + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(raw) + c.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(raw), len(raw))
+    return out
+
+
+@pytest.mark.parametrize("threads", ["3", "0"])
+def test_reader_bgzf_members_inflate_side_by_side(tmp_path, threads):
+    """BGZF input (bgzip; what BBTools writes when bgzip is installed): the members are inflated by several threads and handed over in file
+    order (MP_INFLATE_THREADS=0: one after the other, like any gzip file).  Records as kseq reads the plain text; a flipped bit is an error."""
+    import random
+    rng = random.Random(5)
+    texts = []
+    for k in range(2):
+        t = "".join("@q%d/%d\n%s\n+\n%s\n" % (i, k + 1, "".join(rng.choice("ACGT") for _ in range(150)), "".join(rng.choice("F:,#") for _ in range(150))) for i in range(20000))
+        texts.append(t.encode())
+    files = []
+    for k in range(2):
+        f = tmp_path / ("b_%d.fq.gz" % (k + 1))
+        f.write_bytes(_bgzf(texts[k], 60000 if k == 0 else 9000))
+        files.append(f)
+    env = {"MP_BATCH_PAIRS": "3500", "MP_INFLATE_THREADS": threads}
+    r = _plumb(tmp_path, files[0], files[1], env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == _expected_plumbing(_kseq_records(texts[0]), _kseq_records(texts[1]), 151)
+    raw = bytearray(files[0].read_bytes())
+    for i in (len(raw) // 2, len(raw) // 3 + 7, 3 * len(raw) // 4):
+        bad = bytearray(raw)
+        if bad[i - 18:i - 14] == b"\x1f\x8b\x08\x04":
+            i += 40                                                       # (not a member's time stamp / OS byte: those are not checked by anybody)
+        bad[i] ^= 0x10
+        b1 = tmp_path / "badb_1.fq.gz"
+        b1.write_bytes(bytes(bad))
+        r = _plumb(tmp_path, b1, files[1], env)
+        assert r.returncode == 1 and b"error while reading" in r.stderr, (i, r.returncode, r.stderr[-300:])

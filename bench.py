@@ -732,8 +732,10 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
         try:
             t0 = time.time()
             b1, b2 = os.path.join(d, "b_1.fq.gz"), os.path.join(d, "b_2.fq.gz")
-            write_bgzf(f1, b1, rec_bytes * gz_pairs)
-            write_bgzf(f2, b2, rec_bytes * gz_pairs)
+            # (in child processes of their own: the compression pool forks, and this process has the GPU open)
+            ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--write-bgzf", src, dst, str(rec_bytes * gz_pairs)]) for src, dst in ((f1, b1), (f2, b2))]
+            if any(pr.wait() != 0 for pr in ps):
+                raise RuntimeError("writing the BGZF files failed")
             res["bgzf"] = run(b1, b2, gz_pairs)
             res["bgzf"]["input"] = "%d pairs as BGZF (%.2f GB per file, written in %.0f s)" % (gz_pairs, os.path.getsize(b1) / 1e9, time.time() - t0)
         except Exception as e:  # noqa: BLE001
@@ -798,6 +800,9 @@ def launch_ranks(n, argv, script=None, extra_env=None):
 
 # ------------------------------------------------------------------------------------------------ main
 def main():
+    if sys.argv[1:2] == ["--write-bgzf"]:                       # helper mode of the e2e leg (no GPU is touched)
+        write_bgzf(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)

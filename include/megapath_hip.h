@@ -231,6 +231,11 @@ typedef struct {
     uint64_t instances, cells_full_table;
     uint64_t cells_band_score, cells_band_trace, cells_full_score, cells_full_trace;
 } mp_dp_census;
+/* The certificate in front of the rescue filter (kernels_thermo.hip): instances that provably cannot reach their cutoff skip the filter.
+ * 0 switches it off (test aid: the results are the same either way); stats: [0] certified, [1] overflow, [2] bound too high, [3] not eligible. */
+int mp_ctx_set_dp_thermo(mp_ctx *ctx, int on);
+int mp_ctx_dp_thermo_stats(mp_ctx *ctx, uint64_t out[4]);
+int mp_test_dp_thermo(mp_ctx *ctx, const mp_dp_task *tasks, uint32_t n, uint8_t *out_cert, uint64_t out_stats[4]);
 int mp_ctx_set_dp_census(mp_ctx *ctx, int on);
 int mp_ctx_get_dp_census(mp_ctx *ctx, mp_dp_census *out);
 /* The hit list is grouped by pair, pairs in ascending order (the hits of one pair in no particular order). */

@@ -13,6 +13,7 @@
 #include "kernels_dp.hip"
 #include "kernels_dp_band.hip"
 #include "kernels_rescue.hip"
+#include "kernels_thermo.hip"
 #include "kernels_cov.hip"
 #include "kernels_reduce.hip"
 #include "kernels_build.hip"
@@ -66,6 +67,7 @@ struct mp_ctx {
     size_t slab_budget = 0;          // bytes of traceback flags per DP launch (decided at the first DP call)
     bool use_prefilter = true;       // mp_ctx_set_prefilter
     bool use_band = true;            // mp_ctx_set_dp_band
+    bool use_thermo = true;          // mp_ctx_set_dp_thermo
     bool seeded = false;
     // seeding
     DevBuf<mp_seed_rec> slabs, big_slabs;
@@ -84,6 +86,9 @@ struct mp_ctx {
     DevBuf<mp_fill_result> fill;
     DevBuf<mp_dp_result> res_l, res_r, res_tmp;
     DevBuf<uint8_t> flags, ops;
+    DevBuf<uint8_t> th_cert;                     // dp_thermo_kernel: instances certified unable to reach their cutoff
+    DevBuf<unsigned long long> th_stats;
+    unsigned long long th_total[4] = {0, 0, 0, 0};
     DevBuf<uint32_t> sel_flag, sel_idx;          // score-only pre-pass of the rescue DP batches
     DevBuf<mp_dp_task> sel_tasks;
     DevBuf<mp_dp_result> sel_res;
@@ -794,7 +799,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->seedpos.release(); c->hit_row.release(); c->seeds_per_rs.release(); c->hits_per_rs.release(); c->rs_base.release(); c->overflow_rs.release(); c->over_slot.release();
     c->queue.release(); c->n_pos.release(); c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
     c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
-    c->ops.release(); c->pair_hits.release(); c->pair_cnt.release(); c->pair_off.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
+    c->ops.release(); c->th_cert.release(); c->th_stats.release(); c->pair_hits.release(); c->pair_cnt.release(); c->pair_off.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
     if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
     if (c->red_keys) (void)hipFree(c->red_keys);
     if (c->red_sorted) (void)hipFree(c->red_sorted);
@@ -990,6 +995,47 @@ extern "C" int mp_ctx_set_dp_band(mp_ctx *c, int on)
     return MP_OK;
 }
 
+extern "C" int mp_ctx_set_dp_thermo(mp_ctx *c, int on)
+{
+    if (!c) return MP_EINVAL;
+    c->use_thermo = on != 0;
+    return MP_OK;
+}
+
+// instances the certificate kernel has seen since the context was created: [0] certified (no alignment possible), [1] a score of 12 or more
+// somewhere besides the seed, [2] bound not below the cutoff, [3] not eligible (shape)
+extern "C" int mp_ctx_dp_thermo_stats(mp_ctx *c, uint64_t out[4])
+{
+    if (!c || !out) return MP_EINVAL;
+    for (int k = 0; k < 4; k++) out[k] = c->th_total[k];
+    return MP_OK;
+}
+
+// test hook: the certificate kernel on caller-given instances of the reads now set
+extern "C" int mp_test_dp_thermo(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, uint8_t *out_cert, uint64_t out_stats[4])
+{
+    if (!c || !tasks || !out_cert || !c->d_reads) return MP_EINVAL;
+    if (n == 0) return MP_OK;
+    for (uint32_t t = 0; t < n; t++) {
+        if (tasks[t].read_id >= c->n_reads || (tasks[t].strand != 1 && tasks[t].strand != 2)) return MP_EINVAL;
+        if (tasks[t].win_len > MP_DP_MAX_WIN || tasks[t].win_start + tasks[t].win_len > c->ix->n) return MP_ERANGE;
+    }
+    HIPCHK(hipSetDevice(c->ix->device));
+    hipStream_t s = c->stream;
+    if (c->tasks_tmp.reserve(n) || c->th_cert.reserve(n + 64) || c->th_stats.reserve(4)) return MP_ENOMEM;
+    HIPCHK(hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(dp_thermo_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p,
+                       (const uint32_t *)nullptr, c->th_stats.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_cert, c->th_cert.p, n, hipMemcpyDeviceToHost, s));
+    unsigned long long ths[4];
+    HIPCHK(hipMemcpyAsync(ths, c->th_stats.p, sizeof ths, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (out_stats) for (int k = 0; k < 4; k++) out_stats[k] = ths[k];
+    return MP_OK;
+}
+
 extern "C" int mp_ctx_set_dp_census(mp_ctx *c, int on)
 {
     if (!c) return MP_EINVAL;
@@ -1100,8 +1146,15 @@ void fill_round(const mp_ctx *c, bool count, uint32_t *out)
 }
 
 template <int LPI, int C>
-void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, mp_fill_result *fill)
+void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, mp_fill_result *fill, const uint32_t *only = nullptr, uint32_t n_only = 0)
 {
+    if (only && c->max_len <= 8 * 20) {
+        // the instances the certificate kernel left undecided (dp_thermo_kernel), by list
+        if (c->max_len <= 8 * 19) hipLaunchKernelGGL((dp_score_kernel<8, 19>), dim3(grid_for((n_only + 1) / 2, MP_DP_BLOCK / 8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, tasks, n_only, fill, only);
+        else hipLaunchKernelGGL((dp_score_kernel<8, 20>), dim3(grid_for((n_only + 1) / 2, MP_DP_BLOCK / 8)), dim3(MP_DP_BLOCK), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, tasks, n_only, fill, only);
+        MP_TRACE(s, "dp_score_kernel (list)");
+        return;
+    }
     if (c->max_len <= 320) {
         // the leaner filter kernel (kernels_dp.hip): 8 lanes x 19 or 20 columns per instance pair for reads of up to 152 / 160 bases
         // (150-base reads then leave 2 idle columns instead of 10), 16 lanes x 12 / 16 / 20 columns up to 192 / 256 / 320 bases
@@ -1240,6 +1293,15 @@ int run_dp(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, i
 
 // For batches where most instances cannot reach their cutoff (the rescue passes): one score-only pass over all of them
 // (no traceback bits, no slab, one launch), then fill + traceback of the few that can pass.  Same results as run_dp.
+static int exclusive_scan_inclusive_u32(mp_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    size_t tmp_bytes = 0;
+    if (hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, in, out, (int)n, c->stream) != hipSuccess) return MP_ENODEV;
+    if (c->cub_tmp.reserve(tmp_bytes + 256)) return MP_ENOMEM;
+    if (hipcub::DeviceScan::InclusiveSum(c->cub_tmp.p, tmp_bytes, in, out, (int)n, c->stream) != hipSuccess) return MP_ENODEV;
+    return MP_OK;
+}
+
 int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,
                     float *ms_fill, float *ms_trace, bool count)
 {
@@ -1250,9 +1312,35 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     hipStream_t s = c->stream;
     if (c->fill.reserve(n + 2) || c->sel_flag.reserve(n + 2) || c->sel_idx.reserve(n + 2)) return MP_ENOMEM;
     while (c->ev_pool.size() < 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
-    census_add(c, CENSUS_FULL_SCORE, d_tasks, nullptr, n, 0);
+    // Windows around a seed (read + 2 x 30) of reads of 101 .. 160 bases: most are chance seeds whose table holds nothing else.  dp_thermo_kernel
+    // certifies that for 32 instances per word (kernels_thermo.hip); only what it leaves undecided goes through the score-only filter.
+    static const bool thermo_env = !getenv("MP_DP_THERMO") || atoi(getenv("MP_DP_THERMO")) != 0;
+    const bool thermo = thermo_env && c->use_thermo && c->max_len > 100 && c->max_len <= MP_TH_MAXL && max_win <= MP_TH_MAXM && n >= 64;
     HIPCHK(hipEventRecord(c->ev_pool[0], s));
-    MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p);
+    if (thermo) {
+        if (c->th_cert.reserve(n + 64) || c->th_stats.reserve(4) || c->score_list.reserve(n + 2)) return MP_ENOMEM;
+        HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(dp_thermo_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
+                           (const uint32_t *)nullptr, c->th_stats.p);
+        MP_TRACE(s, "dp_thermo_kernel");
+        hipLaunchKernelGGL(thermo_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint8_t *)c->th_cert.p, n, c->sel_flag.p, c->fill.p);
+        int rc0 = exclusive_scan_inclusive_u32(c, c->sel_flag.p, c->sel_idx.p, n);
+        if (rc0) return rc0;
+        uint32_t n_und = 0;
+        unsigned long long ths[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(&n_und, c->sel_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ths, c->th_stats.p, sizeof ths, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int k = 0; k < 4; k++) c->th_total[k] += ths[k];
+        if (n_und) {
+            hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, n, c->score_list.p, (const uint32_t *)nullptr);
+            census_add(c, CENSUS_FULL_SCORE, d_tasks, c->score_list.p, n_und, 0);
+            MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p, (const uint32_t *)c->score_list.p, n_und);
+        }
+    } else {
+        census_add(c, CENSUS_FULL_SCORE, d_tasks, nullptr, n, 0);
+        MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p);
+    }
     HIPCHK(hipEventRecord(c->ev_pool[1], s));
     hipLaunchKernelGGL(dp_select_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->fill.p, c->d_lens, n, c->sel_flag.p, d_res);
     MP_TRACE(s, "dp_select_kernel");

@@ -1,0 +1,275 @@
+// megapath_amd/csrc/kernels_thermo.hip -- product code: an exact, cheaper rejection in front of the score-only filter of the single-end
+// rescue (dp_score_kernel): a CERTIFICATE that an instance cannot reach its cutoff.  Included by api.hip.
+//
+// The instances of the single-end rescue (DV-DPForSingleReads.cpp:121-215, SingleEndAlgnBatch::pack DV-DPfunctions.cpp:401-445) are windows
+// around a seed: read (L <= 160) x window (m = L + 60) with an exact match of >= 17 bases on diagonal 30.  With 17-base seeds nearly all of
+// them are chance matches whose table holds nothing else; the filter still fills all 31 500 cells.  What this kernel computes instead
+// (proof: DESIGN.md section 4, "Why the rescue filter is not cheaper"; numerically: scripts/dp_decomposition_check.py, scripts/thermo_bound_proto.py):
+//
+//   T'   the table with the cells of the longest exact run R on the seed's diagonal turned into mismatches;
+//   H'   its LOCAL scores (+1 / -2, gaps -3 / -1, floor 0 in every cell: never below what callDP computes, CPU_DP.cpp:122-619);
+//   max(T) <= max( max H',  max over the cells of R but its last, and the cell diagonally before R, of H'  +  |R|  +  max of H' right of and below R's first cell )
+//
+// because a path either never uses a cell of R diagonally (a path of T') or is a path of T' into R, a stretch of R (leaving R and coming
+// back costs two gaps and skips matches), and a path of T' out of R.  If that bound is below the cutoff the instance is decided: no alignment.
+//
+// H' is never formed as numbers.  PLANES H_t = [H' >= t], t = 1 .. 12, one bit per instance: a word holds the SAME cell of 32 instances, so
+//   E_t = Hup_{t+3} | Eup_{t+1}        F_t = Hleft_{t+3} | Fleft_{t+1}        D_t = (M & Hdiag_{t-1}) | Hdiag_{t+2}        H_t = D_t | E_t | F_t
+// are four logic instructions per plane and cell for 32 instances at once, with no shifts and no carries (M = the instances whose window base
+// equals their read base in this cell).  A plane 12 bit anywhere means max H' >= 12: no certificate (the filter runs as before).
+// Mapping: a wavefront takes 64 instances, 32 per half; lane l of a half owns read columns 5l .. 5l+4 and walks the window rows on an
+// anti-diagonal (row = step - l): what it needs from the column to its left comes from lane l-1's previous step by DPP.  The reads and
+// windows are transposed into bit-sliced form with one ballot per word (both halves at once), straight into LDS.
+#pragma once
+
+#define MP_TH_T 12                 // planes: values 1 .. 12; plane 12 set anywhere = overflow, no certificate
+#define MP_TH_TE 9                 // E and F never exceed max H' - 3
+#define MP_TH_COLS 5               // read columns per lane: 32 lanes x 5 = 160
+#define MP_TH_MAXL 160
+#define MP_TH_MAXM 224
+#define MP_TH_MARGIN 30            // DP2_MARGIN for reads longer than 100 bases (DV-DPfunctions.cpp:1760): the seed's diagonal
+#define MP_TH_MINRUN 12            // a run shorter than this is no seed: no certificate
+
+// lane l receives lane l-1's value (whole wavefront; lane 0 keeps its own, masked by the caller)
+__device__ __forceinline__ uint32_t th_from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
+// the same and the mask of "has a left neighbour" in ONE instruction (lane 0, which has no source, reads 0)
+__device__ __forceinline__ uint32_t th_from_left_and(uint32_t v, uint32_t mask)
+{
+    uint32_t r;
+    asm("v_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(mask));
+    return r;
+}
+
+// cert[t] = 1: instance t cannot reach its cutoff (no alignment); 0: undecided, the filter has to look at it.
+// `list` (may be null): slot s stands for instance list[s].
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
+                 const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list,
+                 unsigned long long *__restrict__ stats /* [0] certified [1] overflow [2] bound too high [3] not eligible */)
+{
+    constexpr int T = MP_TH_T, TE = MP_TH_TE, NC = MP_TH_COLS;
+    // bit-sliced inputs of the two halves (index h = lane >> 5): one word = one column (row) of 32 instances
+    __shared__ uint32_t s_r0[2][MP_TH_MAXL], s_r1[2][MP_TH_MAXL], s_rv[2][MP_TH_MAXL], s_run[2][MP_TH_MAXL], s_lc[2][MP_TH_MAXL], s_gt[2][MP_TH_MAXL + 1];
+    // window rows are stored 32 further down with 32 empty rows on either side: the anti-diagonal sweep reads rows -31 .. mmax + 30 without a test
+    __shared__ uint32_t s_w0[2][MP_TH_MAXM + 64], s_w1[2][MP_TH_MAXM + 64], s_wv[2][MP_TH_MAXM + 64], s_rg[2][MP_TH_MAXM + 64];
+    const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
+    const uint32_t slot = blockIdx.x * 64 + lane;
+    const bool have = slot < n_tasks;
+    const uint32_t t_id = have ? (list ? list[slot] : slot) : 0;
+    // ---------------------------------------------------------------- this lane's instance: oriented read, window, the seed's run
+    int L = 0, m = 0, j0 = 0, rlen = 0;
+    bool ok = false;
+    uint32_t a[MP_TH_MAXL / 16 + 1], w[MP_TH_MAXM / 16 + 2];
+#pragma unroll
+    for (int k = 0; k <= MP_TH_MAXL / 16; k++) a[k] = 0;
+#pragma unroll
+    for (int k = 0; k < MP_TH_MAXM / 16 + 2; k++) w[k] = 0;
+    if (have) {
+        const mp_dp_task task = tasks[t_id];
+        L = (int)lens[task.read_id]; m = (int)task.win_len;
+        ok = L > 100 && L <= MP_TH_MAXL && m >= L && m <= MP_TH_MAXM && m <= L + 2 * MP_TH_MARGIN;
+        if (ok) {
+            const uint32_t *rd = reads + (uint64_t)task.read_id * Wr;
+            const int nw = (L + 15) / 16;
+#pragma unroll
+            for (int k = 0; k < MP_TH_MAXL / 16; k++) a[k] = mp_oriented_word(rd, nw, L, task.strand, k);
+            const uint64_t q0 = task.win_start >> 4;
+            const uint32_t sh = 2u * (uint32_t)(task.win_start & 15);
+            const int tw = (m + 15) / 16;
+#pragma unroll
+            for (int k = 0; k < MP_TH_MAXM / 16 + 1; k++)
+                if (k < tw) {
+                    uint64_t two = (uint64_t)text[q0 + k];
+                    if (sh) two |= (uint64_t)text[q0 + k + 1] << 32;              // (as dp_score_kernel: never a word past the window's last)
+                    w[k] = (uint32_t)(two >> sh);
+                }
+            // the longest run of matches on diagonal MARGIN (window row = read column + MARGIN)
+            int best = 0, best_at = 0, cur = 0;
+            const int lim = min(L, m - MP_TH_MARGIN);
+#pragma unroll
+            for (int k = 0; k < MP_TH_MAXL / 16; k++) {
+                const int at = 16 * k + MP_TH_MARGIN;                        // window base of read base 16 k
+                const uint64_t two = ((uint64_t)w[(at >> 4) + 1] << 32) | w[at >> 4];
+                uint32_t x = (uint32_t)(two >> (2 * (at & 15))) ^ a[k];
+                x = (x | (x >> 1)) & 0x55555555u;                           // bit 2u set: base 16 k + u differs
+                for (int u = 0; u < 16; u++) {
+                    const int j = 16 * k + u;
+                    const bool eq = j < lim && !((x >> (2 * u)) & 1u);
+                    cur = eq ? cur + 1 : 0;
+                    if (cur > best) { best = cur; best_at = j - cur + 1; }
+                }
+            }
+            j0 = best_at; rlen = best;
+            if (rlen < MP_TH_MINRUN) ok = false;
+        }
+    }
+    // ---------------------------------------------------------------- transposition: one ballot per word, both halves at once
+#pragma unroll
+    for (int k = 0; k < MP_TH_MAXL / 16; k++) {
+        uint32_t x = a[k];
+        for (int u = 0; u < 16; u++, x >>= 2) {
+            const int j = 16 * k + u;
+            const bool v = ok && j < L;
+            const unsigned long long b0 = __ballot(v && (x & 1u)), b1 = __ballot(v && (x & 2u)), bv = __ballot(v);
+            const unsigned long long br = __ballot(ok && j >= j0 && j < j0 + rlen);                 // a cell of the run sits in this column
+            const unsigned long long bl = __ballot(ok && j >= j0 - 1 && j < j0 + rlen - 1);         // the cells whose H' enters the bound on the run's left
+            const unsigned long long bg = __ballot(ok && j > j0);                                   // right of the run's first cell
+            if (l == 0) {
+                s_r0[h][j] = (uint32_t)(b0 >> (32 * h)); s_r1[h][j] = (uint32_t)(b1 >> (32 * h)); s_rv[h][j] = (uint32_t)(bv >> (32 * h));
+                s_run[h][j] = (uint32_t)(br >> (32 * h)); s_lc[h][j] = (uint32_t)(bl >> (32 * h)); s_gt[h][j] = (uint32_t)(bg >> (32 * h));
+            }
+        }
+    }
+    {
+        const unsigned long long bok = __ballot(ok);
+        if (l == 0) s_gt[h][MP_TH_MAXL] = (uint32_t)(bok >> (32 * h));
+    }
+    int mmax = 0;
+    s_w0[h][l] = 0; s_w1[h][l] = 0; s_wv[h][l] = 0; s_rg[h][l] = 0;
+    s_w0[h][MP_TH_MAXM + 32 + l] = 0; s_w1[h][MP_TH_MAXM + 32 + l] = 0; s_wv[h][MP_TH_MAXM + 32 + l] = 0; s_rg[h][MP_TH_MAXM + 32 + l] = 0;
+#pragma unroll
+    for (int k = 0; k < MP_TH_MAXM / 16; k++) {
+        uint32_t x = w[k];
+        for (int u = 0; u < 16; u++, x >>= 2) {
+            const int i = 16 * k + u;
+            const bool v = ok && i < m;
+            const unsigned long long b0 = __ballot(v && (x & 1u)), b1 = __ballot(v && (x & 2u)), bv = __ballot(v);
+            const unsigned long long bg = __ballot(ok && i > j0 + MP_TH_MARGIN);                    // rows below the run's first cell
+            if (l == 0) {
+                s_w0[h][32 + i] = (uint32_t)(b0 >> (32 * h)); s_w1[h][32 + i] = (uint32_t)(b1 >> (32 * h)); s_wv[h][32 + i] = (uint32_t)(bv >> (32 * h));
+                s_rg[h][32 + i] = (uint32_t)(bg >> (32 * h));
+            }
+            if (bv) mmax = i + 1;                                              // (wave-uniform)
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- this lane's columns
+    uint32_t R0[NC], R1[NC], RV[NC], RUN[NC], LC[NC], GT[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int j = NC * l + c;
+        R0[c] = s_r0[h][j]; R1[c] = s_r1[h][j]; RV[c] = s_rv[h][j]; RUN[c] = s_run[h][j]; LC[c] = s_lc[h][j]; GT[c] = s_gt[h][j];
+    }
+    uint32_t H[NC][T + 1], E[NC][TE + 1];          // [t], t = 1 ..; index 0 unused
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int t = 0; t <= T; t++) H[c][t] = 0;
+#pragma unroll
+        for (int t = 0; t <= TE; t++) E[c][t] = 0;
+    }
+    uint32_t inH[T + 1], inG[TE + 1];              // from the lane to the left: H planes of its last column one row up; G_t = H_{t+3} | F_{t+1} of that column, this row
+#pragma unroll
+    for (int t = 0; t <= T; t++) inH[t] = 0;
+#pragma unroll
+    for (int t = 0; t <= TE; t++) inG[t] = 0;
+    uint32_t outH[T + 1], outG[TE + 1];
+#pragma unroll
+    for (int t = 0; t <= T; t++) outH[t] = 0;
+#pragma unroll
+    for (int t = 0; t <= TE; t++) outG[t] = 0;
+    uint32_t accR[T + 1], accL[T + 1], ov = 0;     // accR: planes 5 .. 11 (a region maximum below 4 counts as 4); accL: planes 1 .. 5
+#pragma unroll
+    for (int t = 0; t <= T; t++) { accR[t] = 0; accL[t] = 0; }
+    const uint32_t nb = l ? 0xFFFFFFFFu : 0u;       // the first lane of a half has no left neighbour: its column -1 is the table's edge (H = 0)
+    const int steps = mmax + 31;
+    // Rows above the table (a lane starts l steps late) need no test: every input there is 0 and stays 0.  Rows below it are computed as rows
+    // that match nothing: what appears there is never above the cell it came from, so the accumulators may see it.
+    auto step = [&](const int s) __attribute__((always_inline)) {
+        // what the left neighbour published at the end of the previous step: its last column in MY row (G) and, kept from the step before, one row up (H)
+        uint32_t gotH[T + 1], gotG[TE + 1];
+#pragma unroll
+        for (int t = 1; t <= T; t++) gotH[t] = th_from_left_and(outH[t], nb);
+#pragma unroll
+        for (int t = 1; t <= TE; t++) gotG[t] = th_from_left_and(outG[t], nb);
+        const int ri = s - l + 32;                                              // my window row (i = s - l), as stored
+        const uint32_t wv = s_wv[h][ri], w0 = s_w0[h][ri], w1 = s_w1[h][ri], rowgt = s_rg[h][ri];
+        const int cd = s - (NC + 1) * l - MP_TH_MARGIN;                         // which of my columns lies on the seed's diagonal in this row (i - MARGIN - NC l)
+        // diagonal predecessor of column 0 = the neighbour's last column one row up (kept in inH); F-input of column 0 = gotG
+        uint32_t dH[T + 3];                           // H planes of the cell diagonally before the current column; [0] = all instances, [T+1 ..] = 0
+        dH[0] = 0xFFFFFFFFu; dH[T + 1] = 0; dH[T + 2] = 0;
+#pragma unroll
+        for (int t = 1; t <= T; t++) dH[t] = inH[t];
+        // G_t = F_t of the current cell = H_{t+3} | F_{t+1} of the cell to its left; for column 0 it arrives from the neighbour
+        uint32_t G[TE + 2];
+        G[TE + 1] = 0;
+#pragma unroll
+        for (int t = 1; t <= TE; t++) G[t] = gotG[t];
+        uint32_t U[T + 1];                            // planes 5 .. T-1 of this row, the lane's columns of the region OR-ed
+#pragma unroll
+        for (int t = 0; t <= T; t++) U[t] = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const uint32_t dm = cd == c ? 0xFFFFFFFFu : 0u;
+            // T': the run's cells are mismatches
+            const uint32_t M = ~((R0[c] ^ w0) | (R1[c] ^ w1)) & RV[c] & wv & ~(RUN[c] & dm);
+            // vertical gaps first: they read this column's planes of the row above, which are overwritten below
+#pragma unroll
+            for (int t = 1; t <= TE; t++) E[c][t] = H[c][t + 3] | (t < TE ? E[c][t + 1] : 0u);
+            uint32_t nH[T + 4];
+            nH[T + 1] = 0; nH[T + 2] = 0; nH[T + 3] = 0;
+#pragma unroll
+            for (int t = T; t >= 1; t--) {
+                const uint32_t d = (M & dH[t - 1]) | dH[t + 2];
+                nH[t] = t <= TE ? (d | E[c][t] | G[t]) : d;
+            }
+            // next column: its diagonal predecessor is this column's row above, the cell to its left this column's new row
+#pragma unroll
+            for (int t = 1; t <= T; t++) { dH[t] = H[c][t]; H[c][t] = nH[t]; }
+#pragma unroll
+            for (int t = 1; t <= TE; t++) G[t] = nH[t + 3] | G[t + 1];         // ascending: G[t + 1] is still the current cell's F_{t+1}
+            // the bound's ingredients
+            ov |= nH[T];
+#pragma unroll
+            for (int t = 5; t < T; t++) U[t] |= nH[t] & GT[c];
+            const uint32_t lcm = LC[c] & dm;
+#pragma unroll
+            for (int t = 1; t <= 5; t++) accL[t] |= nH[t] & lcm;
+        }
+#pragma unroll
+        for (int t = 5; t < T; t++) accR[t] |= U[t] & rowgt;
+        // publish for the right neighbour's next step; remember what the left neighbour's row was for my next step's diagonal
+#pragma unroll
+        for (int t = 1; t <= T; t++) { inH[t] = gotH[t]; outH[t] = H[NC - 1][t]; }
+#pragma unroll
+        for (int t = 1; t <= TE; t++) outG[t] = G[t];
+    };
+    for (int s = 0; s < steps; s += 2) { step(s); step(s + 1); }          // (an odd count runs one row further down: rows that match nothing)
+    // ---------------------------------------------------------------- per instance: OR over the lanes of its half, then read its bit
+    auto half_or = [&](uint32_t v) -> uint32_t {
+        for (int o = 1; o < 32; o <<= 1) v |= (uint32_t)__shfl_xor((int)v, o);
+        return v;
+    };
+    ov = half_or(ov);
+    int Rs = 4, Lm = 0;
+    bool l_big = false;
+#pragma unroll
+    for (int t = 5; t < T; t++) { const uint32_t v = half_or(accR[t]); if ((v >> l) & 1u) Rs = t; }
+#pragma unroll
+    for (int t = 1; t <= 5; t++) { const uint32_t v = half_or(accL[t]); if ((v >> l) & 1u) { Lm = t; if (t == 5) l_big = true; } }
+    if (!have) return;
+    // lane l of the half speaks for instance l of the half
+    const bool over = (ov >> l) & 1u;
+    const int cutoff = mp_dp_cutoff(L);
+    const bool certified = ok && !over && !l_big && T - 1 < cutoff && Lm + rlen + Rs < cutoff;       // (max H' <= 11 when there is no overflow)
+    cert[t_id] = certified ? 1 : 0;
+    if (stats) {
+        const unsigned long long c0 = __ballot(certified), c1 = __ballot(ok && over), c2 = __ballot(ok && !over && !certified), c3 = __ballot(!ok);
+        if (lane == 0) {
+            if (c0) atomicAdd(&stats[0], (unsigned long long)__popcll(c0));
+            if (c1) atomicAdd(&stats[1], (unsigned long long)__popcll(c1));
+            if (c2) atomicAdd(&stats[2], (unsigned long long)__popcll(c2));
+            if (c3) atomicAdd(&stats[3], (unsigned long long)__popcll(c3));
+        }
+    }
+}
+
+// flag[t] = 1 for the instances the certificate left undecided; the certified ones get the filter's answer "score 0"
+__global__ void thermo_flag_kernel(const uint8_t *__restrict__ cert, uint32_t n, uint32_t *__restrict__ flag, mp_fill_result *__restrict__ fill)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool c = cert[t] != 0;
+    flag[t] = c ? 0u : 1u;
+    if (c) { mp_fill_result z; z.score = 0; z.row = 0; z.col = 0; z.count = 0; fill[t] = z; }
+}

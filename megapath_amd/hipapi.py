@@ -57,6 +57,9 @@ class DpTask(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+DP_TASK_DTYPE = np.dtype([("read_id", "<u4"), ("strand", "<u4"), ("win_start", "<u8"), ("win_len", "<u4"), ("reserved", "<u4")])
+
+
 class DpResult(C.Structure):
     _fields_ = [("score", C.c_int32), ("hit_loc", C.c_uint32), ("max_score_count", C.c_uint32), ("n_ops", C.c_uint32)]
 
@@ -103,7 +106,7 @@ class IndexInfo(C.Structure):
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_clone", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_target_chr", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy", "mp_ctx_set_index",
-           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
+           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_thermo", "mp_ctx_dp_thermo_stats", "mp_test_dp_thermo", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_ctx_set_hit_copies", "mp_reduce_begin", "mp_reduce_chunk", "mp_reduce_finish", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
            "mp_test_sort_longer_seed", "mp_coverage_create", "mp_coverage_destroy", "mp_coverage_add", "mp_coverage_finish", "mp_coverage_seq_stats",
            "mp_coverage_spike_intervals", "mp_coverage_spike_bases", "mp_build_index_arrays"]
@@ -174,6 +177,9 @@ def load_library():
     lib.mp_ctx_set_dp_band.argtypes = [vp, C.c_int]
     lib.mp_ctx_dp_band_stats.argtypes = [vp, u64p, u64p]
     lib.mp_ctx_set_dp_census.argtypes = [vp, C.c_int]
+    lib.mp_ctx_set_dp_thermo.argtypes = [vp, C.c_int]
+    lib.mp_ctx_dp_thermo_stats.argtypes = [vp, vp]
+    lib.mp_test_dp_thermo.argtypes = [vp, vp, C.c_uint32, vp, vp]
     lib.mp_ctx_get_dp_census.argtypes = [vp, C.POINTER(DpCensus)]
     lib.mp_ctx_create.argtypes = [vp, C.POINTER(vp)]
     lib.mp_ctx_destroy.argtypes = [vp]
@@ -438,6 +444,33 @@ class Context:
 
     def set_dp_band(self, on: bool):
         _chk(load_library().mp_ctx_set_dp_band(self._h, int(bool(on))), "mp_ctx_set_dp_band")
+
+    def set_dp_thermo(self, on: bool):
+        _chk(load_library().mp_ctx_set_dp_thermo(self._h, int(bool(on))), "mp_ctx_set_dp_thermo")
+
+    def dp_thermo_stats(self):
+        """instances seen by the certificate kernel: (certified, overflow, bound too high, not eligible)"""
+        out = (C.c_uint64 * 4)()
+        _chk(load_library().mp_ctx_dp_thermo_stats(self._h, out), "mp_ctx_dp_thermo_stats")
+        return tuple(int(x) for x in out)
+
+    def test_dp_thermo(self, tasks_np: np.ndarray):
+        """test hook: the certificate kernel on a numpy array of DP_TASK_DTYPE records -> (cert u8[n], stats)"""
+        assert tasks_np.dtype == DP_TASK_DTYPE and tasks_np.flags.c_contiguous
+        n = len(tasks_np)
+        cert = np.zeros(max(n, 1), dtype=np.uint8)
+        st = (C.c_uint64 * 4)()
+        _chk(load_library().mp_test_dp_thermo(self._h, tasks_np.ctypes.data, n, cert.ctypes.data, st), "mp_test_dp_thermo")
+        return cert[:n], tuple(int(x) for x in st)
+
+    def sgdp_scores(self, tasks_np: np.ndarray, clip_left: int, clip_right: int) -> np.ndarray:
+        """exact DP scores (no operations) of a numpy array of DP_TASK_DTYPE records"""
+        assert tasks_np.dtype == DP_TASK_DTYPE and tasks_np.flags.c_contiguous
+        n = len(tasks_np)
+        res = np.zeros(max(n, 1), dtype=np.dtype([("score", "<i4"), ("hit_loc", "<u4"), ("max_score_count", "<u4"), ("n_ops", "<u4")]))
+        f, t = C.c_float(), C.c_float()
+        _chk(load_library().mp_sgdp_batch(self._h, tasks_np.ctypes.data, n, clip_left, clip_right, res.ctypes.data, None, 0, C.byref(f), C.byref(t)), "mp_sgdp_batch")
+        return res["score"][:n].copy()
 
     def set_dp_census(self, on: bool):
         _chk(load_library().mp_ctx_set_dp_census(self._h, int(bool(on))), "mp_ctx_set_dp_census")

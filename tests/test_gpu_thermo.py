@@ -1,0 +1,131 @@
+"""The certificate kernel in front of the single-end rescue filter (kernels_thermo.hip): it may certify an instance only if the exact DP
+(callDP, CPU_DP.cpp:122-978, here dp_fill_kernel which the golden vectors pin) stays below the cutoff -- never the other way round."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _comp_rev(codes):
+    return (3 - codes)[::-1]
+
+
+def _make_instances(rng, text, n, kinds):
+    """n (read, window) instances of mixed kinds; returns (list of read code arrays as stored, tasks array, kind per instance)"""
+    from megapath_amd import hipapi as H
+    N = len(text)
+    reads, tasks, kind = [], np.zeros(n, dtype=H.DP_TASK_DTYPE), np.zeros(n, dtype=np.int32)
+    for t in range(n):
+        L = int(rng.integers(101, 161))
+        m = L + 60
+        ws = int(rng.integers(0, N - m - 64))
+        win = text[ws:ws + m]
+        k = int(kinds[rng.integers(0, len(kinds))])
+        rd = rng.integers(0, 4, L).astype(np.uint8)
+        if k in (0, 7):     # a chance seed: a run of 17 .. 19 (7: 12 .. 26) on the seed's diagonal, nothing else
+            r = int(rng.integers(17, 20)) if k == 0 else int(rng.integers(12, 27)); j0 = int(rng.integers(0, L - r + 1))
+            rd[j0:j0 + r] = win[30 + j0:30 + j0 + r]
+        elif k == 1:        # near the cutoff: the run, then a second exact stretch right after a mismatch or a short gap (same or shifted diagonal)
+            r = int(rng.integers(14, 24)); e = int(rng.integers(5, 20)); sh = int(rng.integers(-3, 4))
+            j0 = int(rng.integers(0, L - r - e - 8)); j1 = j0 + r + 1 + max(0, -sh)
+            rd[j0:j0 + r] = win[30 + j0:30 + j0 + r]
+            rd[j1:j1 + e] = win[30 + sh + j1:30 + sh + j1 + e]
+        elif k == 2:        # as 1 but the second stretch BEFORE the run
+            r = int(rng.integers(14, 24)); e = int(rng.integers(5, 20)); sh = int(rng.integers(-3, 4))
+            j0 = int(rng.integers(e + 8, L - r)); j1 = j0 - 1 - e - max(0, sh)
+            rd[j0:j0 + r] = win[30 + j0:30 + j0 + r]
+            rd[j1:j1 + e] = win[30 + sh + j1:30 + sh + j1 + e]
+        elif k == 3:        # a true alignment with a few mismatches and possibly an indel
+            rd = win[30:30 + L].copy()
+            for _ in range(int(rng.integers(0, 12))):
+                rd[rng.integers(0, L)] = rng.integers(0, 4)
+            if rng.random() < 0.5:
+                p = int(rng.integers(20, L - 20)); g = int(rng.integers(1, 6))
+                rd = np.concatenate([rd[:p], rd[p + g:], rng.integers(0, 4, g).astype(np.uint8)]) if rng.random() < 0.5 else np.concatenate([rd[:p], rng.integers(0, 4, g).astype(np.uint8), rd[p:L - g]])
+        elif k == 4:        # stretches on both sides of the run, and a partial alignment of ~ cutoff matches with mismatches inside
+            r = int(rng.integers(12, 20)); j0 = int(rng.integers(30, L - r - 30))
+            rd[j0:j0 + r] = win[30 + j0:30 + j0 + r]
+            a = int(rng.integers(4, 14)); b = int(rng.integers(4, 14))
+            rd[j0 - 1 - a:j0 - 1] = win[30 + j0 - 1 - a:30 + j0 - 1]
+            rd[j0 + r + 1:j0 + r + 1 + b] = win[30 + j0 + r + 1:30 + j0 + r + 1 + b]
+        elif k == 5:        # low complexity: read and window share a short tandem repeat (many diagonals match)
+            unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.uint8)
+            rep = np.tile(unit, 300)
+            a = int(rng.integers(0, 40)); b = min(int(rng.integers(20, 90)), L - a)
+            win = win.copy(); win[30 + a:30 + a + b] = rep[:b]
+            text[ws:ws + m] = win
+            rd[a:a + b] = rep[:b]
+        # k == 6: a random read (no run: not eligible)
+        strand = 1 + int(rng.integers(0, 2))
+        reads.append(rd if strand == 1 else _comp_rev(rd))
+        tasks[t] = (t, strand, ws, m, 0)
+        kind[t] = k
+    return reads, tasks, kind
+
+
+@pytest.mark.parametrize("kinds,seed", [((0,), 1), ((7, 1, 2, 4), 2), ((0, 1, 2, 3, 4, 5, 6, 7), 3)])
+def test_certificate_never_rejects_an_alignment(kinds, seed):
+    from megapath_amd import hipapi as H
+    from megapath_amd.index_builder import build_index_arrays
+    import oracle_lib as O
+    rng = np.random.default_rng(seed)
+    text = rng.integers(0, 4, 1 << 20).astype(np.uint8)
+    n = 60000
+    reads, tasks, kind = _make_instances(rng, text, n, kinds)          # (kind 5 plants repeats into the text: build the index afterwards)
+    arrs = build_index_arrays([("t", text)], sa_interval=16)
+    ix = H.Index.from_arrays(0, **arrs)
+    ctx = H.Context(ix)
+    seqs = [bytes(b"ACGT"[c] for c in r) for r in reads]
+    packed, lens, W = H.pack_reads(seqs, 161)
+    ctx.set_reads(packed, lens)
+    cert, st = ctx.test_dp_thermo(tasks)
+    score = ctx.sgdp_scores(tasks, 130, 130)
+    cutoff = np.maximum(30, (0.2 * lens[tasks["read_id"]]).astype(np.int64))
+    bad = np.nonzero((cert != 0) & (score >= cutoff))[0]
+    assert len(bad) == 0, (bad[:10], score[bad[:10]], kind[bad[:10]])
+    assert sum(st) == n and st[0] == int((cert != 0).sum())
+    # the exact scores themselves against the oracle's callDP on a sample (dp_fill_kernel is pinned by the golden vectors; this guards the harness)
+    for t in rng.integers(0, n, 40):
+        rd = reads[t] if tasks["strand"][t] == 1 else _comp_rev(reads[t])
+        ws, m = int(tasks["win_start"][t]), int(tasks["win_len"][t])
+        want = O.sgdp(text[ws:ws + m], np.ascontiguousarray(rd), 130, 130)
+        got = int(score[t])
+        assert (got if got >= cutoff[t] else 0) == (want[0] if want[0] >= cutoff[t] else 0), t
+    # usefulness: pure chance seeds are nearly all certified
+    if kinds == (0,):
+        assert st[0] > 0.9 * n, st
+    if 3 in kinds:
+        assert not cert[(kind == 3) & (score >= cutoff)].any()
+    ctx.close()
+    ix.close()
+
+
+def test_rescue_round_equal_with_and_without_certificate():
+    """the product path: the same single-end and mate-rescue hits with the certificate on and off (17-base seeds, many random and broken mates)"""
+    import ctypes as C
+    from megapath_amd import hipapi as H, index_builder, synth
+    genome = synth.random_genome(3000000, 77, n_seqs=2, repeat_frac=0.05)
+    arrs = index_builder.build_index_arrays(genome, sa_interval=16)
+    ix = H.Index.from_arrays(0, **arrs)
+    names, r1, r2 = synth.simulate_pairs(genome, 20000, 151, 78, sub=0.02, ins=0.001, dele=0.001, random_frac=0.3, broken_mate_frac=0.3, noisy_mate_frac=0.2,
+                                         junk_end_frac=0.2)
+    seqs = [x for pr in zip(r1, r2) for x in pr]
+    packed, lens, W = H.pack_reads(seqs, 152)
+    outs = []
+    for on in (True, False):
+        ctx = H.Context(ix)
+        ctx.set_dp_thermo(on)
+        ctx.set_reads(packed, lens)
+        ctx.seed_batch(H.MmpParams.nt2())
+        ap = H.AlignParams(1, 750, 130, 130, H.MmpParams.nt2())
+        ctx.deep_dp_round(ap)
+        (sh, ns), (rh, nr), st = ctx.rescue_round(ap)
+        a = C.string_at(C.addressof(sh), ns * C.sizeof(H.SingleHit)) if ns else b""
+        b = C.string_at(C.addressof(rh), nr * C.sizeof(H.RescueHit)) if nr else b""
+        outs.append((a, b, ns, nr, ctx.dp_thermo_stats()))
+        ctx.close()
+    assert outs[0][2] > 1000 and outs[0][3] > 100
+    assert outs[0][:4] == outs[1][:4]
+    assert outs[0][4][0] > 0 and outs[1][4] == (0, 0, 0, 0)
+    ix.close()

@@ -483,10 +483,12 @@ def nt_replica_leg(args, H, index_builder, simulate, arrs_a, text_a, dev, device
         one_step(None)                                            # first touch of the batch buffers
         torch.cuda.synchronize()
         acc = {"source_chunk": {}, "other_chunks": {}}
+        th_a = ctx.dp_thermo_stats()
         t3 = time.perf_counter()
         one_step(acc)
         torch.cuda.synchronize()
         el_single = time.perf_counter() - t3
+        th_b = ctx.dp_thermo_stats()
         # how many reads have NO seed of >= 17 bases in a chunk that is not theirs (what a per-chunk pre-screen could skip): the kept seed
         # positions of the batch against chunk 1, per read
         seedless = None
@@ -564,6 +566,10 @@ def nt_replica_leg(args, H, index_builder, simulate, arrs_a, text_a, dev, device
                              if cpu_nt else None),
             "kernel_ms_per_chunk_other_chunks": per_chunk_ms, "kernel_ms_source_chunk": {k: acc["source_chunk"].get(k, 0.0) for k in keys},
             "foreign_chunk_seed_census": seedless,
+            "rescue_certificate_per_pair_per_chunk": dict(zip(("certified_no_alignment", "score_of_%d_elsewhere" % 10, "bound_reaches_cutoff", "not_eligible"),
+                                                              [(b - a) / (lp * n_chunks) for a, b in zip(th_a, th_b)]),
+                                                          note="dp_thermo_kernel (kernels_thermo.hip) over the single-end rescue instances of the one-context step: "
+                                                               "only what it does not certify goes through the score-only filter"),
             "per_pair_per_other_chunk": {k: o.get(k, 0) / (n_o * lp) for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seeds", "n_hits", "n_seedpos", "single_dp_tasks", "single_hits", "pair_hits")},
             "roofline": {"bound": "hbm", "kernel": "seed_kernel+seed_overflow_kernel+expand_hits_kernel+locate_kernel (lean layout, all chunks of the step)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -909,9 +915,9 @@ def main():
             _, _, st0, _ = step(ctx, wl, params)
             ref_events = dict(occ=int(st0.seed.n_occ), lkt=int(st0.seed.n_lkt), sa=int(st0.seed.n_sa), seedpos=int(st0.seed.n_seedpos))
             ctx.set_prefilter(True)
-    band0 = ctx.dp_band_stats()
+    band0, th0 = ctx.dp_band_stats(), ctx.dp_thermo_stats()
     elapsed_single, acc = run_steps(ctx, wl, params, args.steps, barrier)
-    band1 = ctx.dp_band_stats()
+    band1, th1 = ctx.dp_band_stats(), ctx.dp_thermo_stats()
     elapsed = elapsed_single
     n_ctx = max(1, args.contexts) if not args.pmc_child else 1
     if n_ctx > 1:
@@ -1008,6 +1014,8 @@ def main():
                                                    "note": "(window+1) x read length of every instance submitted (SURVEY 8d; what callDP computes): a work-equivalent "
                                                            "rate, the kernels skip most of these cells"},
                          "band_instances_per_step": (band1[0] - band0[0]) / K, "band_left_to_full_table_per_step": (band1[1] - band0[1]) / K,
+                         "rescue_certificate_per_step": dict(zip(("certified_no_alignment", "score_of_10_elsewhere", "bound_reaches_cutoff", "not_eligible"),
+                                                                 [(b - a) / K for a, b in zip(th0, th1)])),
                          "fill_ms_per_step": t_dp_s * 1e3,
                          "note": "integer max/add recurrences: VALU-bound, no MFMA, not an HBM roofline (SURVEY 8d).  Cells counted on the device by "
                                  "mp_ctx_set_dp_census in one untimed step of the same batch; empty mate-rescue slots and instances the block-match "

@@ -1025,7 +1025,7 @@ extern "C" int mp_test_dp_thermo(mp_ctx *c, const mp_dp_task *tasks, uint32_t n,
     if (c->tasks_tmp.reserve(n) || c->th_cert.reserve(n + 64) || c->th_stats.reserve(4)) return MP_ENOMEM;
     HIPCHK(hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(dp_thermo_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p,
+    hipLaunchKernelGGL(dp_thermo_kernel<MP_TH_T>, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p,
                        (const uint32_t *)nullptr, c->th_stats.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_cert, c->th_cert.p, n, hipMemcpyDeviceToHost, s));
@@ -1320,7 +1320,7 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     if (thermo) {
         if (c->th_cert.reserve(n + 64) || c->th_stats.reserve(4) || c->score_list.reserve(n + 2)) return MP_ENOMEM;
         HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(dp_thermo_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
+        hipLaunchKernelGGL(dp_thermo_kernel<MP_TH_T>, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
                            (const uint32_t *)nullptr, c->th_stats.p);
         MP_TRACE(s, "dp_thermo_kernel");
         hipLaunchKernelGGL(thermo_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint8_t *)c->th_cert.p, n, c->sel_flag.p, c->fill.p);

@@ -13,26 +13,26 @@
 // because a path either never uses a cell of R diagonally (a path of T') or is a path of T' into R, a stretch of R (leaving R and coming
 // back costs two gaps and skips matches), and a path of T' out of R.  If that bound is below the cutoff the instance is decided: no alignment.
 //
-// H' is never formed as numbers.  PLANES H_t = [H' >= t], t = 1 .. 12, one bit per instance: a word holds the SAME cell of 32 instances, so
+// H' is never formed as numbers.  PLANES H_t = [H' >= t], t = 1 .. T (10), one bit per instance: a word holds the SAME cell of 32 instances, so
 //   E_t = Hup_{t+3} | Eup_{t+1}        F_t = Hleft_{t+3} | Fleft_{t+1}        D_t = (M & Hdiag_{t-1}) | Hdiag_{t+2}        H_t = D_t | E_t | F_t
 // are four logic instructions per plane and cell for 32 instances at once, with no shifts and no carries (M = the instances whose window base
-// equals their read base in this cell).  A plane 12 bit anywhere means max H' >= 12: no certificate (the filter runs as before).
+// equals their read base in this cell).  A plane T bit anywhere means max H' >= T: no certificate (the filter runs as before).  T = 10: a
+// random 150 x 210 table reaches 10 in about 2 % of the instances (12: 0.2 %), and two planes fewer are 20 % fewer instructions.
 // Mapping: a wavefront takes 64 instances, 32 per half; lane l of a half owns read columns 5l .. 5l+4 and walks the window rows on an
 // anti-diagonal (row = step - l): what it needs from the column to its left comes from lane l-1's previous step by DPP.  The reads and
 // windows are transposed into bit-sliced form with one ballot per word (both halves at once), straight into LDS.
+// Measured (profiles/r03_*): 60 single-end instances per pair and chunk of the NT stage, 95 % certified; 6.6 ms for 3.95 M instances where
+// dp_score_kernel took 18.5 ms -- 230 instructions per step of five cells x 32 instances, 1.4 per cell and instance.
 #pragma once
 
-#define MP_TH_T 12                 // planes: values 1 .. 12; plane 12 set anywhere = overflow, no certificate
-#define MP_TH_TE 9                 // E and F never exceed max H' - 3
+#define MP_TH_T 10                 // planes: values 1 .. T; plane T set anywhere = overflow, no certificate (E and F never exceed max H' - 3: T - 3 planes)
 #define MP_TH_COLS 5               // read columns per lane: 32 lanes x 5 = 160
 #define MP_TH_MAXL 160
 #define MP_TH_MAXM 224
 #define MP_TH_MARGIN 30            // DP2_MARGIN for reads longer than 100 bases (DV-DPfunctions.cpp:1760): the seed's diagonal
 #define MP_TH_MINRUN 12            // a run shorter than this is no seed: no certificate
 
-// lane l receives lane l-1's value (whole wavefront; lane 0 keeps its own, masked by the caller)
-__device__ __forceinline__ uint32_t th_from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
-// the same and the mask of "has a left neighbour" in ONE instruction (lane 0, which has no source, reads 0)
+// lane l receives lane l-1's value AND-ed with the mask of "has a left neighbour", in ONE instruction (lane 0, which has no source, reads 0)
 __device__ __forceinline__ uint32_t th_from_left_and(uint32_t v, uint32_t mask)
 {
     uint32_t r;
@@ -42,16 +42,18 @@ __device__ __forceinline__ uint32_t th_from_left_and(uint32_t v, uint32_t mask)
 
 // cert[t] = 1: instance t cannot reach its cutoff (no alignment); 0: undecided, the filter has to look at it.
 // `list` (may be null): slot s stands for instance list[s].
+template <int T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                  const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list,
                  unsigned long long *__restrict__ stats /* [0] certified [1] overflow [2] bound too high [3] not eligible */)
 {
-    constexpr int T = MP_TH_T, TE = MP_TH_TE, NC = MP_TH_COLS;
+    constexpr int TE = T - 3, NC = MP_TH_COLS;
+    static_assert(T >= 8 && T <= 14, "planes");
     // bit-sliced inputs of the two halves (index h = lane >> 5): one word = one column (row) of 32 instances
-    __shared__ uint32_t s_r0[2][MP_TH_MAXL], s_r1[2][MP_TH_MAXL], s_rv[2][MP_TH_MAXL], s_run[2][MP_TH_MAXL], s_lc[2][MP_TH_MAXL], s_gt[2][MP_TH_MAXL + 1];
-    // window rows are stored 32 further down with 32 empty rows on either side: the anti-diagonal sweep reads rows -31 .. mmax + 30 without a test
-    __shared__ uint32_t s_w0[2][MP_TH_MAXM + 64], s_w1[2][MP_TH_MAXM + 64], s_wv[2][MP_TH_MAXM + 64], s_rg[2][MP_TH_MAXM + 64];
+    __shared__ uint32_t s_r0[2][MP_TH_MAXL], s_r1[2][MP_TH_MAXL], s_rv[2][MP_TH_MAXL], s_run[2][MP_TH_MAXL], s_lc[2][MP_TH_MAXL], s_gt[2][MP_TH_MAXL];
+    // window rows are stored 32 further down with empty rows on either side: the anti-diagonal sweep reads rows -31 .. mmax + 35 without a test
+    __shared__ uint32_t s_w0[2][MP_TH_MAXM + 72], s_w1[2][MP_TH_MAXM + 72], s_wv[2][MP_TH_MAXM + 72], s_rg[2][MP_TH_MAXM + 72];
     const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
     const uint32_t slot = blockIdx.x * 64 + lane;
     const bool have = slot < n_tasks;
@@ -120,13 +122,10 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
             }
         }
     }
-    {
-        const unsigned long long bok = __ballot(ok);
-        if (l == 0) s_gt[h][MP_TH_MAXL] = (uint32_t)(bok >> (32 * h));
-    }
     int mmax = 0;
     s_w0[h][l] = 0; s_w1[h][l] = 0; s_wv[h][l] = 0; s_rg[h][l] = 0;
     s_w0[h][MP_TH_MAXM + 32 + l] = 0; s_w1[h][MP_TH_MAXM + 32 + l] = 0; s_wv[h][MP_TH_MAXM + 32 + l] = 0; s_rg[h][MP_TH_MAXM + 32 + l] = 0;
+    if (l < 8) { s_w0[h][MP_TH_MAXM + 64 + l] = 0; s_w1[h][MP_TH_MAXM + 64 + l] = 0; s_wv[h][MP_TH_MAXM + 64 + l] = 0; s_rg[h][MP_TH_MAXM + 64 + l] = 0; }
 #pragma unroll
     for (int k = 0; k < MP_TH_MAXM / 16; k++) {
         uint32_t x = w[k];
@@ -168,14 +167,18 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
     for (int t = 0; t <= T; t++) outH[t] = 0;
 #pragma unroll
     for (int t = 0; t <= TE; t++) outG[t] = 0;
-    uint32_t accR[T + 1], accL[T + 1], ov = 0;     // accR: planes 5 .. 11 (a region maximum below 4 counts as 4); accL: planes 1 .. 5
+    uint32_t accR[T + 1], accL[T + 1], ov = 0;     // accR: planes 5 .. T-1 (a region maximum below 4 counts as 4); accL: planes 1 .. 5
 #pragma unroll
     for (int t = 0; t <= T; t++) { accR[t] = 0; accL[t] = 0; }
     const uint32_t nb = l ? 0xFFFFFFFFu : 0u;       // the first lane of a half has no left neighbour: its column -1 is the table's edge (H = 0)
     const int steps = mmax + 31;
     // Rows above the table (a lane starts l steps late) need no test: every input there is 0 and stays 0.  Rows below it are computed as rows
     // that match nothing: what appears there is never above the cell it came from, so the accumulators may see it.
-    auto step = [&](const int s) __attribute__((always_inline)) {
+    // The seed's diagonal meets lane l in its column K at step s = (NC + 1) l + MARGIN + K: with the steps taken NC + 1 at a time, K is a
+    // compile-time constant of each of them (K = NC: between two lanes) and only ONE lane of a half is on the diagonal at all.
+    static_assert(MP_TH_MARGIN % (NC + 1) == 0, "the diagonal's column must be the step number modulo NC + 1");
+    auto step = [&](auto kc, const int s) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;
         // what the left neighbour published at the end of the previous step: its last column in MY row (G) and, kept from the step before, one row up (H)
         uint32_t gotH[T + 1], gotG[TE + 1];
 #pragma unroll
@@ -184,7 +187,7 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
         for (int t = 1; t <= TE; t++) gotG[t] = th_from_left_and(outG[t], nb);
         const int ri = s - l + 32;                                              // my window row (i = s - l), as stored
         const uint32_t wv = s_wv[h][ri], w0 = s_w0[h][ri], w1 = s_w1[h][ri], rowgt = s_rg[h][ri];
-        const int cd = s - (NC + 1) * l - MP_TH_MARGIN;                         // which of my columns lies on the seed's diagonal in this row (i - MARGIN - NC l)
+        const uint32_t onl = (NC + 1) * l + MP_TH_MARGIN + K == s ? 0xFFFFFFFFu : 0u;   // this lane's column K is on the seed's diagonal
         // diagonal predecessor of column 0 = the neighbour's last column one row up (kept in inH); F-input of column 0 = gotG
         uint32_t dH[T + 3];                           // H planes of the cell diagonally before the current column; [0] = all instances, [T+1 ..] = 0
         dH[0] = 0xFFFFFFFFu; dH[T + 1] = 0; dH[T + 2] = 0;
@@ -195,14 +198,13 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
         G[TE + 1] = 0;
 #pragma unroll
         for (int t = 1; t <= TE; t++) G[t] = gotG[t];
-        uint32_t U[T + 1];                            // planes 5 .. T-1 of this row, the lane's columns of the region OR-ed
+        uint32_t U[T + 1];                            // planes 5 .. T-1 of this row, OR-ed over the lane's columns
 #pragma unroll
         for (int t = 0; t <= T; t++) U[t] = 0;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            const uint32_t dm = cd == c ? 0xFFFFFFFFu : 0u;
-            // T': the run's cells are mismatches
-            const uint32_t M = ~((R0[c] ^ w0) | (R1[c] ^ w1)) & RV[c] & wv & ~(RUN[c] & dm);
+            uint32_t M = ~((R0[c] ^ w0) | (R1[c] ^ w1)) & RV[c] & wv;
+            if (c == K) M &= ~(RUN[c] & onl);                                   // T': the run's cells are mismatches
             // vertical gaps first: they read this column's planes of the row above, which are overwritten below
 #pragma unroll
             for (int t = 1; t <= TE; t++) E[c][t] = H[c][t + 3] | (t < TE ? E[c][t + 1] : 0u);
@@ -221,20 +223,29 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
             // the bound's ingredients
             ov |= nH[T];
 #pragma unroll
-            for (int t = 5; t < T; t++) U[t] |= nH[t] & GT[c];
-            const uint32_t lcm = LC[c] & dm;
+            for (int t = 5; t < T; t++) U[t] |= nH[t];
+            if (c == K) {
+                const uint32_t lcm = LC[c] & onl;
 #pragma unroll
-            for (int t = 1; t <= 5; t++) accL[t] |= nH[t] & lcm;
+                for (int t = 1; t <= 5; t++) accL[t] |= nH[t] & lcm;
+            }
         }
+        // the region right of and below the run's first cell, a lane's columns taken together (up to NC - 1 columns more than the region:
+        // a larger maximum can only withhold a certificate)
+        const uint32_t reg = rowgt & GT[NC - 1];
 #pragma unroll
-        for (int t = 5; t < T; t++) accR[t] |= U[t] & rowgt;
+        for (int t = 5; t < T; t++) accR[t] |= U[t] & reg;
         // publish for the right neighbour's next step; remember what the left neighbour's row was for my next step's diagonal
 #pragma unroll
         for (int t = 1; t <= T; t++) { inH[t] = gotH[t]; outH[t] = H[NC - 1][t]; }
 #pragma unroll
         for (int t = 1; t <= TE; t++) outG[t] = G[t];
     };
-    for (int s = 0; s < steps; s += 2) { step(s); step(s + 1); }          // (an odd count runs one row further down: rows that match nothing)
+    static_assert(NC == 5, "six steps per turn");
+    for (int s = 0; s < steps; s += NC + 1) {         // (the last turn may run up to five rows further down: rows that match nothing)
+        step(std::integral_constant<int, 0>{}, s); step(std::integral_constant<int, 1>{}, s + 1); step(std::integral_constant<int, 2>{}, s + 2);
+        step(std::integral_constant<int, 3>{}, s + 3); step(std::integral_constant<int, 4>{}, s + 4); step(std::integral_constant<int, 5>{}, s + 5);
+    }
     // ---------------------------------------------------------------- per instance: OR over the lanes of its half, then read its bit
     auto half_or = [&](uint32_t v) -> uint32_t {
         for (int o = 1; o < 32; o <<= 1) v |= (uint32_t)__shfl_xor((int)v, o);
@@ -251,7 +262,7 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
     // lane l of the half speaks for instance l of the half
     const bool over = (ov >> l) & 1u;
     const int cutoff = mp_dp_cutoff(L);
-    const bool certified = ok && !over && !l_big && T - 1 < cutoff && Lm + rlen + Rs < cutoff;       // (max H' <= 11 when there is no overflow)
+    const bool certified = ok && !over && !l_big && T - 1 < cutoff && Lm + rlen + Rs < cutoff;       // (max H' <= T - 1 when there is no overflow)
     cert[t_id] = certified ? 1 : 0;
     if (stats) {
         const unsigned long long c0 = __ballot(certified), c1 = __ballot(ok && over), c2 = __ballot(ok && !over && !certified), c3 = __ballot(!ok);

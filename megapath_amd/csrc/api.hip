@@ -1025,8 +1025,10 @@ extern "C" int mp_test_dp_thermo(mp_ctx *c, const mp_dp_task *tasks, uint32_t n,
     if (c->tasks_tmp.reserve(n) || c->th_cert.reserve(n + 64) || c->th_stats.reserve(4)) return MP_ENOMEM;
     HIPCHK(hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(dp_thermo_kernel<MP_TH_T>, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p,
-                       (const uint32_t *)nullptr, c->th_stats.p);
+    if (c->max_len <= MP_TH_MAXL) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                                                     (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p, (const uint32_t *)nullptr, c->th_stats.p);
+    else hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), dim3(grid_for(n, 32)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
+                            (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p, (const uint32_t *)nullptr, c->th_stats.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_cert, c->th_cert.p, n, hipMemcpyDeviceToHost, s));
     unsigned long long ths[4];
@@ -1146,7 +1148,8 @@ void fill_round(const mp_ctx *c, bool count, uint32_t *out)
 }
 
 template <int LPI, int C>
-void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, mp_fill_result *fill, const uint32_t *only = nullptr, uint32_t n_only = 0)
+void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int cl, int cr, mp_fill_result *fill, const uint32_t *only = nullptr, uint32_t n_only = 0,
+                  const uint8_t *skip = nullptr /* instances the certificate kernel decided (mixed-length batches: the lists are made per length class) */)
 {
     if (only && c->max_len <= 8 * 20) {
         // the instances the certificate kernel left undecided (dp_thermo_kernel), by list
@@ -1172,7 +1175,7 @@ void launch_score(hipStream_t s, const mp_ctx *c, const mp_dp_task *tasks, uint3
                 for (int k = 0; k < 4; k++) {
                     if (c->max_len <= bounds[k]) break;
                     if (cc->sel_flag.reserve(n + 2) || cc->sel_idx.reserve(n + 2)) return false;
-                    hipLaunchKernelGGL(dp_len_class_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, tasks, c->d_lens, n, bounds[k], bounds[k + 1], cc->sel_flag.p);
+                    hipLaunchKernelGGL(dp_len_class_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, tasks, c->d_lens, n, bounds[k], bounds[k + 1], cc->sel_flag.p, skip);
                     size_t tmp_bytes = 0;
                     (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, cc->sel_flag.p, cc->sel_idx.p, (int)n, s);
                     if (cc->cub_tmp.reserve(tmp_bytes + 256)) return false;
@@ -1315,13 +1318,16 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     // Windows around a seed (read + 2 x 30) of reads of 101 .. 160 bases: most are chance seeds whose table holds nothing else.  dp_thermo_kernel
     // certifies that for 32 instances per word (kernels_thermo.hip); only what it leaves undecided goes through the score-only filter.
     static const bool thermo_env = !getenv("MP_DP_THERMO") || atoi(getenv("MP_DP_THERMO")) != 0;
-    const bool thermo = thermo_env && c->use_thermo && c->max_len > 100 && c->max_len <= MP_TH_MAXL && max_win <= MP_TH_MAXM && n >= 64;
+    const bool narrow = c->max_len <= MP_TH_MAXL && max_win <= MP_TH_MAXM;             // two sets of 32 instances per wavefront; otherwise one (reads of up to 320 bases)
+    const bool thermo = thermo_env && c->use_thermo && c->max_len > 100 && (narrow || (c->max_len <= MP_TH_MAXL_WIDE && max_win <= MP_TH_MAXM_WIDE)) && n >= 64;
     HIPCHK(hipEventRecord(c->ev_pool[0], s));
     if (thermo) {
         if (c->th_cert.reserve(n + 64) || c->th_stats.reserve(4) || c->score_list.reserve(n + 2)) return MP_ENOMEM;
         HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(dp_thermo_kernel<MP_TH_T>, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
-                           (const uint32_t *)nullptr, c->th_stats.p);
+        if (narrow) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
+                                       (const uint32_t *)nullptr, c->th_stats.p);
+        else hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), dim3(grid_for(n, 32)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
+                                (const uint32_t *)nullptr, c->th_stats.p);
         MP_TRACE(s, "dp_thermo_kernel");
         hipLaunchKernelGGL(thermo_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint8_t *)c->th_cert.p, n, c->sel_flag.p, c->fill.p);
         int rc0 = exclusive_scan_inclusive_u32(c, c->sel_flag.p, c->sel_idx.p, n);
@@ -1335,7 +1341,8 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
         if (n_und) {
             hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, n, c->score_list.p, (const uint32_t *)nullptr);
             census_add(c, CENSUS_FULL_SCORE, d_tasks, c->score_list.p, n_und, 0);
-            MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p, (const uint32_t *)c->score_list.p, n_und);
+            if (narrow) { MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p, (const uint32_t *)c->score_list.p, n_und); }
+            else { MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p, (const uint32_t *)nullptr, 0u, (const uint8_t *)c->th_cert.p); }
         }
     } else {
         census_add(c, CENSUS_FULL_SCORE, d_tasks, nullptr, n, 0);

@@ -648,12 +648,14 @@ dp_trace_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict
 
 // flag[t] = 1 for the instances whose read has lo < length <= hi (length classes of a mixed batch: the score-only pre-pass
 // runs a kernel of matching width over each class)
-__global__ void dp_len_class_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, uint32_t n, uint32_t lo, uint32_t hi, uint32_t *__restrict__ flag)
+// `skip` (may be null): instances already decided (dp_thermo_kernel's certificates) belong to no class
+__global__ void dp_len_class_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ lens, uint32_t n, uint32_t lo, uint32_t hi, uint32_t *__restrict__ flag,
+                                    const uint8_t *__restrict__ skip)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t L = lens[tasks[t].read_id];
-    flag[t] = (L > lo && L <= hi) ? 1u : 0u;
+    flag[t] = (L > lo && L <= hi && !(skip && skip[t])) ? 1u : 0u;
 }
 
 // flag[t] = 1 for the task slots that hold an instance (mate rescue reserves four slots per read and fills those it has a hit for)

@@ -4,7 +4,7 @@
 // The instances of the single-end rescue (DV-DPForSingleReads.cpp:121-215, SingleEndAlgnBatch::pack DV-DPfunctions.cpp:401-445) are windows
 // around a seed: read (L <= 160) x window (m = L + 60) with an exact match of >= 17 bases on diagonal 30.  With 17-base seeds nearly all of
 // them are chance matches whose table holds nothing else; the filter still fills all 31 500 cells.  What this kernel computes instead
-// (proof: DESIGN.md section 4, "Why the rescue filter is not cheaper"; numerically: scripts/dp_decomposition_check.py, scripts/thermo_bound_proto.py):
+// (proof: DESIGN.md section 4, "The rescue filter"; numerically: scripts/dp_decomposition_check.py, scripts/thermo_bound_proto.py):
 //
 //   T'   the table with the cells of the longest exact run R on the seed's diagonal turned into mismatches;
 //   H'   its LOCAL scores (+1 / -2, gaps -3 / -1, floor 0 in every cell: never below what callDP computes, CPU_DP.cpp:122-619);
@@ -26,9 +26,12 @@
 #pragma once
 
 #define MP_TH_T 10                 // planes: values 1 .. T; plane T set anywhere = overflow, no certificate (E and F never exceed max H' - 3: T - 3 planes)
-#define MP_TH_COLS 5               // read columns per lane: 32 lanes x 5 = 160
+#define MP_TH_T_WIDE 11             // the wide variant's tables are up to four times larger: one plane more keeps the overflows at a few per cent
+#define MP_TH_COLS 5               // read columns per lane: 32 lanes x 5 = 160 (two sets of 32 instances per wavefront), or 64 lanes x 5 = 320 (one set)
 #define MP_TH_MAXL 160
 #define MP_TH_MAXM 224
+#define MP_TH_MAXL_WIDE 320
+#define MP_TH_MAXM_WIDE 384
 #define MP_TH_MARGIN 30            // DP2_MARGIN for reads longer than 100 bases (DV-DPfunctions.cpp:1760): the seed's diagonal
 #define MP_TH_MINRUN 12            // a run shorter than this is no seed: no certificate
 
@@ -42,7 +45,8 @@ __device__ __forceinline__ uint32_t th_from_left_and(uint32_t v, uint32_t mask)
 
 // cert[t] = 1: instance t cannot reach its cutoff (no alignment); 0: undecided, the filter has to look at it.
 // `list` (may be null): slot s stands for instance list[s].
-template <int T>
+// LPS = lanes per set of 32 instances: 32 (reads of up to 160 bases, two sets per wavefront) or 64 (up to 320 bases, one set: lanes 0 .. 31 bring the instances)
+template <int T, int LPS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                  const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list,
@@ -50,36 +54,41 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
 {
     constexpr int TE = T - 3, NC = MP_TH_COLS;
     static_assert(T >= 8 && T <= 14, "planes");
-    // bit-sliced inputs of the two halves (index h = lane >> 5): one word = one column (row) of 32 instances
-    __shared__ uint32_t s_r0[2][MP_TH_MAXL], s_r1[2][MP_TH_MAXL], s_rv[2][MP_TH_MAXL], s_run[2][MP_TH_MAXL], s_lc[2][MP_TH_MAXL], s_gt[2][MP_TH_MAXL];
-    // window rows are stored 32 further down with empty rows on either side: the anti-diagonal sweep reads rows -31 .. mmax + 35 without a test
-    __shared__ uint32_t s_w0[2][MP_TH_MAXM + 72], s_w1[2][MP_TH_MAXM + 72], s_wv[2][MP_TH_MAXM + 72], s_rg[2][MP_TH_MAXM + 72];
-    const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
-    const uint32_t slot = blockIdx.x * 64 + lane;
-    const bool have = slot < n_tasks;
+    static_assert(LPS == 32 || LPS == 64, "lanes per set");
+    constexpr int SETS = 64 / LPS, MAXL = NC * LPS, MAXM = LPS == 32 ? MP_TH_MAXM : MP_TH_MAXM_WIDE;
+    constexpr int OFF = LPS, ROWS = MAXM + 2 * LPS + 8;      // window rows are stored OFF further down, with empty rows on either side: the anti-diagonal
+                                                             // sweep reads rows -(LPS - 1) .. mmax + LPS + 4 without a test
+    // bit-sliced inputs of the sets (index h): one word = one column (row) of 32 instances
+    __shared__ uint32_t s_r0[SETS][MAXL], s_r1[SETS][MAXL], s_rv[SETS][MAXL], s_run[SETS][MAXL], s_lc[SETS][MAXL], s_gt[SETS][MAXL];
+    __shared__ uint32_t s_w0[SETS][ROWS], s_w1[SETS][ROWS], s_wv[SETS][ROWS], s_rg[SETS][ROWS];
+    const int lane = threadIdx.x, h = LPS == 32 ? lane >> 5 : 0, l = lane & (LPS - 1);
+    const int bit = lane & 31;                                // the instance this lane brings (and speaks for at the end), if it brings one
+    const bool carrier = lane < 32 * SETS;
+    const uint32_t slot = blockIdx.x * (32 * SETS) + lane;
+    const bool have = carrier && slot < n_tasks;
     const uint32_t t_id = have ? (list ? list[slot] : slot) : 0;
     // ---------------------------------------------------------------- this lane's instance: oriented read, window, the seed's run
     int L = 0, m = 0, j0 = 0, rlen = 0;
     bool ok = false;
-    uint32_t a[MP_TH_MAXL / 16 + 1], w[MP_TH_MAXM / 16 + 2];
+    uint32_t a[MAXL / 16 + 1], w[MAXM / 16 + 2];
 #pragma unroll
-    for (int k = 0; k <= MP_TH_MAXL / 16; k++) a[k] = 0;
+    for (int k = 0; k <= MAXL / 16; k++) a[k] = 0;
 #pragma unroll
-    for (int k = 0; k < MP_TH_MAXM / 16 + 2; k++) w[k] = 0;
+    for (int k = 0; k < MAXM / 16 + 2; k++) w[k] = 0;
     if (have) {
         const mp_dp_task task = tasks[t_id];
         L = (int)lens[task.read_id]; m = (int)task.win_len;
-        ok = L > 100 && L <= MP_TH_MAXL && m >= L && m <= MP_TH_MAXM && m <= L + 2 * MP_TH_MARGIN;
+        ok = L > 100 && L <= MAXL && m >= L && m <= MAXM && m <= L + 2 * MP_TH_MARGIN;
         if (ok) {
             const uint32_t *rd = reads + (uint64_t)task.read_id * Wr;
             const int nw = (L + 15) / 16;
 #pragma unroll
-            for (int k = 0; k < MP_TH_MAXL / 16; k++) a[k] = mp_oriented_word(rd, nw, L, task.strand, k);
+            for (int k = 0; k < MAXL / 16; k++) a[k] = mp_oriented_word(rd, nw, L, task.strand, k);
             const uint64_t q0 = task.win_start >> 4;
             const uint32_t sh = 2u * (uint32_t)(task.win_start & 15);
             const int tw = (m + 15) / 16;
 #pragma unroll
-            for (int k = 0; k < MP_TH_MAXM / 16 + 1; k++)
+            for (int k = 0; k < MAXM / 16 + 1; k++)
                 if (k < tw) {
                     uint64_t two = (uint64_t)text[q0 + k];
                     if (sh) two |= (uint64_t)text[q0 + k + 1] << 32;              // (as dp_score_kernel: never a word past the window's last)
@@ -89,7 +98,7 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
             int best = 0, best_at = 0, cur = 0;
             const int lim = min(L, m - MP_TH_MARGIN);
 #pragma unroll
-            for (int k = 0; k < MP_TH_MAXL / 16; k++) {
+            for (int k = 0; k < MAXL / 16; k++) {
                 const int at = 16 * k + MP_TH_MARGIN;                        // window base of read base 16 k
                 const uint64_t two = ((uint64_t)w[(at >> 4) + 1] << 32) | w[at >> 4];
                 uint32_t x = (uint32_t)(two >> (2 * (at & 15))) ^ a[k];
@@ -107,7 +116,7 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
     }
     // ---------------------------------------------------------------- transposition: one ballot per word, both halves at once
 #pragma unroll
-    for (int k = 0; k < MP_TH_MAXL / 16; k++) {
+    for (int k = 0; k < MAXL / 16; k++) {
         uint32_t x = a[k];
         for (int u = 0; u < 16; u++, x >>= 2) {
             const int j = 16 * k + u;
@@ -123,11 +132,12 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
         }
     }
     int mmax = 0;
-    s_w0[h][l] = 0; s_w1[h][l] = 0; s_wv[h][l] = 0; s_rg[h][l] = 0;
-    s_w0[h][MP_TH_MAXM + 32 + l] = 0; s_w1[h][MP_TH_MAXM + 32 + l] = 0; s_wv[h][MP_TH_MAXM + 32 + l] = 0; s_rg[h][MP_TH_MAXM + 32 + l] = 0;
-    if (l < 8) { s_w0[h][MP_TH_MAXM + 64 + l] = 0; s_w1[h][MP_TH_MAXM + 64 + l] = 0; s_wv[h][MP_TH_MAXM + 64 + l] = 0; s_rg[h][MP_TH_MAXM + 64 + l] = 0; }
+    for (int hh = 0; hh < SETS; hh++) {
+        for (int x = lane; x < OFF; x += 64) { s_w0[hh][x] = 0; s_w1[hh][x] = 0; s_wv[hh][x] = 0; s_rg[hh][x] = 0; }
+        for (int x = OFF + MAXM + lane; x < ROWS; x += 64) { s_w0[hh][x] = 0; s_w1[hh][x] = 0; s_wv[hh][x] = 0; s_rg[hh][x] = 0; }
+    }
 #pragma unroll
-    for (int k = 0; k < MP_TH_MAXM / 16; k++) {
+    for (int k = 0; k < MAXM / 16; k++) {
         uint32_t x = w[k];
         for (int u = 0; u < 16; u++, x >>= 2) {
             const int i = 16 * k + u;
@@ -135,8 +145,8 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
             const unsigned long long b0 = __ballot(v && (x & 1u)), b1 = __ballot(v && (x & 2u)), bv = __ballot(v);
             const unsigned long long bg = __ballot(ok && i > j0 + MP_TH_MARGIN);                    // rows below the run's first cell
             if (l == 0) {
-                s_w0[h][32 + i] = (uint32_t)(b0 >> (32 * h)); s_w1[h][32 + i] = (uint32_t)(b1 >> (32 * h)); s_wv[h][32 + i] = (uint32_t)(bv >> (32 * h));
-                s_rg[h][32 + i] = (uint32_t)(bg >> (32 * h));
+                s_w0[h][OFF + i] = (uint32_t)(b0 >> (32 * h)); s_w1[h][OFF + i] = (uint32_t)(b1 >> (32 * h)); s_wv[h][OFF + i] = (uint32_t)(bv >> (32 * h));
+                s_rg[h][OFF + i] = (uint32_t)(bg >> (32 * h));
             }
             if (bv) mmax = i + 1;                                              // (wave-uniform)
         }
@@ -171,7 +181,7 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
 #pragma unroll
     for (int t = 0; t <= T; t++) { accR[t] = 0; accL[t] = 0; }
     const uint32_t nb = l ? 0xFFFFFFFFu : 0u;       // the first lane of a half has no left neighbour: its column -1 is the table's edge (H = 0)
-    const int steps = mmax + 31;
+    const int steps = mmax + LPS - 1;
     // Rows above the table (a lane starts l steps late) need no test: every input there is 0 and stays 0.  Rows below it are computed as rows
     // that match nothing: what appears there is never above the cell it came from, so the accumulators may see it.
     // The seed's diagonal meets lane l in its column K at step s = (NC + 1) l + MARGIN + K: with the steps taken NC + 1 at a time, K is a
@@ -185,7 +195,7 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
         for (int t = 1; t <= T; t++) gotH[t] = th_from_left_and(outH[t], nb);
 #pragma unroll
         for (int t = 1; t <= TE; t++) gotG[t] = th_from_left_and(outG[t], nb);
-        const int ri = s - l + 32;                                              // my window row (i = s - l), as stored
+        const int ri = s - l + OFF;                                             // my window row (i = s - l), as stored
         const uint32_t wv = s_wv[h][ri], w0 = s_w0[h][ri], w1 = s_w1[h][ri], rowgt = s_rg[h][ri];
         const uint32_t onl = (NC + 1) * l + MP_TH_MARGIN + K == s ? 0xFFFFFFFFu : 0u;   // this lane's column K is on the seed's diagonal
         // diagonal predecessor of column 0 = the neighbour's last column one row up (kept in inH); F-input of column 0 = gotG
@@ -248,19 +258,19 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
     }
     // ---------------------------------------------------------------- per instance: OR over the lanes of its half, then read its bit
     auto half_or = [&](uint32_t v) -> uint32_t {
-        for (int o = 1; o < 32; o <<= 1) v |= (uint32_t)__shfl_xor((int)v, o);
+        for (int o = 1; o < LPS; o <<= 1) v |= (uint32_t)__shfl_xor((int)v, o);
         return v;
     };
     ov = half_or(ov);
     int Rs = 4, Lm = 0;
     bool l_big = false;
 #pragma unroll
-    for (int t = 5; t < T; t++) { const uint32_t v = half_or(accR[t]); if ((v >> l) & 1u) Rs = t; }
+    for (int t = 5; t < T; t++) { const uint32_t v = half_or(accR[t]); if ((v >> bit) & 1u) Rs = t; }
 #pragma unroll
-    for (int t = 1; t <= 5; t++) { const uint32_t v = half_or(accL[t]); if ((v >> l) & 1u) { Lm = t; if (t == 5) l_big = true; } }
+    for (int t = 1; t <= 5; t++) { const uint32_t v = half_or(accL[t]); if ((v >> bit) & 1u) { Lm = t; if (t == 5) l_big = true; } }
     if (!have) return;
-    // lane l of the half speaks for instance l of the half
-    const bool over = (ov >> l) & 1u;
+    // the lane that brought an instance speaks for it
+    const bool over = (ov >> bit) & 1u;
     const int cutoff = mp_dp_cutoff(L);
     const bool certified = ok && !over && !l_big && T - 1 < cutoff && Lm + rlen + Rs < cutoff;       // (max H' <= T - 1 when there is no overflow)
     cert[t_id] = certified ? 1 : 0;

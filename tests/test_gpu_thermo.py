@@ -11,13 +11,13 @@ def _comp_rev(codes):
     return (3 - codes)[::-1]
 
 
-def _make_instances(rng, text, n, kinds):
+def _make_instances(rng, text, n, kinds, lo=101, hi=160):
     """n (read, window) instances of mixed kinds; returns (list of read code arrays as stored, tasks array, kind per instance)"""
     from megapath_amd import hipapi as H
     N = len(text)
     reads, tasks, kind = [], np.zeros(n, dtype=H.DP_TASK_DTYPE), np.zeros(n, dtype=np.int32)
     for t in range(n):
-        L = int(rng.integers(101, 161))
+        L = int(rng.integers(lo, hi + 1))
         m = L + 60
         ws = int(rng.integers(0, N - m - 64))
         win = text[ws:ws + m]
@@ -64,20 +64,21 @@ def _make_instances(rng, text, n, kinds):
     return reads, tasks, kind
 
 
-@pytest.mark.parametrize("kinds,seed", [((0,), 1), ((7, 1, 2, 4), 2), ((0, 1, 2, 3, 4, 5, 6, 7), 3)])
-def test_certificate_never_rejects_an_alignment(kinds, seed):
+@pytest.mark.parametrize("kinds,seed,lo,hi", [((0,), 1, 101, 160), ((7, 1, 2, 4), 2, 101, 160), ((0, 1, 2, 3, 4, 5, 6, 7), 3, 101, 160),
+                                              ((0,), 4, 161, 320), ((0, 1, 2, 3, 4, 5, 6, 7), 5, 140, 320), ((7, 1, 2, 4), 6, 290, 320)])
+def test_certificate_never_rejects_an_alignment(kinds, seed, lo, hi):
     from megapath_amd import hipapi as H
     from megapath_amd.index_builder import build_index_arrays
     import oracle_lib as O
     rng = np.random.default_rng(seed)
     text = rng.integers(0, 4, 1 << 20).astype(np.uint8)
-    n = 60000
-    reads, tasks, kind = _make_instances(rng, text, n, kinds)          # (kind 5 plants repeats into the text: build the index afterwards)
+    n = 60000 if hi <= 160 else 30000
+    reads, tasks, kind = _make_instances(rng, text, n, kinds, lo, hi)  # (kind 5 plants repeats into the text: build the index afterwards)
     arrs = build_index_arrays([("t", text)], sa_interval=16)
     ix = H.Index.from_arrays(0, **arrs)
     ctx = H.Context(ix)
     seqs = [bytes(b"ACGT"[c] for c in r) for r in reads]
-    packed, lens, W = H.pack_reads(seqs, 161)
+    packed, lens, W = H.pack_reads(seqs, 161 if hi <= 160 else 321)
     ctx.set_reads(packed, lens)
     cert, st = ctx.test_dp_thermo(tasks)
     score = ctx.sgdp_scores(tasks, 130, 130)
@@ -94,38 +95,39 @@ def test_certificate_never_rejects_an_alignment(kinds, seed):
         assert (got if got >= cutoff[t] else 0) == (want[0] if want[0] >= cutoff[t] else 0), t
     # usefulness: pure chance seeds are nearly all certified
     if kinds == (0,):
-        assert st[0] > 0.9 * n, st
+        assert st[0] > (0.9 if hi <= 160 else 0.8) * n, st
     if 3 in kinds:
         assert not cert[(kind == 3) & (score >= cutoff)].any()
     ctx.close()
     ix.close()
 
 
-def test_rescue_round_equal_with_and_without_certificate():
+@pytest.mark.parametrize("read_len,len_range", [(151, None), (250, None), (300, (75, 300))])
+def test_rescue_round_equal_with_and_without_certificate(read_len, len_range):
     """the product path: the same single-end and mate-rescue hits with the certificate on and off (17-base seeds, many random and broken mates)"""
     import ctypes as C
     from megapath_amd import hipapi as H, index_builder, synth
     genome = synth.random_genome(3000000, 77, n_seqs=2, repeat_frac=0.05)
     arrs = index_builder.build_index_arrays(genome, sa_interval=16)
     ix = H.Index.from_arrays(0, **arrs)
-    names, r1, r2 = synth.simulate_pairs(genome, 20000, 151, 78, sub=0.02, ins=0.001, dele=0.001, random_frac=0.3, broken_mate_frac=0.3, noisy_mate_frac=0.2,
-                                         junk_end_frac=0.2)
+    names, r1, r2 = synth.simulate_pairs(genome, 20000 if read_len < 200 else 8000, read_len, 78, sub=0.02, ins=0.001, dele=0.001, random_frac=0.3, broken_mate_frac=0.3,
+                                         noisy_mate_frac=0.2, junk_end_frac=0.2, len_range=len_range, frag_mean=read_len + 200.0, frag_max=read_len + 450)
     seqs = [x for pr in zip(r1, r2) for x in pr]
-    packed, lens, W = H.pack_reads(seqs, 152)
+    packed, lens, W = H.pack_reads(seqs, read_len + 1)
     outs = []
     for on in (True, False):
         ctx = H.Context(ix)
         ctx.set_dp_thermo(on)
         ctx.set_reads(packed, lens)
         ctx.seed_batch(H.MmpParams.nt2())
-        ap = H.AlignParams(1, 750, 130, 130, H.MmpParams.nt2())
+        ap = H.AlignParams(int(lens.max()), 750, 130, 130, H.MmpParams.nt2())
         ctx.deep_dp_round(ap)
         (sh, ns), (rh, nr), st = ctx.rescue_round(ap)
         a = C.string_at(C.addressof(sh), ns * C.sizeof(H.SingleHit)) if ns else b""
         b = C.string_at(C.addressof(rh), nr * C.sizeof(H.RescueHit)) if nr else b""
         outs.append((a, b, ns, nr, ctx.dp_thermo_stats()))
         ctx.close()
-    assert outs[0][2] > 1000 and outs[0][3] > 100
+    assert outs[0][2] > 500 and outs[0][3] > 50
     assert outs[0][:4] == outs[1][:4]
     assert outs[0][4][0] > 0 and outs[1][4] == (0, 0, 0, 0)
     ix.close()

@@ -1324,7 +1324,10 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     if (thermo) {
         if (c->th_cert.reserve(n + 64) || c->th_stats.reserve(4) || c->score_list.reserve(n + 2)) return MP_ENOMEM;
         HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
-        if (narrow) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
+        static const bool occ1 = getenv("MP_THERMO_OCC") && atoi(getenv("MP_THERMO_OCC")) == 1;
+        if (narrow && occ1) hipLaunchKernelGGL((dp_thermo_kernel_w1<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
+                                               (const uint32_t *)nullptr, c->th_stats.p);
+        else if (narrow) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
                                        (const uint32_t *)nullptr, c->th_stats.p);
         else hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), dim3(grid_for(n, 32)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
                                 (const uint32_t *)nullptr, c->th_stats.p);

@@ -47,10 +47,10 @@ __device__ __forceinline__ uint32_t th_from_left_and(uint32_t v, uint32_t mask)
 // `list` (may be null): slot s stands for instance list[s].
 // LPS = lanes per set of 32 instances: 32 (reads of up to 160 bases, two sets per wavefront) or 64 (up to 320 bases, one set: lanes 0 .. 31 bring the instances)
 template <int T, int LPS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
-                 const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list,
-                 unsigned long long *__restrict__ stats /* [0] certified [1] overflow [2] bound too high [3] not eligible */)
+__device__ __forceinline__ void
+dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
+               const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list,
+               unsigned long long *__restrict__ stats /* [0] certified [1] overflow [2] bound too high [3] not eligible */)
 {
     constexpr int TE = T - 3, NC = MP_TH_COLS;
     static_assert(T >= 8 && T <= 14, "planes");
@@ -283,6 +283,23 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
             if (c3) atomicAdd(&stats[3], (unsigned long long)__popcll(c3));
         }
     }
+}
+
+template <int T, int LPS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
+                 const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list, unsigned long long *__restrict__ stats)
+{
+    dp_thermo_body<T, LPS>(text, reads, lens, Wr, tasks, n_tasks, cert, list, stats);
+}
+
+// the same with the registers it asks for (one wavefront per SIMD, half of the register file left to the kernels of other contexts): measurement aid, MP_THERMO_OCC=1
+template <int T, int LPS>
+__global__ void __launch_bounds__(64)
+dp_thermo_kernel_w1(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
+                    const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list, unsigned long long *__restrict__ stats)
+{
+    dp_thermo_body<T, LPS>(text, reads, lens, Wr, tasks, n_tasks, cert, list, stats);
 }
 
 // flag[t] = 1 for the instances the certificate left undecided; the certified ones get the filter's answer "score 0"

@@ -642,7 +642,7 @@ def write_bgzf(plain_path, dst, n_bytes, block=65280):
         fo.write(_bgzf_block(b""))
 
 
-def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=12, gz_pairs=1 << 22):
+def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=12, gz_pairs=1 << 23):
     """FASTQ files in, annotated FASTQ out, through bin/soap4-mi355x (the boundary a pipeline maintainer sees): pairs/s of the
     executable's alignment loop (index load excluded, as for the CPU soap4), stdout to /dev/null; plain input and gzip'ed input."""
     from megapath_amd import simulate
@@ -732,8 +732,12 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
         procs = [subprocess.Popen(["gzip", "-1", g]) for g in (g1, g2)]
         for pr in procs:
             pr.wait()
-        res["gz"] = run(g1 + ".gz", g2 + ".gz", gz_pairs)
+        res["gz"] = run(g1 + ".gz", g2 + ".gz", gz_pairs)                                       # several threads per stream (host/par_gzip.h)
+        res["gz_one_thread_per_file"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_PARGZ_MIN": str(1 << 60)})     # the reader's own decoder, one thread per stream
         res["gz_zlib"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_INFLATE": "zlib"})        # the same files through zlib's gzread, as the reference reads them
+        for spec in filter(None, os.environ.get("MP_BENCH_GZ_VARIANTS", "").split(";")):      # tuning aid, as MP_BENCH_E2E_VARIANTS
+            nm, _, kv = spec.partition(":")
+            res["gz_" + nm] = run(g1 + ".gz", g2 + ".gz", gz_pairs, dict(x.split("=", 1) for x in kv.split(",") if "=" in x))
         # the same reads as BGZF (bgzip; what BBTools writes when bgzip is installed): independent members, inflated by several threads per file
         try:
             t0 = time.time()

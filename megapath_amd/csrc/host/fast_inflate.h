@@ -16,12 +16,24 @@
 
 namespace mpz {
 
-enum { OK = 0, NEED_OUTPUT = 1, MEMBER_END = 2, STREAM_END = 3, ERR = -1 };
+enum { OK = 0, NEED_OUTPUT = 1, MEMBER_END = 2, STREAM_END = 3, AT_BLOCK = 4, ERR = -1 };
 
 class Inflater {
 public:
     // the whole compressed file
-    void init(const uint8_t *data, size_t len) { in_ = data; in_end_ = data + len; p_ = data; bb_ = 0; bc_ = 0; virt_ = 0; state_ = S_HEADER; err_.clear(); }
+    void init(const uint8_t *data, size_t len) { in_ = data; in_end_ = data + len; p_ = data; bb_ = 0; bc_ = 0; virt_ = 0; state_ = S_HEADER; err_.clear(); resumed_ = false; }
+    // the same, but decoding starts at a deflate block header `bitpos` bits into the data (the parallel reader: par_gzip in soap4_main.cpp)
+    void init_at_block(const uint8_t *data, size_t len, uint64_t bitpos)
+    {
+        init(data, len);
+        p_ = data + (size_t)(bitpos >> 3);
+        refill();
+        drop((unsigned)(bitpos & 7u));
+        state_ = S_BLOCK;
+    }
+    // run() returns AT_BLOCK every time it is about to read a block header (bit_position() says where); calling it again goes on
+    void stop_at_blocks(bool on) { block_stops_ = on; }
+    uint64_t bit_position() const { return (uint64_t)(p_ - in_) * 8u + (uint64_t)virt_ * 8u - bc_; }
     const std::string &error() const { return err_; }
     uint32_t member_crc() const { return crc_; }        // valid after MEMBER_END: the trailer's CRC-32 and length (mod 2^32)
     uint32_t member_isize() const { return isize_; }
@@ -30,7 +42,11 @@ public:
     //   NEED_OUTPUT  fewer than 320 bytes of room left before `cap` (call again with a fresh chunk that starts with the history)
     //   MEMBER_END   a gzip member ended (check its CRC, then call again: another member or the end of the file may follow)
     //   STREAM_END   the input is used up     ERR  malformed input (error())
-    int run(uint8_t *out, size_t &pos, size_t cap)
+    // Out = uint8_t: bytes.  Out = uint16_t: the same symbols one per 16-bit word, for a decoder that does not know the 32 KiB in front
+    // of its first block: the caller fills out[0 .. 32768) with markers 0x8000 | i and starts at pos = 32768, so that a match reaching
+    // back before the start copies markers, to be replaced once the window is known.
+    template <typename Out>
+    int run(Out *out, size_t &pos, size_t cap)
     {
         for (;;) {
             switch (state_) {
@@ -40,6 +56,8 @@ public:
                 break;
             }
             case S_BLOCK: {
+                if (block_stops_ && !resumed_) { resumed_ = true; return AT_BLOCK; }
+                resumed_ = false;
                 refill();
                 if (virt_ > 8) return fail("truncated deflate stream (block header)");
                 last_ = (bb_ & 1u) != 0;
@@ -64,12 +82,13 @@ public:
                 while (stored_left_) {
                     if (pos + 320 > cap) return NEED_OUTPUT;
                     // bytes still in the bit buffer first (it is byte-aligned here), then straight from the input
-                    if (bc_ >= 8) { out[pos++] = (uint8_t)bb_; drop(8); stored_left_--; continue; }
+                    if (bc_ >= 8) { out[pos++] = (Out)(uint8_t)bb_; drop(8); stored_left_--; continue; }
                     bb_ = 0; bc_ = 0;                                          // (bits of the next byte that refill() had OR-ed in without counting them)
                     const size_t room = cap - 320 - pos + 1, avail = (size_t)(in_end_ - p_);
                     size_t n = stored_left_ < room ? stored_left_ : room;
                     if (n > avail) { if (avail == 0) return fail("truncated stored block"); n = avail; }
-                    memcpy(out + pos, p_, n);
+                    if (sizeof(Out) == 1) memcpy(out + pos, p_, n);
+                    else for (size_t i = 0; i < n; i++) out[pos + i] = (Out)p_[i];
                     p_ += n; pos += n; stored_left_ -= (unsigned)n;
                 }
                 state_ = last_ ? S_TRAILER : S_BLOCK;
@@ -107,7 +126,7 @@ private:
     uint64_t bb_ = 0;
     unsigned bc_ = 0;
     int state_ = S_HEADER;
-    bool last_ = false;
+    bool last_ = false, block_stops_ = false, resumed_ = false;
     unsigned stored_left_ = 0;
     unsigned virt_ = 0;          // zero bytes appended past the end of the input (refill)
     uint32_t crc_ = 0, isize_ = 0;
@@ -294,7 +313,8 @@ private:
         }
     }
 
-    int huffman(uint8_t *out, size_t &pos_io, size_t cap)
+    template <typename Out>
+    int huffman(Out *out, size_t &pos_io, size_t cap)
     {
         size_t pos = pos_io;
         const uint32_t *lit = lit_, *dist = dist_;
@@ -307,7 +327,7 @@ private:
                 uint32_t f = fast_[bb_ & ((1u << LBITS) - 1u)];
                 int n = 0;
                 while (f && n < 4) {
-                    out[pos] = (uint8_t)f; out[pos + 1] = (uint8_t)(f >> 8);
+                    out[pos] = (Out)(uint8_t)f; out[pos + 1] = (Out)(uint8_t)(f >> 8);
                     pos += f >> 24;
                     drop(f >> 16 & 31u);
                     f = fast_[bb_ & ((1u << LBITS) - 1u)];
@@ -322,7 +342,7 @@ private:
                 drop(e & 31u);
                 e = lit[(e >> 16) + (bb_ & ((1u << (e >> 8 & 31u)) - 1u))];
                 kind = e >> 5 & 7u;
-                if (kind == K_LIT) { drop(e & 31u); out[pos++] = (uint8_t)(e >> 16); continue; }
+                if (kind == K_LIT) { drop(e & 31u); out[pos++] = (Out)(uint8_t)(e >> 16); continue; }
             }
             if (bc_ < (e & 31u)) { pos_io = pos; return fail("truncated deflate stream"); }
             drop(e & 31u);
@@ -341,13 +361,14 @@ private:
             const size_t distance = (d >> 16) + (size_t)(bb_ & ((1u << db) - 1u));
             drop(db);
             if (distance > pos) { pos_io = pos; return fail("distance reaches before the start of the output"); }
-            uint8_t *dst = out + pos;
-            const uint8_t *src = dst - distance;
+            Out *dst = out + pos;
+            const Out *src = dst - distance;
             pos += len;
-            if (distance >= 8) {
-                // 8 bytes at a time; may write up to 7 bytes past the match (room is kept: 320 bytes of slack)
-                do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 8; dst += 8; len = len > 8 ? len - 8 : 0; } while (len);
-            } else if (distance == 1) memset(dst, *src, len);
+            constexpr unsigned PER = 8 / sizeof(Out);                       // symbols per 8-byte copy
+            if (distance >= PER) {
+                // 8 bytes at a time; may write up to 7 bytes past the match (room is kept: 320 symbols of slack)
+                do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += PER; dst += PER; len = len > PER ? len - PER : 0; } while (len);
+            } else if (distance == 1) { const Out v = *src; for (unsigned i = 0; i < len; i++) dst[i] = v; }
             else while (len--) *dst++ = *src++;
         }
     }

@@ -43,6 +43,7 @@
 #include "../../../include/megapath_hip.h"
 #include "bam_out.h"
 #include "fast_inflate.h"
+#include "par_gzip.h"
 #include <deque>
 
 namespace {
@@ -93,11 +94,32 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // where a record's lines sit in its block of text (offsets from the block's base); sn/qn of a wrapped record span several lines
 struct RawRec { uint64_t h; uint32_t hn; uint64_t s; uint32_t sn; uint64_t q; uint32_t qn; bool fasta, wrapped; };
 
+// a batch's inflated text: grows by realloc (large blocks are remapped, not copied) and is never zero-filled -- a std::vector would
+// write every byte once before the inflated bytes are written over it
+struct TextBuf {
+    char *p = nullptr;
+    size_t cap = 0;
+    TextBuf() = default;
+    TextBuf(const TextBuf &) = delete;
+    TextBuf &operator=(const TextBuf &) = delete;
+    ~TextBuf() { free(p); }
+    char *data() { return p; }
+    const char *data() const { return p; }
+    size_t size() const { return cap; }
+    void resize(size_t n)
+    {
+        if (n <= cap) return;
+        char *q = (char *)realloc(p, n);
+        if (!q) { fprintf(stderr, "[soap4-mi355x] out of memory (%zu bytes of read text)\n", n); exit(1); }
+        p = q; cap = n;
+    }
+};
+
 struct Batch {
     // ---- stage 1: parsed and packed reads (2 per pair)
     std::vector<Rec> recs[2];               // per mate file, grown on demand
     std::vector<RawRec> raw[2];
-    std::vector<char> text[2];              // gz input: the inflated bytes of this batch's records (plain files are mapped instead)
+    TextBuf text[2];                        // gz input: the inflated bytes of this batch's records (plain files are mapped instead)
     std::vector<uint32_t> nl[2];            // scratch of the splitter: where the lines of the block end
     std::vector<uint32_t> packed, lens;     // interleaved 2q / 2q+1 as the device wants them
     uint32_t W = 0, n_reads = 0;
@@ -261,7 +283,8 @@ void fan_out(int n, F &&body, Pool *pool = nullptr)
 // the bytes into the batch's buffer, computing each member's CRC-32 on the way and comparing it with the trailer's.
 struct GzProducer {
     struct MemberEnd { size_t pos; uint32_t crc, isize; };
-    struct Chunk { std::vector<uint8_t> buf; size_t begin = 0, end = 0; std::vector<MemberEnd> ends; bool eof = false, verified = false; std::string err; };
+    struct Chunk { std::vector<uint8_t> buf; size_t begin = 0, end = 0; std::vector<MemberEnd> ends; bool eof = false, verified = false; std::string err;
+                   mpz::ParGzip::Piece *piece = nullptr; };
     static constexpr size_t H = 32768, C = (size_t)8 << 20;
     mpz::Inflater z;
     std::vector<std::thread> th;
@@ -277,6 +300,8 @@ struct GzProducer {
     size_t next_group = 0, deliver = 0;
     std::map<size_t, Chunk *> done;
     const uint8_t *data_ = nullptr;
+    // an ordinary gzip file of some size: several threads on the one stream (par_gzip.h)
+    std::unique_ptr<mpz::ParGzip> par;
 
     // the members of a BGZF file as groups; false when the file is not BGZF from its first to its last byte
     static bool scan_bgzf(const uint8_t *d, size_t len, std::vector<Group> &out)
@@ -327,7 +352,7 @@ struct GzProducer {
                         for (;;) {
                             const int rc = zz.run(c->buf.data(), pos, H + C);
                             if (rc == mpz::MEMBER_END) {
-                                if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), c->buf.data() + mstart, (uInt)(pos - mstart)) != zz.member_crc() || (uint32_t)(pos - mstart) != zz.member_isize())
+                                if (mpz::fast_crc32(0u, c->buf.data() + mstart, pos - mstart) != zz.member_crc() || (uint32_t)(pos - mstart) != zz.member_isize())
                                     { c->err = "incorrect data check (gzip CRC-32 or length)"; break; }
                                 mstart = pos;
                                 continue;
@@ -344,6 +369,13 @@ struct GzProducer {
             return;
         }
         groups.clear();
+        {
+            // one deflate stream, several threads: worth it from a few segments on (MP_PARGZ_MIN bytes of compressed input, segments of MP_PARGZ_SEG)
+            const size_t min_len = getenv("MP_PARGZ_MIN") ? (size_t)atoll(getenv("MP_PARGZ_MIN")) : ((size_t)24 << 20);
+            const size_t seg = getenv("MP_PARGZ_SEG") ? (size_t)atoll(getenv("MP_PARGZ_SEG")) : ((size_t)4 << 20);
+            // (pieces of ~4 x the segment: as far ahead of the splitter as the one-thread reader runs, about one batch)
+            if (bgzf_threads >= 2 && len >= min_len) { par.reset(new mpz::ParGzip(data, len, bgzf_threads, seg, bgzf_threads + 2, (int)std::max<size_t>(6, ((size_t)96 << 20) / seg))); return; }
+        }
         z.init(data, len);
         th.emplace_back([this]() {
             std::vector<uint8_t> hist(H);
@@ -375,6 +407,14 @@ struct GzProducer {
     }
     Chunk *pop()
     {
+        if (par) {
+            mpz::ParGzip::Piece *p = par->pop();
+            Chunk *c = nullptr;
+            { std::lock_guard<std::mutex> lk(mu); c = free_.front(); free_.pop_front(); }     // (the reader holds one chunk at a time: there is always a free one)
+            c->buf.swap(p->bytes);
+            c->begin = 0; c->end = p->n; c->ends.clear(); c->eof = p->eof; c->verified = true; c->err = p->err; c->piece = p;
+            return c;
+        }
         std::unique_lock<std::mutex> lk(mu);
         if (!groups.empty()) {
             cv.wait(lk, [&] { return done.count(deliver) != 0; });
@@ -386,7 +426,12 @@ struct GzProducer {
         Chunk *c = ready.front(); ready.pop_front();
         return c;
     }
-    void give_back(Chunk *c) { { std::lock_guard<std::mutex> lk(mu); free_.push_back(c); } cv.notify_all(); }
+    void give_back(Chunk *c)
+    {
+        if (c->piece) { c->buf.swap(c->piece->bytes); par->recycle(c->piece); c->piece = nullptr; }
+        { std::lock_guard<std::mutex> lk(mu); free_.push_back(c); }
+        cv.notify_all();
+    }
     ~GzProducer() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : th) if (t.joinable()) t.join(); }
 };
 
@@ -423,7 +468,7 @@ struct Source {
         });
     }
 
-    bool open(const char *file)
+    bool open(const char *file, int host_threads = 4)
     {
         path = file;
         const int fd = ::open(file, O_RDONLY);
@@ -443,7 +488,9 @@ struct Source {
             map = (const char *)m;
             m_crc = (uint32_t)crc32(0L, Z_NULL, 0);
             fast.reset(new GzProducer());
-            const int bg = getenv("MP_INFLATE_THREADS") ? atoi(getenv("MP_INFLATE_THREADS")) : 3;          // BGZF only: members inflate side by side
+            // BGZF: members inflate side by side; gzip: segments of the one stream (par_gzip.h).  Three eighths of -T per file, as for the splitters
+            // (inflating and splitting alternate), at least 3 and at most 8
+            const int bg = getenv("MP_INFLATE_THREADS") ? atoi(getenv("MP_INFLATE_THREADS")) : std::min(8, std::max(3, host_threads * 3 / 8));
             fast->start((const uint8_t *)map, map_len, 48, bg);             // up to 384 MiB inflated ahead of the splitter: about one batch
             return true;
         }
@@ -468,7 +515,7 @@ struct Source {
     ~Source() { if (toucher.joinable()) toucher.join(); fast.reset(); if (f) gzclose(f); if (map) munmap((void *)map, map_len); }
 
     // gz: appends up to `want` more inflated bytes to buf; false at the end of the stream
-    bool inflate_more(std::vector<char> &buf, size_t &end, size_t want)
+    bool inflate_more(TextBuf &buf, size_t &end, size_t want)
     {
         if (eof) return false;
         if (end + want > buf.size()) buf.resize(std::max(buf.size() * 2, end + want));
@@ -480,7 +527,7 @@ struct Source {
                 const size_t n = std::min(want, lim - cur_pos);
                 if (n) {
                     memcpy(buf.data() + end, cur->buf.data() + cur_pos, n);
-                    if (!cur->verified) m_crc = (uint32_t)crc32(m_crc, (const Bytef *)cur->buf.data() + cur_pos, (uInt)n);      // (BGZF members are checked by the thread that inflates them)
+                    if (!cur->verified) m_crc = mpz::fast_crc32(m_crc, cur->buf.data() + cur_pos, n);      // (BGZF members are checked by the thread that inflates them)
                     m_size += (uint32_t)n; end += n; cur_pos += n; want -= n; got = true;
                 }
                 if (cur_pos < lim) continue;
@@ -637,7 +684,7 @@ const char *next_block(Source &src, Batch &out, int k, size_t max_recs, int thre
     raw.clear();
     n_recs = 0;
     if (!src.gz && src.pos >= src.map_len) return src.map;
-    std::vector<char> &buf = out.text[k];
+    TextBuf &buf = out.text[k];
     size_t end = 0;                                             // gz: bytes of buf in use
     if (src.gz) {
         if (buf.size() < (1u << 22)) buf.resize(1u << 22);
@@ -654,6 +701,7 @@ const char *next_block(Source &src, Batch &out, int k, size_t max_recs, int thre
         double est = src.bytes_per_rec > 0 ? src.bytes_per_rec * 1.03 * (double)max_recs + 4096 : 512.0 * (double)max_recs + (1u << 20);
         for (;;) {
             if (src.gz) {
+                if (buf.size() < (size_t)est + (1u << 24)) buf.resize((size_t)est + (1u << 25));      // once, instead of doubling on the way
                 while (end < (size_t)est && src.inflate_more(buf, end, 1u << 24)) {}
                 win = end;
             } else win = std::min(src.map_len - src.pos, (size_t)est);
@@ -1937,7 +1985,7 @@ int main(int argc, char **argv)
     } else if (!pass1_path.empty()) { fprintf(stderr, "[soap4-mi355x] -pass1 counts taxids: it needs -lsamid\n"); return 1; }
     Pass1 pass1_total;
     Source ra, rb;
-    if (!ra.open(fq1) || !rb.open(fq2)) { fprintf(stderr, "[soap4-mi355x] cannot open read files\n"); return 1; }
+    if (!ra.open(fq1, threads) || !rb.open(fq2, threads)) { fprintf(stderr, "[soap4-mi355x] cannot open read files\n"); return 1; }
     BamState bam_state, *bam = nullptr;
     if (p.want_bam && !plumbing_only) {
         // as in the chained runs of runMegaPath.sh:191-227 -- every run writes the same -o prefix -- the files that remain are the last chunk's

@@ -52,6 +52,8 @@ for kind in thread address,undefined; do
     MP_BATCH_PAIRS=11 run wrapped_fasta 0 "$exe" pair x "$B/w_1.fa" "$B/w_2.fa" "${common[@]}" -T 4 -F -nc
     MP_BATCH_PAIRS=13 run odd_shapes 0 "$exe" pair x "$B/odd_1.fq" "$B/odd_2.fq" "${common[@]}" -T 4 -F -nc
     MP_BATCH_PAIRS=9 MP_INFLATE_THREADS=4 run bgzf 0 "$exe" pair x "$B/bg_1.fq.gz" "$B/bg_2.fq.gz" "${common[@]}" -T 4 -F -nc
+    MP_BATCH_PAIRS=9 MP_INFLATE_THREADS=4 MP_PARGZ_MIN=0 MP_PARGZ_SEG=65536 run pargz 0 "$exe" pair x "$B/a_1.fq.gz" "$B/a_2.fq.gz" "${common[@]}" -T 4 -F -nc
+    TSAN_OPTIONS="$TSAN_OPTIONS report_thread_leaks=0" ASAN_OPTIONS="$ASAN_OPTIONS detect_leaks=0" MP_INFLATE_THREADS=4 MP_PARGZ_MIN=0 MP_PARGZ_SEG=65536 MP_BATCH_PAIRS=20 run pargz_corrupt 1 "$exe" pair x "$B/bad_1.fq.gz" "$G1/reads_a_2.fq" "${common[@]}" -T 2 -F -nc
     MP_BATCH_PAIRS=50 run lsam 0 "$exe" pair x "$G1/reads_e_1.fq" "$G1/reads_e_2.fq" "${common[@]}" -T 4 -F -top 95 -lsam
     # fatal() leaves through _exit() from whichever thread met the error, on purpose (no atexit handlers while other stages write):
     # the threads it leaves behind are not a leak to report

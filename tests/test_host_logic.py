@@ -346,7 +346,7 @@ def test_reader_rejects_garbage_and_mate_count_mismatch(tmp_path):
     assert r.returncode == 1 and b"ends inside" in r.stderr
 
 
-@pytest.mark.parametrize("inflate", ["fast", "zlib"])
+@pytest.mark.parametrize("inflate", ["fast", "zlib", "parallel"])
 def test_reader_gzip_members_levels_and_corruption(tmp_path, inflate):
     """The executable's own gzip decoder (host/fast_inflate.h; MP_INFLATE=zlib keeps zlib's gzread): concatenated members (bgzip, `cat a.gz b.gz`),
     an empty member, stored blocks (level 0), fixed-Huffman blocks, levels 1-9 -- the records must be what kseq reads from the plain text; a flipped
@@ -362,6 +362,10 @@ def test_reader_gzip_members_levels_and_corruption(tmp_path, inflate):
     env = {"MP_BATCH_PAIRS": "700"}
     if inflate == "zlib":
         env["MP_INFLATE"] = "zlib"
+    if inflate == "parallel":                                             # several threads on the one stream (host/par_gzip.h), segments of 64 KiB
+        env.update(MP_PARGZ_MIN="0", MP_PARGZ_SEG="65536", MP_INFLATE_THREADS="4")
+    else:
+        env["MP_PARGZ_MIN"] = str(1 << 40)
     want = _expected_plumbing(_kseq_records(texts[0]), _kseq_records(texts[1]), 151)
 
     def members(data, k):
@@ -445,3 +449,50 @@ def test_reader_bgzf_members_inflate_side_by_side(tmp_path, threads):
         b1.write_bytes(bytes(bad))
         r = _plumb(tmp_path, b1, files[1], env)
         assert r.returncode == 1 and b"error while reading" in r.stderr, (i, r.returncode, r.stderr[-300:])
+
+
+def _pargz_tool(tmp_path):
+    exe = tmp_path / "pargz_check"
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", str(exe), os.path.join(ROOT, "tests", "tools", "pargz_check.cpp"), "-lz"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    return str(exe)
+
+
+def test_parallel_gzip_reader_equals_zlib_on_every_stream_shape(tmp_path):
+    """host/par_gzip.h (several threads on ONE deflate stream: block starts found by search, segments decoded without their window into
+    16-bit symbols, markers resolved in file order) against zlib's gzread, byte for byte: compression levels, concatenated members, fixed
+    and stored blocks, full-flush points, long matches (a window full of markers), tiny members, input that is not text (no start is ever
+    found: one thread decodes everything).  Also the folding CRC-32 (host/crc32_fold.h) is what checks every member here."""
+    import gzip
+    import random
+    import zlib
+    exe = _pargz_tool(tmp_path)
+    rng = random.Random(9)
+
+    def fastq(n, tag):
+        return "".join("@%s%d\n%s\n+\n%s\n" % (tag, i, "".join(rng.choice("ACGT") for _ in range(150)), "".join(rng.choice("FFFFF:,#") for _ in range(150))) for i in range(n)).encode()
+    base = fastq(12000, "r")
+    shapes = {}
+    for lv in (1, 6, 9):
+        shapes["level%d" % lv] = gzip.compress(base, lv)
+    shapes["members"] = b"".join(gzip.compress(base[a:a + 700000], [6, 1, 9, 0][k % 4]) for k, a in enumerate(range(0, len(base), 700000))) + gzip.compress(b"")
+    c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
+    shapes["fixed"] = c.compress(base) + c.flush()
+    shapes["stored"] = gzip.compress(base, 0)
+    c = zlib.compressobj(6, zlib.DEFLATED, 31)
+    shapes["flushes"] = b"".join(c.compress(base[a:a + 200000]) + c.flush(zlib.Z_FULL_FLUSH if k % 2 else zlib.Z_SYNC_FLUSH) for k, a in enumerate(range(0, len(base), 200000))) + c.flush()
+    rep = fastq(40, "x")
+    shapes["repeats"] = gzip.compress(rep * 3000 + base[:500000] + rep * 3000, 6)          # matches that reach back 32 KiB again and again: markers throughout a segment
+    shapes["binary"] = gzip.compress(bytes(rng.randrange(256) for _ in range(300000)) + base[:2000000], 6)
+    shapes["tiny"] = gzip.compress(b"@a\nA\n+\nF\n")
+    for name, data in shapes.items():
+        f = tmp_path / (name + ".gz")
+        f.write_bytes(data)
+        for threads, seg in ((4, 65536), (3, 262144)):
+            r = subprocess.run([exe, str(f), str(threads), str(seg)], capture_output=True)
+            assert r.returncode == 0 and b"DIFFERENT" not in r.stdout, (name, threads, seg, r.stdout.decode()[-600:], r.stderr.decode()[-300:])
+    # the search does find starts in ordinary files (otherwise everything above ran on one thread)
+    r = subprocess.run([exe, str(tmp_path / "level6.gz"), "4", "65536"], capture_output=True)
+    import re
+    m = re.search(rb"(\d+) segments, (\d+) started without their window", r.stdout)
+    assert m and int(m.group(2)) >= int(m.group(1)) // 2, r.stdout

@@ -1329,8 +1329,28 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
                                                (const uint32_t *)nullptr, c->th_stats.p);
         else if (narrow) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
                                        (const uint32_t *)nullptr, c->th_stats.p);
-        else hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), dim3(grid_for(n, 32)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
-                                (const uint32_t *)nullptr, c->th_stats.p);
+        else {
+            // a batch with reads of more than 160 bases is usually one of mixed lengths: the instances of 101 .. 160 bases go through the narrow
+            // kernel, those of 161 .. 320 through the wide one, each as a list (a wavefront then sweeps as many rows as ITS longest window has);
+            // shorter reads are left to the filter
+            HIPCHK(hipMemsetAsync(c->th_cert.p, 0, n, s));
+            const uint32_t lo[2] = {100u, MP_TH_MAXL}, hi[2] = {MP_TH_MAXL, MP_TH_MAXL_WIDE};
+            for (int k = 0; k < 2; k++) {
+                hipLaunchKernelGGL(dp_len_class_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, n, lo[k], hi[k], c->sel_flag.p, (const uint8_t *)nullptr);
+                int rck = exclusive_scan_inclusive_u32(c, c->sel_flag.p, c->sel_idx.p, n);
+                if (rck) return rck;
+                uint32_t n_k = 0;
+                HIPCHK(hipMemcpyAsync(&n_k, c->sel_idx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (n_k == 0) continue;
+                hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, n, c->score_list.p, (const uint32_t *)nullptr);
+                if (k == 0) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n_k, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_k, c->th_cert.p,
+                                               (const uint32_t *)c->score_list.p, c->th_stats.p);
+                else hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), dim3(grid_for(n_k, 32)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_k, c->th_cert.p,
+                                        (const uint32_t *)c->score_list.p, c->th_stats.p);
+                HIPCHK(hipStreamSynchronize(s));                                 // the list buffer is reused by the next class
+            }
+        }
         MP_TRACE(s, "dp_thermo_kernel");
         hipLaunchKernelGGL(thermo_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint8_t *)c->th_cert.p, n, c->sel_flag.p, c->fill.p);
         int rc0 = exclusive_scan_inclusive_u32(c, c->sel_flag.p, c->sel_idx.p, n);

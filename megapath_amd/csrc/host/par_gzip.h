@@ -158,6 +158,7 @@ public:
     {
         n_seg_ = (len_ + seg_ - 1) / seg_;
         if (n_seg_ == 0) n_seg_ = 1;
+        cap_sym_ = H + 8 * seg_ + ((size_t)16 << 20);                      // symbols a segment holds before it hands over what it has (flush_part)
         segs_.reset(new Seg[n_seg_]);
         for (size_t k = 0; k < n_seg_; k++) segs_[k].find_state = k == 0 ? 2 : 0;
         memset(win_prev_, 0, H);
@@ -184,6 +185,7 @@ public:
     size_t segments() const { return n_seg_; }
     size_t segments_started_blind() const { return blind_.load(); }
     size_t false_starts() const { return false_starts_.load(); }
+    size_t parts_handed_over_early() const { return parts_.load(); }
     // thread-seconds spent looking for starts / decoding / resolving (over all threads)
     double seconds_find() const { return ns_find_.load() * 1e-9; }
     double seconds_decode() const { return ns_decode_.load() * 1e-9; }
@@ -205,7 +207,7 @@ private:
         std::string err;
     };
     const uint8_t *d_;
-    size_t len_, seg_, n_seg_;
+    size_t len_, seg_, n_seg_, cap_sym_ = 0;
     int ahead_, max_pieces_;
     std::unique_ptr<Seg[]> segs_;
     std::vector<std::thread> th_;
@@ -223,7 +225,8 @@ private:
     std::deque<std::pair<uint64_t, Piece *>> finished_;  // resolved out of order
     // member check, in delivery order
     uint32_t running_crc_ = 0, running_size_ = 0;
-    std::atomic<size_t> blind_{0}, false_starts_{0};
+    std::atomic<size_t> blind_{0}, false_starts_{0}, parts_{0}, none_found_{0}, starts_found_{0};
+    std::atomic<int> searches_given_up_{0};
     std::atomic<uint64_t> ns_find_{0}, ns_decode_{0}, ns_resolve_{0};
     static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -235,10 +238,14 @@ private:
         if (len_ < 64) return NONE;
         const uint64_t safe = (uint64_t)(len_ - 40) * 8u;                   // the look-ahead of the checks stays inside the file
         if (hi > safe) hi = safe;
+        if (searches_given_up_.load()) return NONE;
         BitPeek in{d_, len_};
         std::vector<uint16_t> trial;
+        uint64_t word = 0;
         for (uint64_t b = lo; b < hi; b++) {
-            if ((in.at(b) & 7u) != 4u) continue;
+            // BFINAL = 0, BTYPE = 10 first: eight positions per load
+            if ((b & 7u) == 0 || b == lo) word = in.at(b & ~(uint64_t)7);
+            if (((word >> (b & 7u)) & 7u) != 4u) continue;
             if (!plausible_dynamic_header(in, b)) continue;
             // decode this block and the next one: no error, text only
             if (trial.empty()) { trial.resize(H + (1u << 20)); for (size_t i = 0; i < H; i++) trial[i] = (uint16_t)(0x8000u | i); }
@@ -277,6 +284,9 @@ private:
             const uint64_t t0 = now_ns();
             const uint64_t b = find_start(k);
             ns_find_ += now_ns() - t0;
+            // a file in which the first few segments hold no start at all (stored blocks, input that is not text) is not searched any further:
+            // scanning every bit costs more than decoding, and one thread decodes such a file anyway
+            if (b == NONE) { if (++none_found_ >= 3 && starts_found_.load() == 0) searches_given_up_ = 1; } else starts_found_++;
             lk.lock();
             s.start_bit = b; s.find_state = 2;
             cv_.notify_all();
@@ -311,7 +321,13 @@ private:
         for (;;) {
             { std::lock_guard<std::mutex> lk(mu_); if (stop_ || s.dead) break; }
             const int rc = z.run(s.sym.data(), pos, s.sym.size());
-            if (rc == NEED_OUTPUT) { s.sym.resize(s.sym.size() + s.sym.size() / 2); continue; }
+            if (rc == NEED_OUTPUT) {
+                if (s.sym.size() < cap_sym_) { s.sym.resize(std::min(cap_sym_, s.sym.size() + s.sym.size() / 2)); continue; }
+                // a segment that inflates to more than eight times its size (or runs through many segments without a start): what it has
+                // is handed over as a piece of its own as soon as the segment heads the chain, and the buffer is used again
+                if (!flush_part(k, pos)) break;
+                continue;
+            }
             if (rc == MEMBER_END) { s.ends.push_back(MemberEnd{pos - H, z.member_crc(), z.member_isize()}); continue; }
             if (rc == STREAM_END) { s.eof = true; break; }
             if (rc == ERR) { s.err = z.error(); break; }
@@ -350,45 +366,24 @@ private:
         cv_.notify_all();
     }
 
-    // the chain: segment `k` is the next one in file order, win_prev_ the 32 KiB in front of it
-    void resolve_segment(size_t k, Piece *piece, uint64_t order)
+    // symbols -> bytes of a piece, the CRC-32 of its stretches between member ends
+    void fill_piece(Piece *piece, const uint16_t *sym, size_t n, const uint8_t *window, const std::vector<MemberEnd> &ends)
     {
-        Seg &s = segs_[k];
-        uint8_t window[H];
-        memcpy(window, win_prev_, H);
-        // the window of what follows first, so that the chain can move on while the bulk of this segment is resolved
-        {
-            uint8_t next_win[H];
-            if (s.n_sym >= H) resolve_symbols(s.sym.data() + H + s.n_sym - H, H, window, next_win);
-            else {
-                memcpy(next_win, window + s.n_sym, H - s.n_sym);
-                resolve_symbols(s.sym.data() + H, s.n_sym, window, next_win + H - s.n_sym);
-            }
-            std::lock_guard<std::mutex> lk(mu_);
-            memcpy(win_prev_, next_win, H);
-            // the segments between this one and the one its decoder stopped on never enter the chain: whatever they decoded is void
-            for (size_t i = k + 1; i < s.next_seg && i < n_seg_; i++) { if (segs_[i].find_state == 2 && segs_[i].start_bit != NONE) false_starts_++; segs_[i].dead = true; }
-            chain_ = s.next_seg;
-            if (s.eof || !s.err.empty() || s.next_seg >= n_seg_) chain_done_ = true;
-            chain_busy_ = false;
-            cv_.notify_all();
-        }
-        if (piece->bytes.size() < s.n_sym + 64) piece->bytes.resize(s.n_sym + 64);
-        resolve_symbols(s.sym.data() + H, s.n_sym, window, piece->bytes.data());
-        piece->n = s.n_sym;
-        piece->eof = s.eof || s.next_seg >= n_seg_;
-        piece->err = s.err;
-        if (piece->err.empty() && !s.eof && s.next_seg >= n_seg_) piece->err = "truncated deflate stream";     // (the last segment ends with the stream or not at all)
+        if (piece->bytes.size() < n + 64) piece->bytes.resize(n + 64);
+        resolve_symbols(sym, n, window, piece->bytes.data());
+        piece->n = n;
         piece->crc_parts.clear(); piece->ends.clear();
         size_t from = 0;
-        for (const MemberEnd &e : s.ends) {
+        for (const MemberEnd &e : ends) {
             piece->crc_parts.emplace_back(e.pos - from, fast_crc32(0u, piece->bytes.data() + from, e.pos - from));
             piece->ends.push_back(e);
             from = e.pos;
         }
-        piece->crc_parts.emplace_back(s.n_sym - from, fast_crc32(0u, piece->bytes.data() + from, s.n_sym - from));
-        // hand over in order; the member checks run here, in order, on the combined CRCs
-        std::lock_guard<std::mutex> lk(mu_);
+        piece->crc_parts.emplace_back(n - from, fast_crc32(0u, piece->bytes.data() + from, n - from));
+    }
+    // hands a finished piece over in order (mu_ held); the member checks run here, in order, on the combined CRCs
+    void deliver_locked(Piece *piece, uint64_t order)
+    {
         finished_.emplace_back(order, piece);
         for (bool moved = true; moved;) {
             moved = false;
@@ -403,6 +398,85 @@ private:
                     break;
                 }
         }
+    }
+    // a job of the chain, if there is one (mu_ held): the segment at its head is decoded and a piece may be taken
+    bool claim_resolve(size_t &k, Piece *&piece, uint64_t &order)
+    {
+        if (chain_done_ || chain_busy_ || chain_ >= n_seg_ || !segs_[chain_].decoded || segs_[chain_].dead || outstanding_ >= max_pieces_) return false;
+        k = chain_; chain_busy_ = true;
+        piece = take_piece_locked();
+        order = order_seq_++;
+        return true;
+    }
+    Piece *take_piece_locked()
+    {
+        Piece *piece;
+        if (!free_pieces_.empty()) { piece = free_pieces_.front(); free_pieces_.pop_front(); }
+        else { all_pieces_.emplace_back(new Piece()); piece = all_pieces_.back().get(); }
+        outstanding_++;
+        return piece;
+    }
+
+    // Segment k's buffer is full: wait until k heads the chain (doing the chain's work meanwhile), hand over the symbols so far as a piece,
+    // keep the last 32 Ki symbols as the history of what follows.  The markers keep referring to the window in front of the SEGMENT, which
+    // does not change before the segment is done.  false: the reader is shutting down or the segment is dead.
+    bool flush_part(size_t k, size_t &pos)
+    {
+        Seg &s = segs_[k];
+        Piece *piece = nullptr;
+        uint64_t order = 0;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            for (;;) {
+                if (stop_ || s.dead) return false;
+                if (chain_ == k && !chain_busy_ && outstanding_ < max_pieces_) break;
+                size_t rk; Piece *rp; uint64_t ro;
+                if (claim_resolve(rk, rp, ro)) { lk.unlock(); resolve_segment(rk, rp, ro); lk.lock(); continue; }
+                cv_.wait(lk);
+            }
+            chain_busy_ = true;
+            piece = take_piece_locked();
+            order = order_seq_++;
+        }
+        fill_piece(piece, s.sym.data() + H, pos - H, win_prev_, s.ends);     // (win_prev_ is written by the head of the chain only: this thread)
+        piece->eof = false; piece->err.clear();
+        s.ends.clear();
+        memmove(s.sym.data(), s.sym.data() + pos - H, H * sizeof(uint16_t));
+        pos = H;
+        std::lock_guard<std::mutex> lk(mu_);
+        deliver_locked(piece, order);
+        chain_busy_ = false;
+        parts_++;
+        cv_.notify_all();
+        return true;
+    }
+
+    // the chain: segment `k` is the next one in file order, win_prev_ the 32 KiB in front of it
+    void resolve_segment(size_t k, Piece *piece, uint64_t order)
+    {
+        Seg &s = segs_[k];
+        uint8_t window[H];
+        memcpy(window, win_prev_, H);
+        // the window of what follows first, so that the chain can move on while the bulk of this segment is resolved: the last 32 Ki
+        // symbols of the buffer, history included (a fresh segment's history are the markers themselves)
+        {
+            uint8_t next_win[H];
+            resolve_symbols(s.sym.data() + s.n_sym, H, window, next_win);
+            std::lock_guard<std::mutex> lk(mu_);
+            memcpy(win_prev_, next_win, H);
+            // the segments between this one and the one its decoder stopped on never enter the chain: whatever they decoded is void
+            for (size_t i = k + 1; i < s.next_seg && i < n_seg_; i++) { if (segs_[i].find_state == 2 && segs_[i].start_bit != NONE) false_starts_++; segs_[i].dead = true; }
+            chain_ = s.next_seg;
+            if (s.eof || !s.err.empty() || s.next_seg >= n_seg_) chain_done_ = true;
+            chain_busy_ = false;
+            cv_.notify_all();
+        }
+        fill_piece(piece, s.sym.data() + H, s.n_sym, window, s.ends);
+        piece->eof = s.eof || s.next_seg >= n_seg_;
+        piece->err = s.err;
+        if (piece->err.empty() && !s.eof && s.next_seg >= n_seg_) piece->err = "truncated deflate stream";     // (the last segment ends with the stream or not at all)
+        std::lock_guard<std::mutex> lk(mu_);
+        deliver_locked(piece, order);
         in_flight_--;
         s.claimed = false; s.decoded = false;
         sym_pool_.emplace_back();
@@ -435,14 +509,7 @@ private:
                     if (stop_) return;
                     // dead segments at the head of the chain cannot occur (the chain only ever points at segments a decoder stopped on), but a
                     // dead segment that finished decoding gives its slot back
-                    if (!chain_done_ && !chain_busy_ && chain_ < n_seg_ && segs_[chain_].decoded && !segs_[chain_].dead && outstanding_ < max_pieces_) {
-                        k = chain_; job = 1; chain_busy_ = true;
-                        if (!free_pieces_.empty()) { piece = free_pieces_.front(); free_pieces_.pop_front(); }
-                        else { all_pieces_.emplace_back(new Piece()); piece = all_pieces_.back().get(); }
-                        outstanding_++;
-                        order = order_seq_++;
-                        break;
-                    }
+                    if (claim_resolve(k, piece, order)) { job = 1; break; }
                     if (next_decode_ < n_seg_ && in_flight_ < ahead_ && !chain_done_) {
                         k = next_decode_++;
                         if (segs_[k].dead) continue;                        // already known to be run through by the segment before it

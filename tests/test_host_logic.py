@@ -485,6 +485,9 @@ def test_parallel_gzip_reader_equals_zlib_on_every_stream_shape(tmp_path):
     shapes["repeats"] = gzip.compress(rep * 3000 + base[:500000] + rep * 3000, 6)          # matches that reach back 32 KiB again and again: markers throughout a segment
     shapes["binary"] = gzip.compress(bytes(rng.randrange(256) for _ in range(300000)) + base[:2000000], 6)
     shapes["tiny"] = gzip.compress(b"@a\nA\n+\nF\n")
+    one = fastq(1, "same")
+    shapes["ratio"] = gzip.compress(one * 150000, 6)                      # inflates 150-fold: a segment hands over what it has before it is done (bounded memory)
+    shapes["stored_big"] = gzip.compress(base * 6, 0)                     # no dynamic block anywhere: the search gives up, one thread decodes, in parts
     for name, data in shapes.items():
         f = tmp_path / (name + ".gz")
         f.write_bytes(data)

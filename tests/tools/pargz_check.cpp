@@ -69,8 +69,8 @@ int main(int argc, char **argv)
             const double dt = now() - t0;
             printf("           thread-seconds: finding starts %.3f, decoding (incl. finding) %.3f, resolving %.3f; wall %.3f\n", pg.seconds_find(), pg.seconds_decode(), pg.seconds_resolve(), dt);
             if (pos != want.size() || !err.empty()) same = false;
-            printf("parallel   %8.1f MB/s %s  (%d threads, %zu segments, %zu started without their window, %zu false starts)%s%s\n", pos / dt / 1e6, same ? "equal" : "DIFFERENT",
-                   threads, pg.segments(), pg.segments_started_blind(), pg.false_starts(), err.empty() ? "" : "  error: ", err.c_str());
+            printf("parallel   %8.1f MB/s %s  (%d threads, %zu segments, %zu started without their window, %zu false starts, %zu early parts)%s%s\n", pos / dt / 1e6, same ? "equal" : "DIFFERENT",
+                   threads, pg.segments(), pg.segments_started_blind(), pg.false_starts(), pg.parts_handed_over_early(), err.empty() ? "" : "  error: ", err.c_str());
             if (!same) rc = 1;
         }
     }

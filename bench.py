@@ -395,7 +395,7 @@ def nt_replica_leg(args, H, index_builder, simulate, arrs_a, text_a, dev, device
     copied device-to-device into its own arrays (mp_index_clone) -- so that, as with the real database, a read has its true
     alignment in one chunk and only chance matches in the others.  Read mix of SURVEY 8d C3: 60 % drawn from chunk 0 at 0-8 %
     divergence, 40 % random."""
-    knobs = {"MP_KMER_FILTER": "0", "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}
+    knobs = {"MP_KMER_FILTER": os.environ.get("MP_BENCH_NT_KMER", "0"), "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}
     saved = {k: os.environ.get(k) for k in knobs}
     os.environ.update(knobs)
     chunks = []

@@ -324,16 +324,19 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         bool on = n >= (1ull << 25) && free_b >= (12ull << 30);
-        if (e) on = atoi(e) != 0;
-        const size_t kb = (size_t)1 << 31;
+        uint32_t K = 17;
+        if (e) { on = atoi(e) != 0; if (atoi(e) == 16) K = 16; }          // MP_KMER_FILTER=16: one bit per 16-mer, 512 MiB (the lean layout of many chunks)
+        const size_t kb = (size_t)1 << (2 * K - 3);
+        ix->d.kmer_k = 0;
         if (on && n >= 17 && hipMalloc(&ix->d_kmer, kb) == hipSuccess) {
             if (hipMemset(ix->d_kmer, 0, kb) != hipSuccess) return fail(MP_ENODEV);
-            hipLaunchKernelGGL(kmer17_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, (uint32_t *)ix->d_kmer);
+            hipLaunchKernelGGL(kmer17_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, (const uint32_t *)ix->d_text, n, (uint32_t *)ix->d_kmer, K);
             if (hipDeviceSynchronize() != hipSuccess) return fail(MP_ENODEV);
             ix->device_bytes += kb; ix->bytes_kmer = kb;
+            ix->d.kmer_k = K;
         }
     }
-    if (ix->d_kmer) {
+    if (ix->d_kmer && ix->d.kmer_k == 17) {
         // the pre-filter's bits once more, per 15-mer (kernels_index.hip): 8.6 GB, one load per three probed positions;
         // automatic when that leaves >= 16 GiB free, MP_KMER15=0 / 1 overrides
         const char *e = getenv("MP_KMER15");
@@ -349,7 +352,7 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
             ix->device_bytes += bytes; ix->bytes_kmer15 = bytes;
         }
     }
-    if (ix->d_kmer) {
+    if (ix->d_kmer && ix->d.kmer_k == 17) {
         // 16-mer look-up table behind the pre-filter (kernels_index.hip): 17 GB, three backward-search steps less per seed
         // start; automatic when that leaves >= 16 GiB free, MP_LKT16=0 / 1 overrides
         const char *e = getenv("MP_LKT16");
@@ -518,7 +521,7 @@ extern "C" int mp_index_get_info(const mp_index *ix, mp_index_info *out)
     for (int i = 0; i < 5; i++) out->cum_freq[i] = ix->cum[i];
     out->sa_interval = ix->sa_interval; out->num_seq = (uint32_t)ix->seq_names.size();
     out->device_bytes = ix->device_bytes;
-    out->prefilter_k = ix->d_kmer ? 17u : 0u; out->reserved = 0;
+    out->prefilter_k = ix->d_kmer ? ix->d.kmer_k : 0u; out->reserved = 0;
     return MP_OK;
 }
 
@@ -690,7 +693,7 @@ extern "C" int mp_index_copy_lkt(const mp_index *ix, uint32_t *out)
 extern "C" int mp_index_prefilter(const mp_index *ix, const uint64_t *keys, uint64_t n, uint8_t *out)
 {
     if (!ix || !keys || !out) return MP_EINVAL;
-    if (!ix->d_kmer) return MP_EINVAL;
+    if (!ix->d_kmer || ix->d.kmer_k != 17) return MP_EINVAL;
     HIPCHK(hipSetDevice(ix->device));
     uint64_t *d_k = nullptr; uint8_t *d_o = nullptr;
     HIPCHK(hipMalloc((void **)&d_k, n * 8 + 8)); HIPCHK(hipMalloc((void **)&d_o, n + 8));

@@ -133,20 +133,22 @@ __global__ void add_offset_kernel(uint32_t *__restrict__ a, uint64_t n, uint32_t
 // "Can be extended to" is what the reference's own procedure reaches: the 13-mer table is built over the text continued
 // with 12 'A's (LTConstruct.c:44-105), the four further bases are true backward-search steps; that is the set of
 // 17-base windows of (text + 12 'A') starting at 0 .. n-5.  Key: leftmost text base in the top bits, as for the LKT.
-__global__ void kmer17_build_kernel(const uint32_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ bitmap)
+// K = 16: the same for the first 16 scanned bases (4^16 bits = 512 MiB; windows starting at 0 .. n-4) -- a weaker filter (a 16-mer is in a
+// 2.95 Gbp text with probability 0.50, a 17-mer with 0.16) for index chunks that have no 2 GiB to spare: the lean layout of the NT replica.
+__global__ void kmer17_build_kernel(const uint32_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ bitmap, uint32_t K = 17)
 {
     const uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (n < 5 || p > n - 5) return;
+    if (n < K - 12 || p > n - (K - 12)) return;
     const uint64_t q = p >> 4;
     const uint32_t sh = 2 * (uint32_t)(p & 15);
     const uint64_t lo = ((uint64_t)text[q + 1] << 32) | text[q];
     uint64_t v = lo >> sh;                                         // bases p .. in LSB-first order
     if (sh > 30) v |= (uint64_t)text[q + 2] << (64 - sh);          // cannot happen (sh <= 30 leaves 34 bits), kept for clarity
-    v &= (1ull << 34) - 1;
-    // reverse the order of the 17 two-bit groups: base p goes to bits 33:32
+    v &= (1ull << (2 * K)) - 1;
+    // reverse the order of the K two-bit groups: base p goes to the top bits
     uint64_t r = __brevll(v);                                      // bit i -> 63 - i
     r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);   // restore the bit order inside each pair
-    const uint64_t key = r >> 30;                                  // the 34 significant bits
+    const uint64_t key = r >> (64 - 2 * K);                        // the 2 K significant bits
     atomicOr(&bitmap[key >> 5], 1u << (uint32_t)(key & 31));
 }
 

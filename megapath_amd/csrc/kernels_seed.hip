@@ -368,9 +368,9 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
         const uint32_t wq = (uint32_t)s.i >> 4, sh = 2 * ((uint32_t)s.i & 15);
         const uint64_t two = ((uint64_t)s.sc[wq + 1] << 32) | s.sc[wq];
         bool futile = false;
-        if (ix.kmer17 && P.seed_min_length >= 17) {
-            // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe
-            const uint64_t k17 = (two >> sh) & ((1ull << 34) - 1);
+        if (ix.kmer17 && P.seed_min_length >= (int)ix.kmer_k) {
+            // pre-filter: the next 17 (16) scanned bases (there are at least seed_min_length left) as one bit probe
+            const uint64_t k17 = (two >> sh) & ((1ull << (2 * ix.kmer_k)) - 1);
             if (ix.kmer15x3) {
                 const int a = s.i - s.pg;
                 if (a < 0 || a > 2) {
@@ -393,7 +393,7 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
             ++s.i;                                            // a seed shorter than seed_min_length: nothing reported, restart one base on
             continue;
         }
-        if (ix.lkt16 && ix.kmer17 && P.seed_min_length >= 17 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
+        if (ix.lkt16 && ix.kmer17 && ix.kmer_k == 17 && P.seed_min_length >= 17 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
             // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
             // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
             // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
@@ -547,7 +547,8 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
     const uint32_t S = mp_scan_stride(W);
     uint32_t *const sl = s_scan + threadIdx.x * (S | 1u);
     const uint32_t n = ix.n;
-    const bool pf = ix.kmer17 && P.seed_min_length >= 17;
+    const bool pf = ix.kmer17 && P.seed_min_length >= (int)ix.kmer_k;
+    const uint64_t kmask = (1ull << (2 * ix.kmer_k)) - 1;             // (kmer15x3 and the 16-mer tables exist only with 17-mers)
     const bool text_ok = ix.sa_dense && ix.sa_dense_shift == 0;
     const uint32_t cum0 = ix.cum[0], cum1 = ix.cum[1], cum2 = ix.cum[2], cum3 = ix.cum[3];
     mp_lane_events ev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -745,7 +746,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                                                                                           : 32u + (uint32_t)((k17 >> 30) & 15);
                             nf |= (uint32_t)(((q < 3 ? e1 : e2) >> bit) & 1ull) << q;
                         }
-                    } else nf = (a0 >> (uint32_t)(bases_at(s.i) & 31)) & 1u;
+                    } else nf = (a0 >> (uint32_t)(bases_at(s.i) & 31)) & 1u;       // (bit = the key's low five bits, whatever its length)
                     s.nf = nf; s.pg = s.i;
                 }
                 const int lim = s.len - P.seed_min_length;                    // the last position a seed may start at (`break` of the scan loop beyond)
@@ -765,7 +766,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                             else { ev.kmer += (uint32_t)adv + (bits ? 1u : 0u); s.i += adv; start_here = bits != 0; }
                         } else start_here = false;
                         if (!fin && !start_here) {
-                            const uint64_t k17 = bases_at(s.i) & ((1ull << 34) - 1);
+                            const uint64_t k17 = bases_at(s.i) & kmask;
                             next = MK_PRE;
                             if (ix.kmer15x3) {
                                 // two entries at once: this position's and the one three bases on (runs of futile starts are the rule: every

@@ -37,7 +37,8 @@ struct mp_dev_index {          // passed by value to kernels
                                // three (16-mer table, suffix array, text); pos = 0xFFFFFFFF: no short cut (match within 16 bases of the text start)
     const unsigned long long *kmer15x3;   // optional: per 15-mer, the presence bits of the 48 17-mers around it (three alignments, see
                                // kmer15x3_build_kernel): one load answers the pre-filter for three consecutive scan positions
-    const uint32_t *kmer17;    // optional: one bit per 17-mer, set when backward search can reach length 17 with it (nullptr = off)
+    const uint32_t *kmer17;    // optional: one bit per K-mer (K = kmer_k: 17, or 16 for 512 MiB instead of 2 GiB), set when backward search can reach length K with it (nullptr = off)
+    uint32_t kmer_k;
     const uint32_t *sa_dense;  // optional: SA[k << sa_dense_shift], filled on the device from the file's samples (nullptr = off)
     uint32_t sa_dense_shift;   // 0: the whole suffix array, 1: every 2nd row, 2: every 4th
     uint32_t n;                // text length

@@ -190,6 +190,35 @@ def test_seed_stage_matches_oracle(gidx, oidx, golden_dir, tag, mmp, monkeypatch
     ctx.close()
 
 
+@pytest.mark.parametrize("tag,mmp,sa_dense", [("a", H.MmpParams.nt2(), "0"), ("b", H.MmpParams.human(), "0"), ("c", H.MmpParams.nt2(), "1")])
+def test_seed_stage_with_the_16mer_filter_matches_oracle(oidx, golden_dir, tag, mmp, sa_dense, monkeypatch):
+    """MP_KMER_FILTER=16: one bit per 16-mer (512 MiB) instead of per 17-mer (2 GiB) in front of every seed start -- the filter of the lean
+    layout (many chunks resident).  A weaker filter, the same seeds: equal to the oracle's, with the overflow kernel (tag b) and with the
+    whole suffix array resident (text comparison path)."""
+    for k in ("MP_KMER15", "MP_LKT16", "MP_LKT16U"):
+        monkeypatch.setenv(k, "0")
+    monkeypatch.setenv("MP_KMER_FILTER", "16")
+    monkeypatch.setenv("MP_SA_DENSE", sa_dense)
+    if tag == "b":
+        monkeypatch.setenv("MP_SEED_SLAB_LIMIT", "2")
+    d = os.path.join(golden_dir, "g1")
+    gix = H.Index(os.path.join(d, "ref.fa.index"), 0)
+    assert gix.info.prefilter_k == 16
+    L = int(open(os.path.join(d, "expected_%s.L" % tag)).read())
+    seqs = read_fastq_pairs(os.path.join(d, "reads_%s_1.fq" % tag), os.path.join(d, "reads_%s_2.fq" % tag))
+    packed, lens, W = H.pack_reads(seqs, L)
+    ctx = H.Context(gix)
+    ctx.set_reads(packed, lens)
+    st = ctx.seed_batch(mmp)
+    arr, off = ctx.get_seeds()
+    want, ctr = oracle_seeds(oidx, seqs, L, to_oracle_mmp(mmp))
+    got = [[(arr[i].pos, arr[i].strand_read_id, arr[i].paired_seed_length) for i in range(int(off[r]), int(off[r + 1]))] for r in range(len(seqs))]
+    assert got == want
+    assert st.n_prefilter > 0 and (st.n_seeds, st.n_hits) == (ctr.n_seeds, ctr.n_hits)
+    ctx.close()
+    gix.close()
+
+
 @pytest.mark.parametrize("dense", [False, True])
 def test_merge_kernel_paths_that_do_not_stage_in_lds(golden_dir, oidx, monkeypatch, dense):
     """merge_kernel handles a block of 64 reads whose hits do not fit in its 32 KB of LDS one lane per read in global memory.  Forced for every

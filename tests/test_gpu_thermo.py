@@ -72,7 +72,7 @@ def test_certificate_never_rejects_an_alignment(kinds, seed, lo, hi):
     import oracle_lib as O
     rng = np.random.default_rng(seed)
     text = rng.integers(0, 4, 1 << 20).astype(np.uint8)
-    n = 60000 if hi <= 160 else 30000
+    n = (60000 if hi <= 160 else 30000) * int(os.environ.get("MP_THERMO_TEST_SCALE", "1"))      # (one-off campaigns: MP_THERMO_TEST_SCALE=10)
     reads, tasks, kind = _make_instances(rng, text, n, kinds, lo, hi)  # (kind 5 plants repeats into the text: build the index afterwards)
     arrs = build_index_arrays([("t", text)], sa_interval=16)
     ix = H.Index.from_arrays(0, **arrs)

@@ -10,6 +10,7 @@
 #include "mp_internal.h"
 #include "kernels_index.hip"
 #include "kernels_seed.hip"
+#include "kernels_seed_x2.hip"
 #include "kernels_dp.hip"
 #include "kernels_dp_band.hip"
 #include "kernels_rescue.hip"
@@ -898,10 +899,11 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     // persistent grid: as many blocks of 256 lanes as the kernel's registers and its LDS rows (one scan row per lane) let a CU hold
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
-    const size_t seed_lds = (size_t)256 * (mp_scan_stride(W) | 1u) * sizeof(uint32_t);
+    static const int seed_items = getenv("MP_SEED_ITEMS") ? atoi(getenv("MP_SEED_ITEMS")) : 1;  // experiment switch: 2 = two items per lane (kernels_seed_x2.hip)
+    const size_t seed_lds = (size_t)256 * (seed_items == 2 ? 2 : 1) * (mp_scan_stride(W) | 1u) * sizeof(uint32_t);
     int per_cu = 0;
     static const int seed_occ = getenv("MP_SEED_OCC") ? atoi(getenv("MP_SEED_OCC")) : 0;      // experiment switch: 6 = the 80-register build
-    auto kern = seed_occ == 6 ? seed_kernel<6> : seed_kernel<1>;
+    auto kern = seed_items == 2 ? seed_kernel_x2 : seed_occ == 6 ? seed_kernel<6> : seed_kernel<1>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, seed_lds) != hipSuccess || per_cu < 1) per_cu = 4;
     const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * (unsigned)per_cu);
     HIPCHK(hipEventRecord(c->ev[0], s));

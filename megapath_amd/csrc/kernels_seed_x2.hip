@@ -249,13 +249,30 @@ seed_kernel_x2(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_
                             // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe.  A futile start
                             // (they occur nowhere) costs no look-up -- a seed shorter than seed_min_length, nothing reported, restart one base
                             // on: the scan jumps to the first position that is not futile, or past what the entries answer.
+                            // A seed is reported only from seed_min_length bases on, so a start at p is futile as well when ANY of the
+                            // 17-mers at p .. p + seed_min_length - 17 is absent (with 22-base seeds: six windows = what one trip's two entries
+                            // answer), and an absent 17-mer at z rules out every start in [z - (need - 1), z]: the scan jumps behind the highest
+                            // such z.  Each of those starts would have been a table look-up, rank queries and a text comparison that end below
+                            // seed_min_length at the read's next mismatch -- nothing reported, restart one base on (CHECK_AND_ADD_RANGE).
                             const int span = ix.kmer15x3 ? 6 : 1;
-                            const int a = s.i - s.pg;
+                            int need = P.seed_min_length - (int)ix.kmer_k + 1;
+                            if (need > span) need = span;
+                            int a = s.i - s.pg;
                             if (a >= 0 && a < span) {
-                                const uint32_t bits = s.nf >> a;
-                                const int adv = bits ? __ffs((int)bits) - 1 : span - a;
-                                if (s.i + adv > lim) { ev.kmer += (uint32_t)(lim - s.i + 1); s.i = lim + 1; fin = true; start_here = false; }
-                                else { ev.kmer += (uint32_t)adv + (bits ? 1u : 0u); s.i += adv; start_here = bits != 0; }
+                                const int a0p = a;
+                                const uint32_t zeros = ~s.nf & ((1u << span) - 1u), wmask = (1u << need) - 1u;
+                                for (;;) {
+                                    const uint32_t win = (zeros >> a) & wmask;     // (positions beyond the entries read as "present": unknown)
+                                    if (!win) break;
+                                    a += 32 - __clz((int)win);
+                                }
+                                const int p = s.pg + a;
+                                if (p > lim) { ev.kmer += (uint32_t)(lim - s.i + 1); s.i = lim + 1; fin = true; start_here = false; }
+                                else {
+                                    start_here = a + need <= span;                  // every window of this start is known, and present
+                                    ev.kmer += (uint32_t)(a - a0p) + (start_here ? (uint32_t)need : 0u);
+                                    s.i = p;
+                                }
                             } else start_here = false;
                             if (!fin && !start_here) {
                                 const uint64_t k17 = bases_at(s.i) & kmask;

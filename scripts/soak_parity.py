@@ -20,9 +20,17 @@ from megapath_amd import index_builder, synth  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--inis", default="both", help="both (drawn per round), soap4.ini or soap4-nt2.ini")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 lib = O.oracle()
+
+
+def set_ini(p, ini):
+    if ini == "soap4.ini":             # the two keys in which the shipped ini files differ (mmpSeedMinLength, mmpReseedLen)
+        p.mmp.seed_min_length, p.mmp.reseed_len = 22, 23
+
+
 for rnd in range(args.rounds):
     read_len = int(rng.choice([76, 100, 150, 150, 150, 250, 300]))
     cfg = dict(n_bases=int(rng.integers(100000, 800000)), n_seqs=int(rng.integers(1, 8)), rep=float(rng.choice([0.0, 0.05, 0.2, 0.5])),
@@ -31,6 +39,8 @@ for rnd in range(args.rounds):
                # the database cut into 1-4 index chunks resident at once (the NT loop in one process): the oracle is chained chunk after chunk,
                # each run reading the previous run's stdout (runMegaPath.sh:191-227); 0 = one index, no chain
                chunks=int(rng.choice([0, 0, 2, 3, 4])), host_merge=bool(rng.random() < 0.3),
+               # soap4.ini (seeds of >= 22 bases: the pre-filter then rules a start out by any of six 17-mers) or soap4-nt2.ini (17)
+               ini=str(rng.choice(["soap4-nt2.ini", "soap4-nt2.ini", "soap4.ini"])) if args.inis == "both" else args.inis,
                # which optional index tables the run may build (every combination takes another path through the seeding kernels)
                env={k: str(int(v)) for k, v in (("MP_KMER_FILTER", rng.choice([0, 1, 1, 1, 16])), ("MP_KMER15", rng.random() < 0.7), ("MP_LKT16", rng.random() < 0.7),
                                                 ("MP_SA_DENSE", rng.random() < 0.7), ("MP_LKT16U", rng.random() < 0.7), ("MP_SA_DENSE_SPACING", rng.choice([1, 1, 2, 4])),
@@ -63,7 +73,7 @@ for rnd in range(args.rounds):
         synth.write_fastq_pair(f1, f2, names, r1, r2)
         L = read_len + 1
         out = os.path.join(tmp, "out.fq")
-        cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix, f1, f2, "-o", os.path.join(tmp, "o"), "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"),
+        cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefix, f1, f2, "-o", os.path.join(tmp, "o"), "-C", os.path.join(ROOT, "tests", cfg["ini"]),
                "-L", str(L), "-T", str(cfg["threads"]), "-u", "750", "-F" if cfg["mode"] == 1 else "-P", "-nc"] + (["-b", "-p", "-D", "rg1", "-A", "default"] if cfg["bam"] else [])
         env = dict(os.environ, MP_BATCH_PAIRS=str(max(64, cfg["n_pairs"] // 3)), **cfg["env"])
         if cfg["host_merge"]:
@@ -79,6 +89,7 @@ for rnd in range(args.rounds):
             for c, pc in enumerate(prefixes):
                 ix = lib.mpo_index_open(pc.encode())
                 p = O.default_params(L=L, mode=cfg["mode"], nc=(c == 0))
+                set_ini(p, cfg["ini"])
                 st = O.AlignStats()
                 assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), want.encode(), None, C.byref(st)) == 0
                 lib.mpo_index_close(ix)
@@ -93,6 +104,7 @@ for rnd in range(args.rounds):
         else:
             ix = lib.mpo_index_open(prefix.encode())
             p = O.default_params(L=L, mode=cfg["mode"], nc=True)
+            set_ini(p, cfg["ini"])
             st = O.AlignStats()
         if n_chunks:
             pass

@@ -208,6 +208,7 @@ seed_kernel_x2(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_
                     }
                 }
                 mp_seed_rec *slab = slabs + (uint64_t)s.rs * MP_SEED_SLAB;
+                const int i_end = s.i;                                     // (where a seed that ends in this trip ended: the base that did not extend it)
                 if (mid_close || fin) {
                     const int x = mid_close ? (s.strand == 0 ? s.len - s.i : s.i - s.seed_len) : (s.strand == 0 ? 0 : s.len - s.seed_len);
                     mp_close_seed<MP_SEED_SLAB>(s, P, n, x, slab);
@@ -217,28 +218,32 @@ seed_kernel_x2(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_
                 if (!fin && next == MK_NONE && s.seed_len == 0) {
                     // the scan bases from here on as a 96-bit window: enough for the six positions two pre-filter entries answer and for the
                     // keys of the two entries after them
-                    const uint32_t wq0 = (uint32_t)s.i >> 4;
-                    const uint32_t w0 = sl[wq0], w1 = sl[wq0 + 1], w2 = sl[wq0 + 2];
-                    auto bases_at = [&](int pos) -> uint64_t {                   // scan bases pos .. pos + 16 at least (pos - 16 wq0 <= 24)
+                    uint32_t wq0 = (uint32_t)s.i >> 4;
+                    uint32_t w0 = sl[wq0], w1 = sl[wq0 + 1], w2 = sl[wq0 + 2];
+                    auto bases_at = [&](int pos) -> uint64_t {                   // scan bases pos .. pos + 16 at least (pos - 16 wq0 <= 31)
                         const uint32_t off = (uint32_t)pos - 16u * wq0;
                         const uint64_t win = off < 16 ? (((uint64_t)w1 << 32) | w0) : (((uint64_t)w2 << 32) | w1);
                         return win >> (2 * (off & 15));
                     };
                     if (kind == MK_PRE) {
-                        // what just arrived, as one bit per position: is the 17-mer that starts there anywhere in the text?
+                        // what just arrived, as one bit per position: is the 17-mer that starts there anywhere in the text?  s.nf = present
+                        // bits (low half) and known bits (high half) of the positions pg .. pg + 15; the two entries answer three positions each,
+                        // from the offsets the lane chose when it asked (kept in s.nf meanwhile)
                         uint32_t nf;
                         if (ix.kmer15x3) {
                             const unsigned long long e1 = ((unsigned long long)a1 << 32) | a0, e2 = ((unsigned long long)b1 << 32) | b0;
-                            nf = 0;
+                            const int o1 = (int)(s.nf & 255u), o2 = (int)((s.nf >> 8) & 255u);
+                            nf = ((7u << o1) | (7u << o2)) << 16;
     #pragma unroll
                             for (int q = 0; q < 6; q++) {
-                                const uint64_t k17 = bases_at(s.i + q) & ((1ull << 34) - 1);
+                                const int off = (q < 3 ? o1 : o2 - 3) + q;
+                                const uint64_t k17 = bases_at(s.i + off) & ((1ull << 34) - 1);
                                 const int aa = q % 3;
                                 const uint32_t bit = aa == 0 ? (uint32_t)(k17 & 15) : aa == 1 ? 16u + ((uint32_t)(k17 & 3) | ((uint32_t)(k17 >> 32) & 3u) << 2)
                                                                                               : 32u + (uint32_t)((k17 >> 30) & 15);
-                                nf |= (uint32_t)(((q < 3 ? e1 : e2) >> bit) & 1ull) << q;
+                                nf |= (uint32_t)(((q < 3 ? e1 : e2) >> bit) & 1ull) << off;
                             }
-                        } else nf = (a0 >> (uint32_t)(bases_at(s.i) & 31)) & 1u;       // (bit = the key's low five bits, whatever its length)
+                        } else nf = ((a0 >> (uint32_t)(bases_at(s.i) & 31)) & 1u) | 0x10000u;       // (bit = the key's low five bits, whatever its length)
                         s.nf = nf; s.pg = s.i;
                     }
                     const int lim = s.len - P.seed_min_length;                    // the last position a seed may start at (`break` of the scan loop beyond)
@@ -246,44 +251,47 @@ seed_kernel_x2(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_
                     else {
                         bool start_here = true;
                         if (pf) {
-                            // pre-filter: the next 17 scanned bases (there are at least seed_min_length left) as one bit probe.  A futile start
-                            // (they occur nowhere) costs no look-up -- a seed shorter than seed_min_length, nothing reported, restart one base
-                            // on: the scan jumps to the first position that is not futile, or past what the entries answer.
-                            // A seed is reported only from seed_min_length bases on, so a start at p is futile as well when ANY of the
-                            // 17-mers at p .. p + seed_min_length - 17 is absent (with 22-base seeds: six windows = what one trip's two entries
-                            // answer), and an absent 17-mer at z rules out every start in [z - (need - 1), z]: the scan jumps behind the highest
-                            // such z.  Each of those starts would have been a table look-up, rank queries and a text comparison that end below
-                            // seed_min_length at the read's next mismatch -- nothing reported, restart one base on (CHECK_AND_ADD_RANGE).
-                            const int span = ix.kmer15x3 ? 6 : 1;
-                            int need = P.seed_min_length - (int)ix.kmer_k + 1;
-                            if (need > span) need = span;
+                            // pre-filter: is the 17-mer that starts at a scan position anywhere in the text?  A futile start (a seed shorter than
+                            // seed_min_length: nothing reported, restart one base on -- CHECK_AND_ADD_RANGE) costs no look-up.  A seed is reported
+                            // only from seed_min_length bases on, so a start at p is futile when ANY of the 17-mers at p .. p + seed_min_length - 17
+                            // is absent (`need` windows: six with soap4.ini's 22-base seeds, one with 17), and an absent 17-mer at z rules out every
+                            // start in [z - (need - 1), z]: the scan jumps behind the highest known such z, again and again.  That is all the
+                            // correctness there is to it -- WHICH positions a lane asks about is free: with six windows per start the two entries
+                            // of a trip are taken six positions apart (p + 5 .. 7 and p + 11 .. 13: a read's mismatch makes 22 starts futile, two
+                            // trips rule them out), and a start is tried as soon as nothing known speaks against it and something known speaks for it.
+                            const int need = ix.kmer15x3 ? min(P.seed_min_length - (int)ix.kmer_k + 1, 6) : 1;
+                            const uint32_t present = s.nf & 0xFFFFu, known = s.nf >> 16, zeros = known & ~present, wmask = (1u << need) - 1u;
                             int a = s.i - s.pg;
-                            if (a >= 0 && a < span) {
-                                const int a0p = a;
-                                const uint32_t zeros = ~s.nf & ((1u << span) - 1u), wmask = (1u << need) - 1u;
+                            if (a >= 0 && a < 16) {
+                                const int a_in = a;
                                 for (;;) {
-                                    const uint32_t win = (zeros >> a) & wmask;     // (positions beyond the entries read as "present": unknown)
+                                    const uint32_t win = (zeros >> a) & wmask;     // known absent among the windows of a start at pg + a
                                     if (!win) break;
                                     a += 32 - __clz((int)win);
                                 }
                                 const int p = s.pg + a;
                                 if (p > lim) { ev.kmer += (uint32_t)(lim - s.i + 1); s.i = lim + 1; fin = true; start_here = false; }
                                 else {
-                                    start_here = a + need <= span;                  // every window of this start is known, and present
-                                    ev.kmer += (uint32_t)(a - a0p) + (start_here ? (uint32_t)need : 0u);
+                                    // (not right after a seed ended: what is known then is mostly about the stretch that just matched)
+                                    start_here = ((present >> a) & wmask) != 0 && !(mid_close && need > 1);
+                                    ev.kmer += (uint32_t)(a - a_in) + (start_here ? 1u : 0u);
                                     s.i = p;
+                                    if (a != a_in) { wq0 = (uint32_t)p >> 4; w0 = sl[wq0]; w1 = sl[wq0 + 1]; w2 = sl[wq0 + 2]; }     // the window moves with the scan
                                 }
                             } else start_here = false;
                             if (!fin && !start_here) {
-                                const uint64_t k17 = bases_at(s.i) & kmask;
                                 next = MK_PRE;
                                 if (ix.kmer15x3) {
-                                    // two entries at once: this position's and the one three bases on (runs of futile starts are the rule: every
-                                    // mismatch of the read costs seventeen of them)
-                                    s.ptr = ix.kmer15x3 + ((k17 >> 4) & ((1ull << 30) - 1));
-                                    s.aux = (uint32_t)((bases_at(s.i + 3) >> 4) & ((1ull << 30) - 1));
+                                    // two entries per trip.  Six windows per start: the first entry at the window that contains the base the last seed
+                                    // ended at (i_end - 16, when that is among this start's windows) or at the start's last window, the second six on.
+                                    int o1 = 0, o2 = 3;
+                                    if (need == 6) { o1 = mid_close ? min(max(i_end - 16 - s.i, 0), 5) : 5; o2 = o1 + 6; }
+                                    s.ptr = ix.kmer15x3 + ((bases_at(s.i + o1) >> 4) & ((1ull << 30) - 1));
+                                    s.aux = (uint32_t)((bases_at(s.i + o2) >> 4) & ((1ull << 30) - 1));
+                                    s.nf = (uint32_t)o1 | ((uint32_t)o2 << 8);
+                                    s.pg = -1000;
                                     ev.kload += 2;
-                                } else { s.ptr = ix.kmer17 + (k17 >> 5); ev.kload++; }
+                                } else { s.ptr = ix.kmer17 + ((bases_at(s.i) & kmask) >> 5); s.pg = -1000; ev.kload++; }
                             }
                         }
                         if (start_here) {

@@ -6,8 +6,8 @@ python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py -x -q -m gpu -
 tail -2 gpurun_out/r3/t_seedwin.log
 python -m pytest tests/test_gpu_soap4_cli.py -x -q -m gpu -k "soap4_ini" > gpurun_out/r3/t_seedwin2.log 2>&1 || { tail -40 gpurun_out/r3/t_seedwin2.log; exit 1; }
 tail -2 gpurun_out/r3/t_seedwin2.log
-timeout -k 10 400 python3 scripts/soak_parity.py --rounds 30 --seed 9001 --inis soap4.ini > gpurun_out/r3/soak_9001.log 2>&1 || { tail -5 gpurun_out/r3/soak_9001.log | cut -c1-600; exit 1; }
-tail -1 gpurun_out/r3/soak_9001.log
+timeout -k 10 400 python3 scripts/soak_parity.py --rounds 30 --seed 9002 --inis soap4.ini > gpurun_out/r3/soak_9002.log 2>&1 || { tail -5 gpurun_out/r3/soak_9002.log | cut -c1-600; exit 1; }
+tail -1 gpurun_out/r3/soak_9002.log
 python3 bench.py --no-legs --no-pmc > gpurun_out/r3/bench_seedwin.json 2> gpurun_out/r3/bench_seedwin.err || { tail -30 gpurun_out/r3/bench_seedwin.err; exit 1; }
 python3 -c "
 import json; j=json.load(open('gpurun_out/r3/bench_seedwin.json'))

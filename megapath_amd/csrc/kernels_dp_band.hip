@@ -346,7 +346,7 @@ template <int GBUD, int MINB, int MAXL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                     const mp_dp_task *__restrict__ tasks, uint32_t n, mp_fill_result *__restrict__ fill, uint32_t *__restrict__ cls,
-                    const uint32_t *__restrict__ list = nullptr)
+                    const uint32_t *__restrict__ list = nullptr, int one_mismatch = 1 /* 0: test switch, such instances take the first pass */)
 {
     constexpr int RW = MAXL / 16, TW = (MAXL + MP_BAND_DMAX) / 16 + 2;
     __shared__ uint32_t s_a[RW + 1][64];        // the read in alignment orientation, LSB-first words
@@ -439,7 +439,20 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
     if (dhi - dlo > 4) { fill[t] = r; return; }                 // wide
     const int centre = (dlo + dhi) >> 1;                        // floor: dlo + 2 >= centre >= dhi - 2
     // ---- exact diagonals among the matching ones; fewest mismatches of the read laid on one of them
-    int first = -1, exact = 0, kmin = 1 << 20;
+    // does the read, bases u0 .. u1 (0-based), equal the window on diagonal dl, 0 <= dl <= m - L?  (rows u + dl)
+    auto exact_on = [&](int dl, int u0, int u1) -> bool {
+        for (int w = u0 >> 4; w <= (u1 >> 4); w++) {
+            const int at = 16 * w + dl;
+            const uint64_t two = (((uint64_t)s_t[(at >> 4) + 1][lane] << 32) | s_t[at >> 4][lane]) >> (2 * (at & 15));      // (dl >= 0 here)
+            const uint32_t x = (uint32_t)two ^ s_a[w][lane];
+            uint32_t mm = (x | (x >> 1)) & 0x55555555u;
+            const int lo = u0 > 16 * w ? u0 - 16 * w : 0, hi = u1 < 16 * w + 15 ? u1 - 16 * w : 15;
+            mm &= (hi >= 15 ? 0xFFFFFFFFu : ((1u << (2 * (hi + 1))) - 1u)) & ~((1u << (2 * lo)) - 1u);
+            if (mm) return false;
+        }
+        return true;
+    };
+    int first = -1, exact = 0, kmin = 1 << 20, mcol = 0;         // mcol: column (1-based) of the first mismatch on the last diagonal looked at
     const uint32_t tail = (L & 15) ? ((1u << (2 * (L & 15))) - 1u) : 0xFFFFFFFFu;
     for (int dl = max(dlo, 0); dl <= min(dhi, m - L); dl++) {
         int kk = 0;
@@ -448,7 +461,9 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
             const uint64_t two = ((uint64_t)s_t[(at >> 4) + 1][lane] << 32) | s_t[at >> 4][lane];
             uint32_t x = (uint32_t)(two >> (2 * (at & 15))) ^ s_a[w][lane];
             if (w == nw - 1) x &= tail;
-            kk += __popc((x | (x >> 1)) & 0x55555555u);
+            const uint32_t mm = (x | (x >> 1)) & 0x55555555u;
+            if (kk == 0 && mm) mcol = 16 * w + ((__ffs((int)mm) - 1) >> 1) + 1;
+            kk += __popc(mm);
             if (kk > 2) break;                                  // only 0, 1, 2 matter
         }
         if (kk == 0) { if (first < 0) first = dl; exact++; }
@@ -456,6 +471,22 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
     }
     if (first >= 0) {
         r.score = L; r.row = (uint16_t)(first + L); r.col = (uint16_t)L; r.count = exact > 255 ? 255u : (uint32_t)exact;
+        cls[slot] = MP_PRE_DONE;
+    } else if (one_mismatch && dlo == dhi && dlo >= 0 && dlo <= m - L && kmin == 1 && mcol >= 4 && mcol <= L - 3 &&
+               (mcol <= L - 2 * b + 2 || dlo + 1 > m - L || !exact_on(dlo + 1, mcol - 1, L - 1)) &&
+               (mcol >= 2 * b - 1 || dlo - 1 < 0 || !exact_on(dlo - 1, 0, mcol - 1))) {
+        // ONE matching diagonal d, on it the read differs from the window in exactly one base, at column c, 4 <= c <= L - 3:
+        // the table's maximum is L - 3, in the single cell (d + L, L).  A path of score >= L - 3 has at most one event (each costs >= 3):
+        // none -- an exact run of >= L - 3 >= 2b - 1 bases holds a whole block, so it lies on d, where the longest exact run has
+        // max(c - 1, L - c) <= L - 4 bases; one mismatch -- L - 1 matches, i.e. a whole diagonal with one mismatch, whose longer exact
+        // half holds a block: d itself; one gap -- its k bases cost k + 2, so k = 1, a skipped WINDOW base, and all L read bases match:
+        // read[1..j] on one diagonal, read[j+1..L] on the next, both exact; the longer piece holds a block, so it lies on d and avoids c:
+        // either read[1..j] on d with j < c and read[j+1..L] on d + 1 -- then read[c..L] is exact on d + 1, which a block rules out when
+        // that piece has 2b - 1 bases or more (c <= L - 2b + 2) and the comparison above otherwise -- or read[j+1..L] on d with j >= c and
+        // read[1..j] on d - 1: read[1..c] exact on d - 1, ruled out by a block (c >= 2b - 1) or by the comparison.  (A diagonal whose rows
+        // leave the window carries no path.)  Every other cell stays below: on d a path ending at column j < L scores at most j - 3.
+        // dp_band_classify_kernel then finds the plain diagonal (mp_diag_alignment: c > 3) and writes the result: no table at all.
+        r.score = L - 3; r.row = (uint16_t)(dlo + L); r.col = (uint16_t)L; r.count = 1;
         cls[slot] = MP_PRE_DONE;
     } else {
         r.score = -2; r.row = (uint16_t)(centre + 256); r.col = 256; r.count = 0;      // row - col = centre, read by the MODE 3 pass

@@ -240,6 +240,51 @@ def test_plain_diagonal_alignments_need_no_traceback(monkeypatch, sub, junk):
     gix.close()
 
 
+@pytest.mark.parametrize("low_complexity", [False, True])
+def test_one_mismatch_instances_need_no_table(monkeypatch, low_complexity):
+    """A deep-DP instance whose read lies on ONE matching diagonal of its window with exactly one mismatch, far enough from both read ends, is
+    finished by dp_prefilter_kernel without any table (score L - 3 in the single cell at the diagonal's end; kernels_dp_band.hip has the
+    argument).  Reads with about one substitution each, on a plain genome and on one riddled with homopolymer runs and two-base tandem
+    repeats (shifted diagonals match there, the case the conditions have to keep out): the hit set equals the first pass's
+    (MP_DP_ONE_MISMATCH=0) in every field, tie counts included, and the full-table kernels'."""
+    genome = synth.random_genome(400000, 1311, n_seqs=2, repeat_frac=0.1)
+    if low_complexity:
+        rng = np.random.Generator(np.random.PCG64(1312))
+        letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+        for _, arr in genome:
+            for at in range(40, len(arr) - 60, 90):
+                at += int(rng.integers(0, 50))
+                ln = int(rng.integers(4, 30))
+                if rng.random() < 0.5:
+                    arr[at:at + ln] = letters[rng.integers(0, 4)]
+                else:
+                    arr[at:at + ln] = np.resize(letters[rng.integers(0, 4, size=int(rng.integers(2, 4)))], ln)
+    arrs = index_builder.build_index_arrays(genome, sa_interval=16)
+    gix = H.Index.from_arrays(0, **arrs)
+    names, r1, r2 = synth.simulate_pairs(genome, 5000, 150, 1313, sub=0.007, ins=0.0004, dele=0.0004, random_frac=0.02)
+    seqs = [x for pr in zip(r1, r2) for x in pr]
+    packed, lens, W = H.pack_reads(seqs, 151)
+
+    def run(band, one_mm):
+        monkeypatch.setenv("MP_DP_ONE_MISMATCH", "1" if one_mm else "0")
+        ctx = H.Context(gix)
+        ctx.set_reads(packed, lens)
+        ctx.set_dp_band(band)
+        hits, nh, st = ctx.deep_dp_round(H.AlignParams(1, 750, 130, 130, H.MmpParams.nt2()))
+        got = sorted((h.pair_id, h.left_is_mate, h.algnmt_1, h.algnmt_2, h.score_1, h.score_2, h.start_1, h.start_2, h.dplen_1, h.dplen_2, h.count_1, h.count_2)
+                     for h in hits[:nh])
+        ctx.close()
+        return got
+    full = run(False, True)
+    first_pass = run(True, False)
+    no_table = run(True, True)
+    assert len(full) > 4000
+    assert sum(1 for h in no_table if 147 in (h[4], h[5])) > 1000           # the one-mismatch alignments are there (score L - 3)
+    assert [h[:10] for h in first_pass] == [h[:10] for h in full]
+    assert no_table == first_pass
+    gix.close()
+
+
 def test_seed_projection_wrapping_below_zero(tmp_path):
     """Reads whose first bases are junk and whose match starts within the first bases of the text: the seed projection
     position - query offset wraps below zero in unsigned arithmetic, exactly as in the reference

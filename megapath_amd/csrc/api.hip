@@ -1480,7 +1480,7 @@ int band_tier(mp_ctx *c, const mp_dp_task *d_tasks, const uint32_t *in_list, uin
     };
     HIPCHK(hipEventRecord(c->ev_pool[0], s));
     // block-match pre-filter: finished (exact diagonal), narrow first pass, whole band, or no qualifying alignment at all
-    const int one_mm = getenv("MP_DP_ONE_MISMATCH") ? atoi(getenv("MP_DP_ONE_MISMATCH")) : 1;      // 0: test switch (kernels_dp_band.hip)
+    const int one_mm = getenv("MP_DP_ONE_MISMATCH") ? atoi(getenv("MP_DP_ONE_MISMATCH")) : 2;      // 0, 1: test switch (kernels_dp_band.hip)
     if (small)
         hipLaunchKernelGGL((dp_prefilter_kernel<GBUD, MINB, 160>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n,
                            c->band_fill.p, c->pre_cls.p, in_list, one_mm);

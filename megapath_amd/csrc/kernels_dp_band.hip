@@ -346,7 +346,7 @@ template <int GBUD, int MINB, int MAXL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                     const mp_dp_task *__restrict__ tasks, uint32_t n, mp_fill_result *__restrict__ fill, uint32_t *__restrict__ cls,
-                    const uint32_t *__restrict__ list = nullptr, int one_mismatch = 1 /* 0: test switch, such instances take the first pass */)
+                    const uint32_t *__restrict__ list = nullptr, int one_mismatch = 2 /* test switch: 0 such instances take the first pass, 1 only one-mismatch instances are finished here */)
 {
     constexpr int RW = MAXL / 16, TW = (MAXL + MP_BAND_DMAX) / 16 + 2;
     __shared__ uint32_t s_a[RW + 1][64];        // the read in alignment orientation, LSB-first words
@@ -452,7 +452,7 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
         }
         return true;
     };
-    int first = -1, exact = 0, kmin = 1 << 20, mcol = 0;         // mcol: column (1-based) of the first mismatch on the last diagonal looked at
+    int first = -1, exact = 0, kmin = 1 << 20, mcol = 0, mcol2 = 0;       // mcol, mcol2: columns (1-based) of the first two mismatches on the last diagonal looked at
     const uint32_t tail = (L & 15) ? ((1u << (2 * (L & 15))) - 1u) : 0xFFFFFFFFu;
     for (int dl = max(dlo, 0); dl <= min(dhi, m - L); dl++) {
         int kk = 0;
@@ -463,6 +463,7 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
             if (w == nw - 1) x &= tail;
             const uint32_t mm = (x | (x >> 1)) & 0x55555555u;
             if (kk == 0 && mm) mcol = 16 * w + ((__ffs((int)mm) - 1) >> 1) + 1;
+            { const uint32_t m2 = kk == 0 ? (mm & (mm - 1)) : mm; if (kk <= 1 && kk + __popc(mm) >= 2) mcol2 = 16 * w + ((__ffs((int)m2) - 1) >> 1) + 1; }
             kk += __popc(mm);
             if (kk > 2) break;                                  // only 0, 1, 2 matter
         }
@@ -487,6 +488,21 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
         // leave the window carries no path.)  Every other cell stays below: on d a path ending at column j < L scores at most j - 3.
         // dp_band_classify_kernel then finds the plain diagonal (mp_diag_alignment: c > 3) and writes the result: no table at all.
         r.score = L - 3; r.row = (uint16_t)(dlo + L); r.col = (uint16_t)L; r.count = 1;
+        cls[slot] = MP_PRE_DONE;
+    } else if (one_mismatch >= 2 && dlo == dhi && dlo >= 0 && dlo <= m - L && kmin == 2 && mcol >= 2 * b - 1 && mcol <= L - 2 * (2 * b - 1) &&
+               mcol2 >= 2 * (2 * b - 1) + 1 && mcol2 <= L - (2 * b - 1) + 1 && L >= 3 * (2 * b - 1) + 6) {
+        // The same with TWO mismatches on the one matching diagonal d, at columns c1 < c2 well inside the read.  T = 2b - 1: an exact piece of T
+        // bases holds a block, so it lies on d; conditions T <= c1 <= L - 2T, 2T + 1 <= c2 <= L - T + 1, L >= 3T + 6.  The maximum is L - 6, in
+        // the single cell (d + L, L).  A path that loses at most 6 against L matches has at most two events and three exact pieces with >= L - 6
+        // bases between them, so one piece has >= T bases: it lies on d -- before c1, between c1 and c2, or behind c2 -- and every piece on
+        // another diagonal has fewer than T.  The cases: only clipped bases (no exact run of L - 6 bases on d); one mismatch, <= 3 clipped (one
+        // diagonal: d; it holds c1 or c2 and clips everything from the other one on: >= T bases); two mismatches (one diagonal, d: the path itself);
+        // one gap of 1..4 window bases or 1..2 read bases, <= 3 clipped (two pieces: the one on d ends before c1 and the other covers [c1 + 2, L - 3],
+        // or starts behind c2 and the other covers [4, c2 - 2]: >= T bases either way); a one-base gap and a mismatch, or two one-base gaps, nothing
+        // clipped (three pieces: with the piece(s) on d before c1, what follows on the next diagonal(s) is [c1, L] cut at most once: a piece of
+        // >= (L - c1) / 2 >= T; behind c2: [1, c2] cut at most once, >= c2 / 2 >= T; between c1 and c2, or c1 taken as the mismatch: [1, c1] resp.
+        // [c2, L] in one piece, >= T).  Each time a second matching diagonal would exist: there is none.
+        r.score = L - 6; r.row = (uint16_t)(dlo + L); r.col = (uint16_t)L; r.count = 1;
         cls[slot] = MP_PRE_DONE;
     } else {
         r.score = -2; r.row = (uint16_t)(centre + 256); r.col = 256; r.count = 0;      // row - col = centre, read by the MODE 3 pass

@@ -3,7 +3,7 @@ set -e
 mkdir -p gpurun_out/r3
 python -m pytest tests/test_gpu_scale.py -x -q -m gpu -k "one_mismatch or banded or plain_diagonal or human_genome_scale" > gpurun_out/r3/t_onemm.log 2>&1 || { tail -40 gpurun_out/r3/t_onemm.log; exit 1; }
 tail -2 gpurun_out/r3/t_onemm.log
-timeout -k 10 500 python3 scripts/soak_parity.py --rounds 40 --seed ${SOAK_SEED:-9102} > gpurun_out/r3/soak_onemm.log 2>&1 || { tail -5 gpurun_out/r3/soak_onemm.log | cut -c1-600; exit 1; }
+timeout -k 10 500 python3 scripts/soak_parity.py --rounds 40 --seed ${SOAK_SEED:-9103} > gpurun_out/r3/soak_onemm.log 2>&1 || { tail -5 gpurun_out/r3/soak_onemm.log | cut -c1-600; exit 1; }
 tail -1 gpurun_out/r3/soak_onemm.log
 python3 bench.py --no-legs --no-pmc > gpurun_out/r3/bench_onemm.json 2> gpurun_out/r3/bench_onemm.err || { tail -30 gpurun_out/r3/bench_onemm.err; exit 1; }
 python3 -c "

@@ -243,8 +243,8 @@ def test_plain_diagonal_alignments_need_no_traceback(monkeypatch, sub, junk):
 @pytest.mark.parametrize("low_complexity", [False, True])
 def test_one_mismatch_instances_need_no_table(monkeypatch, low_complexity):
     """A deep-DP instance whose read lies on ONE matching diagonal of its window with exactly one mismatch, far enough from both read ends, is
-    finished by dp_prefilter_kernel without any table (score L - 3 in the single cell at the diagonal's end; kernels_dp_band.hip has the
-    argument).  Reads with about one substitution each, on a plain genome and on one riddled with homopolymer runs and two-base tandem
+    finished by dp_prefilter_kernel without any table (score L - 3 in the single cell at the diagonal's end; two mismatches well inside the read: L - 6; kernels_dp_band.hip has the
+    arguments).  Reads with about one substitution each, on a plain genome and on one riddled with homopolymer runs and two-base tandem
     repeats (shifted diagonals match there, the case the conditions have to keep out): the hit set equals the first pass's
     (MP_DP_ONE_MISMATCH=0) in every field, tie counts included, and the full-table kernels'."""
     genome = synth.random_genome(400000, 1311, n_seqs=2, repeat_frac=0.1)
@@ -266,7 +266,7 @@ def test_one_mismatch_instances_need_no_table(monkeypatch, low_complexity):
     packed, lens, W = H.pack_reads(seqs, 151)
 
     def run(band, one_mm):
-        monkeypatch.setenv("MP_DP_ONE_MISMATCH", "1" if one_mm else "0")
+        monkeypatch.setenv("MP_DP_ONE_MISMATCH", str(one_mm))
         ctx = H.Context(gix)
         ctx.set_reads(packed, lens)
         ctx.set_dp_band(band)
@@ -275,13 +275,14 @@ def test_one_mismatch_instances_need_no_table(monkeypatch, low_complexity):
                      for h in hits[:nh])
         ctx.close()
         return got
-    full = run(False, True)
-    first_pass = run(True, False)
-    no_table = run(True, True)
+    full = run(False, 2)
+    first_pass = run(True, 0)
+    one = run(True, 1)                                                        # one-mismatch instances without a table
+    no_table = run(True, 2)                                                   # and two mismatches well inside the read (the default)
     assert len(full) > 4000
-    assert sum(1 for h in no_table if 147 in (h[4], h[5])) > 1000           # the one-mismatch alignments are there (score L - 3)
+    assert sum(1 for h in no_table if 147 in (h[4], h[5])) > 1000 and sum(1 for h in no_table if 144 in (h[4], h[5])) > 500   # scores L - 3, L - 6
     assert [h[:10] for h in first_pass] == [h[:10] for h in full]
-    assert no_table == first_pass
+    assert one == first_pass and no_table == first_pass
     gix.close()
 
 

@@ -1310,6 +1310,9 @@ static int exclusive_scan_inclusive_u32(mp_ctx *c, const uint32_t *in, uint32_t 
     return MP_OK;
 }
 
+bool band_applicable(const mp_ctx *c, uint32_t max_win, int cl, int cr);
+int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res, float *ms_fill, float *ms_trace, bool count);
+
 int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,
                     float *ms_fill, float *ms_trace, bool count)
 {
@@ -1395,7 +1398,14 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     if (c->sel_tasks.reserve(n_sel + 2) || c->sel_res.reserve(n_sel + 2)) return MP_ENOMEM;
     hipLaunchKernelGGL(dp_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->sel_flag.p, c->sel_idx.p, n, c->sel_tasks.p);
     MP_TRACE(s, "dp_compact_kernel");
-    int rc = run_dp(c, c->sel_tasks.p, n_sel, max_win, cl, cr, c->sel_res.p, nullptr, 0, ms_fill, ms_trace, count);
+    // What passes the filter are mostly real alignments with few differences: windows of read + 60 go through the band scheme (perfect and
+    // one-mismatch diagonals need no table, most others 15 or 27 diagonals), anything else (mate-rescue windows) through the full table.
+    // The scheme is a dozen dependent launches with host round trips between them: measured on the default step it costs 1 ms MORE than the
+    // full table for 66 k instances and wins from roughly twice that on (rescue-heavy batches: C5 3.5 -> 3.9 M pairs/s), hence the threshold.
+    // MP_DP_RESCUE_BAND = 0: never; = n: from n instances on (1 = always: the soak's setting).
+    static const uint32_t band_from = getenv("MP_DP_RESCUE_BAND") ? (uint32_t)atoi(getenv("MP_DP_RESCUE_BAND")) : 160000u;
+    int rc = band_from && n_sel >= band_from && band_applicable(c, max_win, cl, cr) ? run_dp_band(c, c->sel_tasks.p, n_sel, max_win, cl, cr, c->sel_res.p, ms_fill, ms_trace, count)
+                                                            : run_dp(c, c->sel_tasks.p, n_sel, max_win, cl, cr, c->sel_res.p, nullptr, 0, ms_fill, ms_trace, count);
     if (rc) return rc;
     hipLaunchKernelGGL(dp_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, c->sel_res.p, n, d_res);
     MP_TRACE(s, "dp_scatter_kernel");

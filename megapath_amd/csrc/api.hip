@@ -104,6 +104,7 @@ struct mp_ctx {
     uint64_t n_band = 0, n_band_full = 0;        // instances run through the band kernel / re-run by the full kernels
     DevBuf<mp_pair_hit> pair_hits;
     DevBuf<uint32_t> pair_cnt, pair_off;   // hits per pair and where each pair's group starts in pair_hits
+    DevBuf<uint32_t> hit_flag, hit_idx, cand_first;   // per candidate: makes a hit / hits in front of it; per pair: its first candidate
     DevBuf<unsigned long long> n_pair_hits;
     uint64_t n_pair_hits_host = 0;
     mp_pair_hit *h_pair_hits = nullptr;    // pinned staging for mp_get_pair_hits_view
@@ -803,7 +804,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     c->seedpos.release(); c->hit_row.release(); c->seeds_per_rs.release(); c->hits_per_rs.release(); c->rs_base.release(); c->overflow_rs.release(); c->over_slot.release();
     c->queue.release(); c->n_pos.release(); c->n_neg.release(); c->cub_tmp.release(); c->ctr.release(); c->cands.release(); c->tasks_l.release(); c->tasks_r.release();
     c->tasks_tmp.release(); c->fill.release(); c->res_l.release(); c->res_r.release(); c->res_tmp.release(); c->flags.release();
-    c->ops.release(); c->th_cert.release(); c->th_stats.release(); c->pair_hits.release(); c->pair_cnt.release(); c->pair_off.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
+    c->ops.release(); c->th_cert.release(); c->th_stats.release(); c->pair_hits.release(); c->pair_cnt.release(); c->pair_off.release(); c->hit_flag.release(); c->hit_idx.release(); c->cand_first.release(); c->n_pair_hits.release(); c->sel_flag.release(); c->sel_idx.release(); c->sel_tasks.release(); c->sel_res.release();
     if (c->h_pair_hits) (void)hipHostFree(c->h_pair_hits);
     if (c->red_keys) (void)hipFree(c->red_keys);
     if (c->red_sorted) (void)hipFree(c->red_sorted);
@@ -1809,15 +1810,19 @@ extern "C" int mp_deep_dp_round(mp_ctx *c, const mp_align_params *ap, uint64_t *
         if (rc) return rc;
         // the hits leave grouped by pair, pairs ascending: count per pair, scan, store at the group's offset
         const uint32_t np1 = n_pairs + 1;
-        if (c->pair_cnt.reserve(np1) || c->pair_off.reserve(np1)) return MP_ENOMEM;
+        if (c->pair_cnt.reserve(np1) || c->pair_off.reserve(np1) || c->hit_flag.reserve(nc + 2) || c->hit_idx.reserve(nc + 2) || c->cand_first.reserve(np1)) return MP_ENOMEM;
         HIPCHK(hipMemsetAsync(c->pair_cnt.p, 0, (size_t)np1 * 4, s));
+        hipLaunchKernelGGL(cand_first_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->cand_first.p);
         hipLaunchKernelGGL(collect_pair_hits_kernel<true>, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,
-                           c->res_r.p, c->pair_hits.p, c->pair_cnt.p, (const uint32_t *)c->pair_off.p, (uint32_t)c->pair_hits.cap, c->pair_done.p);
+                           c->res_r.p, c->pair_hits.p, c->pair_cnt.p, (const uint32_t *)c->pair_off.p, (uint32_t)c->pair_hits.cap, c->pair_done.p,
+                           c->hit_flag.p, (const uint32_t *)c->hit_idx.p, (const uint32_t *)c->cand_first.p);
         rc = exclusive_scan_u32(c, c->pair_cnt.p, c->pair_off.p, np1);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(c->pair_cnt.p, 0, (size_t)np1 * 4, s));
+        rc = exclusive_scan_u32(c, c->hit_flag.p, c->hit_idx.p, nc);      // a hit's place inside its pair's group: candidate order, not arrival order
+        if (rc) return rc;
         hipLaunchKernelGGL(collect_pair_hits_kernel<false>, dim3(grid_for(nc, 256)), dim3(256), 0, s, c->cands.p, nc, c->d_lens, c->tasks_l.p, c->res_l.p, c->tasks_r.p,
-                           c->res_r.p, c->pair_hits.p, c->pair_cnt.p, (const uint32_t *)c->pair_off.p, (uint32_t)c->pair_hits.cap, c->pair_done.p);
+                           c->res_r.p, c->pair_hits.p, c->pair_cnt.p, (const uint32_t *)c->pair_off.p, (uint32_t)c->pair_hits.cap, c->pair_done.p,
+                           c->hit_flag.p, (const uint32_t *)c->hit_idx.p, (const uint32_t *)c->cand_first.p);
         MP_TRACE(s, "collect_pair_hits_kernel");
         uint32_t nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, c->pair_off.p + n_pairs, sizeof nh, hipMemcpyDeviceToHost, s));

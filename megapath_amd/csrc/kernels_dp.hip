@@ -770,22 +770,35 @@ __global__ void build_right_tasks_kernel(const mp_candidate *__restrict__ cands,
 // that the hit list leaves the device GROUPED BY PAIR in ascending pair order (the host then only orders the few hits inside a
 // group): COUNT adds up each pair's hits, an exclusive scan turns the counts into group offsets, the second pass stores every hit
 // at its group's offset plus a per-pair cursor.
+// The cursor is NOT an atomic counter: equal hits of a pair (same positions and scores, different tie counts or windows) are de-duplicated
+// on the host by "first one wins", so their order must not depend on which wavefront stored first.  A pair's candidates are contiguous in
+// `cands` (pair_kernel emits them from one lane), so the cursor of candidate t is the number of passing candidates of its pair in front
+// of it: hit_idx (exclusive scan of the COUNT pass's flags) minus its value at the pair's first candidate.
+__global__ void cand_first_kernel(const mp_candidate *__restrict__ cands, uint32_t n, uint32_t *__restrict__ cand_first)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t p = cands[t].read_id_left >> 1;
+    if (t == 0 || (cands[t - 1].read_id_left >> 1) != p) cand_first[p] = t;
+}
+
 template <bool COUNT>
 __global__ void collect_pair_hits_kernel(const mp_candidate *__restrict__ cands, uint32_t n, const uint32_t *__restrict__ lens,
                                          const mp_dp_task *__restrict__ lt, const mp_dp_result *__restrict__ lr,
                                          const mp_dp_task *__restrict__ rt, const mp_dp_result *__restrict__ rr,
                                          mp_pair_hit *__restrict__ hits, uint32_t *__restrict__ pair_cnt, const uint32_t *__restrict__ pair_off, uint32_t cap,
-                                         uint32_t *__restrict__ pair_done)
+                                         uint32_t *__restrict__ pair_done, uint32_t *__restrict__ hit_flag, const uint32_t *__restrict__ hit_idx,
+                                         const uint32_t *__restrict__ cand_first)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const mp_candidate c = cands[t];
     const uint32_t left = c.read_id_left, right = left ^ 1u;
     const mp_dp_result a = lr[t], b = rr[t];
-    if (a.score <= 0 || b.score <= 0) return;
-    if (a.score < mp_dp_cutoff((int)lens[left]) || b.score < mp_dp_cutoff((int)lens[right])) return;
-    if (COUNT) { atomicAdd(&pair_cnt[left >> 1], 1u); return; }
-    const uint32_t slot = pair_off[left >> 1] + atomicAdd(&pair_cnt[left >> 1], 1u);
+    const bool pass = a.score > 0 && b.score > 0 && a.score >= mp_dp_cutoff((int)lens[left]) && b.score >= mp_dp_cutoff((int)lens[right]);
+    if (COUNT) { hit_flag[t] = pass ? 1u : 0u; if (pass) atomicAdd(&pair_cnt[left >> 1], 1u); return; }
+    if (!pass) return;
+    const uint32_t slot = pair_off[left >> 1] + (hit_idx[t] - hit_idx[cand_first[left >> 1]]);
     if (slot >= cap) return;
     const int read_side = (int)(left & 1u);          // 0: the read (even id) is the left leg
     mp_pair_hit h;

@@ -958,12 +958,13 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     const int cov_words = (int)((c->max_len + 63) / 64);
     uint32_t stage_cap = MP_MERGE_CAP;
     if (const char *e = getenv("MP_MERGE_STAGE_CAP")) { const int v = atoi(e); if (v >= 0 && v < MP_MERGE_CAP) stage_cap = (uint32_t)v; }   // test knob
+    const int merge_rows = getenv("MP_MERGE_ROWS") ? atoi(getenv("MP_MERGE_ROWS")) : 1;      // 0: test switch (kernels_seed.hip, merge_reads_rows)
     if (fused)
         hipLaunchKernelGGL(merge_kernel<true>, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_THREADS), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, cov_words,
-                           c->seedpos.p, c->n_pos.p, c->n_neg.p, c->ctr.p, dix, c->slabs.p, c->seeds_per_rs.p, c->over_slot.p, c->big_slabs.p, slab_limit, c->d_lens, stage_cap);
+                           c->seedpos.p, c->n_pos.p, c->n_neg.p, c->ctr.p, dix, c->slabs.p, c->seeds_per_rs.p, c->over_slot.p, c->big_slabs.p, slab_limit, c->d_lens, stage_cap, merge_rows);
     else
         hipLaunchKernelGGL(merge_kernel<false>, dim3(grid_for(n_reads, MP_MERGE_BLOCK)), dim3(MP_MERGE_THREADS), 0, s, c->hits.p, c->rs_base.p, n_reads, P, (uint64_t)c->ix->n, cov_words,
-                           c->seedpos.p, c->n_pos.p, c->n_neg.p, c->ctr.p, dix, c->slabs.p, c->seeds_per_rs.p, c->over_slot.p, c->big_slabs.p, slab_limit, c->d_lens, stage_cap);
+                           c->seedpos.p, c->n_pos.p, c->n_neg.p, c->ctr.p, dix, c->slabs.p, c->seeds_per_rs.p, c->over_slot.p, c->big_slabs.p, slab_limit, c->d_lens, stage_cap, merge_rows);
     MP_TRACE(s, "merge_kernel");
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipMemcpyAsync(&h, c->ctr.p, sizeof h, hipMemcpyDeviceToHost, s));

@@ -1226,6 +1226,90 @@ __device__ __forceinline__ uint32_t merge_read_wave(const uint64_t *k, int n, mp
     return w_out;
 }
 
+// ---- four reads per wavefront: a read with at most 16 keys (nearly all of them) is handled by one 16-lane ROW, the four rows of a wavefront
+// working on four reads at once.  Same rules as merge_read_wave; instead of v_readlane broadcasts (wave-wide, one read at a time) every lane
+// meets the other fifteen keys of its row through DPP row rotations (full-rate VALU, no LDS): ranks for the sort, group ends, the row's
+// best covered length.  Rows whose read has more keys (or none in range) sit the call out (active = false) and are handled wave-wide afterwards.
+template <int N> __device__ __forceinline__ uint32_t mp_row_ror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x120 + N, 0xF, 0xF, false); }
+template <int N> __device__ __forceinline__ uint64_t mp_row_ror64(uint64_t v) { return ((uint64_t)mp_row_ror<N>((uint32_t)(v >> 32)) << 32) | mp_row_ror<N>((uint32_t)v); }
+template <int N, class F> __device__ __forceinline__ void mp_row_others(uint64_t x, F &&f) { f(mp_row_ror64<N>(x)); if constexpr (N < 15) mp_row_others<N + 1>(x, f); }
+
+__device__ __forceinline__ uint32_t merge_reads_rows(bool active, uint64_t *ks /* the row's read: its keys in LDS */, int n /* <= 16 */, mp_seedpos *__restrict__ out, uint32_t r,
+                                                     const mp_dev_mmp &P, uint64_t text_len, int cw32, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, int lane)
+{
+    const int sl = lane & 15;
+    const bool valid = active && sl < n;
+    // sort: rank among the row's keys (made distinct by the lane number), scatter to LDS, read back in order
+    const uint64_t key0 = valid ? ks[sl] : ~0ull;
+    const uint64_t sk = valid ? (key0 << 6) | (uint64_t)sl : ~0ull;
+    uint32_t rank = 0;
+    mp_row_others<1>(sk, [&](uint64_t o) { rank += o < sk ? 1u : 0u; });
+    if (valid) ks[rank] = key0;
+    const uint64_t key = valid ? ks[sl] : 0;                            // (LDS operations of one wavefront complete in order)
+    // where the group that would start at this key ends: the keys behind it on the same strand within indelFuzz (DV-DPfunctions.cpp:2514)
+    const uint64_t pos = key_pos(key, text_len), group_end = pos + (uint64_t)P.indel_fuzz;
+    const uint64_t cs = valid ? (key << 4) | (uint64_t)sl : ~0ull;      // keys use 53 bits
+    uint32_t behind = 0;
+    mp_row_others<1>(cs, [&](uint64_t o) {
+        const uint64_t kj = o >> 4;
+        const int j = (int)(o & 15u);
+        behind += (o != ~0ull && j > sl && MP_KEY_STRAND(kj) == MP_KEY_STRAND(key) && key_pos(kj, text_len) <= group_end) ? 1u : 0u;
+    });
+    const uint32_t nxt = (uint32_t)sl + 1u + behind;
+    // the groups of a read: from start to start (each row walks its own chain; the rows of a wavefront in step)
+    uint32_t s = 0, starts = 0;
+    for (;;) {
+        const bool go = active && s < (uint32_t)n;
+        if (!__any(go)) break;
+        if (go) starts |= 1u << s;
+        const uint32_t nx = (uint32_t)__shfl((int)nxt, (lane & 48) | (int)(go ? s : 0u));
+        if (go) s = nx;
+    }
+    const bool is_start = valid && ((starts >> sl) & 1u);
+    uint32_t total = 0;
+    bool has_unique = false;
+    if (is_start && nxt == (uint32_t)sl + 1u) { total = (uint32_t)MP_KEY_LEN(key); has_unique = MP_KEY_UNIQ(key); }      // a group of one: its own length
+    else if (is_start) {
+        uint32_t cov[MP_SEED_BIG / 32];
+#pragma unroll
+        for (int w = 0; w < MP_SEED_BIG / 32; w++) cov[w] = 0;
+        for (uint32_t j = (uint32_t)sl; j < nxt; j++) {
+            const uint64_t cur = j == (uint32_t)sl ? key : ks[j];
+            const int lo = MP_KEY_QO(cur), hi = lo + MP_KEY_LEN(cur);
+            has_unique |= MP_KEY_UNIQ(cur);
+#pragma unroll
+            for (int w = 0; w < MP_SEED_BIG / 32; w++) {
+                if (w >= cw32) break;                  // reads of this batch are no longer than 32 cw32 bases
+                int a = lo - 32 * w, b = hi - 32 * w;
+                a = a < 0 ? 0 : (a > 32 ? 32 : a);
+                b = b < 0 ? 0 : (b > 32 ? 32 : b);
+                const uint32_t below_b = b >= 32 ? ~0u : ((1u << b) - 1u), below_a = a >= 32 ? ~0u : ((1u << a) - 1u);
+                cov[w] |= below_b & ~below_a;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < MP_SEED_BIG / 32; w++) total += (uint32_t)__popc(cov[w]);
+    }
+    // best covered length of the read, rejected groups included (:2547): maximum over the row
+    uint32_t max_cov = is_start ? total : 0u;
+    { uint32_t o = mp_row_ror<8>(max_cov); max_cov = o > max_cov ? o : max_cov; o = mp_row_ror<4>(max_cov); max_cov = o > max_cov ? o : max_cov;
+      o = mp_row_ror<2>(max_cov); max_cov = o > max_cov ? o : max_cov; o = mp_row_ror<1>(max_cov); max_cov = o > max_cov ? o : max_cov; }
+    const bool keep = is_start && (has_unique || total >= (uint32_t)P.good_seed_len) && (double)total >= P.short_seed_ratio * (double)max_cov;
+    const unsigned long long kb = __ballot(keep);
+    const uint32_t strand = MP_KEY_STRAND(key);
+    const unsigned long long nb = __ballot(keep && strand);
+    const uint32_t row_keep = (uint32_t)(kb >> (lane & 48)) & 0xFFFFu, row_neg = (uint32_t)(nb >> (lane & 48)) & 0xFFFFu;
+    if (keep) {
+        mp_seedpos sp;
+        sp.pos = pos;
+        sp.paired_seed_length = total;
+        sp.strand_read_id = (r & ~1u) | (strand << 31);
+        out[__popc(row_keep & ((1u << sl) - 1u))] = sp;
+    }
+    if (active && sl == 0) { const uint32_t nn = (uint32_t)__popc(row_neg); n_pos[r] = (uint32_t)__popc(row_keep) - nn; n_neg[r] = nn; }
+    return (uint32_t)__popcll(kb);
+}
+
 // Output: seedpos[read_base[r] .. ) holds the kept seeds of read r, '+' first; n_pos[r], n_neg[r] their counts.
 // One lane per read, one wavefront per block.  The hits of a block's 64 reads are one contiguous range: it is read with
 // coalesced loads, packed to 8-byte keys and staged in LDS.  Sorting: a lane-per-read sort makes the wavefront wait for
@@ -1294,10 +1378,13 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_bas
              mp_seedpos *__restrict__ seedpos, uint32_t *__restrict__ n_pos, uint32_t *__restrict__ n_neg, mp_counters *ctr,
              mp_dev_index ix, const mp_seed_rec *__restrict__ slabs, const uint32_t *__restrict__ seeds_per_rs, const uint32_t *__restrict__ over_slot,
              const mp_seed_rec *__restrict__ big_slabs, uint32_t slab_limit, const uint32_t *__restrict__ lens,
-             uint32_t stage_cap /* <= MP_MERGE_CAP; smaller only to exercise the path of blocks that do not fit in LDS */)
+             uint32_t stage_cap /* <= MP_MERGE_CAP; smaller only to exercise the path of blocks that do not fit in LDS */,
+             int rows_on /* 0: every read by a whole wavefront (test switch MP_MERGE_ROWS=0) */)
 {
     __shared__ uint64_t s_key[MP_MERGE_CAP];
     __shared__ uint32_t s_base[MP_MERGE_BLOCK + 1];
+    __shared__ uint32_t s_part[2 + MP_MERGE_THREADS / MP_WAVE];     // seeds turned into keys by wavefronts 0, 1; seeds kept by each wavefront
+    static_assert(MP_MERGE_THREADS / MP_WAVE == 4 && 2 * MP_MERGE_BLOCK == 2 * MP_WAVE, "s_part is summed by hand");
     const uint32_t r0 = blockIdx.x * MP_MERGE_BLOCK;
     const uint32_t r1 = min(r0 + MP_MERGE_BLOCK, n_reads);
     const uint32_t b0 = rs_base[2 * r0], T = rs_base[2 * r1] - b0;
@@ -1333,7 +1420,7 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_bas
             nsd = mp_rs_keys(ix, P, rs, slabs, seeds_per_rs, over_slot, big_slabs, slab_limit, lens, s_key + (rs_base[rs] - b0));
         if (threadIdx.x < 2 * MP_MERGE_BLOCK) {
             for (int o = MP_WAVE / 2; o > 0; o >>= 1) nsd += __shfl_down(nsd, o);
-            if (lane == 0 && nsd) atomicAdd(&ctr->n_seeds, (unsigned long long)nsd);
+            if (lane == 0) s_part[wave] = nsd;                  // summed per block below: one counter update per block, not per wavefront
         }
     } else {
         // four independent 16-byte loads in flight per lane
@@ -1346,25 +1433,43 @@ merge_kernel(mp_seed_hit *__restrict__ hits, const uint32_t *__restrict__ rs_bas
         }
     }
     __syncthreads();
-    // ---- one read after the other, each by a whole wavefront: sort (lane = key), then groups (lane = group); the block's wavefronts
-    // take every fourth read
+    // ---- four reads at a time per wavefront, one 16-lane row each (merge_reads_rows); a read with more than 16 keys is then taken by the whole
+    // wavefront: sort (lane = key), then groups (lane = group).  The block's wavefronts take every fourth quad of reads.
     const int cw32 = 2 * cov_words;
     uint32_t wave_kept = 0;
-    for (uint32_t src = (uint32_t)wave; r0 + src < r1; src += MP_MERGE_THREADS / MP_WAVE) {
-        const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_base[src]);          // wave-uniform: the loops below are scalar loops
-        const int ns = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)s_base[src + 1]) - kb);
-        if (ns == 0) { if (lane == 0) { n_pos[r0 + src] = 0; n_neg[r0 + src] = 0; } continue; }
-        uint64_t *ks = s_key + kb;
-        if (ns > 1) {
-            if (ns <= 64) wave_rank_sort(ks, ns, lane);
-            else if (ns <= 128) wave_sort_read<2>(ks, ns, lane);
-            else if (ns <= 256) wave_sort_read<4>(ks, ns, lane);
-            else if (ns <= MP_MERGE_COOP) wave_sort_read<8>(ks, ns, lane);
-            else { if (lane == 0) sort_keys(ks, ns); }                 // the rare very large read (heap sort by one lane)
+    static_assert(MP_MERGE_BLOCK % 4 == 0, "reads are handed out in quads");
+    for (uint32_t q0 = 4u * (uint32_t)wave; r0 + q0 < r1; q0 += 4u * (MP_MERGE_THREADS / MP_WAVE)) {
+        const uint32_t mine = q0 + (uint32_t)(lane >> 4);                       // this row's read
+        const bool in = r0 + mine < r1;
+        const uint32_t kbr = s_base[in ? mine : q0];
+        const int nsr = in ? (int)(s_base[mine + 1] - kbr) : 0;
+        const bool rows = rows_on != 0;
+        wave_kept += merge_reads_rows(in && rows && nsr <= 16, s_key + kbr, nsr, seedpos + b0 + kbr, r0 + mine, P, text_len, cw32, n_pos, n_neg, lane);
+        for (uint32_t src = q0; src < q0 + 4u && r0 + src < r1; src++) {
+            const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_base[src]);          // wave-uniform: the loops below are scalar loops
+            const int ns = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)s_base[src + 1]) - kb);
+            if (rows && ns <= 16) continue;                                                               // done by its row
+            if (ns == 0) { if (lane == 0) { n_pos[r0 + src] = 0; n_neg[r0 + src] = 0; } continue; }
+            uint64_t *ks = s_key + kb;
+            if (ns > 1) {
+                if (ns <= 64) wave_rank_sort(ks, ns, lane);
+                else if (ns <= 128) wave_sort_read<2>(ks, ns, lane);
+                else if (ns <= 256) wave_sort_read<4>(ks, ns, lane);
+                else if (ns <= MP_MERGE_COOP) wave_sort_read<8>(ks, ns, lane);
+                else { if (lane == 0) sort_keys(ks, ns); }                 // the rare very large read (heap sort by one lane)
+            }
+            wave_kept += merge_read_wave(ks, ns, seedpos + b0 + kb, r0 + src, P, text_len, cw32, n_pos, n_neg, lane);
         }
-        wave_kept += merge_read_wave(ks, ns, seedpos + b0 + kb, r0 + src, P, text_len, cw32, n_pos, n_neg, lane);
     }
-    if (lane == 0 && wave_kept) atomicAdd(&ctr->n_seedpos, (unsigned long long)wave_kept);
+    // one update per block and counter: a single address takes only ~100 M atomics per second chip-wide, and a launch over 2 Mi reads has
+    // 131 k wavefronts here -- per-wavefront updates of the two counters were most of this kernel's time
+    if (lane == 0) s_part[2 + wave] = wave_kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t kept = s_part[2] + s_part[3] + s_part[4] + s_part[5], nsd = FUSED ? s_part[0] + s_part[1] : 0u;
+        if (kept) atomicAdd(&ctr->n_seedpos, (unsigned long long)kept);
+        if (nsd) atomicAdd(&ctr->n_seeds, (unsigned long long)nsd);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K4

@@ -44,7 +44,7 @@ for rnd in range(args.rounds):
                # which optional index tables the run may build (every combination takes another path through the seeding kernels)
                env={k: str(int(v)) for k, v in (("MP_KMER_FILTER", rng.choice([0, 1, 1, 1, 16])), ("MP_KMER15", rng.random() < 0.7), ("MP_LKT16", rng.random() < 0.7),
                                                 ("MP_SA_DENSE", rng.random() < 0.7), ("MP_LKT16U", rng.random() < 0.7), ("MP_SA_DENSE_SPACING", rng.choice([1, 1, 2, 4])),
-                                                ("MP_DP_DIAG", rng.random() < 0.8), ("MP_DP_ONE_MISMATCH", rng.choice([0, 1, 2, 2, 2])), ("MP_DP_RESCUE_BAND", rng.random() < 0.8))},
+                                                ("MP_DP_DIAG", rng.random() < 0.8), ("MP_DP_ONE_MISMATCH", rng.choice([0, 1, 2, 2, 2])), ("MP_DP_RESCUE_BAND", rng.random() < 0.8), ("MP_MERGE_ROWS", rng.random() < 0.8))},
                kw=dict(sub=float(rng.choice([0.0, 0.005, 0.01, 0.03, 0.06])), ins=float(rng.choice([0.0, 0.001, 0.004])), dele=float(rng.choice([0.0, 0.001, 0.004])),
                        random_frac=float(rng.choice([0.0, 0.05, 0.3])), broken_mate_frac=float(rng.choice([0.0, 0.1, 0.3])),
                        noisy_mate_frac=float(rng.choice([0.0, 0.2])), noisy_sub=0.15, n_frac=float(rng.choice([0.0, 0.002])),

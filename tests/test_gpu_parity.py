@@ -246,6 +246,50 @@ def test_merge_kernel_paths_that_do_not_stage_in_lds(golden_dir, oidx, monkeypat
     gix.close()
 
 
+@pytest.mark.parametrize("rows", ["1", "0"])
+def test_merge_rows_and_whole_wavefronts_equal_oracle(tmp_path, monkeypatch, rows):
+    """merge_kernel gives a read with at most 16 located hits one 16-lane row of a wavefront (four reads at a time, DPP row rotations) and
+    a read with more the whole wavefront; MP_MERGE_ROWS=0 sends every read the wave-wide way.  A repeat-rich genome (reads with 1, a few,
+    17 .. 64 and more than 64 hits side by side in one quad of reads, groups of several hits within indelFuzz through tandem copies):
+    the kept seeds equal the oracle's either way."""
+    from megapath_amd import index_builder, synth
+    import oracle_lib as O
+    monkeypatch.setenv("MP_MERGE_ROWS", rows)
+    genome = synth.random_genome(300000, 2201, n_seqs=2, repeat_frac=0.35)
+    rng = np.random.Generator(np.random.PCG64(2202))
+    g2 = []
+    for name, arr in genome:
+        arr = arr.copy()
+        for _ in range(300):
+            u = int(rng.integers(3, 30)); k = int(rng.integers(2, 6)); p = int(rng.integers(0, len(arr) - u * (k + 1)))
+            for c in range(1, k + 1):
+                arr[p + c * u:p + (c + 1) * u] = arr[p:p + u]
+        g2.append((name, arr))
+    arrs = index_builder.build_index_arrays(g2, sa_interval=16)
+    prefix = str(tmp_path / "m.index")
+    index_builder.write_index_files(prefix, arrs)
+    gix = H.Index(prefix, 0)
+    names, r1, r2 = synth.simulate_pairs(g2, 2500, 150, 2203, sub=0.01, ins=0.001, dele=0.001, random_frac=0.02)
+    seqs = [x for pr in zip(r1, r2) for x in pr]
+    packed, lens, W = H.pack_reads(seqs, 151)
+    ctx = H.Context(gix)
+    ctx.set_reads(packed, lens)
+    mmp = H.MmpParams.nt2()
+    st = ctx.seed_batch(mmp)
+    arr, off = ctx.get_seeds()
+    lib = O.oracle()
+    oix = lib.mpo_index_open(prefix.encode())
+    want, ctr = oracle_seeds(oix, seqs, 151, to_oracle_mmp(mmp))
+    lib.mpo_index_close(oix)
+    got = [[(arr[i].pos, arr[i].strand_read_id, arr[i].paired_seed_length) for i in range(int(off[r]), int(off[r + 1]))] for r in range(len(seqs))]
+    assert got == want
+    per_read = np.diff(off)
+    assert (per_read == 1).sum() > 200 and (per_read > 4).sum() > 200        # single hits and crowded reads are both there
+    assert st.n_seeds == ctr.n_seeds and st.n_hits == ctr.n_hits and st.n_hits > 17 * len(seqs) // 4
+    ctx.close()
+    gix.close()
+
+
 def test_dp_matches_reference_vectors(golden_dir, tmp_path):
     """callDP golden vectors: build a throw-away index whose text is the concatenation of the windows."""
     v = np.load(os.path.join(golden_dir, "dp_vectors.npz"))

@@ -10,7 +10,6 @@
 #include "mp_internal.h"
 #include "kernels_index.hip"
 #include "kernels_seed.hip"
-#include "kernels_seed_x2.hip"
 #include "kernels_dp.hip"
 #include "kernels_dp_band.hip"
 #include "kernels_rescue.hip"
@@ -900,11 +899,9 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     // persistent grid: as many blocks of 256 lanes as the kernel's registers and its LDS rows (one scan row per lane) let a CU hold
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
-    static const int seed_items = getenv("MP_SEED_ITEMS") ? atoi(getenv("MP_SEED_ITEMS")) : 1;  // experiment switch: 2 = two items per lane (kernels_seed_x2.hip)
-    const size_t seed_lds = (size_t)256 * (seed_items == 2 ? 2 : 1) * (mp_scan_stride(W) | 1u) * sizeof(uint32_t);
+    const size_t seed_lds = (size_t)256 * (mp_scan_stride(W) | 1u) * sizeof(uint32_t);
     int per_cu = 0;
-    static const int seed_occ = getenv("MP_SEED_OCC") ? atoi(getenv("MP_SEED_OCC")) : 0;      // experiment switch: 6 = the 80-register build
-    auto kern = seed_items == 2 ? seed_kernel_x2 : seed_occ == 6 ? seed_kernel<6> : seed_kernel<1>;
+    auto kern = seed_kernel;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, seed_lds) != hipSuccess || per_cu < 1) per_cu = 4;
     const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * (unsigned)per_cu);
     HIPCHK(hipEventRecord(c->ev[0], s));
@@ -1334,10 +1331,7 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     if (thermo) {
         if (c->th_cert.reserve(n + 64) || c->th_stats.reserve(4) || c->score_list.reserve(n + 2)) return MP_ENOMEM;
         HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
-        static const bool occ1 = getenv("MP_THERMO_OCC") && atoi(getenv("MP_THERMO_OCC")) == 1;
-        if (narrow && occ1) hipLaunchKernelGGL((dp_thermo_kernel_w1<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
-                                               (const uint32_t *)nullptr, c->th_stats.p);
-        else if (narrow) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
+        if (narrow) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
                                        (const uint32_t *)nullptr, c->th_stats.p);
         else {
             // a batch with reads of more than 160 bases is usually one of mixed lengths: the instances of 101 .. 160 bases go through the narrow

@@ -21,7 +21,11 @@ enum { OK = 0, NEED_OUTPUT = 1, MEMBER_END = 2, STREAM_END = 3, AT_BLOCK = 4, ER
 class Inflater {
 public:
     // the whole compressed file
-    void init(const uint8_t *data, size_t len) { in_ = data; in_end_ = data + len; p_ = data; bb_ = 0; bc_ = 0; virt_ = 0; state_ = S_HEADER; err_.clear(); resumed_ = false; }
+    void init(const uint8_t *data, size_t len)
+    {
+        in_ = data; in_end_ = data + len; p_ = data; bb_ = 0; bc_ = 0; virt_ = 0; state_ = S_HEADER; err_.clear(); resumed_ = false;
+        member_out_ = 0; member_known_ = false;
+    }
     // the same, but decoding starts at a deflate block header `bitpos` bits into the data (the parallel reader: par_gzip in soap4_main.cpp)
     void init_at_block(const uint8_t *data, size_t len, uint64_t bitpos)
     {
@@ -48,10 +52,21 @@ public:
     template <typename Out>
     int run(Out *out, size_t &pos, size_t cap)
     {
+        ms_ = (int64_t)pos - (int64_t)member_out_;                           // where the current member's output began, in this call's coordinates
+        const int rc = run_states(out, pos, cap);
+        member_out_ = (uint64_t)((int64_t)pos - ms_);
+        return rc;
+    }
+
+private:
+    template <typename Out>
+    int run_states(Out *out, size_t &pos, size_t cap)
+    {
         for (;;) {
             switch (state_) {
             case S_HEADER: {
                 if (!header()) return err_.empty() ? STREAM_END : ERR;
+                ms_ = (int64_t)pos; member_known_ = true;
                 state_ = S_BLOCK;
                 break;
             }
@@ -118,7 +133,6 @@ public:
         }
     }
 
-private:
     enum { S_HEADER, S_BLOCK, S_STORED, S_HUFF, S_TRAILER, S_DONE };
     enum { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4, K_LIT2 = 5 };     // K_LIT2: two literals in one first-level entry
     static constexpr unsigned LBITS = 11, DBITS = 8;
@@ -129,6 +143,13 @@ private:
     bool last_ = false, block_stops_ = false, resumed_ = false;
     unsigned stored_left_ = 0;
     unsigned virt_ = 0;          // zero bytes appended past the end of the input (refill)
+    // Bytes of the CURRENT member written before the run() call in progress: a match may reach back that far plus what this call has written,
+    // not into an earlier member's output (zlib: "invalid distance too far back"), even though that output lies in front of it in the same
+    // buffer (concatenated members, the groups of a BGZF file, the 32 KiB of history a chunked caller keeps).  A decoder started in the
+    // middle of a stream (init_at_block) does not know where its member began: no limit until it reads a member header itself.
+    uint64_t member_out_ = 0;
+    int64_t ms_ = 0;             // run() in progress: out[] index at which the current member's output began (negative: before the buffer)
+    bool member_known_ = false;
     uint32_t crc_ = 0, isize_ = 0;
     std::string err_;
     // entry: value << 16 | extra (or second-level bits) << 8 | kind << 5 | code length
@@ -361,6 +382,7 @@ private:
             const size_t distance = (d >> 16) + (size_t)(bb_ & ((1u << db) - 1u));
             drop(db);
             if (distance > pos) { pos_io = pos; return fail("distance reaches before the start of the output"); }
+            if (member_known_ && (int64_t)distance > (int64_t)pos - ms_) { pos_io = pos; return fail("invalid distance too far back"); }
             Out *dst = out + pos;
             const Out *src = dst - distance;
             pos += len;

@@ -24,8 +24,10 @@
 // only) simply end up decoded by one thread.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -162,6 +164,7 @@ public:
         segs_.reset(new Seg[n_seg_]);
         for (size_t k = 0; k < n_seg_; k++) segs_[k].find_state = k == 0 ? 2 : 0;
         memset(win_prev_, 0, H);
+        if (const char *e = getenv("MP_PARGZ_TEST_BOGUS_START")) test_bogus_every_ = (size_t)std::max(0, atoi(e));      // test hook (tests/test_host_logic.py): every n-th segment gets a false start
         running_crc_ = (uint32_t)crc32(0L, Z_NULL, 0);
         for (int t = 0; t < (threads < 1 ? 1 : threads); t++) th_.emplace_back([this]() { worker(); });
     }
@@ -186,6 +189,7 @@ public:
     size_t segments_started_blind() const { return blind_.load(); }
     size_t false_starts() const { return false_starts_.load(); }
     size_t parts_handed_over_early() const { return parts_.load(); }
+    int segments_in_flight() { std::lock_guard<std::mutex> lk(mu_); return in_flight_; }     // 0 once the last piece has been popped
     // thread-seconds spent looking for starts / decoding / resolving (over all threads)
     double seconds_find() const { return ns_find_.load() * 1e-9; }
     double seconds_decode() const { return ns_decode_.load() * 1e-9; }
@@ -215,6 +219,7 @@ private:
     std::condition_variable cv_;
     bool stop_ = false;
     size_t next_decode_ = 0;                        // the next segment nobody has claimed
+    size_t test_bogus_every_ = 0;
     size_t chain_ = 0;                              // the next segment of the chain to be resolved (its predecessor's window is known)
     bool chain_busy_ = false, chain_done_ = false;
     uint8_t win_prev_[H];                           // the 32 KiB in front of segment chain_
@@ -239,6 +244,7 @@ private:
         const uint64_t safe = (uint64_t)(len_ - 40) * 8u;                   // the look-ahead of the checks stays inside the file
         if (hi > safe) hi = safe;
         if (searches_given_up_.load()) return NONE;
+        if (test_bogus_every_ && k % test_bogus_every_ == test_bogus_every_ - 1 && lo + 3 < hi) return lo + 3;     // test hook: a start that is none
         BitPeek in{d_, len_};
         std::vector<uint16_t> trial;
         uint64_t word = 0;
@@ -317,7 +323,6 @@ private:
         const uint64_t own_end = (uint64_t)std::min(len_, (k + 1) * seg_) * 8u;
         size_t cand = k + 1;                                                // the next segment whose start could end this one
         bool first = true;
-        int passed = 0;                                                     // starts this decoder went past without standing on them
         for (;;) {
             { std::lock_guard<std::mutex> lk(mu_); if (stop_ || s.dead) break; }
             const int rc = z.run(s.sym.data(), pos, s.sym.size());
@@ -343,16 +348,16 @@ private:
                 if (c == b) { s.next_seg = cand; stop_here = true; break; }
                 if (c == NONE || c < b) {
                     // no start in that segment, or one this decoder has passed without standing on it: a false one -- if THIS decoder is on
-                    // the true chain, which only the chain knows (resolve_segment declares the segments it jumps over dead).  A decoder that
-                    // passes three found starts in a row is taken to be the one that is off the rails.
-                    if (c != NONE) passed++;
+                    // the true chain, which only the chain knows (resolve_segment declares the segments it jumps over dead).  A decoder cannot tell
+                    // whether it or the starts it passes are off the rails, so passing them is never an error here: a decoder that is off the rails
+                    // is declared dead by the chain (checked at every block) or runs into a real decoding error, and one the chain reaches is on
+                    // the true chain by construction and decodes on, as zlib would.
                     cand++;
                     continue;
                 }
                 break;                                                      // its start lies ahead
             }
             if (stop_here) break;
-            if (passed >= 3) { s.err = "no block boundary where the next threads found one (corrupt deflate stream?)"; break; }
         }
         s.n_sym = pos - H;
         finish_decode(k, false);
@@ -465,7 +470,14 @@ private:
             std::lock_guard<std::mutex> lk(mu_);
             memcpy(win_prev_, next_win, H);
             // the segments between this one and the one its decoder stopped on never enter the chain: whatever they decoded is void
-            for (size_t i = k + 1; i < s.next_seg && i < n_seg_; i++) { if (segs_[i].find_state == 2 && segs_[i].start_bit != NONE) false_starts_++; segs_[i].dead = true; }
+            for (size_t i = k + 1; i < s.next_seg && i < n_seg_; i++) {
+                Seg &f = segs_[i];
+                if (f.find_state == 2 && f.start_bit != NONE) false_starts_++;
+                f.dead = true;
+                // its decoder may be done already and past its own "am I dead" check (worker()): then nobody else gives the slot and the buffer back.
+                // `claimed` is the token: whoever clears it releases, the other side finds it cleared.
+                if (f.claimed && f.decoded) release_dead_locked(f);
+            }
             chain_ = s.next_seg;
             if (s.eof || !s.err.empty() || s.next_seg >= n_seg_) chain_done_ = true;
             chain_busy_ = false;
@@ -481,6 +493,13 @@ private:
         s.claimed = false; s.decoded = false;
         sym_pool_.emplace_back();
         sym_pool_.back().swap(s.sym);
+        cv_.notify_all();
+    }
+    // a dead segment's slot and buffer are free again (mu_ held)
+    void release_dead_locked(Seg &f)
+    {
+        in_flight_--; f.claimed = false; f.decoded = false;
+        if (!f.sym.empty()) { sym_pool_.emplace_back(); sym_pool_.back().swap(f.sym); }
         cv_.notify_all();
     }
     void check_members(Piece *p)
@@ -525,11 +544,7 @@ private:
                 decode_segment(k);
                 ns_decode_ += now_ns() - t0;
                 std::lock_guard<std::mutex> lk(mu_);
-                if (segs_[k].dead) {                                            // nothing of it enters the chain: its slot and its buffer are free again
-                    in_flight_--; segs_[k].claimed = false;
-                    if (!segs_[k].sym.empty()) { sym_pool_.emplace_back(); sym_pool_.back().swap(segs_[k].sym); }
-                    cv_.notify_all();
-                }
+                if (segs_[k].dead && segs_[k].claimed) release_dead_locked(segs_[k]);   // nothing of it enters the chain (unless the chain has released it already)
             }
         }
     }

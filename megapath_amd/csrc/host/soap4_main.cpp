@@ -522,7 +522,12 @@ struct Source {
         if (fast) {
             bool got = false;
             while (want) {
-                if (!cur) { cur = fast->pop(); cur_pos = cur->begin; cur_end_idx = 0; }
+                if (!cur) {
+                    cur = fast->pop(); cur_pos = cur->begin; cur_end_idx = 0;
+                    // a chunk whose members were checked by the thread that inflated it comes with its verdict: no byte of a chunk known to
+                    // be corrupt is handed to the splitter (a batch cut from it could be aligned and printed before the end of the chunk is reached)
+                    if (cur->verified && !cur->err.empty()) fatal("[soap4-mi355x] error while reading %s: %s\n", path.c_str(), cur->err.c_str());
+                }
                 const size_t lim = cur_end_idx < cur->ends.size() ? cur->ends[cur_end_idx].pos : cur->end;
                 const size_t n = std::min(want, lim - cur_pos);
                 if (n) {

@@ -470,6 +470,11 @@ dp_prefilter_kernel(const uint32_t *__restrict__ text, const uint32_t *__restric
         if (kk == 0) { if (first < 0) first = dl; exact++; }
         kmin = kk < kmin ? kk : kmin;
     }
+    // The two short cuts below (one and two mismatches on the only matching diagonal: score L - 3 / L - 6, one tie, no table) are case analyses
+    // over THIS scoring: a match scores 1, a mismatch -2 (an event costs 3), the first base of a gap -3 and every further one -1 (a gap of k
+    // bases costs k + 2 >= 3).  The scores are compiled in (mp_align_params carries none; the executable refuses any other ini, soap4_main.cpp);
+    // should they ever become parameters, these short cuts must be switched off for anything else.
+    static_assert(MP_DP_MISMATCH == -2 && MP_DP_OPEN == -3 && MP_DP_EXT == -1, "dp_prefilter_kernel's no-table short cuts are proven for +1/-2/-3/-1 only");
     if (first >= 0) {
         r.score = L; r.row = (uint16_t)(first + L); r.col = (uint16_t)L; r.count = exact > 255 ? 255u : (uint32_t)exact;
         cls[slot] = MP_PRE_DONE;

@@ -535,8 +535,8 @@ struct mp_lane_state {
     const void *ptr;        // where that load reads
 };
 
-template <int MINW>      // waves per SIMD the register allocation is held to: 1 = whatever the kernel needs (94 VGPRs: 5), 6 = 80 VGPRs + 72 B of scratch
-__global__ void __launch_bounds__(256, MINW)
+// (94 VGPRs: five waves per SIMD.  Held to 80 registers for a sixth wave, and with two items per lane, the kernel was slower: DESIGN.md section 4)
+__global__ void __launch_bounds__(256)
 seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t n_items, uint32_t W, mp_dev_mmp P,
             mp_seed_rec *__restrict__ slabs, uint32_t *__restrict__ seeds_per_rs, uint32_t *__restrict__ hits_per_rs,
             uint32_t *__restrict__ overflow_rs, uint32_t *__restrict__ over_slot, uint32_t overflow_cap, unsigned int *queue, mp_counters *ctr,

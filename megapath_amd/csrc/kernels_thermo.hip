@@ -293,15 +293,6 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
     dp_thermo_body<T, LPS>(text, reads, lens, Wr, tasks, n_tasks, cert, list, stats);
 }
 
-// the same with the registers it asks for (one wavefront per SIMD, half of the register file left to the kernels of other contexts): measurement aid, MP_THERMO_OCC=1
-template <int T, int LPS>
-__global__ void __launch_bounds__(64)
-dp_thermo_kernel_w1(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
-                    const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list, unsigned long long *__restrict__ stats)
-{
-    dp_thermo_body<T, LPS>(text, reads, lens, Wr, tasks, n_tasks, cert, list, stats);
-}
-
 // flag[t] = 1 for the instances the certificate left undecided; the certified ones get the filter's answer "score 0"
 __global__ void thermo_flag_kernel(const uint8_t *__restrict__ cert, uint32_t n, uint32_t *__restrict__ flag, mp_fill_result *__restrict__ fill)
 {

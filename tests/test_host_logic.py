@@ -499,3 +499,69 @@ def test_parallel_gzip_reader_equals_zlib_on_every_stream_shape(tmp_path):
     import re
     m = re.search(rb"(\d+) segments, (\d+) started without their window", r.stdout)
     assert m and int(m.group(2)) >= int(m.group(1)) // 2, r.stdout
+
+
+def test_parallel_gzip_reader_survives_false_starts(tmp_path):
+    """A start that is none (the chain's decoder runs past it without standing on it) voids its segment: the segment's decoder may be done
+    long before the chain finds that out, and its slot and buffer must still come back -- otherwise the reader stops handing out pieces
+    after `ahead` such segments (advisor finding of round 3).  MP_PARGZ_TEST_BOGUS_START=n plants a bogus start bit in every n-th segment;
+    output equal to zlib's, no slot left claimed, however many such segments go by -- and a decoder that passes three of them in a row is
+    no longer reported as a corrupt stream."""
+    import gzip
+    import random
+    import re
+    exe = _pargz_tool(tmp_path)
+    rng = random.Random(11)
+    data = "".join("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(150)), "".join(rng.choice("FFFFF:,#") for _ in range(150))) for i in range(30000)).encode()
+    f = tmp_path / "fs.gz"
+    f.write_bytes(gzip.compress(data, 6))
+    n_false = {}
+    for every in (2, 3, 1):                        # 1: every segment but the first has a bogus start -- one decoder passes them all
+        for threads, seg in ((4, 65536), (2, 131072)):
+            r = subprocess.run([exe, str(f), str(threads), str(seg)], capture_output=True, env=dict(os.environ, MP_PARGZ_TEST_BOGUS_START=str(every)), timeout=120)
+            out = r.stdout.decode()
+            assert r.returncode == 0 and "DIFFERENT" not in out, (every, threads, seg, out[-600:], r.stderr.decode()[-300:])
+            assert "segments still holding a slot after the last piece: 0" in out, out[-400:]
+            m = re.search(r"(\d+) segments, (\d+) started without their window, (\d+) false starts", out)
+            n_false[(every, threads)] = (int(m.group(1)), int(m.group(3)))
+    segs, false_starts = n_false[(2, 4)]
+    assert false_starts >= segs // 2 - 1 > 6, n_false       # many more than the reader's look-ahead (threads + 2)
+
+
+@pytest.mark.parametrize("shape", ["gzip_members", "bgzf"])
+def test_reader_rejects_a_match_that_reaches_into_the_member_before(tmp_path, shape):
+    """A deflate match must not reach back past the start of ITS gzip member, even though the member before it left its output in the same
+    buffer (concatenated members, the groups of a BGZF file): zlib says "invalid distance too far back"; so does the reader's own decoder,
+    before the CRC has a say (advisor finding of round 3).  The second member is deflated with the first one's text as its preset
+    dictionary, i.e. its matches refer to bytes of the member before; CRC-32 and length in its trailer are those of the text a decoder
+    that accepted the references would produce -- only the distance check can refuse it."""
+    import random
+    import struct
+    import zlib
+    rng = random.Random(17)
+
+    def fastq(n, tag, k):
+        return "".join("@%s%d/%d\n%s\n+\n%s\n" % (tag, i, k, "".join(rng.choice("ACGT") for _ in range(150)), "F" * 150) for i in range(n)).encode()
+    first = fastq(150, "a", 1)
+    second = first[first.index(b"@a70/"):]          # the same records again: every byte is a match into the member before
+    assert len(second) < 32768
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=first[-32768:])
+    body = c.compress(second) + c.flush()
+    with pytest.raises(zlib.error):
+        zlib.decompressobj(-15).decompress(body)    # zlib itself: invalid distance too far back
+    def member(raw_deflate, text):
+        if shape == "bgzf":
+            return b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw_deflate) + 25) + raw_deflate + struct.pack("<II", zlib.crc32(text), len(text))
+        return b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + raw_deflate + struct.pack("<II", zlib.crc32(text), len(text))
+    c0 = zlib.compressobj(6, zlib.DEFLATED, -15)
+    good = member(c0.compress(first) + c0.flush(), first)
+    empty = member(zlib.compressobj(6, zlib.DEFLATED, -15).flush(), b"") if shape == "bgzf" else b""
+    f1 = tmp_path / "x_1.fq.gz"
+    f1.write_bytes(good + member(body, second) + empty)
+    mate = (first + second).replace(b"/1\n", b"/2\n")
+    f2 = tmp_path / "x_2.fq"
+    f2.write_bytes(mate)
+    for threads in ("3", "0"):
+        r = _plumb(tmp_path, f1, f2, {"MP_INFLATE_THREADS": threads})
+        assert r.returncode == 1 and b"error while reading" in r.stderr and b"too far back" in r.stderr, (threads, r.returncode, r.stderr[-300:])
+        assert r.stdout == b"", "records of a corrupt file were printed"

@@ -69,6 +69,11 @@ int main(int argc, char **argv)
             const double dt = now() - t0;
             printf("           thread-seconds: finding starts %.3f, decoding (incl. finding) %.3f, resolving %.3f; wall %.3f\n", pg.seconds_find(), pg.seconds_decode(), pg.seconds_resolve(), dt);
             if (pos != want.size() || !err.empty()) same = false;
+            // every claimed segment has given its slot back (decoders of dead segments notice at their next block)
+            int left = pg.segments_in_flight();
+            for (int w = 0; w < 200 && left != 0; w++) { usleep(10000); left = pg.segments_in_flight(); }
+            printf("           segments still holding a slot after the last piece: %d\n", left);
+            if (left != 0) same = false;
             printf("parallel   %8.1f MB/s %s  (%d threads, %zu segments, %zu started without their window, %zu false starts, %zu early parts)%s%s\n", pos / dt / 1e6, same ? "equal" : "DIFFERENT",
                    threads, pg.segments(), pg.segments_started_blind(), pg.false_starts(), pg.parts_handed_over_early(), err.empty() ? "" : "  error: ", err.c_str());
             if (!same) rc = 1;

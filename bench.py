@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- paired 150 bp reads aligned per second against a 2BWT index on MI355X (BASELINE.json metric).
+"""bench.py -- paired 150 bp reads aligned per second against the NT 2BWT index on MI355X (BASELINE.json metric).
 
-One process per GPU (`torchrun`-style env: RANK / LOCAL_RANK / WORLD_SIZE).  Reads shard across ranks, the index is
-replicated into every GPU's HBM, no data-path collective: `"scaling": "weak"`; the per-reference
-hit counters of the step are what the ranks all-reduce afterwards (RCCL), as the `reassign` pass 1 they feed would.
+Headline (N = 1 and every rank of N > 1): BASELINE configs[2] per GPU -- an NT-sized replica of the database (~89 lean index chunks of
+2.95 Gbp, ~243 GB) resident in the GPU's HBM, every batch of synthetic 2x150 bp pairs aligned against EVERY chunk in turn, exactly what
+`bin/soap4-mi355x pair <chunk 0>,...,<chunk n-1> ... -b -F -C soap4-nt2.ini -top 95` does for the NT stage of runMegaPath.sh:171-227.
 
-A *step* is one pass of the whole hot path over one batch of synthetic pairs: upload of the packed reads (pinned host
-memory -> HBM), deep-DP round (MMP seeding, locate, merge, pairing, both DP legs with traceback, hit assembly), rescue
-round (single-end DP, mate rescue) and the arrival of all three hit lists in pinned host memory.
+One process per GPU (`torchrun`-style env: RANK / LOCAL_RANK / WORLD_SIZE; `--gpus N` without a launcher starts the N ranks itself).
+Reads shard across ranks, the index is replicated into every GPU's HBM, no data-path collective: `"scaling":
+"weak"`; the per-reference entry counts of a step are what the ranks all-reduce afterwards (RCCL), as the `reassign` pass 1 they feed would.
+
+A *step* is one batch through all chunks: upload of the packed reads (pinned host memory -> HBM); per chunk the deep-DP round (MMP seeding,
+locate, merge, pairing, both DP legs with traceback, hit assembly), the rescue round (single-end DP, mate rescue) and the reduction of the
+chunk's hits to per-reference scores on the device; the last chunk's three hit lists to pinned host memory (the BAM files that remain after
+the chain are the last chunk's); one sorted key list per batch to pinned host memory.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields:
-  roofline        seed stage (K1 + K2), priced with the bytes of the events that really load memory; `traffic` = HBM bytes
-                  per launch from rocprofv3 counters collected LIVE in two child runs of this script (FETCH_SIZE,
-                  WRITE_SIZE in separate passes); the work the short cuts stand for is in `equivalent_work`, not in `frac`
-  dp              cells the DP kernels really compute (device census of one untimed step) over their time
-  cpu_baseline    the real reference soap4 (oracle/_ref, when it travelled with the snapshot) on all host cores
-  parity_sample   the same 100 k pairs through the product executable, record by record against that soap4's stdout
-  legs            C3 / C4 / C5 workload shapes, two steps each, with their kernel split
+  roofline        lean seed stage (seed_kernel + locate_kernel per chunk), priced with the bytes of the events that really load memory;
+                  `traffic` = HBM bytes per launch from rocprofv3 counters collected LIVE in two child runs of this script (FETCH_SIZE,
+                  WRITE_SIZE in separate passes)
+  cpu_baseline    the real reference soap4 (oracle/_ref, when it travelled with the snapshot) on the host cores: one chunk's rate / chunks
+  parity_sample   the real soap4 chained over two 2.95 Gbp chunks against the product executable with both resident, record by record
+  legs            human_filter = BASELINE configs[1] (ONE 2.95 Gbp index, every optional table, soap4.ini: the headline of rounds 1-3) with
+                  its own roofline, CPU baseline and parity sample; the C3 / C4 / C5 read shapes; e2e_cli = through the executable
+The process exits with code 3 when a parity sample differs (the JSON line is still printed, with "parity_ok": false).
 """
 from __future__ import annotations
 
@@ -227,14 +233,12 @@ def loaded_bytes(acc, sum_len_per_step, n_steps, fused=False):
 
 
 # ------------------------------------------------------------------------------------------------ PMC child runs
-def pmc_pass(counter, args, tmpdir):
-    """Runs this script once more under rocprofv3 with ONE counter (separate passes, MI355X_MICROARCH.md) and returns
-    {kernel: [value per launch]}.  The child does one step of the same workload; its last launch of each seed-stage kernel is
-    the timed configuration."""
+def pmc_pass(counter, child_args, tmpdir):
+    """Runs this script once more under rocprofv3 with ONE counter (separate passes, MI355X_MICROARCH.md; the program itself follows
+    `--`) and returns {kernel: [value per launch]}.  The child does one single-context step of the same workload."""
     out_dir = os.path.join(tmpdir, "pmc_" + counter)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-include-regex", PMC_REGEX, "--output-format", "csv", "-d", out_dir, "--",
-           sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "0", "--genome-mbp", str(args.genome_mbp),
-           "--pairs-per-step", str(args.pairs_per_step), "--read-len", str(args.read_len), "--ini", args.ini] + (["--L", str(args.L)] if args.L is not None else [])
+           sys.executable, os.path.abspath(__file__)] + list(child_args)
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -248,17 +252,17 @@ def pmc_pass(counter, args, tmpdir):
     for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
             if row.get("Counter_Name") == counter:
-                name = row["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()       # "void seed_kernel<1>(...)" -> "seed_kernel"
+                name = row["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()       # "void merge_kernel<true>(...)" -> "merge_kernel"
                 per.setdefault(name, []).append(float(row["Counter_Value"]))
     log("[bench] PMC pass %s: %.0f s, kernels %s" % (counter, time.time() - t0, {k: len(v) for k, v in per.items()}))
     return per
 
 
-def live_traffic(args, tmpdir, kernels=SEED_STAGE_KERNELS):
+def live_traffic(child_args, tmpdir, kernels=SEED_STAGE_KERNELS):
     if shutil.which("rocprofv3") is None:
         return None
-    fetch = pmc_pass("FETCH_SIZE", args, tmpdir)
-    write = pmc_pass("WRITE_SIZE", args, tmpdir) if fetch else None
+    fetch = pmc_pass("FETCH_SIZE", child_args, tmpdir)
+    write = pmc_pass("WRITE_SIZE", child_args, tmpdir) if fetch else None
     if not fetch or not write:
         return None
     per_kernel = {}
@@ -271,7 +275,7 @@ def live_traffic(args, tmpdir, kernels=SEED_STAGE_KERNELS):
     g = fetch.get("gather64_kernel")
     calib = (sum(g) / len(g)) * 1024.0 / float(1 << 33) if g else None    # the calibration kernel requests exactly 2^33 B per launch
     return {"bytes_per_launch": total, "per_kernel": per_kernel, "gather64_calibration_ratio": calib,
-            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate child runs of this script (one step each), last launch of each "
+            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate child runs of this script (one single-context step each), last launch of each "
                       "seed-stage kernel; KiB x 1024; not rescaled (FETCH_SIZE reads 1.0x the requested bytes for random 64-B sector gathers, see the ratio)"}
 
 
@@ -388,205 +392,236 @@ def cpu_baseline_and_parity(args, arrs, sample_codes, tmpdir, lkt_table, device,
 
 
 # ------------------------------------------------------------------------------------------------ the metric's configuration
-def nt_replica_leg(args, H, index_builder, simulate, arrs_a, text_a, dev, device, n_bases):
+class NtReplica:
     """BASELINE configs[2] on one GPU: an NT-sized replica of the database resident in HBM in the lean layout (0.92 B/base + a 13-mer
     table per chunk), every batch aligned against every chunk in turn (runMegaPath.sh:191-227 in one process).  Chunk 0 is the genome
     the reads come from; every other chunk is a DIFFERENT genome -- one unrelated synthetic genome of the same size, indexed once and
     copied device-to-device into its own arrays (mp_index_clone) -- so that, as with the real database, a read has its true
-    alignment in one chunk and only chance matches in the others.  Read mix of SURVEY 8d C3: 60 % drawn from chunk 0 at 0-8 %
-    divergence, 40 % random."""
-    knobs = {"MP_KMER_FILTER": os.environ.get("MP_BENCH_NT_KMER", "0"), "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}
-    saved = {k: os.environ.get(k) for k in knobs}
-    os.environ.update(knobs)
-    chunks = []
-    try:
-        t0 = time.time()
-        torch.cuda.empty_cache()
-        chunks.append(H.Index.from_arrays(device, **arrs_a))
-        text_b = simulate.genome(n_bases, seed=4, device=dev)
-        tb = text_b.cpu().numpy()
-        del text_b
-        bounds = np.linspace(0, n_bases, 25).astype(np.int64)
-        arrs_b = index_builder.build_index_arrays([("ntB%d" % (i + 1), tb[bounds[i]:bounds[i + 1]]) for i in range(24)], sa_interval=16, device=dev)
-        del tb
-        torch.cuda.empty_cache()
-        chunks.append(H.Index.from_arrays(device, **arrs_b))
-        # the real soap4 beside it: the same read mix against ONE of the other chunks (its files written here), on the host cores; a database
-        # of n chunks costs it n such runs (runMegaPath.sh:191-227), so its rate for the replica is that of one run / n
-        cpu_nt = None
-        ref_bin = os.path.join(ROOT, "oracle", "_ref", "soap4")
-        if os.path.exists(ref_bin) and not args.no_cpu_baseline:
-            td = tempfile.mkdtemp(prefix="mpnt_")
-            try:
-                prefix = os.path.join(td, "ntB.index")
-                index_builder.write_index_files(prefix, arrs_b, write_lkt=True, lkt_table=chunks[1].lkt_table())
-                n_cpu = int(os.environ.get("MP_BENCH_NT_CPU_PAIRS", "20000"))
-                cw = Workload(text_a, n_cpu, seed=4242, read_len=args.read_len, L=args.read_len + 1, sub_max=0.08, random_frac=0.4)
-                f1, f2 = os.path.join(td, "n_1.fq"), os.path.join(td, "n_2.fq")
-                write_fastq(cw.codes.cpu().numpy(), n_cpu, f1, f2)
-                ini = os.path.join(td, "soap4-nt2.ini")
-                with open(ini, "w") as f:
-                    f.write(NT2_INI)
-                T = min(os.cpu_count() or 1, 32)
-                with open(os.devnull, "wb") as fo, open(os.path.join(td, "err"), "wb") as fe:
-                    rc = subprocess.call([ref_bin, "pair", prefix, f1, f2, "-o", os.path.join(td, "o"), "-C", ini, "-L", str(args.read_len + 1), "-T", str(T), "-u", "750", "-F", "-nc"],
-                                         stdout=fo, stderr=fe)
-                al = None
-                for line in open(os.path.join(td, "err"), errors="replace"):
-                    if "Overall alignment time" in line:
-                        al = float(line.split(":")[1].split()[0])
-                if rc == 0 and al:
-                    cpu_nt = {"kind": "reference", "threads": T, "pairs": n_cpu, "alignment_s_one_chunk": al, "pairs_per_s_one_chunk": n_cpu / al}
-            except Exception as e:  # noqa: BLE001
-                log("[bench] NT cpu baseline failed: %r" % (e,))
-            finally:
-                shutil.rmtree(td, ignore_errors=True)
-        del arrs_b
-        per_chunk = int(chunks[0].info.device_bytes)
-        free_b, total_b = torch.cuda.mem_get_info()
-        want = int(args.nt_replica_gb * 1e9 // per_chunk) + 1
-        fit = 2 + max(0, int((free_b - (20 << 30)) // per_chunk))           # 20 GiB stay free for the batch buffers and traceback slabs
-        n_chunks = max(2, min(want, fit))
-        t1 = time.time()
-        while len(chunks) < n_chunks:
-            chunks.append(chunks[1].clone())
-        torch.cuda.synchronize()
-        t2 = time.time()
-        index_bytes = sum(int(x.info.device_bytes) for x in chunks)
-        log("[bench] NT replica: %d chunks of %.0f Mbp, %.1f GB of index in HBM (two genomes built in %.1f s, %d device-to-device copies in %.1f s)"
-            % (n_chunks, n_bases / 1e6, index_bytes / 1e9, t1 - t0, n_chunks - 2, t2 - t1))
-        lp = args.nt_pairs
-        wl = Workload(text_a, lp, seed=4242, read_len=args.read_len, L=args.read_len + 1, sub_max=0.08, random_frac=0.4)
-        params = H.AlignParams(wl.max_len, 750, 130, 130, H.MmpParams.nt2())
-        ctx = H.Context(chunks[0])
-        keys = ("seed", "locate", "merge", "pair", "fill", "trace", "rescue_tasks", "rescue_fill", "rescue_trace")
+    alignment in one chunk and only chance matches in the others."""
 
-        def one_step(acc):
-            ctx.set_reads(wl.packed_np, wl.lens_np)
-            for ci, ix in enumerate(chunks):
-                ctx.set_index(ix)
-                _, nh, st = ctx.deep_dp_round(params, fetch=False)
-                _, _, rst = ctx.rescue_round(params, False, fetch=False)
-                ctx.pair_hits_view(); ctx.single_hits_view(); ctx.rescue_hits_view()
-                if acc is None:
-                    continue
-                grp = acc["source_chunk" if ci == 0 else "other_chunks"]
-                vals = (st.seed.ms_seed, st.seed.ms_locate, st.seed.ms_merge, st.ms_pair, st.ms_dp_fill, st.ms_dp_trace, rst.ms_tasks, rst.ms_dp_fill, rst.ms_dp_trace)
-                for k, v in zip(keys, vals):
-                    grp[k] = grp.get(k, 0.0) + float(v)
-                for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seedpos", "n_seeds", "n_hits"):
-                    grp[k] = grp.get(k, 0) + int(getattr(st.seed, k))
-                grp["pair_hits"] = grp.get("pair_hits", 0) + int(nh)
-                grp["single_dp_tasks"] = grp.get("single_dp_tasks", 0) + int(rst.n_single_tasks)
-                grp["single_hits"] = grp.get("single_hits", 0) + int(rst.n_single_hits)
-                grp["chunks"] = grp.get("chunks", 0) + 1
-        one_step(None)                                            # first touch of the batch buffers
-        torch.cuda.synchronize()
-        acc = {"source_chunk": {}, "other_chunks": {}}
-        th_a = ctx.dp_thermo_stats()
-        t3 = time.perf_counter()
-        one_step(acc)
-        torch.cuda.synchronize()
-        el_single = time.perf_counter() - t3
-        th_b = ctx.dp_thermo_stats()
-        # how many reads have NO seed of >= 17 bases in a chunk that is not theirs (what a per-chunk pre-screen could skip): the kept seed
-        # positions of the batch against chunk 1, per read
-        seedless = None
+    KNOBS = {"MP_KMER_FILTER": "0", "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}      # the lean layout: none of the optional tables
+
+    def __init__(self, args, H, index_builder, simulate, dev, device, n_bases, max_chunks=None, keep_arrays=False):
+        self.chunks = []
+        self.arrs_b = None
+        saved = {k: os.environ.get(k) for k in self.KNOBS}
+        os.environ.update(dict(self.KNOBS, MP_KMER_FILTER=os.environ.get("MP_BENCH_NT_KMER", "0")))
         try:
-            ctx.set_reads(wl.packed_np, wl.lens_np)
-            ctx.set_index(chunks[1])
-            ctx.seed_batch(H.MmpParams.nt2())
-            lib = H.load_library()
-            off = np.zeros(2 * lp + 1, dtype=np.uint64)
-            H._chk(lib.mp_get_seeds(ctx._h, None, 0, off.ctypes.data), "mp_get_seeds")
-            per_read = np.diff(off.astype(np.int64))
-            per_pair = per_read[0::2] + per_read[1::2]
-            seedless = {"reads_without_a_kept_seed_position": float((per_read == 0).mean()), "pairs_without_one": float((per_pair == 0).mean()),
-                        "kept_seed_positions_per_read_mean": float(per_read.mean()), "chunk": 1,
-                        "note": "seed positions that survive the merge / uniqueness / coverage rules (DV-DPfunctions.cpp:2499-2553) of the batch against a chunk none of "
-                                "the reads comes from: a pair without any is the only kind of (pair, chunk) work a pre-screen could skip"}
-        except Exception as e:  # noqa: BLE001
-            log("[bench] seedless census failed: %r" % (e,))
-        ctx.close()
-        # the configuration the executable runs in: the batch cut into contiguous blocks, one context (own streams, own host thread) per
-        # block, each taking its block through every chunk -- the memory-bound seeding of one overlaps with the VALU-bound DP of the others
-        n_ctx = max(1, args.contexts)
-        el = el_single
-        if n_ctx > 1:
-            import threading
-            cuts = [lp * i // n_ctx for i in range(n_ctx + 1)]
-            sl = [WorkloadSlice(wl, cuts[i], cuts[i + 1]) for i in range(n_ctx)]
-            cx = [H.Context(chunks[0]) for _ in range(n_ctx)]
-            errs = []
+            t0 = time.time()
+            self.text_a = simulate.genome(n_bases, seed=3, device=dev)
+            bounds = np.linspace(0, n_bases, 25).astype(np.int64)
+            ta = self.text_a.cpu().numpy()
+            self.arrs_a = index_builder.build_index_arrays([("chr%d" % (i + 1), ta[bounds[i]:bounds[i + 1]]) for i in range(24)], sa_interval=16, device=dev)
+            self.build_info = dict(index_builder.last_build_info or {})
+            del ta
+            torch.cuda.empty_cache()
+            self.chunks.append(H.Index.from_arrays(device, **self.arrs_a))
+            text_b = simulate.genome(n_bases, seed=4, device=dev)
+            tb = text_b.cpu().numpy()
+            del text_b
+            arrs_b = index_builder.build_index_arrays([("ntB%d" % (i + 1), tb[bounds[i]:bounds[i + 1]]) for i in range(24)], sa_interval=16, device=dev)
+            del tb
+            torch.cuda.empty_cache()
+            self.chunks.append(H.Index.from_arrays(device, **arrs_b))
+            if keep_arrays:
+                self.arrs_b = arrs_b
+            del arrs_b
+            per_chunk = int(self.chunks[0].info.device_bytes)
+            free_b, total_b = torch.cuda.mem_get_info()
+            want = int(args.nt_replica_gb * 1e9 // per_chunk) + 1
+            fit = 2 + max(0, int((free_b - (int(args.nt_headroom_gb) << 30)) // per_chunk))     # the rest stays free for the batch buffers and traceback slabs
+            self.n_chunks = max(2, min(want, fit, max_chunks or (1 << 30)))
+            t1 = time.time()
+            while len(self.chunks) < self.n_chunks:
+                self.chunks.append(self.chunks[1].clone())
+            torch.cuda.synchronize()
+            self.load_s = time.time() - t0
+            self.index_bytes = sum(int(x.info.device_bytes) for x in self.chunks)
+            self.hbm_total = int(total_b)
+            self.n_bases = n_bases
+            log("[bench] NT replica: %d chunks of %.0f Mbp, %.1f GB of index in HBM (two genomes built in %.1f s, %d device-to-device copies in %.1f s)"
+                % (self.n_chunks, n_bases / 1e6, self.index_bytes / 1e9, t1 - t0, self.n_chunks - 2, time.time() - t1))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
 
-            def through_all(i):
-                try:
-                    cx[i].set_reads(sl[i].packed_np, sl[i].lens_np)
-                    for ix in chunks:
-                        cx[i].set_index(ix)
-                        cx[i].deep_dp_round(params, fetch=False)
-                        cx[i].rescue_round(params, False, fetch=False)
-                        cx[i].pair_hits_view(); cx[i].single_hits_view(); cx[i].rescue_hits_view()
-                except Exception as e:  # noqa: BLE001
-                    errs.append(e)
-            for rep in range(2):                                      # the first pass touches the new contexts' buffers
-                torch.cuda.synchronize()
-                t4 = time.perf_counter()
-                th = [threading.Thread(target=through_all, args=(i,)) for i in range(n_ctx)]
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
-                torch.cuda.synchronize()
-                el = time.perf_counter() - t4
-            for c in cx:
-                c.close()
-            if errs:
-                raise errs[0]
-        o = acc["other_chunks"]
-        n_o = max(1, o.get("chunks", 1))
-        per_chunk_ms = {k: o.get(k, 0.0) / n_o for k in keys}
-        t_seed_s = sum(g.get("seed", 0.0) + g.get("locate", 0.0) for g in acc.values()) / 1e3
-        ev = {k: sum(g.get(k, 0) for g in acc.values()) for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seedpos")}
-        seed_bytes = 64 * ev["n_occ_loaded"] + 8 * ev["n_lkt"] + 4 * ev["n_sa"] + 0.25 * wl.sum_len * n_chunks + 16 * ev["n_seedpos"]
-        achieved = seed_bytes / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
-        return {
-            "workload": "%d index chunks of %.0f Mbp resident at once in the lean layout = %.1f Gbp, %.1f GB of HBM (BASELINE configs[2] on one GPU): chunk 0 is the genome "
-                        "the reads come from, the other %d hold an unrelated synthetic genome (indexed once, copied device-to-device into separate arrays), so a read "
-                        "finds its true alignment in one chunk and chance matches elsewhere, as in the real database; 2x%d bp, 60 %% of the pairs from chunk 0 at 0-8 %% "
-                        "divergence, 40 %% random (SURVEY 8d C3); soap4-nt2.ini, -L %d; every batch aligned against each chunk in turn by one context, all three hit "
-                        "lists of every chunk fetched" % (n_chunks, n_bases / 1e6, n_chunks * n_bases / 1e9, index_bytes / 1e9, n_chunks - 1, args.read_len, args.read_len + 1),
-            "chunks": n_chunks, "bases_resident": n_chunks * n_bases, "index_bytes_in_hbm": index_bytes, "bytes_per_base": index_bytes / (n_chunks * n_bases),
-            "hbm_total_bytes": int(total_b), "load_s": t2 - t0, "pairs_per_step": lp, "ms_per_step": el * 1e3, "pairs_per_s": lp / el, "contexts": n_ctx,
-            "single_context": {"ms_per_step": el_single * 1e3, "pairs_per_s": lp / el_single, "note": "the step the per-chunk kernel times and the roofline below come from"},
-            "chunk_pair_alignments_per_s": lp * n_chunks / el,
-            "cpu_baseline": (dict(cpu_nt, value=cpu_nt["pairs_per_s_one_chunk"] / n_chunks, unit="pairs/s",
-                                  sample="%d pairs of the same read mix, real soap4 (oracle/_ref) -T %d against ONE chunk (the unrelated genome); the replica's %d "
-                                         "chunks are %d such runs for it, so value = that rate / %d" % (cpu_nt["pairs"], cpu_nt["threads"], n_chunks, n_chunks, n_chunks))
-                             if cpu_nt else None),
-            "kernel_ms_per_chunk_other_chunks": per_chunk_ms, "kernel_ms_source_chunk": {k: acc["source_chunk"].get(k, 0.0) for k in keys},
-            "foreign_chunk_seed_census": seedless,
-            "rescue_certificate_per_pair_per_chunk": dict(zip(("certified_no_alignment", "score_of_%d_elsewhere" % 10, "bound_reaches_cutoff", "not_eligible"),
-                                                              [(b - a) / (lp * n_chunks) for a, b in zip(th_a, th_b)]),
-                                                          note="dp_thermo_kernel (kernels_thermo.hip) over the single-end rescue instances of the one-context step: "
-                                                               "only what it does not certify goes through the score-only filter"),
-            "per_pair_per_other_chunk": {k: o.get(k, 0) / (n_o * lp) for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seeds", "n_hits", "n_seedpos", "single_dp_tasks", "single_hits", "pair_hits")},
-            "roofline": {"bound": "hbm", "kernel": "seed_kernel+seed_overflow_kernel+expand_hits_kernel+locate_kernel (lean layout, all chunks of the step)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "bytes_per_pair_per_chunk": seed_bytes / (lp * n_chunks), "launch_ms_per_chunk": t_seed_s * 1e3 / n_chunks,
-                         "formula": "64*rank_blocks_loaded + 8*lkt13_lookups + 4*sa_reads + 0.25*read_bases + 16*seed_positions_out over the seed-stage kernels' time"},
-        }
-    finally:
-        for x in chunks:
+    def close(self):
+        for x in self.chunks:
             try:
                 x.close()
             except Exception:  # noqa: BLE001
                 pass
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        self.chunks = []
+
+
+NT_KEYS = ("seed", "locate", "merge", "pair", "fill", "trace", "rescue_tasks", "rescue_fill", "rescue_trace")
+NT_EVENTS = ("n_occ_loaded", "n_lkt", "n_sa", "n_seedpos", "n_seeds", "n_hits")
+
+
+def nt_step(ctx, wl, chunks, params, acc=None, bam=True, mode=1):
+    """One batch through every resident chunk, as bin/soap4-mi355x runs the NT stage's command line (`-b ... -F -top 95`, runMegaPath.sh:199):
+    upload of the packed reads; per chunk the deep-DP round, the rescue round and the reduction of the chunk's hits to per-mate
+    (reference, score) keys on the device; the LAST chunk's three hit lists also travel to the host (the BAM side files that remain after
+    the chain are the last chunk's); after the last chunk one sort of the batch's keys and their way to pinned host memory."""
+    n_chunks = len(chunks)
+    ctx.set_reads(wl.packed_np, wl.lens_np)
+    ctx.reduce_begin(n_chunks)
+    cls = np.zeros(wl.n_pairs + 1, dtype=np.uint8)
+    for ci, ix in enumerate(chunks):
+        last = ci + 1 == n_chunks
+        ctx.set_index(ix)
+        ctx.set_hit_copies(bam and last)
+        _, nh, st = ctx.deep_dp_round(params, fetch=False)
+        _, _, rst = ctx.rescue_round(params, False, fetch=False)
+        red = ctx.reduce_chunk(mode, ci, cls if last else None)
+        if bam and last:
+            ctx.pair_hits_view(); ctx.single_hits_view(); ctx.rescue_hits_view()
+        if acc is None:
+            continue
+        grp = acc["source_chunk" if ci == 0 else "other_chunks"]
+        vals = (st.seed.ms_seed, st.seed.ms_locate, st.seed.ms_merge, st.ms_pair, st.ms_dp_fill, st.ms_dp_trace, rst.ms_tasks, rst.ms_dp_fill, rst.ms_dp_trace)
+        for k, v in zip(NT_KEYS, vals):
+            grp[k] = grp.get(k, 0.0) + float(v)
+        for k in NT_EVENTS:
+            grp[k] = grp.get(k, 0) + int(getattr(st.seed, k))
+        grp["pair_hits"] = grp.get("pair_hits", 0) + int(nh)
+        grp["single_dp_tasks"] = grp.get("single_dp_tasks", 0) + int(rst.n_single_tasks)
+        grp["single_hits"] = grp.get("single_hits", 0) + int(rst.n_single_hits)
+        grp["rescue_hits"] = grp.get("rescue_hits", 0) + int(rst.n_rescue_hits)
+        grp["entries"] = grp.get("entries", 0) + int(red[3])
+        grp["chunks"] = grp.get("chunks", 0) + 1
+    return ctx.reduce_finish()
+
+
+def nt_run_contexts(ctxs, slices, chunks, params, n_steps, barrier=None):
+    """n_steps steps; the batch cut into len(ctxs) contiguous blocks, one context (own HIP streams, own host thread) per block, each taking
+    its block through every chunk.  Returns the wall time between the barriers."""
+    import threading
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(n_steps):
+                nt_step(ctxs[i], slices[i], chunks, params)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(ctxs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    if errs:
+        raise errs[0]
+    return time.perf_counter() - t0
+
+
+def nt_seed_bytes(groups, sum_len, n_chunk_steps):
+    """Bytes the lean seed stage (seed_kernel + expand_hits_kernel + locate_kernel) requests from memory, by event, each counted by the kernels
+    themselves: 64 B per rank block loaded (the seeding walk's and the LF walk's), 8 B per 13-mer table look-up (two adjacent 32-bit bounds),
+    4 B per sampled suffix-array entry, 0.25 B per read base, 16 B per kept seed position written."""
+    ev = {k: sum(g.get(k, 0) for g in groups) for k in ("n_occ_loaded", "n_lkt", "n_sa", "n_seedpos")}
+    return 64 * ev["n_occ_loaded"] + 8 * ev["n_lkt"] + 4 * ev["n_sa"] + 0.25 * sum_len * n_chunk_steps + 16 * ev["n_seedpos"]
+
+
+def nt_cpu_baseline(args, index_builder, rep, read_len, n_pairs):
+    """The real soap4 beside it: the same read mix against ONE of the other chunks (its files written here), on the host cores; a database of
+    n chunks costs it n such runs (runMegaPath.sh:191-227), so its rate for the replica is that of one run / n."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "soap4")
+    if not os.path.exists(ref_bin) or rep.arrs_b is None:
+        return None, None
+    td = tempfile.mkdtemp(prefix="mpnt_")
+    try:
+        prefix_b = os.path.join(td, "ntB.index")
+        index_builder.write_index_files(prefix_b, rep.arrs_b, write_lkt=True, lkt_table=rep.chunks[1].lkt_table())
+        cw = Workload(rep.text_a, n_pairs, seed=4242, read_len=read_len, L=read_len + 1, sub_max=0.08, random_frac=0.4)
+        f1, f2 = os.path.join(td, "n_1.fq"), os.path.join(td, "n_2.fq")
+        write_fastq(cw.codes.cpu().numpy(), n_pairs, f1, f2)
+        ini = os.path.join(td, "soap4-nt2.ini")
+        with open(ini, "w") as f:
+            f.write(NT2_INI)
+        T = min(os.cpu_count() or 1, 32)
+        with open(os.devnull, "wb") as fo, open(os.path.join(td, "err"), "wb") as fe:
+            rc = subprocess.call([ref_bin, "pair", prefix_b, f1, f2, "-b", "-o", os.path.join(td, "o"), "-L", str(read_len + 1), "-T", str(T), "-u", "750", "-F", "-C", ini, "-top", "95", "-nc"],
+                                 stdout=fo, stderr=fe)
+        al = None
+        for line in open(os.path.join(td, "err"), errors="replace"):
+            if "Overall alignment time" in line:
+                al = float(line.split(":")[1].split()[0])
+        if rc != 0 or not al:
+            log("[bench] NT cpu baseline: the reference soap4 failed (rc %d)" % rc)
+            return None, td
+        return {"kind": "reference", "threads": T, "pairs": n_pairs, "alignment_s_one_chunk": al, "pairs_per_s_one_chunk": n_pairs / al}, td
+    except Exception as e:  # noqa: BLE001
+        log("[bench] NT cpu baseline failed: %r" % (e,))
+        return None, td
+
+
+def deinterleave(src, out1, out2):
+    lines = open(src, "rb").read().split(b"\n")
+    with open(out1, "wb") as a, open(out2, "wb") as b:
+        for i in range(0, len(lines) - 7, 8):
+            a.write(b"\n".join(lines[i:i + 4]) + b"\n")
+            b.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
+
+
+def nt_parity_sample(args, index_builder, rep, td, device, read_len, n_pairs):
+    """Parity at chunk size: the REAL soap4 chained over two 2.95 Gbp chunks -- chunk 0 (the reads' genome) and one foreign chunk -- with the
+    NT stage's own command lines (runMegaPath.sh:199-208: -b -o <same prefix> ... -F -C soap4-nt2.ini -top 95, -nc for the first run only,
+    the second run reads the de-interleaved stdout of the first), against bin/soap4-mi355x with the two chunks resident in one process."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "soap4")
+    exe = os.path.join(ROOT, "bin", "soap4-mi355x")
+    if td is None or not os.path.exists(ref_bin) or not os.path.exists(exe):
+        return None
+    t_start = time.time()
+    prefix_a, prefix_b = os.path.join(td, "ntA.index"), os.path.join(td, "ntB.index")
+    index_builder.write_index_files(prefix_a, rep.arrs_a, write_lkt=True, lkt_table=rep.chunks[0].lkt_table())
+    cw = Workload(rep.text_a, n_pairs, seed=5151, read_len=read_len, L=read_len + 1, sub_max=0.08, random_frac=0.4)
+    f1, f2 = os.path.join(td, "S.nt.tmp_in_1.fq"), os.path.join(td, "S.nt.tmp_in_2.fq")
+    write_fastq(cw.codes.cpu().numpy(), n_pairs, f1, f2)
+    ini = os.path.join(td, "soap4-nt2.ini")
+    T = min(os.cpu_count() or 1, 32)
+    common = ["-b", "-o", "S.nt.bam", "-L", str(read_len + 1), "-T", str(T), "-u", "750", "-F", "-C", ini, "-top", "95"]
+    # the product first (it reads the original files; the chain below moves them)
+    prod_out = os.path.join(td, "prod.out")
+    env = dict(os.environ, MP_DEVICE=str(device), **NtReplica.KNOBS)
+    env.pop("LOCAL_RANK", None)
+    with open(prod_out, "wb") as fo, open(os.path.join(td, "prod.err"), "wb") as fe:
+        rc = subprocess.call([exe, "pair", prefix_a + "," + prefix_b, "S.nt.tmp_in_1.fq", "S.nt.tmp_in_2.fq"] + common + ["-nc"], stdout=fo, stderr=fe, env=env, cwd=td)
+    if rc != 0:
+        return {"pairs": n_pairs, "records_equal": False, "first_diff": "product executable failed (rc %d): %s" % (rc, open(os.path.join(td, "prod.err"), errors="replace").read()[-300:])}
+    t_prod = time.time() - t_start
+    ref_out = None
+    for i, prefix in enumerate((prefix_a, prefix_b)):
+        ref_out = os.path.join(td, "ref_%d.out" % i)
+        with open(ref_out, "wb") as fo, open(os.path.join(td, "ref.err"), "wb") as fe:
+            rc = subprocess.call([ref_bin, "pair", prefix, "S.nt.tmp_in_1.fq", "S.nt.tmp_in_2.fq"] + common + (["-nc"] if i == 0 else []), stdout=fo, stderr=fe, cwd=td)
+        if rc != 0:
+            return {"pairs": n_pairs, "records_equal": None, "first_diff": "reference soap4 failed on chunk %d (rc %d)" % (i, rc)}
+        deinterleave(ref_out, f1, f2)
+    want, got = fastq_records(ref_out), fastq_records(prod_out)
+    diff = [k for k in want if got.get(k) != want[k]] + [k for k in got if k not in want]
+    first = None
+    if diff:
+        k = sorted(diff)[0]
+        first = {"record": "%s #%d" % (k[0].decode(), k[1]), "reference": want.get(k, (b"<absent>",))[0].decode(errors="replace")[:300],
+                 "product": got.get(k, (b"<absent>",))[0].decode(errors="replace")[:300]}
+    two = sum(1 for v in want.values() if v[0].count(b",chr") + v[0].count(b",ntB") >= 2)
+    return {"pairs": n_pairs, "records": len(want), "records_equal": not diff, "records_differing": len(diff), "first_diff": first,
+            "reference_records_with_a_hit": sum(1 for v in want.values() if b"SCORE:0;" not in v[0]), "reference_records_listing_two_or_more_references": two, "against": "reference",
+            "how": "the real soap4 chained over chunk 0 and one foreign chunk of %.0f Mbp each (runMegaPath.sh:199-208 command lines: -b -o <same prefix> -L %d -T %d -u 750 -F -C soap4-nt2.ini "
+                   "-top 95, -nc for the first run, the second run reads the de-interleaved stdout of the first) against bin/soap4-mi355x pair <chunk0>,<chunk1> with the same options "
+                   "(both chunks resident, %.0f s whole-process); last stdout compared record by record, order-insensitive; whole sample %.0f s"
+                   % (rep.n_bases / 1e6, read_len + 1, T, t_prod, time.time() - t_start)}
 
 
 # ------------------------------------------------------------------------------------------------ through the boundary
@@ -642,7 +677,7 @@ def write_bgzf(plain_path, dst, n_bytes, block=65280):
         fo.write(_bgzf_block(b""))
 
 
-def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=12, gz_pairs=1 << 23):
+def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=12, gz_pairs=1 << 22):
     """FASTQ files in, annotated FASTQ out, through bin/soap4-mi355x (the boundary a pipeline maintainer sees): pairs/s of the
     executable's alignment loop (index load excluded, as for the CPU soap4), stdout to /dev/null; plain input and gzip'ed input."""
     from megapath_amd import simulate
@@ -708,8 +743,9 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
             env.pop("LOCAL_RANK", None)
             rc8 = {}
             for k in (2, 8):
-                for label, extra in (("device_reduce", {}), ("host_merge", {"MP_HOST_MERGE": "1"})):
-                    cmd = [exe, "pair", ",".join([prefix] * k), n1, n2, "-o", os.path.join(d, "o"), "-C", nt_ini, "-L", str(args.read_len + 1), "-T", str(threads), "-u", "750", "-F", "-nc", "-top", "95"]
+                for label, extra, flags in (("device_reduce", {}, []), ("host_merge", {"MP_HOST_MERGE": "1"}, []),
+                                            ("bam_device_reduce", {}, ["-b"]), ("bam_host_merge", {"MP_BAM_HOST_MERGE": "1"}, ["-b"])):
+                    cmd = [exe, "pair", ",".join([prefix] * k), n1, n2, "-o", os.path.join(d, "o"), "-C", nt_ini, "-L", str(args.read_len + 1), "-T", str(threads), "-u", "750", "-F", "-nc", "-top", "95"] + flags
                     with open(os.devnull, "wb") as fo:
                         r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(env, **extra))
                     err = r.stderr.decode(errors="replace")
@@ -718,7 +754,9 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
                                                         "stage_seconds": next((l.split("seconds:")[1].strip() for l in err.splitlines() if "seconds:" in l), None)}
             rc8["input"] = ("%d pairs of the NT read mix (60 %% at 0-8 %% divergence, 40 %% random) against the same lean index given 2 and 8 times; device_reduce = the "
                             "per-reference scores reduced on the device over all chunks, ONE printer pass per batch (mp_reduce_*); host_merge = hit lists to the host, header "
-                            "comments merged chunk after chunk (MP_HOST_MERGE=1, the path -b takes).  'output of ...' in stage_seconds is the printer's time" % ntp)
+                            "comments merged chunk after chunk (MP_HOST_MERGE=1); bam_* = the same with -b, the NT stage's own flag (runMegaPath.sh:199): by default only the "
+                            "LAST chunk's hit lists travel to the host for the BAM records, MP_BAM_HOST_MERGE=1 is the round-3 path (every chunk's).  'output of ...' in "
+                            "stage_seconds is the printer's time" % ntp)
             res["resident_chunks"] = rc8
         except Exception as e:  # noqa: BLE001
             res["resident_chunks"] = {"error": repr(e)}
@@ -733,8 +771,9 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
         for pr in procs:
             pr.wait()
         res["gz"] = run(g1 + ".gz", g2 + ".gz", gz_pairs)                                       # several threads per stream (host/par_gzip.h)
-        res["gz_one_thread_per_file"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_PARGZ_MIN": str(1 << 60)})     # the reader's own decoder, one thread per stream
-        res["gz_zlib"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_INFLATE": "zlib"})        # the same files through zlib's gzread, as the reference reads them
+        if os.environ.get("MP_BENCH_E2E_FULL") == "1":                                            # the round-3 comparisons, not part of the default run
+            res["gz_one_thread_per_file"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_PARGZ_MIN": str(1 << 60)})     # the reader's own decoder, one thread per stream
+            res["gz_zlib"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_INFLATE": "zlib"})        # the same files through zlib's gzread, as the reference reads them
         for spec in filter(None, os.environ.get("MP_BENCH_GZ_VARIANTS", "").split(";")):      # tuning aid, as MP_BENCH_E2E_VARIANTS
             nm, _, kv = spec.partition(":")
             res["gz_" + nm] = run(g1 + ".gz", g2 + ".gz", gz_pairs, dict(x.split("=", 1) for x in kv.split(",") if "=" in x))
@@ -808,6 +847,160 @@ def launch_ranks(n, argv, script=None, extra_env=None):
     return 0 if not bad else max([c for c in bad if c > 0] or [1])       # the worst exit code; a rank killed by a signal counts as 1
 
 
+# ------------------------------------------------------------------------------------------------ configs[1] and the read-shape legs
+def human_filter_leg(args, H, index_builder, simulate, text, arrs, dev, device, rank, n_bases, want_leg, child_args_base):
+    """BASELINE configs[1] as the pipeline runs it (runMegaPath.sh:136: -C soap4.ini -L <read length>): the every-table layout of ONE 2.95 Gbp
+    index (111 GB), 1 Mi pairs per step.  Until round 3 this was the bench's headline; it is now a leg with its own small roofline, its CPU
+    baseline and its parity sample.  Returns (leg dict, sub-legs dict, parity ok)."""
+    legs = {}
+    torch.cuda.empty_cache()
+    t1 = time.time()
+    gix = H.Index.from_arrays(device, **arrs)
+    log("[bench] human-filter leg: every-table layout of the %.0f Mbp index in HBM in %.1f s, %.2f GB" % (args.genome_mbp, time.time() - t1, gix.info.device_bytes / 1e9))
+    torch.cuda.empty_cache()
+    g_ms, g_bytes = gix.bench_gather64()
+    gather_gbs = g_bytes / (g_ms * 1e-3) / 1e9
+    P = args.pairs_per_step
+    K = max(1, args.leg_steps)
+    read_L = args.L if args.L is not None else (args.read_len if args.ini == "soap4.ini" else args.read_len + 1)
+    wl = Workload(text, P, seed=1000 + rank, read_len=args.read_len, L=read_L)
+    ctx = H.Context(gix)
+    params = H.AlignParams(wl.max_len, 750, 130, 130, mmp_of(args.ini))       # insert_low = the longest read of the first batch (SOAP4.cpp:465-474)
+    step(ctx, wl, params)
+    ctx.set_dp_census(True)
+    step(ctx, wl, params)
+    census = ctx.dp_census()
+    ctx.set_dp_census(False)
+    band0, th0 = ctx.dp_band_stats(), ctx.dp_thermo_stats()
+    elapsed_single, acc = run_steps(ctx, wl, params, K)
+    band1, th1 = ctx.dp_band_stats(), ctx.dp_thermo_stats()
+    elapsed = elapsed_single
+    n_ctx = max(1, args.contexts)
+    if n_ctx > 1:
+        cuts = [P * i // n_ctx for i in range(n_ctx + 1)]
+        slices = [WorkloadSlice(wl, cuts[i], cuts[i + 1]) for i in range(n_ctx)]
+        ctxs = [ctx] + [H.Context(gix) for _ in range(n_ctx - 1)]
+        run_overlapped(ctxs, slices, params, 1)                      # first touch of the new contexts' buffers
+        elapsed = run_overlapped(ctxs, slices, params, K)
+        for c in ctxs[1:]:
+            c.close()
+    t_seed_s = (acc["ms_seed"] + acc["ms_locate"]) / 1e3
+    fused = acc["ms_locate"] / K < 0.05          # whole suffix array resident: no expand / locate launch (merge_kernel<true> makes its keys from the seed records)
+    roof_kernels = ("seed_kernel", "seed_overflow_kernel") if fused else SEED_STAGE_KERNELS
+    b_loaded = loaded_bytes(acc, wl.sum_len, K, fused)
+    achieved = b_loaded / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
+    per_pair = lambda k: acc[k] / (K * P)      # noqa: E731
+    leg = {
+        "workload": "2x%dbp synthetic pairs vs ONE synthetic %.0f Mbp genome in 24 sequences, every optional table resident (BASELINE configs[1], human-filter stage; GRCh38 indexes "
+                    "~2.95 Gbp of non-N bases), %d pairs/step; a step = upload of the packed reads + deep-DP round + rescue round + all three hit lists back in pinned host memory; "
+                    "%d contexts side by side" % (args.read_len, args.genome_mbp, P, n_ctx),
+        "command_line": "soap4 pair <index> r1.fq r2.fq -C %s -L %d -u 750 -F -nc (runMegaPath.sh:136)" % (args.ini, read_L),
+        "pairs_per_s": K * P / elapsed, "ms_per_step": elapsed / K * 1e3, "steps": K, "contexts": n_ctx, "index_bytes_in_hbm": int(gix.info.device_bytes),
+        "single_context": {"pairs_per_s": K * P / elapsed_single, "ms_per_step": elapsed_single / K * 1e3},
+        "kernel_ms_per_step": {k[3:]: acc[k] / K for k in acc if k.startswith("ms_")},
+        "roofline": {"bound": "hbm", "kernel": "+".join(roof_kernels), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_launch": b_loaded / K, "bytes_per_pair": b_loaded / (K * P), "launch_ms": (acc["ms_seed"] + acc["ms_locate"]) / K,
+                     "random64_gather_ceiling_gbs": gather_gbs,
+                     "formula": "64*rank_blocks_loaded + 8*(lkt13 + lkt16 look-ups) + 8*prefilter_entries_loaded + 4*sa_reads + 8*text_words_compared + 0.25*read_bases + 16*seed_positions_out"},
+        "events_per_pair": {"rank_blocks_loaded": per_pair("n_occ_loaded"), "lkt13_lookups": per_pair("n_lkt"), "lkt16_lookups": per_pair("n_lkt16"), "sa_reads": per_pair("n_sa"),
+                            "prefilter_entries_loaded": per_pair("n_prefilter_loads"), "text_words_compared": per_pair("n_text_words"), "seeds": per_pair("n_seeds"),
+                            "seed_positions_out": per_pair("n_seedpos"), "candidates": per_pair("cand"), "pair_hits": per_pair("pair_hits"), "failed_pairs": per_pair("failed"),
+                            "single_dp_tasks": per_pair("stasks")},
+    }
+    t_dp_s = (acc["ms_fill"] + acc["ms_rescue_fill"]) / 1e3 / K
+    if t_dp_s > 0:
+        computed = census.cells_band_score + census.cells_band_trace + census.cells_full_score + census.cells_full_trace
+        leg["dp"] = {"bound": "valu", "unit": "Gcells/s", "achieved": computed / t_dp_s / 1e9, "instances_per_step": int(census.instances),
+                     "cells_computed_per_step": {"band_score_pass": int(census.cells_band_score), "band_traceback_pass": int(census.cells_band_trace),
+                                                 "full_table_score_only": int(census.cells_full_score), "full_table_with_traceback": int(census.cells_full_trace)},
+                     "full_table_equivalent_gcells_per_s": census.cells_full_table / t_dp_s / 1e9,
+                     "band_instances_per_step": (band1[0] - band0[0]) / K, "band_left_to_full_table_per_step": (band1[1] - band0[1]) / K,
+                     "rescue_certificate_per_step": dict(zip(("certified_no_alignment", "score_of_10_elsewhere", "bound_reaches_cutoff", "not_eligible"), [(b - a) / K for a, b in zip(th0, th1)])),
+                     "fill_ms_per_step": t_dp_s * 1e3}
+    parity_ok = True
+    tmpdir = tempfile.mkdtemp(prefix="mpbench_")
+    try:
+        if not args.no_pmc and want_leg("human_filter_pmc"):
+            try:
+                tr = live_traffic(child_args_base + ["--pmc-child", "human"], tmpdir, roof_kernels)
+            except Exception as e:  # noqa: BLE001
+                log("[bench] PMC passes of the human-filter leg failed: %r" % (e,))
+                tr = None
+            if tr:
+                rf = leg["roofline"]
+                rf["traffic"] = tr["bytes_per_launch"]
+                rf["traffic_gbs"] = tr["bytes_per_launch"] / (rf["launch_ms"] / 1e3) / 1e9
+                rf["frac_of_gather_ceiling"] = rf["traffic_gbs"] / gather_gbs
+                rf["traffic_over_requested"] = tr["bytes_per_launch"] / rf["bytes_per_launch"]
+        if not args.no_cpu_baseline:
+            try:
+                cb, parity = cpu_baseline_and_parity(args, arrs, wl.codes[: 2 * min(args.cpu_sample_pairs, P)], tmpdir, gix.lkt_table(), device, read_L,
+                                                     threads_list=[min(os.cpu_count() or 1, 32)])
+                leg["cpu_baseline"] = cb
+                leg["parity_sample"] = parity
+                if parity and parity.get("records_equal") is False:
+                    parity_ok = False
+            except Exception as e:  # noqa: BLE001 -- auxiliary; report its absence
+                log("[bench] cpu baseline / parity sample of the human-filter leg failed: %r" % (e,))
+        if not args.no_e2e and want_leg("e2e_cli"):
+            try:
+                prefix = os.path.join(tmpdir, "ref.index")
+                if not os.path.exists(prefix + ".bwt"):
+                    index_builder.write_index_files(prefix, arrs, write_lkt=False)
+                ini_path = os.path.join(tmpdir, args.ini)
+                with open(ini_path, "w") as f:
+                    f.write(INIS[args.ini])
+                legs["e2e_cli"] = e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=args.e2e_batches)
+            except Exception as e:  # noqa: BLE001
+                legs["e2e_cli"] = {"error": repr(e)}
+                log("[bench] e2e leg failed: %r" % (e,))
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    # ---- the other configs' read shapes against the same index, NT-stage parameters (soap4-nt2.ini, -L = read length + 1, runMegaPath.sh:206)
+    specs = [
+        ("C3_divergent", "2x150 bp, per-pair divergence uniform 0-8 %, 40 % random pairs (NT-stage read mix)", dict(read_len=150, sub_max=0.08, random_frac=0.4)),
+        ("C4_2x250", "2x250 bp, -L 251, fragments ~N(450,50): 311-row windows, 32-lane DP shapes", dict(read_len=250, frag_mean=450.0, frag_sd=50.0, frag_max=700)),
+        ("C5_mixed_rescue", "lengths uniform 75-300 (-L 301), 30 % of pairs with one mate random: rescue stress", dict(
+            read_len=300, len_range=(75, 300), broken_mate_frac=0.3, frag_mean=450.0, frag_sd=50.0, frag_max=700)),
+    ]
+    nt_L = args.read_len + 1
+    nt_wl = Workload(text, max(P // 4, 1 << 16), seed=1000 + rank, read_len=args.read_len, L=nt_L)
+    nt_params = H.AlignParams(nt_wl.max_len, 750, 130, 130, H.MmpParams.nt2())
+    if want_leg("nt2_ini_same_reads"):
+        try:
+            lp = nt_wl.n_pairs
+            lctx = H.Context(gix)
+            step(lctx, nt_wl, nt_params)
+            el, la = run_steps(lctx, nt_wl, nt_params, 2)
+            legs["nt2_ini_same_reads"] = {"workload": "the human-filter leg's read mix with the NT stage's parameters (-C soap4-nt2.ini -L %d: 17-base seeds) against the same index, one context" % nt_L,
+                                          "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3, "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")}}
+            lctx.close()
+        except Exception as e:  # noqa: BLE001
+            legs["nt2_ini_same_reads"] = {"error": repr(e)}
+    for name, desc, sim in specs:
+        if not want_leg(name):
+            continue
+        try:
+            lp = max(P // 4, 1 << 16)
+            lw = Workload(text, lp, seed=2000 + len(legs), **sim)
+            lpar = H.AlignParams(lw.max_len, 750, 130, 130, H.MmpParams.nt2())
+            lctx = H.Context(gix)
+            step(lctx, lw, lpar)
+            el, la = run_steps(lctx, lw, lpar, 2)
+            legs[name] = {"workload": desc, "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3,
+                          "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")},
+                          "per_pair": {"candidates": la["cand"] / (2 * lp), "pair_hits": la["pair_hits"] / (2 * lp), "failed_pairs": la["failed"] / (2 * lp),
+                                       "single_dp_tasks": la["stasks"] / (2 * lp), "rank_blocks_loaded": la["n_occ_loaded"] / (2 * lp)}}
+            lctx.close()
+            del lw
+        except Exception as e:  # noqa: BLE001
+            legs[name] = {"workload": desc, "error": repr(e)}
+            log("[bench] leg %s failed: %r" % (name, e))
+    ctx.close()
+    gix.close()
+    return leg, legs, parity_ok
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     if sys.argv[1:2] == ["--write-bgzf"]:                       # helper mode of the e2e leg (no GPU is touched)
@@ -815,35 +1008,36 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MP_BENCH_GENOME_MBP", "2950")))
-    ap.add_argument("--pairs-per-step", type=int, default=int(os.environ.get("MP_BENCH_PAIRS", str(1 << 20))))
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--ini", choices=sorted(INIS), default=os.environ.get("MP_BENCH_INI", "soap4.ini"),
-                    help="soap4.ini + -L <read-len> is how runMegaPath.sh:136 runs the human-filter stage (configs[1]); soap4-nt2.ini + -L <read-len + 1> is the NT stage's")
-    ap.add_argument("--L", type=int, default=None, help="-L value (maxReadLength; reads are cut to L - 1); default: read-len for soap4.ini, read-len + 1 for soap4-nt2.ini")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MP_BENCH_CPU_PAIRS", "100000")))
-    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity sample")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs (roofline.traffic = null)")
-    ap.add_argument("--no-legs", action="store_true", help="skip the C3/C4/C5 workload legs, the lean-layout leg and the resident-chunks leg")
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MP_BENCH_GENOME_MBP", "2950")), help="bases per index chunk (< 4295 Mbp: 32-bit positions per chunk)")
+    ap.add_argument("--nt-replica-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_GB", "242")),
+                    help="HBM bytes (GB) of index the replica makes resident (as many lean chunks of --genome-mbp as that takes and as fit)")
+    ap.add_argument("--nt-headroom-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_HEADROOM_GB", "24")), help="GiB of HBM kept free of index for the batch buffers")
+    ap.add_argument("--nt-pairs", type=int, default=int(os.environ.get("MP_BENCH_NT_PAIRS", str(1 << 18))), help="pairs per step and GPU of the headline workload")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "3")),
                     help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")
-    ap.add_argument("--nt-replica-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_GB", "242")),
-                    help="HBM bytes (GB) of index the nt_replica leg makes resident (as many lean chunks of --genome-mbp as that takes; 0 = skip the leg)")
-    ap.add_argument("--nt-pairs", type=int, default=int(os.environ.get("MP_BENCH_NT_PAIRS", "65536")), help="pairs per step of the nt_replica leg")
-    ap.add_argument("--legs", default=os.environ.get("MP_BENCH_LEGS", "all"), help="comma-separated legs to run (e2e_cli, nt2_ini_same_reads, C3_divergent, C4_2x250, "
-                    "C5_mixed_rescue, lean_layout, nt_replica) or 'all'")
+    ap.add_argument("--single-steps", type=int, default=int(os.environ.get("MP_BENCH_SINGLE_STEPS", "1")), help="untimed one-context steps the per-kernel HIP-event times and the roofline come from")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--pairs-per-step", type=int, default=int(os.environ.get("MP_BENCH_PAIRS", str(1 << 20))), help="pairs per step of the human-filter leg")
+    ap.add_argument("--leg-steps", type=int, default=int(os.environ.get("MP_BENCH_LEG_STEPS", "5")), help="timed steps of the human-filter leg")
+    ap.add_argument("--ini", choices=sorted(INIS), default=os.environ.get("MP_BENCH_INI", "soap4.ini"), help="ini of the human-filter leg (soap4.ini + -L <read-len>: runMegaPath.sh:136)")
+    ap.add_argument("--L", type=int, default=None, help="-L of the human-filter leg (default: read-len for soap4.ini, read-len + 1 for soap4-nt2.ini)")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=int(os.environ.get("MP_BENCH_CPU_PAIRS", "100000")), help="pairs of the human-filter leg's CPU baseline / parity sample")
+    ap.add_argument("--nt-cpu-pairs", type=int, default=int(os.environ.get("MP_BENCH_NT_CPU_PAIRS", "20000")), help="pairs of the headline's CPU baseline (one chunk) and of its two-chunk parity sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the parity samples")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child runs (roofline.traffic = null)")
+    ap.add_argument("--no-legs", action="store_true", help="skip every leg (configs[1], read shapes, the executable)")
+    ap.add_argument("--legs", default=os.environ.get("MP_BENCH_LEGS", "all"), help="comma-separated legs to run (human_filter, human_filter_pmc, e2e_cli, nt2_ini_same_reads, C3_divergent, "
+                    "C4_2x250, C5_mixed_rescue) or 'all'")
     ap.add_argument("--no-e2e", action="store_true", help="skip the leg through the executable (FASTQ files in, annotated FASTQ out)")
-    ap.add_argument("--e2e-batches", type=int, default=int(os.environ.get("MP_BENCH_E2E_BATCHES", "24")), help="batches of --pairs-per-step pairs in the e2e leg's input files")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--e2e-batches", type=int, default=int(os.environ.get("MP_BENCH_E2E_BATCHES", "12")), help="batches of --pairs-per-step pairs in the e2e leg's input files")
+    ap.add_argument("--pmc-child", default=None, choices=["nt", "human"], help=argparse.SUPPRESS)
     args = ap.parse_args()
     leg_set = None if args.legs == "all" else set(x for x in args.legs.split(",") if x)
 
     def want_leg(name):
         return leg_set is None or name in leg_set
-    if args.pmc_child:
-        args.no_cpu_baseline = args.no_pmc = args.no_legs = True
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: be the launcher (nothing here has touched the GPU yet)
@@ -876,306 +1070,198 @@ def main():
     from megapath_amd import index_builder, simulate, taxcount
 
     n_bases = int(args.genome_mbp * 1e6)
-    t0 = time.time()
-    text = simulate.genome(n_bases, seed=3, device=dev)
-    n_seqs = 24
-    bounds = np.linspace(0, n_bases, n_seqs + 1).astype(np.int64)
-    text_cpu = text.cpu().numpy()
-    seqs = [("chr%d" % (i + 1), text_cpu[bounds[i]:bounds[i + 1]]) for i in range(n_seqs)]
-    arrs = index_builder.build_index_arrays(seqs, sa_interval=16, device=dev)
-    t1 = time.time()
-    torch.cuda.empty_cache()                       # the suffix sort's cached blocks would hide the free HBM from the index loader
-    gix = H.Index.from_arrays(local_rank, **arrs)
-    t2 = time.time()
-    if rank == 0:
-        bi = index_builder.last_build_info or {}
-        log("[bench] genome %.0f Mbp: generated + index built in %.1fs (mp_build_index_arrays: suffix array in %.2f s, %s doubling rounds), HBM re-layout + upload %.1fs, "
-            "index %.2f GB in HBM" % (args.genome_mbp, t1 - t0, bi.get("ms_suffix_sort", 0.0) / 1e3, bi.get("rounds", "?"), t2 - t1, gix.info.device_bytes / 1e9))
-    torch.cuda.empty_cache()
-    g_ms, g_bytes = gix.bench_gather64()
+    child_args_base = ["--genome-mbp", str(args.genome_mbp), "--nt-pairs", str(args.nt_pairs), "--pairs-per-step", str(args.pairs_per_step), "--read-len", str(args.read_len),
+                       "--ini", args.ini, "--nt-headroom-gb", str(args.nt_headroom_gb)] + (["--L", str(args.L)] if args.L is not None else [])
+
+    if args.pmc_child == "human":
+        # one step of the human-filter leg's batch under the profiler's counters
+        text = simulate.genome(n_bases, seed=3, device=dev)
+        bounds = np.linspace(0, n_bases, 25).astype(np.int64)
+        tc = text.cpu().numpy()
+        arrs = index_builder.build_index_arrays([("chr%d" % (i + 1), tc[bounds[i]:bounds[i + 1]]) for i in range(24)], sa_interval=16, device=dev)
+        del tc
+        torch.cuda.empty_cache()
+        gix = H.Index.from_arrays(local_rank, **arrs)
+        gix.bench_gather64()
+        read_L = args.L if args.L is not None else (args.read_len if args.ini == "soap4.ini" else args.read_len + 1)
+        wl = Workload(text, args.pairs_per_step, seed=1000, read_len=args.read_len, L=read_L)
+        ctx = H.Context(gix)
+        step(ctx, wl, H.AlignParams(wl.max_len, 750, 130, 130, mmp_of(args.ini)))
+        ctx.close(); gix.close()
+        return
+
+    # ---------------------------------------------------------------- the headline: the NT replica (BASELINE configs[2] per GPU)
+    pmc_nt = args.pmc_child == "nt"
+    rep = NtReplica(args, H, index_builder, simulate, dev, local_rank, n_bases, max_chunks=3 if pmc_nt else None,
+                    keep_arrays=(rank == 0 and world == 1 and not args.no_cpu_baseline and not pmc_nt))
+    if pmc_nt:
+        rep.chunks[1].bench_gather64()                                # the calibration launches the traffic figure is read against
+    lp = args.nt_pairs
+    wl = Workload(rep.text_a, lp, seed=4242 + rank, read_len=args.read_len, L=args.read_len + 1, sub_max=0.08, random_frac=0.4)      # 60 % from chunk 0 at 0-8 % divergence, 40 % random
+    params = H.AlignParams(wl.max_len, 750, 130, 130, H.MmpParams.nt2())
+    n_chunks = rep.n_chunks
+    ctx0 = H.Context(rep.chunks[0])
+    if pmc_nt:
+        nt_step(ctx0, wl, rep.chunks, params)
+        ctx0.close(); rep.close()
+        return
+    g_ms, g_bytes = rep.chunks[1].bench_gather64()
     gather_gbs = g_bytes / (g_ms * 1e-3) / 1e9
     if rank == 0:
-        log("[bench] random 64-B gather ceiling over the rank blocks: %.0f GB/s" % gather_gbs)
-
-    P = args.pairs_per_step
-    read_L = args.L if args.L is not None else (args.read_len if args.ini == "soap4.ini" else args.read_len + 1)
-    wl = Workload(text, P, seed=1000 + rank, read_len=args.read_len, L=read_L)
-    ctx = H.Context(gix)
-    # insert_low = the longest read of the first batch (SOAP4.cpp:465-474), as the executable settles it
-    params = H.AlignParams(wl.max_len, 750, 130, 130, mmp_of(args.ini))
-
-    for _ in range(max(args.warmup, 0 if args.pmc_child else 1)):
-        step(ctx, wl, params)
-    census = ref_events = None
-    if not args.pmc_child:
-        # two untimed steps over the same resident batch: (1) the cells every DP launch computes, counted on the device;
-        # (2) the look-ups of the reference algorithm itself -- every optional table ignored -- for `equivalent_work`
-        ctx.set_dp_census(True)
-        step(ctx, wl, params)
-        census = ctx.dp_census()
-        ctx.set_dp_census(False)
-        if gix.info.prefilter_k:
-            ctx.set_prefilter(False)
-            _, _, st0, _ = step(ctx, wl, params)
-            ref_events = dict(occ=int(st0.seed.n_occ), lkt=int(st0.seed.n_lkt), sa=int(st0.seed.n_sa), seedpos=int(st0.seed.n_seedpos))
-            ctx.set_prefilter(True)
-    band0, th0 = ctx.dp_band_stats(), ctx.dp_thermo_stats()
-    elapsed_single, acc = run_steps(ctx, wl, params, args.steps, barrier)
-    band1, th1 = ctx.dp_band_stats(), ctx.dp_thermo_stats()
-    elapsed = elapsed_single
-    n_ctx = max(1, args.contexts) if not args.pmc_child else 1
-    if n_ctx > 1:
-        # the configuration the drop-in executable runs in (MP_WORKERS_PER_GPU): the batch cut into contiguous blocks, one context each
-        cuts = [P * i // n_ctx for i in range(n_ctx + 1)]
-        slices = [WorkloadSlice(wl, cuts[i], cuts[i + 1]) for i in range(n_ctx)]
-        ctxs = [ctx] + [H.Context(gix) for _ in range(n_ctx - 1)]
-        run_overlapped(ctxs, slices, params, 1)                      # first touch of the new contexts' buffers
-        elapsed = run_overlapped(ctxs, slices, params, args.steps, barrier)
-        for c in ctxs[1:]:
-            c.close()
-        step(ctx, wl, params)                                        # leave the whole batch's hit lists in ctx for the exchange step below
-    # the exchange step of the path: per-reference hit counts of this rank's last step, summed over the ranks
-    hits, nh = ctx.pair_hits_view()
-    ref_counts = taxcount.count_pair_hits_per_reference(gix, hits, nh)
+        log("[bench] random 64-B gather ceiling over a chunk's rank blocks: %.0f GB/s" % gather_gbs)
+    n_ctx = max(1, args.contexts)
+    cuts = [lp * i // n_ctx for i in range(n_ctx + 1)]
+    slices = [WorkloadSlice(wl, cuts[i], cuts[i + 1]) for i in range(n_ctx)]
+    ctxs = [ctx0] + [H.Context(rep.chunks[0]) for _ in range(n_ctx - 1)]
+    K, Wm = args.steps, max(args.warmup, 1)                          # (at least one untimed step: the first touch of every context's buffers)
+    t_w = time.time()
+    nt_run_contexts(ctxs, slices, rep.chunks, params, Wm)
+    if rank == 0:
+        log("[bench] %d warm-up step(s) of %d pairs through %d chunks: %.1f s" % (Wm, lp, n_chunks, time.time() - t_w))
+    elapsed = nt_run_contexts(ctxs, slices, rep.chunks, params, K, barrier)          # THE timed region: K steps between barriers + device syncs
+    for c in ctxs[1:]:
+        c.close()
+    # the run the per-kernel HIP-event times, the event counts and the roofline come from: ONE context doing the whole batch on one stream (kernels of
+    # several contexts overlap and stretch each other); this is also the last step whose keys feed the exchange step below
+    S = max(1, args.single_steps)
+    acc = {"source_chunk": {}, "other_chunks": {}}
+    th_a = ctx0.dp_thermo_stats()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for _ in range(S):
+        keys = nt_step(ctx0, wl, rep.chunks, params, acc)
+    torch.cuda.synchronize()
+    el_single = (time.perf_counter() - t3) / S
+    th_b = ctx0.dp_thermo_stats()
+    # the exchange step of the path: per-reference entry counts of this rank's last step, summed over the ranks (RCCL)
+    kk = np.array(keys, dtype=np.uint64)
+    n_seq = int(rep.chunks[0].info.num_seq)
+    chunk_of = (n_chunks - 1) - ((kk >> np.uint64(32)) & np.uint64(1023)).astype(np.int64)
+    seq_of = ((kk >> np.uint64(10)) & np.uint64(0x3FFFFF)).astype(np.int64)
+    ref_counts = np.bincount(chunk_of * (n_seq + 1) + seq_of, minlength=n_chunks * (n_seq + 1)).astype(np.int64)
     if world > 1:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         ref_counts = taxcount.allreduce_counts(ref_counts, dev if backend == "nccl" else "cpu")
+    ctx0.close()
 
+    parity_ok = True
     if rank == 0:
-        K = args.steps
-        total_pairs = world * K * P
-        t_seed_s = (acc["ms_seed"] + acc["ms_locate"]) / 1e3
-        # whole suffix array resident: expand_hits_kernel / locate_kernel are not launched (merge_kernel<true> makes its keys from the seed records)
-        fused = acc["ms_locate"] / K < 0.05
-        roof_kernels = ("seed_kernel", "seed_overflow_kernel") if fused else SEED_STAGE_KERNELS
-        b_loaded = loaded_bytes(acc, wl.sum_len, K, fused)
-        achieved = b_loaded / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
-        kernel_ms = {k[3:]: acc[k] / K for k in acc if k.startswith("ms_")}
-        per_pair = lambda k: acc[k] / (K * P)      # noqa: E731
+        o, src = acc["other_chunks"], acc["source_chunk"]
+        n_o = max(1, o.get("chunks", 1))
+        t_seed_s = (o.get("seed", 0.0) + o.get("locate", 0.0) + src.get("seed", 0.0) + src.get("locate", 0.0)) / 1e3
+        n_launch = S * n_chunks
+        seed_bytes = nt_seed_bytes([o, src], wl.sum_len, n_launch)
+        achieved = seed_bytes / t_seed_s / 1e9 if t_seed_s > 0 else 0.0
+        seed_bytes_other = nt_seed_bytes([o], wl.sum_len, n_o)
         out = {
-            "metric": "paired 150bp reads aligned/sec vs 2BWT index",
-            "value": total_pairs / elapsed,
+            "metric": "paired 150bp reads aligned/sec vs NT 2BWT index",
+            "value": world * K * lp / elapsed,
             "unit": "pairs/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3,
-            "contexts_per_gpu": n_ctx,
-            "single_context": {"pairs_per_s": world * K * P / elapsed_single, "ms_per_step": elapsed_single / K * 1e3,
-                               "note": "the same %d steps with ONE context doing the whole batch on one stream: the run the per-kernel HIP-event times, "
-                                       "event counts and the roofline below come from (kernels of several contexts would overlap and stretch each other)" % K},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "2x%dbp synthetic pairs vs synthetic %.0f Mbp genome in 24 sequences (BASELINE configs[1], human-filter stage; GRCh38 indexes ~2.95 Gbp of "
-                                   "non-N bases), %d pairs/step/GPU; a step = upload of the packed reads + deep-DP round (MMP seeding, pairing, both DP legs + traceback) + "
-                                   "rescue round (single-end DP, mate rescue) + all three hit lists back in pinned host memory; the batch is cut into %d contiguous blocks "
-                                   "that as many contexts work on side by side" % (args.read_len, args.genome_mbp, P, n_ctx),
-                       "index_replicated_per_gpu": True, "pairs_per_step_per_gpu": P, "genome_mbp": args.genome_mbp,
-                       "index_bytes_in_hbm": int(gix.info.device_bytes), "ini": args.ini, "L": read_L, "u": 750,
-                       "command_line": "soap4 pair <index> r1.fq r2.fq -C %s -L %d -u 750 -F -nc (runMegaPath.sh:136)" % (args.ini, read_L)},
-            "roofline": {"bound": "hbm", "kernel": "+".join(roof_kernels), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_launch": b_loaded / K, "bytes_per_pair": b_loaded / (K * P), "launch_ms": (acc["ms_seed"] + acc["ms_locate"]) / K,
-                         "formula": ("64*rank_blocks_loaded + 8*(lkt13 + lkt16 look-ups) + 8*prefilter_entries_loaded + 4*sa_reads%s + 8*text_words_compared + "
-                                     "0.25*read_bases + 16*seed_positions_out; every count is emitted by the kernels (events_per_pair) and only events "
-                                     "that load memory are priced") % (" (the seeding kernel's own, %.2f per pair: the kernels in the denominator)" % (acc["n_sa_seed_kernel"] / (K * P)) if fused else ""),
-                         "random64_gather_ceiling_gbs": gather_gbs,
-                         "note": "dependent random 4..64-byte gathers: the physical ceiling of this access shape is the measured random-64-B-gather rate, "
-                                 "not the streaming peak; traffic_frac / frac_of_gather_ceiling say how close the sectors actually moved come to either"},
-            "kernel_ms_per_step": kernel_ms,
-            "events_per_pair": {"rank_queries_issued": per_pair("n_occ"), "rank_blocks_loaded": per_pair("n_occ_loaded"), "lkt13_lookups": per_pair("n_lkt"),
-                                "lkt16_lookups": per_pair("n_lkt16"), "sa_reads": per_pair("n_sa"), "prefilter_probes": per_pair("n_prefilter"),
-                                "prefilter_entries_loaded": per_pair("n_prefilter_loads"), "text_words_compared": per_pair("n_text_words"),
-                                "extension_steps_skipped": per_pair("n_steps_skipped"), "seeds": per_pair("n_seeds"), "located_hits": per_pair("n_hits"),
-                                "seed_positions_out": per_pair("n_seedpos"), "candidates": per_pair("cand"), "pair_hits": per_pair("pair_hits"),
-                                "failed_pairs": per_pair("failed"), "single_dp_tasks": per_pair("stasks"), "rescue_dp_slots": per_pair("rtasks"),
-                                "single_hits": per_pair("single_hits"), "rescue_hits": per_pair("rescue_hits")},
-            "hit_count_allreduce": {"references": int(len(ref_counts)), "pair_hits_counted": int(ref_counts.sum()), "ranks": world,
-                                    "backend": (backend if world > 1 else None)},
+            "config": {"workload": "BASELINE configs[2] per GPU: %d index chunks of %.0f Mbp resident at once in the lean layout = %.1f Gbp, %.1f GB of HBM; chunk 0 is the genome the reads "
+                                   "come from, the other %d hold an unrelated synthetic genome (indexed once, copied device-to-device into separate arrays), so a read finds its true "
+                                   "alignment in one chunk and chance matches elsewhere, as in the real database; 2x%d bp, 60 %% of the pairs from chunk 0 at 0-8 %% divergence, 40 %% "
+                                   "random (SURVEY 8d C3); %d pairs/step/GPU; a step = one batch through EVERY chunk as bin/soap4-mi355x runs the NT stage: upload of the packed reads, per "
+                                   "chunk deep-DP round + rescue round + reduction of the hits to per-reference scores on the device, the last chunk's three hit lists to the host "
+                                   "(the BAM files that remain are the last chunk's), one sorted key list per batch in pinned host memory; the batch is cut into %d contiguous blocks "
+                                   "that as many contexts work on side by side" % (n_chunks, n_bases / 1e6, n_chunks * n_bases / 1e9, rep.index_bytes / 1e9, n_chunks - 1,
+                                                                                    args.read_len, lp, n_ctx),
+                       "command_line": "soap4 pair <chunk i> in_1.fq in_2.fq -b -o <prefix>.nt.bam -L %d -T <n> -u 750 -F -C soap4-nt2.ini -top 95 [-nc for i = 0], i = 0 .. %d "
+                                       "(runMegaPath.sh:191-208), as ONE process: bin/soap4-mi355x pair <chunk 0>,...,<chunk %d> ..." % (args.read_len + 1, n_chunks - 1, n_chunks - 1),
+                       "index_replicated_per_gpu": True, "chunks": n_chunks, "bases_resident": n_chunks * n_bases, "index_bytes_in_hbm": rep.index_bytes,
+                       "bytes_per_base": rep.index_bytes / (n_chunks * n_bases), "hbm_total_bytes": rep.hbm_total, "pairs_per_step_per_gpu": lp, "contexts_per_gpu": n_ctx,
+                       "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750, "top": 95, "replica_load_s": rep.load_s},
+            "chunk_pair_alignments_per_s": world * K * lp * n_chunks / elapsed,
+            "single_context": {"ms_per_step": el_single * 1e3, "pairs_per_s": lp / el_single, "steps": S,
+                               "note": "ONE context taking the whole batch through every chunk on one stream, after the timed region: the run the per-kernel HIP-event times, "
+                                       "the event counts and the roofline come from (kernels of several contexts overlap and stretch each other)"},
+            "roofline": {"bound": "hbm", "kernel": "seed_kernel+seed_overflow_kernel+expand_hits_kernel+locate_kernel (lean layout: the seed stage K1 + K2 of one chunk)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": seed_bytes / n_launch, "launch_ms": t_seed_s * 1e3 / n_launch, "launches": n_launch,
+                         "bytes_per_pair_per_chunk": seed_bytes / (lp * n_launch),
+                         "other_chunks": {"bytes_per_launch": seed_bytes_other / n_o, "launch_ms": (o.get("seed", 0.0) + o.get("locate", 0.0)) / n_o},
+                         "formula": "64*rank_blocks_loaded + 8*lkt13_lookups + 4*sa_reads + 0.25*read_bases + 16*seed_positions_out per chunk-launch of the seed stage (every count emitted by "
+                                    "the kernels), over the HIP-event time of those kernels on the context's stream, averaged over the %d chunk-launches of the one-context step(s)" % n_launch,
+                         "random64_gather_ceiling_gbs": gather_gbs, "frac_of_gather_ceiling_requested": achieved / gather_gbs,
+                         "note": "dependent random 64-byte gathers: the physical ceiling of this access shape is the measured random-64-B-gather rate, not the streaming peak"},
+            "kernel_ms_per_chunk_other_chunks": {k: o.get(k, 0.0) / n_o for k in NT_KEYS},
+            "kernel_ms_source_chunk": {k: src.get(k, 0.0) / max(1, src.get("chunks", 1)) for k in NT_KEYS},
+            "per_pair_per_other_chunk": {k: o.get(k, 0) / (n_o * lp) for k in NT_EVENTS + ("single_dp_tasks", "single_hits", "rescue_hits", "pair_hits", "entries")},
+            "per_pair_source_chunk": {k: src.get(k, 0) / (max(1, src.get("chunks", 1)) * lp) for k in NT_EVENTS + ("single_dp_tasks", "single_hits", "rescue_hits", "pair_hits", "entries")},
+            "rescue_certificate_per_pair_per_chunk": dict(zip(("certified_no_alignment", "score_of_10_elsewhere", "bound_reaches_cutoff", "not_eligible"),
+                                                              [(b - a) / (S * lp * n_chunks) for a, b in zip(th_a, th_b)])),
+            "hit_count_allreduce": {"references": int(len(ref_counts)), "entries_counted": int(ref_counts.sum()), "ranks": world, "backend": (backend if world > 1 else None),
+                                    "note": "per-(chunk, reference) counts of the last step's reduced (read, reference, best score) entries, summed over the ranks: the dense vector "
+                                            "cc/reassign's pass-1 counters are all-reduced as (megapath_amd/taxcount.py)"},
         }
-        # ---- what the short cuts stand for (NOT in frac): the same walk priced as if every step had issued its rank queries,
-        # and the reference algorithm's own look-ups (SURVEY 8d formula, reference layouts: 64 B/occ, 16 B/lkt, 8 B/sa)
-        eq_occ = acc["n_occ"] + 2 * acc["n_steps_skipped"]
-        eq = {"rank_queries_incl_skipped_steps_per_pair": eq_occ / (K * P),
-              "note": "extension steps the 16-mer table and the in-text comparison stand for, counted as 2 rank queries each; no memory is touched for them"}
-        if ref_events:
-            b_ref = 64 * ref_events["occ"] + 16 * ref_events["lkt"] + 8 * ref_events["sa"] + 0.25 * wl.sum_len + 16 * ref_events["seedpos"]
-            eq["reference_algorithm"] = {"bytes_per_pair": b_ref / P, "events_per_pair": {k: v / P for k, v in ref_events.items()},
-                                         "delivered_gbs": b_ref * K / t_seed_s / 1e9 if t_seed_s > 0 else 0.0,
-                                         "note": "every table look-up and rank query soap4 itself issues for this batch (one untimed step with the optional "
-                                                 "tables ignored), SURVEY 8d prices; 'delivered' = those bytes over the timed kernels' duration -- a work-"
-                                                 "equivalent rate, not a bandwidth"}
-        out["equivalent_work"] = eq
-        # ---- DP: cells the kernels really compute (census step) over the DP fill time
-        t_dp_s = (acc["ms_fill"] + acc["ms_rescue_fill"]) / 1e3 / K
-        if census is not None and t_dp_s > 0:
-            computed = census.cells_band_score + census.cells_band_trace + census.cells_full_score + census.cells_full_trace
-            out["dp"] = {"bound": "valu", "unit": "Gcells/s", "achieved": computed / t_dp_s / 1e9,
-                         "cells_computed_per_step": {"band_score_pass": int(census.cells_band_score), "band_traceback_pass": int(census.cells_band_trace),
-                                                     "full_table_score_only": int(census.cells_full_score), "full_table_with_traceback": int(census.cells_full_trace)},
-                         "instances_per_step": int(census.instances),
-                         "full_table_equivalent": {"cells_per_step": int(census.cells_full_table), "gcells_per_s": census.cells_full_table / t_dp_s / 1e9,
-                                                   "note": "(window+1) x read length of every instance submitted (SURVEY 8d; what callDP computes): a work-equivalent "
-                                                           "rate, the kernels skip most of these cells"},
-                         "band_instances_per_step": (band1[0] - band0[0]) / K, "band_left_to_full_table_per_step": (band1[1] - band0[1]) / K,
-                         "rescue_certificate_per_step": dict(zip(("certified_no_alignment", "score_of_10_elsewhere", "bound_reaches_cutoff", "not_eligible"),
-                                                                 [(b - a) / K for a, b in zip(th0, th1)])),
-                         "fill_ms_per_step": t_dp_s * 1e3,
-                         "note": "integer max/add recurrences: VALU-bound, no MFMA, not an HBM roofline (SURVEY 8d).  Cells counted on the device by "
-                                 "mp_ctx_set_dp_census in one untimed step of the same batch; empty mate-rescue slots and instances the block-match "
-                                 "pre-filter finishes as exact matches compute no cells.  VALU occupancy per kernel: profiles/ (SQ counter pass)"}
         tmpdir = tempfile.mkdtemp(prefix="mpbench_")
+        td_cpu = None
         try:
             if world == 1 and not args.no_pmc:
                 try:
-                    tr = live_traffic(args, tmpdir, roof_kernels)
+                    tr = live_traffic(child_args_base + ["--pmc-child", "nt"], tmpdir, SEED_STAGE_KERNELS)
                 except Exception as e:  # noqa: BLE001
                     log("[bench] PMC passes failed: %r" % (e,))
                     tr = None
                 if tr:
                     rf = out["roofline"]
                     rf["traffic"] = tr["bytes_per_launch"]
-                    t_launch = rf["launch_ms"] / 1e3
+                    t_launch = rf["other_chunks"]["launch_ms"] / 1e3
                     rf["traffic_gbs"] = tr["bytes_per_launch"] / t_launch / 1e9
                     rf["traffic_frac"] = rf["traffic_gbs"] / HBM_PEAK_GBS
                     rf["frac_of_gather_ceiling"] = rf["traffic_gbs"] / gather_gbs
-                    rf["traffic_over_requested"] = tr["bytes_per_launch"] / rf["bytes_per_launch"]
-                    rf["traffic_detail"] = tr
-            cb = parity = None
+                    rf["traffic_over_requested"] = tr["bytes_per_launch"] / rf["other_chunks"]["bytes_per_launch"]
+                    rf["traffic_detail"] = dict(tr, launch="the seed-stage kernels' last launch of the child's step = a chunk none of the reads comes from; compared with other_chunks' bytes and time")
             if world == 1 and not args.no_cpu_baseline:
+                cpu_nt, td_cpu = nt_cpu_baseline(args, index_builder, rep, args.read_len, args.nt_cpu_pairs)
+                if cpu_nt:
+                    out["cpu_baseline"] = dict(cpu_nt, value=cpu_nt["pairs_per_s_one_chunk"] / n_chunks, unit="pairs/s", cores=cpu_nt["threads"], host_cores=os.cpu_count(),
+                                               sample="%d pairs of the same read mix, real soap4 (oracle/_ref) -T %d with the NT stage's command line against ONE chunk (the unrelated genome), "
+                                                      "alignment phase only; the replica's %d chunks are %d such runs for it (runMegaPath.sh:191-227), so value = that rate / %d"
+                                                      % (cpu_nt["pairs"], cpu_nt["threads"], n_chunks, n_chunks, n_chunks))
+                else:
+                    out["cpu_baseline"] = None
                 try:
-                    cb, parity = cpu_baseline_and_parity(args, arrs, wl.codes[: 2 * min(args.cpu_sample_pairs, P)], tmpdir, gix.lkt_table(), local_rank, read_L)
-                except Exception as e:  # noqa: BLE001 -- the baseline is auxiliary; report its absence, never hide the GPU number
-                    log("[bench] cpu baseline / parity sample failed: %r" % (e,))
-            out["cpu_baseline"] = cb
-            out["parity_sample"] = parity
-            if world == 1 and not args.no_cpu_baseline and args.ini != "soap4-nt2.ini" and cb and cb.get("kind") == "reference":
-                # the NT stage's parameters on the same index (17-base seeds: the single-end rescue over chance seeds is exercised): a second sample
-                try:
-                    os.remove(os.path.join(tmpdir, "ref.out")) if os.path.exists(os.path.join(tmpdir, "ref.out")) else None
-                    nt_sample = Workload(text, min(args.cpu_sample_pairs, P) // 2, seed=1000 + rank, read_len=args.read_len, L=args.read_len + 1)
-                    cb2, parity2 = cpu_baseline_and_parity(args, arrs, nt_sample.codes, tmpdir, None, local_rank, args.read_len + 1, ini_name="soap4-nt2.ini", threads_list=[min(os.cpu_count() or 1, 32)])
-                    out["parity_sample_nt2_ini"] = dict(parity2 or {}, cpu_pairs_per_s=(cb2 or {}).get("value"))
-                    del nt_sample
+                    ps = nt_parity_sample(args, index_builder, rep, td_cpu, local_rank, args.read_len, args.nt_cpu_pairs)
                 except Exception as e:  # noqa: BLE001
-                    log("[bench] nt2 parity sample failed: %r" % (e,))
-            if world == 1 and not args.no_legs and not args.no_e2e and want_leg("e2e_cli"):
-                try:
-                    from megapath_amd import index_builder as _ib
-                    prefix = os.path.join(tmpdir, "ref.index")
-                    if not os.path.exists(prefix + ".bwt"):
-                        _ib.write_index_files(prefix, arrs, write_lkt=False)
-                    ini_path = os.path.join(tmpdir, args.ini)
-                    with open(ini_path, "w") as f:
-                        f.write(INIS[args.ini])
-                    out["e2e_cli"] = e2e_cli_leg(args, text, prefix, ini_path, read_L, local_rank, tmpdir, n_batches=args.e2e_batches)
-                except Exception as e:  # noqa: BLE001
-                    out["e2e_cli"] = {"error": repr(e)}
-                    log("[bench] e2e leg failed: %r" % (e,))
+                    log("[bench] NT parity sample failed: %r" % (e,))
+                    ps = {"records_equal": None, "first_diff": repr(e)}
+                out["parity_sample"] = ps
+                if ps and ps.get("records_equal") is False:
+                    parity_ok = False
         finally:
             shutil.rmtree(tmpdir, ignore_errors=True)
-        # ---- workload legs: the other configs' read shapes against the same index (sensitivity of the fast paths)
-        if world == 1 and not args.no_legs:
-            legs = {}
-            specs = [
-                ("C3_divergent", "2x150 bp, per-pair divergence uniform 0-8 %, 40 % random pairs (NT-stage read mix)", dict(read_len=150, sub_max=0.08, random_frac=0.4)),
-                ("C4_2x250", "2x250 bp, -L 251, fragments ~N(450,50): 311-row windows, 32-lane DP shapes", dict(read_len=250, frag_mean=450.0, frag_sd=50.0, frag_max=700)),
-                ("C5_mixed_rescue", "lengths uniform 75-300 (-L 301), 30 % of pairs with one mate random: rescue stress", dict(
-                    read_len=300, len_range=(75, 300), broken_mate_frac=0.3, frag_mean=450.0, frag_sd=50.0, frag_max=700)),
-            ]
-            # every leg below is an NT-stage shape: soap4-nt2.ini (17-base seeds), -L = read length + 1 (runMegaPath.sh:206)
-            nt_L = args.read_len + 1
-            nt_wl = wl if (args.ini == "soap4-nt2.ini" and read_L == nt_L) else Workload(text, max(P // 4, 1 << 16), seed=1000 + rank, read_len=args.read_len, L=nt_L)
-            nt_params = H.AlignParams(nt_wl.max_len, 750, 130, 130, H.MmpParams.nt2())
+            if td_cpu:
+                shutil.rmtree(td_cpu, ignore_errors=True)
+    # ---------------------------------------------------------------- legs (one GPU only): configs[1], the other read shapes, the executable
+    text, arrs = rep.text_a, rep.arrs_a
+    rep.close()
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_legs:
+        legs = {}
+        if want_leg("human_filter"):
             try:
-                if not want_leg("nt2_ini_same_reads"):
-                    raise KeyError("skipped")
-                lp = nt_wl.n_pairs
-                lctx = H.Context(gix)
-                step(lctx, nt_wl, nt_params)
-                el, la = run_steps(lctx, nt_wl, nt_params, 2)
-                legs["nt2_ini_same_reads"] = {"workload": "the default read mix with the NT stage's parameters (-C soap4-nt2.ini -L %d: 17-base seeds, reads of %d bases) against the same "
-                                                          "index, one context: the configuration rounds 1 and 2 quoted" % (nt_L, nt_wl.max_len),
-                                              "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3,
-                                              "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")}}
-                lctx.close()
-            except KeyError:
-                pass
+                leg, sub, ok = human_filter_leg(args, H, index_builder, simulate, text, arrs, dev, local_rank, rank, n_bases, want_leg, child_args_base)
+                legs["human_filter"] = leg
+                legs.update(sub)
+                parity_ok = parity_ok and ok
             except Exception as e:  # noqa: BLE001
-                legs["nt2_ini_same_reads"] = {"error": repr(e)}
-            for name, desc, sim in specs:
-                if not want_leg(name):
-                    continue
-                try:
-                    lp = max(P // 4, 1 << 16)
-                    lw = Workload(text, lp, seed=2000 + len(legs), **sim)
-                    lpar = H.AlignParams(lw.max_len, 750, 130, 130, H.MmpParams.nt2())
-                    lctx = H.Context(gix)
-                    step(lctx, lw, lpar)
-                    el, la = run_steps(lctx, lw, lpar, 2)
-                    legs[name] = {"workload": desc, "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3,
-                                  "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")},
-                                  "per_pair": {"candidates": la["cand"] / (2 * lp), "pair_hits": la["pair_hits"] / (2 * lp), "failed_pairs": la["failed"] / (2 * lp),
-                                               "single_dp_tasks": la["stasks"] / (2 * lp), "rank_blocks_loaded": la["n_occ_loaded"] / (2 * lp)}}
-                    lctx.close()
-                    del lw
-                except Exception as e:  # noqa: BLE001
-                    legs[name] = {"workload": desc, "error": repr(e)}
-                    log("[bench] leg %s failed: %r" % (name, e))
-            # ---- lean layout: what a chunk of a 250 GB NT replica gets -- rank blocks, 13-mer table, the file's SA samples, text
-            # (1.09 B/base), none of the optional tables -- and N such chunks resident at once, every batch aligned against each
-            try:
-                if not want_leg("lean_layout"):
-                    raise KeyError("skipped")
-                knobs = {"MP_KMER_FILTER": "0", "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}
-                saved = {k: os.environ.get(k) for k in knobs}
-                os.environ.update(knobs)
-                lean = [H.Index.from_arrays(local_rank, **arrs)]
-                for k, v in saved.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
-                lean_bytes = sum(int(x.info.device_bytes) for x in lean)
-                lp = max(P // 4, 1 << 16)
-                lw = WorkloadSlice(nt_wl, 0, min(lp, nt_wl.n_pairs))
-                params_default, params = params, nt_params                       # (the chunk loop below uses `params`)
-                lctx = H.Context(lean[0])
-                step(lctx, lw, params)
-                el, la = run_steps(lctx, lw, params, 2)
-                legs["lean_layout"] = {"workload": "the default workload against ONE index in the lean layout (no 17-mer pre-filter, no 16-mer table, SA samples every 16th row as in "
-                                                   "the index files): %.2f B/base in HBM" % (lean[0].info.device_bytes / n_bases),
-                                       "index_bytes_in_hbm": int(lean[0].info.device_bytes), "pairs_per_step": lp, "pairs_per_s": 2 * lp / el, "ms_per_step": el / 2 * 1e3,
-                                       "kernel_ms_per_step": {k[3:]: la[k] / 2 for k in la if k.startswith("ms_")},
-                                       "per_pair": {"rank_blocks_loaded": la["n_occ_loaded"] / (2 * lp), "lkt13_lookups": la["n_lkt"] / (2 * lp), "sa_reads": la["n_sa"] / (2 * lp)}}
-
-                lctx.close()
-                for x in lean:
-                    x.close()
-            except KeyError:
-                pass
-            except Exception as e:  # noqa: BLE001
-                legs["lean_layout"] = {"error": repr(e)}
-                log("[bench] lean-layout leg failed: %r" % (e,))
-            # ---- the metric's own configuration: a full-size NT replica resident in this GPU's HBM (BASELINE configs[2])
-            if want_leg("nt_replica") and args.nt_replica_gb > 0:
-                try:
-                    ctx.close(); gix.close()                       # the 111 GB every-table layout of the human index makes room
-                    ctx = gix = None
-                    legs["nt_replica"] = nt_replica_leg(args, H, index_builder, simulate, arrs, text, dev, local_rank, n_bases)
-                except Exception as e:  # noqa: BLE001
-                    legs["nt_replica"] = {"error": repr(e)}
-                    log("[bench] NT replica leg failed: %r" % (e,))
-            if "e2e_cli" in out:
-                legs["e2e_cli"] = out.pop("e2e_cli")
-            out["legs"] = legs
+                legs["human_filter"] = {"error": repr(e)}
+                log("[bench] human-filter leg failed: %r" % (e,))
+        out["legs"] = legs
+    if rank == 0:
+        out["parity_ok"] = parity_ok
         print(json.dumps(out), flush=True)
-    if ctx is not None:
-        ctx.close()
-    if gix is not None:
-        gix.close()
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and not parity_ok:
+        log("[bench] A PARITY SAMPLE DIFFERS FROM THE REFERENCE soap4: see parity_sample / legs.human_filter.parity_sample in the line above")
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -232,10 +232,15 @@ typedef struct {
     uint64_t cells_band_score, cells_band_trace, cells_full_score, cells_full_trace;
 } mp_dp_census;
 /* The certificate in front of the rescue filter (kernels_thermo.hip): instances that provably cannot reach their cutoff skip the filter.
- * 0 switches it off (test aid: the results are the same either way); stats: [0] certified, [1] overflow, [2] bound too high, [3] not eligible. */
+ * 0 switches it off, 2 keeps it to the single-end windows of 101 .. 320-base reads (round 3's coverage), 1 (default) every shape it has a variant
+ * for: reads of 30 .. 100 bases and the windows of the mate rescue too (test aid: the results are the same either way); stats: [0] certified,
+ * [1] overflow, [2] bound too high, [3] not eligible. */
 int mp_ctx_set_dp_thermo(mp_ctx *ctx, int on);
 int mp_ctx_dp_thermo_stats(mp_ctx *ctx, uint64_t out[4]);
 int mp_test_dp_thermo(mp_ctx *ctx, const mp_dp_task *tasks, uint32_t n, uint8_t *out_cert, uint64_t out_stats[4]);
+/* the same for one given variant: kind 0 windows around a seed of reads of <= 100 bases, 1 of 101 .. 160, 2 of 161 .. 320, 3 mate-rescue windows (no seed, <= 768 rows) of reads
+ * of <= 160 bases, 4 of <= 320; -1 = 1 or 2 by the longest read */
+int mp_test_dp_thermo_kind(mp_ctx *ctx, const mp_dp_task *tasks, uint32_t n, int kind, uint8_t *out_cert, uint64_t out_stats[4]);
 int mp_ctx_set_dp_census(mp_ctx *ctx, int on);
 int mp_ctx_get_dp_census(mp_ctx *ctx, mp_dp_census *out);
 /* The hit list is grouped by pair, pairs in ascending order (the hits of one pair in no particular order). */

@@ -63,11 +63,11 @@ struct mp_ctx {
     // reads
     DevBuf<uint32_t> reads, lens, scan;
     const uint32_t *d_reads = nullptr, *d_lens = nullptr;   // either our buffers or caller-owned device memory
-    uint32_t n_reads = 0, W = 0, max_len = 0;
+    uint32_t n_reads = 0, W = 0, max_len = 0, min_len = 0;      // (min_len 0: not known -- reads handed over in device memory)
     size_t slab_budget = 0;          // bytes of traceback flags per DP launch (decided at the first DP call)
     bool use_prefilter = true;       // mp_ctx_set_prefilter
     bool use_band = true;            // mp_ctx_set_dp_band
-    bool use_thermo = true;          // mp_ctx_set_dp_thermo
+    int use_thermo = 1;              // mp_ctx_set_dp_thermo: 0 off, 1 every shape it has a variant for, 2 the single-end windows of 101 .. 320-base reads only (round 3)
     bool seeded = false;
     // seeding
     DevBuf<mp_seed_rec> slabs, big_slabs;
@@ -845,14 +845,14 @@ extern "C" int mp_set_reads(mp_ctx *c, const uint32_t *packed, uint32_t W, const
 {
     if (!c || !packed || !lengths || W == 0 || (n_reads & 1)) return MP_EINVAL;
     HIPCHK(hipSetDevice(c->ix->device));
-    uint32_t mx = 0;
-    for (uint32_t i = 0; i < n_reads; i++) { if (lengths[i] > mx) mx = lengths[i]; if (lengths[i] > W * 16) return MP_EINVAL; }
+    uint32_t mx = 0, mn = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n_reads; i++) { if (lengths[i] > mx) mx = lengths[i]; if (lengths[i] < mn) mn = lengths[i]; if (lengths[i] > W * 16) return MP_EINVAL; }
     if (c->reads.reserve((size_t)n_reads * W + 16) || c->lens.reserve(n_reads + 16)) return MP_ENOMEM;
     HIPCHK(hipMemcpyAsync(c->reads.p, packed, (size_t)n_reads * W * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->lens.p, lengths, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->d_reads = c->reads.p; c->d_lens = c->lens.p;
-    c->n_reads = n_reads; c->W = W; c->max_len = mx;
+    c->n_reads = n_reads; c->W = W; c->max_len = mx; c->min_len = n_reads ? mn : 0;
     return forget_batch(c);
 }
 
@@ -860,7 +860,7 @@ extern "C" int mp_set_reads_device(mp_ctx *c, const uint32_t *d_packed, uint32_t
 {
     if (!c || !d_packed || !d_lengths || W == 0 || (n_reads & 1) || max_length > W * 16) return MP_EINVAL;
     c->d_reads = d_packed; c->d_lens = d_lengths;
-    c->n_reads = n_reads; c->W = W; c->max_len = max_length;
+    c->n_reads = n_reads; c->W = W; c->max_len = max_length; c->min_len = 0;
     return forget_batch(c);
 }
 
@@ -901,7 +901,10 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
     const size_t seed_lds = (size_t)256 * (mp_scan_stride(W) | 1u) * sizeof(uint32_t);
     int per_cu = 0;
-    auto kern = seed_kernel;
+    // an index without any optional table (an NT chunk's lean layout, or every table switched off): the build of the kernel without their states
+    const bool lean = !dix.kmer17 && !dix.kmer15x3 && !dix.lkt16 && !dix.lkt16u && !dix.sa_dense;
+    static const bool lean_env = !getenv("MP_SEED_LEAN") || atoi(getenv("MP_SEED_LEAN")) != 0;     // 0: measurement switch -- the general build on a lean index
+    auto kern = lean && lean_env ? seed_kernel<true> : seed_kernel<false>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, seed_lds) != hipSuccess || per_cu < 1) per_cu = 4;
     const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * (unsigned)per_cu);
     HIPCHK(hipEventRecord(c->ev[0], s));
@@ -1002,7 +1005,7 @@ extern "C" int mp_ctx_set_dp_band(mp_ctx *c, int on)
 extern "C" int mp_ctx_set_dp_thermo(mp_ctx *c, int on)
 {
     if (!c) return MP_EINVAL;
-    c->use_thermo = on != 0;
+    c->use_thermo = on < 0 || on > 2 ? 1 : on;
     return MP_OK;
 }
 
@@ -1015,24 +1018,33 @@ extern "C" int mp_ctx_dp_thermo_stats(mp_ctx *c, uint64_t out[4])
     return MP_OK;
 }
 
-// test hook: the certificate kernel on caller-given instances of the reads now set
-extern "C" int mp_test_dp_thermo(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, uint8_t *out_cert, uint64_t out_stats[4])
+// test hook: the certificate kernel on caller-given instances of the reads now set.  kind: -1 by the longest read (narrow up to 160 bases, else wide),
+// 0 reads of up to 100 bases (margin 25), 1 narrow, 2 wide, 3 mate-rescue windows / reads of up to 160 bases, 4 mate-rescue windows / up to 320
+extern "C" int mp_test_dp_thermo_kind(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int kind, uint8_t *out_cert, uint64_t out_stats[4])
 {
-    if (!c || !tasks || !out_cert || !c->d_reads) return MP_EINVAL;
+    if (!c || !tasks || !out_cert || !c->d_reads || kind < -1 || kind > 4) return MP_EINVAL;
     if (n == 0) return MP_OK;
     for (uint32_t t = 0; t < n; t++) {
         if (tasks[t].read_id >= c->n_reads || (tasks[t].strand != 1 && tasks[t].strand != 2)) return MP_EINVAL;
         if (tasks[t].win_len > MP_DP_MAX_WIN || tasks[t].win_start + tasks[t].win_len > c->ix->n) return MP_ERANGE;
     }
+    if (kind < 0) kind = c->max_len <= MP_TH_MAXL ? 1 : 2;
+    if (c->max_len > ((kind == 2 || kind == 4) ? MP_TH_MAXL_WIDE : MP_TH_MAXL)) return MP_ERANGE;
     HIPCHK(hipSetDevice(c->ix->device));
     hipStream_t s = c->stream;
     if (c->tasks_tmp.reserve(n) || c->th_cert.reserve(n + 64) || c->th_stats.reserve(4)) return MP_ENOMEM;
     HIPCHK(hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
-    if (c->max_len <= MP_TH_MAXL) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                                                     (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p, (const uint32_t *)nullptr, c->th_stats.p);
-    else hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), dim3(grid_for(n, 32)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W,
-                            (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p, (const uint32_t *)nullptr, c->th_stats.p);
+    const dim3 g2(grid_for(n, 64)), g1(grid_for(n, 32)), blk(64);
+#define MP_TH_ARGS c->ix->d.text, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->tasks_tmp.p, n, c->th_cert.p, (const uint32_t *)nullptr, c->th_stats.p
+    switch (kind) {
+        case 0: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32, MP_TH_MARGIN_SHORT, false, MP_TH_MAXM_SHORT>), g2, blk, 0, s, MP_TH_ARGS); break;
+        case 1: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), g2, blk, 0, s, MP_TH_ARGS); break;
+        case 2: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), g1, blk, 0, s, MP_TH_ARGS); break;
+        case 3: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_RESCUE, 32, 0, true, MP_TH_MAXM_RESCUE>), g2, blk, 0, s, MP_TH_ARGS); break;
+        default: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_RESCUE_WIDE, 64, 0, true, MP_TH_MAXM_RESCUE>), g1, blk, 0, s, MP_TH_ARGS); break;
+    }
+#undef MP_TH_ARGS
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_cert, c->th_cert.p, n, hipMemcpyDeviceToHost, s));
     unsigned long long ths[4];
@@ -1040,6 +1052,11 @@ extern "C" int mp_test_dp_thermo(mp_ctx *c, const mp_dp_task *tasks, uint32_t n,
     HIPCHK(hipStreamSynchronize(s));
     if (out_stats) for (int k = 0; k < 4; k++) out_stats[k] = ths[k];
     return MP_OK;
+}
+
+extern "C" int mp_test_dp_thermo(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, uint8_t *out_cert, uint64_t out_stats[4])
+{
+    return mp_test_dp_thermo_kind(c, tasks, n, -1, out_cert, out_stats);
 }
 
 extern "C" int mp_ctx_set_dp_census(mp_ctx *c, int on)
@@ -1313,7 +1330,7 @@ bool band_applicable(const mp_ctx *c, uint32_t max_win, int cl, int cr);
 int run_dp_band(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res, float *ms_fill, float *ms_trace, bool count);
 
 int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t max_win, int cl, int cr, mp_dp_result *d_res,
-                    float *ms_fill, float *ms_trace, bool count)
+                    float *ms_fill, float *ms_trace, bool count, bool rescue_windows = false /* mate-rescue windows: no seed inside (HalfEndAlgnBatch) */)
 {
     if (n == 0) return MP_OK;
     DpShape shape;
@@ -1322,25 +1339,52 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
     hipStream_t s = c->stream;
     if (c->fill.reserve(n + 2) || c->sel_flag.reserve(n + 2) || c->sel_idx.reserve(n + 2)) return MP_ENOMEM;
     while (c->ev_pool.size() < 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
-    // Windows around a seed (read + 2 x 30) of reads of 101 .. 160 bases: most are chance seeds whose table holds nothing else.  dp_thermo_kernel
-    // certifies that for 32 instances per word (kernels_thermo.hip); only what it leaves undecided goes through the score-only filter.
+    // Most instances of the rescue passes hold nothing: windows around a chance seed (read + 2 x margin), windows of a mate that is not there
+    // (mate rescue, up to 751 rows).  dp_thermo_kernel certifies that for 32 instances per word (kernels_thermo.hip); only what it leaves
+    // undecided goes through the score-only filter.  One variant per shape, each over the list of its length class:
+    //   windows around a seed   reads of 30 .. 100 bases (margin 25) | 101 .. 160 (margin 30) | 161 .. 320 (margin 30, one set of 32 instances per wavefront)
+    //   mate-rescue windows     reads of 30 .. 160 bases | 161 .. 320, windows of up to 768 rows, no seed
     static const bool thermo_env = !getenv("MP_DP_THERMO") || atoi(getenv("MP_DP_THERMO")) != 0;
-    const bool narrow = c->max_len <= MP_TH_MAXL && max_win <= MP_TH_MAXM;             // two sets of 32 instances per wavefront; otherwise one (reads of up to 320 bases)
-    const bool thermo = thermo_env && c->use_thermo && c->max_len > 100 && (narrow || (c->max_len <= MP_TH_MAXL_WIDE && max_win <= MP_TH_MAXM_WIDE)) && n >= 64;
+    static const bool thermo_more_env = !getenv("MP_DP_THERMO_MORE") || atoi(getenv("MP_DP_THERMO_MORE")) != 0;      // 0: round 3's coverage only (test / measurement switch)
+    const bool thermo_more = thermo_more_env && c->use_thermo == 1;
+    struct ThClass { uint32_t lo, hi; int kind; };                                     // kind: 0 short, 1 narrow, 2 wide, 3 rescue narrow, 4 rescue wide
+    ThClass cls[3];
+    int n_cls = 0;
+    if (!rescue_windows) {
+        if (thermo_more && c->min_len <= MP_TH_MAXL_SHORT && max_win <= MP_TH_MAXM_WIDE) cls[n_cls++] = ThClass{(uint32_t)MP_MIN_ALIGNABLE_LEN - 1, MP_TH_MAXL_SHORT, 0};
+        if (c->max_len > 100 && max_win <= MP_TH_MAXM_WIDE) cls[n_cls++] = ThClass{100u, MP_TH_MAXL, 1};
+        if (c->max_len > MP_TH_MAXL && c->max_len <= MP_TH_MAXL_WIDE && max_win <= MP_TH_MAXM_WIDE) cls[n_cls++] = ThClass{MP_TH_MAXL, MP_TH_MAXL_WIDE, 2};
+    } else if (thermo_more && max_win <= MP_TH_MAXM_RESCUE && c->max_len <= MP_TH_MAXL_WIDE) {
+        cls[n_cls++] = ThClass{(uint32_t)MP_MIN_ALIGNABLE_LEN - 1, MP_TH_MAXL, 3};
+        if (c->max_len > MP_TH_MAXL) cls[n_cls++] = ThClass{MP_TH_MAXL, MP_TH_MAXL_WIDE, 4};
+    }
+    // every instance in ONE class and no list needed: the single-end windows of a batch of 101 .. 160-base reads (the NT stage's shape)
+    const bool one_launch = !rescue_windows && n_cls == 1 && cls[0].kind == 1 && c->min_len > 100 && c->max_len <= MP_TH_MAXL && max_win <= MP_TH_MAXM;
+    const bool use_list = c->max_len <= 8 * 20;                                        // the filter takes the undecided instances by list (dp_score_kernel<8, C>); otherwise per length class with `skip`
+    const bool thermo = thermo_env && c->use_thermo != 0 && n_cls > 0 && n >= 64;
     HIPCHK(hipEventRecord(c->ev_pool[0], s));
     if (thermo) {
         if (c->th_cert.reserve(n + 64) || c->th_stats.reserve(4) || c->score_list.reserve(n + 2)) return MP_ENOMEM;
         HIPCHK(hipMemsetAsync(c->th_stats.p, 0, 4 * sizeof(unsigned long long), s));
-        if (narrow) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n, c->th_cert.p,
-                                       (const uint32_t *)nullptr, c->th_stats.p);
+        auto launch_class = [&](int kind, uint32_t n_k, const uint32_t *lst) {
+            const dim3 g2(grid_for(n_k, 64)), g1(grid_for(n_k, 32)), blk(64);
+#define MP_TH_ARGS c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_k, c->th_cert.p, lst, c->th_stats.p
+            switch (kind) {
+                case 0: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32, MP_TH_MARGIN_SHORT, false, MP_TH_MAXM_SHORT>), g2, blk, 0, s, MP_TH_ARGS); break;
+                case 1: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), g2, blk, 0, s, MP_TH_ARGS); break;
+                case 2: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), g1, blk, 0, s, MP_TH_ARGS); break;
+                case 3: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_RESCUE, 32, 0, true, MP_TH_MAXM_RESCUE>), g2, blk, 0, s, MP_TH_ARGS); break;
+                default: hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_RESCUE_WIDE, 64, 0, true, MP_TH_MAXM_RESCUE>), g1, blk, 0, s, MP_TH_ARGS); break;
+            }
+#undef MP_TH_ARGS
+        };
+        if (one_launch) launch_class(1, n, (const uint32_t *)nullptr);
         else {
-            // a batch with reads of more than 160 bases is usually one of mixed lengths: the instances of 101 .. 160 bases go through the narrow
-            // kernel, those of 161 .. 320 through the wide one, each as a list (a wavefront then sweeps as many rows as ITS longest window has);
-            // shorter reads are left to the filter
+            // mixed lengths (trimmed reads) or a shape with its own variant: each class as a list (a wavefront then sweeps as many rows as ITS
+            // longest window has); what belongs to no class is left to the filter
             HIPCHK(hipMemsetAsync(c->th_cert.p, 0, n, s));
-            const uint32_t lo[2] = {100u, MP_TH_MAXL}, hi[2] = {MP_TH_MAXL, MP_TH_MAXL_WIDE};
-            for (int k = 0; k < 2; k++) {
-                hipLaunchKernelGGL(dp_len_class_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, n, lo[k], hi[k], c->sel_flag.p, (const uint8_t *)nullptr);
+            for (int k = 0; k < n_cls; k++) {
+                hipLaunchKernelGGL(dp_len_class_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tasks, c->d_lens, n, cls[k].lo, cls[k].hi, c->sel_flag.p, (const uint8_t *)nullptr);
                 int rck = exclusive_scan_inclusive_u32(c, c->sel_flag.p, c->sel_idx.p, n);
                 if (rck) return rck;
                 uint32_t n_k = 0;
@@ -1348,14 +1392,12 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
                 HIPCHK(hipStreamSynchronize(s));
                 if (n_k == 0) continue;
                 hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, n, c->score_list.p, (const uint32_t *)nullptr);
-                if (k == 0) hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T, 32>), dim3(grid_for(n_k, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_k, c->th_cert.p,
-                                               (const uint32_t *)c->score_list.p, c->th_stats.p);
-                else hipLaunchKernelGGL((dp_thermo_kernel<MP_TH_T_WIDE, 64>), dim3(grid_for(n_k, 32)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, d_tasks, n_k, c->th_cert.p,
-                                        (const uint32_t *)c->score_list.p, c->th_stats.p);
+                launch_class(cls[k].kind, n_k, (const uint32_t *)c->score_list.p);
                 HIPCHK(hipStreamSynchronize(s));                                 // the list buffer is reused by the next class
             }
         }
         MP_TRACE(s, "dp_thermo_kernel");
+        HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(thermo_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint8_t *)c->th_cert.p, n, c->sel_flag.p, c->fill.p);
         int rc0 = exclusive_scan_inclusive_u32(c, c->sel_flag.p, c->sel_idx.p, n);
         if (rc0) return rc0;
@@ -1368,7 +1410,7 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
         if (n_und) {
             hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, n, c->score_list.p, (const uint32_t *)nullptr);
             census_add(c, CENSUS_FULL_SCORE, d_tasks, c->score_list.p, n_und, 0);
-            if (narrow) { MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p, (const uint32_t *)c->score_list.p, n_und); }
+            if (use_list) { MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p, (const uint32_t *)c->score_list.p, n_und); }
             else { MP_DP_DISPATCH(launch_score, s, c, d_tasks, n, cl, cr, c->fill.p, (const uint32_t *)nullptr, 0u, (const uint8_t *)c->th_cert.p); }
         }
     } else {
@@ -1989,7 +2031,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
                     hipLaunchKernelGGL(dp_gather_tasks_kernel, dim3(grid_for(n_filled, 256)), dim3(256), 0, s, (const mp_dp_task *)c->rtasks.p, (const uint32_t *)c->rlist.p, n_filled, c->rtasks_c.p);
                     MP_TRACE(s, "dp_gather_tasks_kernel");
                     rc = run_dp_filtered(c, c->rtasks_c.p, n_filled, rwin, ap->clip_left, ap->clip_right, c->rres_c.p, &st.ms_dp_fill, &st.ms_dp_trace,
-                                         ap->want_tie_counts != 0);
+                                         ap->want_tie_counts != 0, true);
                     if (rc) return rc;
                     hipLaunchKernelGGL(dp_scatter_list_kernel, dim3(grid_for(n_filled, 256)), dim3(256), 0, s, (const mp_dp_result *)c->rres_c.p, (const uint32_t *)c->rlist.p, n_filled, c->rres.p);
                     MP_TRACE(s, "dp_scatter_list_kernel");

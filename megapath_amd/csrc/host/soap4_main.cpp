@@ -1091,6 +1091,9 @@ struct Writer {
     // ("SCORE:..." or "IGNORE") replaces the record's own: exactly what the next run of the chained NT loop would read back
     // from this run's stdout (runMegaPath.sh:191-227, getMappingFromHeader BGS-IO.cpp:1348-1371), without the file round trip.
     bool carry;
+    // mute = true: the record's text is made elsewhere (output_reduced, from the device's reduced list); pair() / single() are still called
+    // for what they do to the RESULTS -- the BAM writer that runs next sees boundary-spanning mates un-aligned and the scores normalised
+    bool mute = false;
     Writer(const mp_index *i, const Params &pp, std::string &out_, bool carry_ = false) : ix(i), p(pp), out(out_), carry(carry_) {}
     // -lsam: the line cc/fastq2lsam would print for a record (print_lsam_line, cc/fastq2lsam.cpp:28-78)
     void lsam_line(std::string_view name, const std::string &comm, std::string_view seq, std::string_view qual, int which_end)
@@ -1177,6 +1180,7 @@ struct Writer {
     // one output record: the annotated FASTQ header + sequence + qualities, or its LSAM line
     void record(const Rec &r, int best, const std::vector<ChrHit> &hits, const std::vector<HdrMap> &v)
     {
+        if (mute) return;
         const bool to_comment = p.lsam || carry;
         std::string &o = to_comment ? comm_ : out;
         if (to_comment) comm_.clear(); else { out += '@'; out.append(r.name, r.name_len); out += '\t'; }
@@ -1464,7 +1468,8 @@ void upload_reads(mp_ctx *ctx, Batch &bt, Stats &st)
     st.t_upload += now_s() - t0;
 }
 
-void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, bool bam, int threads, Stats &st)
+void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, bool bam, int threads, Stats &st,
+               int reduce_chunk = -1 /* >= 0: the batch's per-reference scores are being reduced on the device (mp_reduce_*) and this is the LAST chunk, whose hit lists -b needs on the host as well */)
 {
     const uint32_t n_reads = bt.n_reads, n_pairs = n_reads / 2;
     double t0 = now_s();
@@ -1496,6 +1501,14 @@ void gpu_stage(mp_ctx *ctx, const Params &p, Batch &bt, Batch::ChunkHits &b, boo
         b.resc.assign(rv, rv + nr);
     }
     st.t_rescue += now_s() - t0; t0 = now_s();
+    if (reduce_chunk >= 0) {
+        // (before the CIGAR batches below reuse the context's DP buffers: the hit lists are still on the device)
+        mp_reduce_stats red{};
+        bt.red_class.resize(n_pairs + 1);
+        die(mp_reduce_chunk(ctx, p.mode, (uint32_t)reduce_chunk, &red, bt.red_class.data()), "mp_reduce_chunk");
+        bt.red_last = red;
+        bt.red_dp_instances += b.dp_instances;
+    }
     if (getenv("MP_TIMING"))
         fprintf(stderr, "[Main] batch %llu: %llu seed positions, %llu candidates, %llu pair hits, %u of %u pairs done, %zu single hits, %zu rescues (insert %d..%d)\n",
                 (unsigned long long)bt.seq, (unsigned long long)rs.seed.n_seedpos, (unsigned long long)rs.n_candidates, (unsigned long long)nh, n_done, n_pairs,
@@ -1568,14 +1581,16 @@ void for_chunks(size_t n_items, Formatters &fm, BamState *bam, Pass1 *pass1, F &
 
 // `carry`: not the last resident chunk -- the records keep their new header comments for the next chunk instead of being printed.
 void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b, BamState *bam, int threads, Formatters &fm, Stats &st, bool carry, Pass1 *pass1,
-                  bool keep_unchanged = false /* carry mode, second chunk on: a read without a hit in this chunk keeps the comment the chunk before left */)
+                  bool keep_unchanged = false /* carry mode, second chunk on: a read without a hit in this chunk keeps the comment the chunk before left */,
+                  bool bam_only = false /* the batch's text has been printed from the device's reduced list (output_reduced): only the BAM records of this chunk are made here */)
 {
     const uint32_t n_pairs = bt.n_reads / 2;
     double t0 = now_s();
     prepare_lists(bt, b, threads);
     st.t_sort += now_s() - t0; t0 = now_s();
+    if (bam_only) { carry = true; pass1 = nullptr; }        // (carry: the counters below belong to the pass that printed the text)
+    else st.dp += b.dp_instances;
     if (!carry) st.pairs += n_pairs;
-    st.dp += b.dp_instances;
     const auto &hits = b.hits;
     auto best_of = [](const std::vector<PairAln> &v) {           // first maximum of score_1 + score_2 (OutputDPResult.cpp:156-232)
         size_t best = 0;
@@ -1596,7 +1611,8 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
     for (size_t i = 0; i < hits.size(); i++) if (i == 0 || hits[i].pair_id != hits[i - 1].pair_id) grp.push_back(i);
     grp.push_back(hits.size());
     for_chunks(grp.size() - 1, fm, bam, pass1, [&](size_t g0, size_t g1, Sink &sink) {
-        Writer w(ix, p, sink.text, carry);
+        Writer w(ix, p, sink.text, carry && !bam_only);
+        w.mute = bam_only;
         PairText text;
         std::vector<PairAln> res;
         for (size_t g = g0; g < g1; g++) {
@@ -1634,7 +1650,8 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
     for (size_t i = 0; i < rows.size(); i++) if (i == 0 || rows[i].pair != rows[i - 1].pair) grp.push_back(i);
     grp.push_back(rows.size());
     for_chunks(grp.size() - 1, fm, bam, pass1, [&](size_t g0, size_t g1, Sink &sink) {
-        Writer w(ix, p, sink.text, carry);
+        Writer w(ix, p, sink.text, carry && !bam_only);
+        w.mute = bam_only;
         PairText text;
         std::vector<PairAln> res;
         for (size_t g = g0; g < g1; g++) {
@@ -1678,7 +1695,8 @@ void output_stage(mp_index *ix, const Params &p, Batch &bt, Batch::ChunkHits &b,
         }
     }
     for_chunks(rest.size(), fm, bam, pass1, [&](size_t i0, size_t i1, Sink &sink) {
-        Writer w(ix, p, sink.text, carry);
+        Writer w(ix, p, sink.text, carry && !bam_only);
+        w.mute = bam_only;
         std::vector<Side> lst[2];
         std::vector<mpbam::Writer::RefText> ref_of[2];
         std::vector<uint8_t> tbuf[2];
@@ -2036,7 +2054,9 @@ int main(int argc, char **argv)
     // Without -b only the per-reference best scores are needed: they are reduced on the device over all chunks (mp_reduce_*), the printer
     // makes one pass per batch.  MP_HOST_MERGE=1 (and -b, and databases beyond the key's limits) keeps the hit lists and the per-chunk merge
     // of the header comments on the host: the reference's chain, step by step.
-    bool reduce_on_device = !plumbing_only && bam == nullptr && p.mode != 0 && !getenv("MP_HOST_MERGE") && n_chunks <= 1024;
+    // With -b the reduction still does the comments: the chained runs all write the same -o prefix (runMegaPath.sh:199), so the BAM files that
+    // remain are the LAST chunk's -- only that chunk's hit lists travel to the host (MP_BAM_HOST_MERGE=1: the round-3 path, every chunk's).
+    bool reduce_on_device = !plumbing_only && (bam == nullptr || !getenv("MP_BAM_HOST_MERGE")) && p.mode != 0 && !getenv("MP_HOST_MERGE") && n_chunks <= 1024;
     if (reduce_on_device)
         for (mp_index *ix : devices[0].chunks) { mp_index_info info; mp_index_get_info(ix, &info); if (info.num_seq >= (1u << 22)) reduce_on_device = false; }
     if (p.max_read_length > 512 || p.batch_pairs > (1u << 21)) reduce_on_device = false;       // scores must stay below 1024, read ids below 2^22
@@ -2048,6 +2068,8 @@ int main(int argc, char **argv)
             if (!b) break;
             if (b->reduced) {
                 output_reduced(devices[0].chunks.data(), (uint32_t)n_chunks, p, *b, fm, st_printer, p.tax ? &pass1_total : nullptr);
+                // -b: the BAM records of the last chunk, from its hit lists, in the same three sections
+                if (bam) output_stage(devices[0].chunks[n_chunks - 1], p, *b, b->ch[n_chunks - 1], bam, threads, fm, st_printer, false, nullptr, false, true);
                 b->reduced = false;
                 free_q.push(b);
                 continue;
@@ -2068,7 +2090,7 @@ int main(int argc, char **argv)
             Stats &st = st_worker[w];
             mp_ctx *ctx = nullptr;
             if (!plumbing_only) die(mp_ctx_create(dev.chunks[0], &ctx), "mp_ctx_create");
-            if (ctx && reduce_on_device) die(mp_ctx_set_hit_copies(ctx, 0), "mp_ctx_set_hit_copies");
+            if (ctx && reduce_on_device && !bam) die(mp_ctx_set_hit_copies(ctx, 0), "mp_ctx_set_hit_copies");
             for (;;) {
                 Batch *b = filled_q.pop();
                 if (!b) break;
@@ -2080,7 +2102,10 @@ int main(int argc, char **argv)
                     b->red_dp_instances = 0;
                     for (size_t c = 0; c < n_chunks; c++) {
                         if (n_chunks > 1 || c > 0) die(mp_ctx_set_index(ctx, dev.chunks[c]), "mp_ctx_set_index");
-                        gpu_stage_reduced(ctx, p, *b, (uint32_t)c, c + 1 == n_chunks, st);
+                        const bool last = c + 1 == n_chunks;
+                        if (bam) die(mp_ctx_set_hit_copies(ctx, last ? 1 : 0), "mp_ctx_set_hit_copies");
+                        if (bam && last) gpu_stage(ctx, p, *b, b->ch[c], true, threads, st, (int)c);
+                        else gpu_stage_reduced(ctx, p, *b, (uint32_t)c, last, st);
                     }
                     finish_reduced(ctx, *b, st);
                 } else if (!plumbing_only) {

@@ -536,7 +536,10 @@ struct mp_lane_state {
 };
 
 // (94 VGPRs: five waves per SIMD.  Held to 80 registers for a sixth wave, and with two items per lane, the kernel was slower: DESIGN.md section 4)
-__global__ void __launch_bounds__(256)
+// LEAN: the index has none of the optional tables (the layout of an NT chunk: rank blocks, 13-mer table, sampled suffix array) -- the states that
+// read them (pre-filter entries, 16-mer tables, text comparison) are compiled out: the same walk with fewer registers, more wavefronts per SIMD.
+template <bool LEAN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
 seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t n_items, uint32_t W, mp_dev_mmp P,
             mp_seed_rec *__restrict__ slabs, uint32_t *__restrict__ seeds_per_rs, uint32_t *__restrict__ hits_per_rs,
             uint32_t *__restrict__ overflow_rs, uint32_t *__restrict__ over_slot, uint32_t overflow_cap, unsigned int *queue, mp_counters *ctr,
@@ -547,9 +550,9 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
     const uint32_t S = mp_scan_stride(W);
     uint32_t *const sl = s_scan + threadIdx.x * (S | 1u);
     const uint32_t n = ix.n;
-    const bool pf = ix.kmer17 && P.seed_min_length >= (int)ix.kmer_k;
+    const bool pf = !LEAN && ix.kmer17 && P.seed_min_length >= (int)ix.kmer_k;
     const uint64_t kmask = (1ull << (2 * ix.kmer_k)) - 1;             // (kmer15x3 and the 16-mer tables exist only with 17-mers)
-    const bool text_ok = ix.sa_dense && ix.sa_dense_shift == 0;
+    const bool text_ok = !LEAN && ix.sa_dense && ix.sa_dense_shift == 0;
     const uint32_t cum0 = ix.cum[0], cum1 = ix.cum[1], cum2 = ix.cum[2], cum3 = ix.cum[3];
     mp_lane_events ev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mp_lane_state s;
@@ -611,10 +614,10 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 if (kind == MK_BEGIN && s.aux == 0) alen = lens[s.rs >> 1];
             } else if (kind != MK_NONE) {
                 const uint32_t *p = reinterpret_cast<const uint32_t *>(s.ptr);
-                const bool one = kind == MK_SA || (kind == MK_PRE && !ix.kmer15x3) || (kind == MK_LKT13 && s.aux);
+                const bool one = LEAN ? s.aux != 0 : (kind == MK_SA || (kind == MK_PRE && !ix.kmer15x3) || (kind == MK_LKT13 && s.aux));      // (LEAN: the only word loads are the 13-mer table's)
                 a0 = p[0];
                 a1 = p[one ? 0 : 1];
-                if (kind == MK_PRE && ix.kmer15x3) { const uint2 e2 = *reinterpret_cast<const uint2 *>(ix.kmer15x3 + s.aux); b0 = e2.x; b1 = e2.y; }
+                if (!LEAN && kind == MK_PRE && ix.kmer15x3) { const uint2 e2 = *reinterpret_cast<const uint2 *>(ix.kmer15x3 + s.aux); b0 = e2.x; b1 = e2.y; }
             }
         }
         // the one wait of the trip: everything issued above (and the stores of the trip before) has landed
@@ -640,11 +643,11 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 }
                 s.aux++;
                 if (s.aux * 16u < S) { next = MK_BEGIN; s.ptr = reinterpret_cast<const uint4 *>(s.ptr) + 4; }
-            } else if (kind == MK_LKT13 || kind == MK_LKT16 || kind == MK_LKT16U) {
+            } else if (kind == MK_LKT13 || (!LEAN && (kind == MK_LKT16 || kind == MK_LKT16U))) {
                 // LKT (re)start: the table stands for the first 13 (16) bases of the seed
                 uint32_t nextl, nextr;
                 int k;
-                if (kind == MK_LKT13) { nextl = s.aux ? 1u : a0 + 1; nextr = a1; k = MP_LKT_K - 1; ev.lkt++; }
+                if (LEAN || kind == MK_LKT13) { nextl = s.aux ? 1u : a0 + 1; nextr = a1; k = MP_LKT_K - 1; ev.lkt++; }
                 else {
                     if (kind == MK_LKT16U) { nextl = q0.x; nextr = q0.y; } else { nextl = a0 + 1; nextr = a1; }
                     k = 15; ev.lkt16++; ev.skipped += 3;                  // the three extension steps the table stands for
@@ -653,7 +656,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 if (nextl <= nextr) {
                     s.l = nextl; s.r = nextr; ++s.seed_len; ++s.i;
                     if (s.i >= s.len) fin = true;
-                    else if (kind == MK_LKT16U && nextl == nextr && q0.z != 0xFFFFFFFFu) {
+                    else if (!LEAN && kind == MK_LKT16U && nextl == nextr && q0.z != 0xFFFFFFFFu) {
                         // a 16-mer that occurs once: the entry says where, and what stands in front of it -- compared right away
                         s.upos = q0.z; s.uvalid = true; trev = q0.w; text_now = true;
                     }
@@ -684,11 +687,11 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                         if (s.i >= s.len) fin = true;
                     } else mid_close = true;
                 }
-            } else if (kind == MK_SA) {
+            } else if (!LEAN && kind == MK_SA) {
                 // the text position of a match whose range became a single row: from here on it is extended by comparing with the text
                 s.upos = a0; s.uvalid = true;
                 if (a0 == 0) { mid_close = true; ev.skipped++; }           // the text starts here: what the failing rank query reports
-            } else if (kind == MK_TEXT) {
+            } else if (!LEAN && kind == MK_TEXT) {
                 const uint32_t pend = s.upos - 1;                          // text base that must equal scan base s.i
                 uint32_t t16;                                               // text bases pend-15 .. pend, LSB-first
                 if (pend >= 15) t16 = (uint32_t)((((uint64_t)a1 << 32) | a0) >> (2 * ((pend - 15) & 15)));
@@ -697,7 +700,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 trev = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);    // text base pend in bits 1:0, pend - 1 in 3:2, ...
                 text_now = true; ev.text++;
             }
-            if (text_now) {
+            if (!LEAN && text_now) {
                 // The next base of the backward search is the text base in front of the match, 16 of them per word instead of one
                 // rank block each.  The range cannot shrink any more (the re-seed bookkeeping stands still) and the seed is
                 // reported by its text position (MP_SEED_LOCATED).
@@ -733,7 +736,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                     const uint64_t win = off < 16 ? (((uint64_t)w1 << 32) | w0) : (((uint64_t)w2 << 32) | w1);
                     return win >> (2 * (off & 15));
                 };
-                if (kind == MK_PRE) {
+                if (!LEAN && kind == MK_PRE) {
                     // what just arrived, as one bit per position: is the 17-mer that starts there anywhere in the text?  s.nf = present
                     // bits (low half) and known bits (high half) of the positions pg .. pg + 15; the two entries answer three positions each,
                     // from the offsets the lane chose when it asked (kept in s.nf meanwhile)
@@ -804,7 +807,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                     }
                     if (start_here) {
                         const uint32_t key16 = (uint32_t)bases_at(s.i);
-                        if (pf && ix.lkt16 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
+                        if (!LEAN && pf && ix.lkt16 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
                             // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
                             // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
                             // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).

@@ -23,6 +23,11 @@
 // windows are transposed into bit-sliced form with one ballot per word (both halves at once), straight into LDS.
 // Measured (profiles/r03_*): 60 single-end instances per pair and chunk of the NT stage, 95 % certified; 6.6 ms for 3.95 M instances where
 // dp_score_kernel took 18.5 ms -- 230 instructions per step of five cells x 32 instances, 1.4 per cell and instance.
+//
+// Round 4: the same planes for what the single-end windows of 101 .. 320-base reads left out.  MARGIN = 25: reads of up to 100 bases (their
+// windows are read + 2 x 25, DV-DPfunctions.cpp:1760).  RUNLESS: the windows of the MATE RESCUE (HalfEndAlgnBatch::pack,
+// DV-DPfunctions.cpp:1151-1231: up to insert_high - insert_low + L + 1 = 751 rows) hold no seed at all -- where the mate is not there the table
+// is a random one, no plane T bit appears, max H' <= T - 1 < 30 <= cutoff and the instance is decided; no run, no bound, one accumulator.
 #pragma once
 
 #define MP_TH_T 10                 // planes: values 1 .. T; plane T set anywhere = overflow, no certificate (E and F never exceed max H' - 3: T - 3 planes)
@@ -33,6 +38,12 @@
 #define MP_TH_MAXL_WIDE 320
 #define MP_TH_MAXM_WIDE 384
 #define MP_TH_MARGIN 30            // DP2_MARGIN for reads longer than 100 bases (DV-DPfunctions.cpp:1760): the seed's diagonal
+#define MP_TH_MARGIN_SHORT 25      // ... and for reads of up to 100 bases
+#define MP_TH_MAXL_SHORT 100
+#define MP_TH_MAXM_SHORT 160       // (reads of <= 100 bases: windows of <= 150)
+#define MP_TH_MAXM_RESCUE 768      // mate-rescue windows: 751 rows with the pipeline's -u 750 (insert_low = the longest read of the first batch)
+#define MP_TH_T_RESCUE 11          // their tables are 3.6 times larger than a single-end window's: one plane more keeps the overflows at a few per cent
+#define MP_TH_T_RESCUE_WIDE 12
 #define MP_TH_MINRUN 12            // a run shorter than this is no seed: no certificate
 
 // lane l receives lane l-1's value AND-ed with the mask of "has a left neighbour", in ONE instruction (lane 0, which has no source, reads 0)
@@ -46,7 +57,8 @@ __device__ __forceinline__ uint32_t th_from_left_and(uint32_t v, uint32_t mask)
 // cert[t] = 1: instance t cannot reach its cutoff (no alignment); 0: undecided, the filter has to look at it.
 // `list` (may be null): slot s stands for instance list[s].
 // LPS = lanes per set of 32 instances: 32 (reads of up to 160 bases, two sets per wavefront) or 64 (up to 320 bases, one set: lanes 0 .. 31 bring the instances)
-template <int T, int LPS>
+// MARGIN: the diagonal the seed lies on (window row = read column + MARGIN); RUNLESS: no seed (mate-rescue windows); MAXM_P: longest window
+template <int T, int LPS, int MARGIN, bool RUNLESS, int MAXM_P>
 __device__ __forceinline__ void
 dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list,
@@ -55,12 +67,14 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     constexpr int TE = T - 3, NC = MP_TH_COLS;
     static_assert(T >= 8 && T <= 14, "planes");
     static_assert(LPS == 32 || LPS == 64, "lanes per set");
-    constexpr int SETS = 64 / LPS, MAXL = NC * LPS, MAXM = LPS == 32 ? MP_TH_MAXM : MP_TH_MAXM_WIDE;
+    constexpr int SETS = 64 / LPS, MAXL = NC * LPS, MAXM = MAXM_P;
+    static_assert(MAXM % 16 == 0, "whole words of window");
     constexpr int OFF = LPS, ROWS = MAXM + 2 * LPS + 8;      // window rows are stored OFF further down, with empty rows on either side: the anti-diagonal
                                                              // sweep reads rows -(LPS - 1) .. mmax + LPS + 4 without a test
     // bit-sliced inputs of the sets (index h): one word = one column (row) of 32 instances
-    __shared__ uint32_t s_r0[SETS][MAXL], s_r1[SETS][MAXL], s_rv[SETS][MAXL], s_run[SETS][MAXL], s_lc[SETS][MAXL], s_gt[SETS][MAXL];
-    __shared__ uint32_t s_w0[SETS][ROWS], s_w1[SETS][ROWS], s_wv[SETS][ROWS], s_rg[SETS][ROWS];
+    constexpr int XL = RUNLESS ? 1 : MAXL, XR = RUNLESS ? 1 : ROWS;             // (the run's planes do not exist without a run)
+    __shared__ uint32_t s_r0[SETS][MAXL], s_r1[SETS][MAXL], s_rv[SETS][MAXL], s_run[SETS][XL], s_lc[SETS][XL], s_gt[SETS][XL];
+    __shared__ uint32_t s_w0[SETS][ROWS], s_w1[SETS][ROWS], s_wv[SETS][ROWS], s_rg[SETS][XR];
     const int lane = threadIdx.x, h = LPS == 32 ? lane >> 5 : 0, l = lane & (LPS - 1);
     const int bit = lane & 31;                                // the instance this lane brings (and speaks for at the end), if it brings one
     const bool carrier = lane < 32 * SETS;
@@ -78,7 +92,9 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     if (have) {
         const mp_dp_task task = tasks[t_id];
         L = (int)lens[task.read_id]; m = (int)task.win_len;
-        ok = L > 100 && L <= MAXL && m >= L && m <= MAXM && m <= L + 2 * MP_TH_MARGIN;
+        if (RUNLESS) ok = L >= MP_MIN_ALIGNABLE_LEN && L <= MAXL && m >= 1 && m <= MAXM;
+        else if (MARGIN == MP_TH_MARGIN) ok = L > 100 && L <= MAXL && m >= L && m <= MAXM && m <= L + 2 * MARGIN;
+        else ok = L >= MP_MIN_ALIGNABLE_LEN && L <= 100 && L <= MAXL && m >= L && m <= MAXM && m <= L + 2 * MARGIN;
         if (ok) {
             const uint32_t *rd = reads + (uint64_t)task.read_id * Wr;
             const int nw = (L + 15) / 16;
@@ -96,10 +112,11 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
                 }
             // the longest run of matches on diagonal MARGIN (window row = read column + MARGIN)
             int best = 0, best_at = 0, cur = 0;
-            const int lim = min(L, m - MP_TH_MARGIN);
+            const int lim = min(L, m - MARGIN);
+            if (!RUNLESS)
 #pragma unroll
             for (int k = 0; k < MAXL / 16; k++) {
-                const int at = 16 * k + MP_TH_MARGIN;                        // window base of read base 16 k
+                const int at = 16 * k + MARGIN;                              // window base of read base 16 k
                 const uint64_t two = ((uint64_t)w[(at >> 4) + 1] << 32) | w[at >> 4];
                 uint32_t x = (uint32_t)(two >> (2 * (at & 15))) ^ a[k];
                 x = (x | (x >> 1)) & 0x55555555u;                           // bit 2u set: base 16 k + u differs
@@ -111,7 +128,7 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
                 }
             }
             j0 = best_at; rlen = best;
-            if (rlen < MP_TH_MINRUN) ok = false;
+            if (!RUNLESS && rlen < MP_TH_MINRUN) ok = false;
         }
     }
     // ---------------------------------------------------------------- transposition: one ballot per word, both halves at once
@@ -122,19 +139,19 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             const int j = 16 * k + u;
             const bool v = ok && j < L;
             const unsigned long long b0 = __ballot(v && (x & 1u)), b1 = __ballot(v && (x & 2u)), bv = __ballot(v);
-            const unsigned long long br = __ballot(ok && j >= j0 && j < j0 + rlen);                 // a cell of the run sits in this column
-            const unsigned long long bl = __ballot(ok && j >= j0 - 1 && j < j0 + rlen - 1);         // the cells whose H' enters the bound on the run's left
-            const unsigned long long bg = __ballot(ok && j > j0);                                   // right of the run's first cell
-            if (l == 0) {
-                s_r0[h][j] = (uint32_t)(b0 >> (32 * h)); s_r1[h][j] = (uint32_t)(b1 >> (32 * h)); s_rv[h][j] = (uint32_t)(bv >> (32 * h));
-                s_run[h][j] = (uint32_t)(br >> (32 * h)); s_lc[h][j] = (uint32_t)(bl >> (32 * h)); s_gt[h][j] = (uint32_t)(bg >> (32 * h));
+            if (l == 0) { s_r0[h][j] = (uint32_t)(b0 >> (32 * h)); s_r1[h][j] = (uint32_t)(b1 >> (32 * h)); s_rv[h][j] = (uint32_t)(bv >> (32 * h)); }
+            if (!RUNLESS) {
+                const unsigned long long br = __ballot(ok && j >= j0 && j < j0 + rlen);                 // a cell of the run sits in this column
+                const unsigned long long bl = __ballot(ok && j >= j0 - 1 && j < j0 + rlen - 1);         // the cells whose H' enters the bound on the run's left
+                const unsigned long long bg = __ballot(ok && j > j0);                                   // right of the run's first cell
+                if (l == 0) { s_run[h][j] = (uint32_t)(br >> (32 * h)); s_lc[h][j] = (uint32_t)(bl >> (32 * h)); s_gt[h][j] = (uint32_t)(bg >> (32 * h)); }
             }
         }
     }
     int mmax = 0;
     for (int hh = 0; hh < SETS; hh++) {
-        for (int x = lane; x < OFF; x += 64) { s_w0[hh][x] = 0; s_w1[hh][x] = 0; s_wv[hh][x] = 0; s_rg[hh][x] = 0; }
-        for (int x = OFF + MAXM + lane; x < ROWS; x += 64) { s_w0[hh][x] = 0; s_w1[hh][x] = 0; s_wv[hh][x] = 0; s_rg[hh][x] = 0; }
+        for (int x = lane; x < OFF; x += 64) { s_w0[hh][x] = 0; s_w1[hh][x] = 0; s_wv[hh][x] = 0; if (!RUNLESS) s_rg[hh][x] = 0; }
+        for (int x = OFF + MAXM + lane; x < ROWS; x += 64) { s_w0[hh][x] = 0; s_w1[hh][x] = 0; s_wv[hh][x] = 0; if (!RUNLESS) s_rg[hh][x] = 0; }
     }
 #pragma unroll
     for (int k = 0; k < MAXM / 16; k++) {
@@ -143,10 +160,10 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             const int i = 16 * k + u;
             const bool v = ok && i < m;
             const unsigned long long b0 = __ballot(v && (x & 1u)), b1 = __ballot(v && (x & 2u)), bv = __ballot(v);
-            const unsigned long long bg = __ballot(ok && i > j0 + MP_TH_MARGIN);                    // rows below the run's first cell
-            if (l == 0) {
-                s_w0[h][OFF + i] = (uint32_t)(b0 >> (32 * h)); s_w1[h][OFF + i] = (uint32_t)(b1 >> (32 * h)); s_wv[h][OFF + i] = (uint32_t)(bv >> (32 * h));
-                s_rg[h][OFF + i] = (uint32_t)(bg >> (32 * h));
+            if (l == 0) { s_w0[h][OFF + i] = (uint32_t)(b0 >> (32 * h)); s_w1[h][OFF + i] = (uint32_t)(b1 >> (32 * h)); s_wv[h][OFF + i] = (uint32_t)(bv >> (32 * h)); }
+            if (!RUNLESS) {
+                const unsigned long long bg = __ballot(ok && i > j0 + MARGIN);                      // rows below the run's first cell
+                if (l == 0) s_rg[h][OFF + i] = (uint32_t)(bg >> (32 * h));
             }
             if (bv) mmax = i + 1;                                              // (wave-uniform)
         }
@@ -157,7 +174,8 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int j = NC * l + c;
-        R0[c] = s_r0[h][j]; R1[c] = s_r1[h][j]; RV[c] = s_rv[h][j]; RUN[c] = s_run[h][j]; LC[c] = s_lc[h][j]; GT[c] = s_gt[h][j];
+        R0[c] = s_r0[h][j]; R1[c] = s_r1[h][j]; RV[c] = s_rv[h][j];
+        if (RUNLESS) { RUN[c] = 0; LC[c] = 0; GT[c] = 0; } else { RUN[c] = s_run[h][j]; LC[c] = s_lc[h][j]; GT[c] = s_gt[h][j]; }
     }
     uint32_t H[NC][T + 1], E[NC][TE + 1];          // [t], t = 1 ..; index 0 unused
 #pragma unroll
@@ -186,9 +204,9 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     // that match nothing: what appears there is never above the cell it came from, so the accumulators may see it.
     // The seed's diagonal meets lane l in its column K at step s = (NC + 1) l + MARGIN + K: with the steps taken NC + 1 at a time, K is a
     // compile-time constant of each of them (K = NC: between two lanes) and only ONE lane of a half is on the diagonal at all.
-    static_assert(MP_TH_MARGIN % (NC + 1) == 0, "the diagonal's column must be the step number modulo NC + 1");
+    // (another margin: the same with the columns rotated -- K = step number - MARGIN modulo NC + 1)
     auto step = [&](auto kc, const int s) __attribute__((always_inline)) {
-        constexpr int K = decltype(kc)::value;
+        constexpr int K = RUNLESS ? NC + 1 : (decltype(kc)::value + (NC + 1) - MARGIN % (NC + 1)) % (NC + 1);      // (run-less: no column is ever on a seed's diagonal)
         // what the left neighbour published at the end of the previous step: its last column in MY row (G) and, kept from the step before, one row up (H)
         uint32_t gotH[T + 1], gotG[TE + 1];
 #pragma unroll
@@ -196,8 +214,8 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #pragma unroll
         for (int t = 1; t <= TE; t++) gotG[t] = th_from_left_and(outG[t], nb);
         const int ri = s - l + OFF;                                             // my window row (i = s - l), as stored
-        const uint32_t wv = s_wv[h][ri], w0 = s_w0[h][ri], w1 = s_w1[h][ri], rowgt = s_rg[h][ri];
-        const uint32_t onl = (NC + 1) * l + MP_TH_MARGIN + K == s ? 0xFFFFFFFFu : 0u;   // this lane's column K is on the seed's diagonal
+        const uint32_t wv = s_wv[h][ri], w0 = s_w0[h][ri], w1 = s_w1[h][ri], rowgt = RUNLESS ? 0u : s_rg[h][ri];
+        const uint32_t onl = !RUNLESS && (NC + 1) * l + MARGIN + K == s ? 0xFFFFFFFFu : 0u;   // this lane's column K is on the seed's diagonal
         // diagonal predecessor of column 0 = the neighbour's last column one row up (kept in inH); F-input of column 0 = gotG
         uint32_t dH[T + 3];                           // H planes of the cell diagonally before the current column; [0] = all instances, [T+1 ..] = 0
         dH[0] = 0xFFFFFFFFu; dH[T + 1] = 0; dH[T + 2] = 0;
@@ -232,9 +250,10 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             for (int t = 1; t <= TE; t++) G[t] = nH[t + 3] | G[t + 1];         // ascending: G[t + 1] is still the current cell's F_{t+1}
             // the bound's ingredients
             ov |= nH[T];
+            if (!RUNLESS)
 #pragma unroll
             for (int t = 5; t < T; t++) U[t] |= nH[t];
-            if (c == K) {
+            if (!RUNLESS && c == K) {
                 const uint32_t lcm = LC[c] & onl;
 #pragma unroll
                 for (int t = 1; t <= 5; t++) accL[t] |= nH[t] & lcm;
@@ -243,6 +262,7 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         // the region right of and below the run's first cell, a lane's columns taken together (up to NC - 1 columns more than the region:
         // a larger maximum can only withhold a certificate)
         const uint32_t reg = rowgt & GT[NC - 1];
+        if (!RUNLESS)
 #pragma unroll
         for (int t = 5; t < T; t++) accR[t] |= U[t] & reg;
         // publish for the right neighbour's next step; remember what the left neighbour's row was for my next step's diagonal
@@ -272,7 +292,8 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     // the lane that brought an instance speaks for it
     const bool over = (ov >> bit) & 1u;
     const int cutoff = mp_dp_cutoff(L);
-    const bool certified = ok && !over && !l_big && T - 1 < cutoff && Lm + rlen + Rs < cutoff;       // (max H' <= T - 1 when there is no overflow)
+    const bool certified = RUNLESS ? (ok && !over && T - 1 < cutoff)                                 // no cell reaches T: max H' <= T - 1 < cutoff
+                                   : (ok && !over && !l_big && T - 1 < cutoff && Lm + rlen + Rs < cutoff);       // (max H' <= T - 1 when there is no overflow)
     cert[t_id] = certified ? 1 : 0;
     if (stats) {
         const unsigned long long c0 = __ballot(certified), c1 = __ballot(ok && over), c2 = __ballot(ok && !over && !certified), c3 = __ballot(!ok);
@@ -285,12 +306,12 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
     }
 }
 
-template <int T, int LPS>
+template <int T, int LPS, int MARGIN = MP_TH_MARGIN, bool RUNLESS = false, int MAXM_P = (LPS == 32 ? MP_TH_MAXM : MP_TH_MAXM_WIDE)>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
                  const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, uint8_t *__restrict__ cert, const uint32_t *__restrict__ list, unsigned long long *__restrict__ stats)
 {
-    dp_thermo_body<T, LPS>(text, reads, lens, Wr, tasks, n_tasks, cert, list, stats);
+    dp_thermo_body<T, LPS, MARGIN, RUNLESS, MAXM_P>(text, reads, lens, Wr, tasks, n_tasks, cert, list, stats);
 }
 
 // flag[t] = 1 for the instances the certificate left undecided; the certified ones get the filter's answer "score 0"

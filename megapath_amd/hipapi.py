@@ -106,7 +106,7 @@ class IndexInfo(C.Structure):
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_clone", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_target_chr", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy", "mp_ctx_set_index",
-           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_thermo", "mp_ctx_dp_thermo_stats", "mp_test_dp_thermo", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
+           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_thermo", "mp_ctx_dp_thermo_stats", "mp_test_dp_thermo", "mp_test_dp_thermo_kind", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_ctx_set_hit_copies", "mp_reduce_begin", "mp_reduce_chunk", "mp_reduce_finish", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
            "mp_test_sort_longer_seed", "mp_coverage_create", "mp_coverage_destroy", "mp_coverage_add", "mp_coverage_finish", "mp_coverage_seq_stats",
            "mp_coverage_spike_intervals", "mp_coverage_spike_bases", "mp_build_index_arrays"]
@@ -180,6 +180,7 @@ def load_library():
     lib.mp_ctx_set_dp_thermo.argtypes = [vp, C.c_int]
     lib.mp_ctx_dp_thermo_stats.argtypes = [vp, vp]
     lib.mp_test_dp_thermo.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.mp_test_dp_thermo_kind.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, vp]
     lib.mp_ctx_get_dp_census.argtypes = [vp, C.POINTER(DpCensus)]
     lib.mp_ctx_create.argtypes = [vp, C.POINTER(vp)]
     lib.mp_ctx_destroy.argtypes = [vp]
@@ -197,6 +198,10 @@ def load_library():
     lib.mp_get_rescue_hits.argtypes = [vp, vp, C.c_uint64, u64p]
     lib.mp_get_single_hits_view.argtypes = [vp, C.POINTER(vp), u64p]
     lib.mp_get_rescue_hits_view.argtypes = [vp, C.POINTER(vp), u64p]
+    lib.mp_ctx_set_hit_copies.argtypes = [vp, C.c_int]
+    lib.mp_reduce_begin.argtypes = [vp, C.c_uint32]
+    lib.mp_reduce_chunk.argtypes = [vp, C.c_int, C.c_uint32, vp, vp]
+    lib.mp_reduce_finish.argtypes = [vp, C.POINTER(vp), u64p]
     lib.mp_bench_gather64.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]
     lib.mp_device_check.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     lib.mp_test_sort_longer_seed.argtypes = [C.c_int, vp, vp, C.c_uint32, vp]
@@ -445,8 +450,9 @@ class Context:
     def set_dp_band(self, on: bool):
         _chk(load_library().mp_ctx_set_dp_band(self._h, int(bool(on))), "mp_ctx_set_dp_band")
 
-    def set_dp_thermo(self, on: bool):
-        _chk(load_library().mp_ctx_set_dp_thermo(self._h, int(bool(on))), "mp_ctx_set_dp_thermo")
+    def set_dp_thermo(self, on):
+        """0 / False off, 1 / True every shape the certificate has a variant for, 2 round 3's coverage (single-end windows of 101 .. 320-base reads)"""
+        _chk(load_library().mp_ctx_set_dp_thermo(self._h, int(on)), "mp_ctx_set_dp_thermo")
 
     def dp_thermo_stats(self):
         """instances seen by the certificate kernel: (certified, overflow, bound too high, not eligible)"""
@@ -454,13 +460,14 @@ class Context:
         _chk(load_library().mp_ctx_dp_thermo_stats(self._h, out), "mp_ctx_dp_thermo_stats")
         return tuple(int(x) for x in out)
 
-    def test_dp_thermo(self, tasks_np: np.ndarray):
-        """test hook: the certificate kernel on a numpy array of DP_TASK_DTYPE records -> (cert u8[n], stats)"""
+    def test_dp_thermo(self, tasks_np: np.ndarray, kind: int = -1):
+        """test hook: the certificate kernel on a numpy array of DP_TASK_DTYPE records -> (cert u8[n], stats); kind: the variant
+        (mp_test_dp_thermo_kind: 0 short reads, 1 narrow, 2 wide, 3 / 4 mate-rescue windows; -1 by the longest read)"""
         assert tasks_np.dtype == DP_TASK_DTYPE and tasks_np.flags.c_contiguous
         n = len(tasks_np)
         cert = np.zeros(max(n, 1), dtype=np.uint8)
         st = (C.c_uint64 * 4)()
-        _chk(load_library().mp_test_dp_thermo(self._h, tasks_np.ctypes.data, n, cert.ctypes.data, st), "mp_test_dp_thermo")
+        _chk(load_library().mp_test_dp_thermo_kind(self._h, tasks_np.ctypes.data, n, kind, cert.ctypes.data, st), "mp_test_dp_thermo_kind")
         return cert[:n], tuple(int(x) for x in st)
 
     def sgdp_scores(self, tasks_np: np.ndarray, clip_left: int, clip_right: int) -> np.ndarray:
@@ -527,6 +534,30 @@ class Context:
         ptr, n = C.c_void_p(), C.c_uint64()
         _chk(load_library().mp_get_rescue_hits_view(self._h, C.byref(ptr), C.byref(n)), "mp_get_rescue_hits_view")
         return ((RescueHit * n.value).from_address(ptr.value) if n.value else (RescueHit * 1)()), n.value
+
+    # ---- per-reference best scores reduced on the device over the chunks a batch is aligned against (mp_reduce_*, what the executable
+    # prints its header comments from): begin, one call per chunk after its two rounds, finish
+    def set_hit_copies(self, on: bool):
+        """False: the rounds leave their hit lists on the device (the *_view calls then fail): only the reduced list is wanted."""
+        _chk(load_library().mp_ctx_set_hit_copies(self._h, int(bool(on))), "mp_ctx_set_hit_copies")
+
+    def reduce_begin(self, n_chunks: int):
+        _chk(load_library().mp_reduce_begin(self._h, n_chunks), "mp_reduce_begin")
+
+    def reduce_chunk(self, mode: int, chunk_index: int, pair_class: np.ndarray = None):
+        """-> (n_deep_pairs, n_rescued_pairs, n_unpaired_pairs, n_entries); pair_class (uint8[n_pairs], optional) is filled"""
+        st = (C.c_uint64 * 4)()
+        _chk(load_library().mp_reduce_chunk(self._h, mode, chunk_index, st, pair_class.ctypes.data if pair_class is not None else None), "mp_reduce_chunk")
+        return tuple(int(x) for x in st)
+
+    def reduce_finish(self) -> np.ndarray:
+        """the batch's keys (read << 42 | chunks after << 32 | sequence << 10 | 1023 - score), sorted, best score per (read, chunk, sequence):
+        a view of the context's pinned buffer, valid until the next reduce_begin"""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _chk(load_library().mp_reduce_finish(self._h, C.byref(ptr), C.byref(n)), "mp_reduce_finish")
+        if not n.value:
+            return np.zeros(0, dtype=np.uint64)
+        return np.frombuffer((C.c_uint64 * n.value).from_address(ptr.value), dtype=np.uint64)
 
     def deep_dp_round(self, params: AlignParams, fetch: bool = True):
         nh = C.c_uint64()

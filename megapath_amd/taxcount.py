@@ -82,9 +82,10 @@ def read_pass1_file(path: str) -> Pass1:
     return p
 
 
-def all_reduce_pass1(p: Pass1, device=None) -> Pass1:
-    """Sum of the ranks' pass-1 counters; identical on every rank afterwards."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+def all_reduce_pass1(p: Pass1, device=None, always: bool = False) -> Pass1:
+    """Sum of the ranks' pass-1 counters; identical on every rank afterwards.  `always`: run the collectives even in a group of one rank
+    (the test that executes RCCL on a one-GPU box)."""
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return p
     world = dist.get_world_size()
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))

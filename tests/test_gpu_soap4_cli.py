@@ -380,6 +380,62 @@ def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, re
     assert fastq_records(str(out)) == fastq_records(os.path.join(g6, "expected_chain.fq"))
 
 
+@pytest.mark.parametrize("path", ["device_reduce", "host_merge"])
+@pytest.mark.parametrize("db", ["g6", "g3"])
+def test_cli_bam_with_resident_chunks_equals_reference_chain(golden_dir, tmp_path, db, path):
+    """The NT stage's real command line has -b (runMegaPath.sh:199) and every run of the chain writes the same -o prefix: what remains are the
+    LAST chunk's BAM files and the last run's stdout (goldens from the real chain, tests/golden/make_golden_g7.py).  With the chunks resident
+    the comments come from the device reduction over all chunks and only the last chunk's hit lists travel to the host for the BAM records
+    (default); MP_BAM_HOST_MERGE=1 is the round-3 path (every chunk's lists to the host).  Both: stdout and every BAM record equal."""
+    import shutil
+    import bamtext
+    from conftest import bam_golden
+    g1 = os.path.join(golden_dir, "g1")
+    d = os.path.join(golden_dir, db)
+    n = 9 if db == "g6" else 3
+    reads = (os.path.join(d, "reads_1.fq"), os.path.join(d, "reads_2.fq")) if db == "g6" else (os.path.join(g1, "reads_a_1.fq"), os.path.join(g1, "reads_a_2.fq"))
+    want_fq = os.path.join(d, "expected_chain.fq" if db == "g6" else "expected_chain_a.fq")
+    want = bam_golden(os.path.join(d, "expected_chain_b.bam.txt" if db == "g6" else "expected_chain_a_b.bam.txt"))
+    # the chain's runs read <prefix>.nt.tmp_in_1.fq; the read group is the first read file as given (SOAP4.cpp:297-300)
+    for m in (1, 2):
+        shutil.copy(reads[m - 1], tmp_path / ("S.nt.tmp_in_%d.fq" % m))
+    prefixes = ",".join(os.path.join(d, "c%d.fa.index" % k) for k in range(n))
+    out = tmp_path / "out.fq"
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", prefixes, "S.nt.tmp_in_1.fq", "S.nt.tmp_in_2.fq", "-b", "-o", "S.nt.bam", "-L", "151", "-T", "1", "-u", "750", "-F",
+           "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-top", "95", "-nc"]
+    env = dict(os.environ, MP_BATCH_PAIRS="64")
+    if path == "host_merge":
+        env["MP_BAM_HOST_MERGE"] = "1"
+    with open(out, "wb") as fo:
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr.decode()
+    assert (b"reduced on the device" in r.stderr) == (path == "device_reduce")
+    assert fastq_records(str(out)) == fastq_records(want_fq)
+    prefix = str(tmp_path / "S.nt.bam")
+    text, refs, dp = bamtext.read_bam(prefix + ".dpout.1")
+    gout = bamtext.read_bam(prefix + ".gout.1")[2]
+    unpair = bamtext.read_bam(prefix + ".unpair")[2]
+    # batches of 64 pairs: the sections of the files are per batch; the reference made one batch of everything -- same records, compared as sorted lists per file
+    from conftest import split_heap_garbage_trims
+
+    def same(got_recs, want_recs):
+        w, g, _ = split_heap_garbage_trims(want_recs, got_recs)     # (g3: two records the reference damages through an out-of-bounds read, INTEGRATION.md)
+        return sorted(g) == sorted(w)
+    assert same(dp, want["dpout"]) and same(gout, want["gout"]) and same(unpair, want["unpair"])
+    sq = [l for l in want["header"].splitlines() if not l.startswith("@PG")]
+    assert [l for l in text.splitlines() if not l.startswith("@PG")] == sq
+    # (the ORDER of the records is the chain's own business: every run prints its deep-DP pairs first, then the rescued ones, then the rest, and the
+    # next run reads that as its input order -- the last run of the chain sees the reads permuted by the eight before it; SURVEY App. D12: order is
+    # not part of the contract, it also changes with -T)
+    env["MP_BATCH_PAIRS"] = "1048576"                  # one batch
+    with open(out, "wb") as fo:
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr.decode()
+    assert same(bamtext.read_bam(prefix + ".dpout.1")[2], want["dpout"]) and same(bamtext.read_bam(prefix + ".gout.1")[2], want["gout"])
+    assert same(bamtext.read_bam(prefix + ".unpair")[2], want["unpair"])
+    assert fastq_records(str(out)) == fastq_records(want_fq)
+
+
 @pytest.mark.parametrize("mode", ["-F", "-P"])
 def test_cli_many_resident_chunks_leave_untouched_comments_alone(golden_dir, tmp_path, mode):
     """With many chunks most reads hit few of them: from the second chunk on, a read without a hit in a chunk keeps the comment the

@@ -11,49 +11,49 @@ def _comp_rev(codes):
     return (3 - codes)[::-1]
 
 
-def _make_instances(rng, text, n, kinds, lo=101, hi=160):
+def _make_instances(rng, text, n, kinds, lo=101, hi=160, margin=30):
     """n (read, window) instances of mixed kinds; returns (list of read code arrays as stored, tasks array, kind per instance)"""
     from megapath_amd import hipapi as H
     N = len(text)
     reads, tasks, kind = [], np.zeros(n, dtype=H.DP_TASK_DTYPE), np.zeros(n, dtype=np.int32)
     for t in range(n):
         L = int(rng.integers(lo, hi + 1))
-        m = L + 60
+        m = L + 2 * margin
         ws = int(rng.integers(0, N - m - 64))
         win = text[ws:ws + m]
         k = int(kinds[rng.integers(0, len(kinds))])
         rd = rng.integers(0, 4, L).astype(np.uint8)
         if k in (0, 7):     # a chance seed: a run of 17 .. 19 (7: 12 .. 26) on the seed's diagonal, nothing else
             r = int(rng.integers(17, 20)) if k == 0 else int(rng.integers(12, 27)); j0 = int(rng.integers(0, L - r + 1))
-            rd[j0:j0 + r] = win[30 + j0:30 + j0 + r]
+            rd[j0:j0 + r] = win[margin + j0:30 + j0 + r]
         elif k == 1:        # near the cutoff: the run, then a second exact stretch right after a mismatch or a short gap (same or shifted diagonal)
             r = int(rng.integers(14, 24)); e = int(rng.integers(5, 20)); sh = int(rng.integers(-3, 4))
             j0 = int(rng.integers(0, L - r - e - 8)); j1 = j0 + r + 1 + max(0, -sh)
-            rd[j0:j0 + r] = win[30 + j0:30 + j0 + r]
-            rd[j1:j1 + e] = win[30 + sh + j1:30 + sh + j1 + e]
+            rd[j0:j0 + r] = win[margin + j0:30 + j0 + r]
+            rd[j1:j1 + e] = win[margin + sh + j1:30 + sh + j1 + e]
         elif k == 2:        # as 1 but the second stretch BEFORE the run
             r = int(rng.integers(14, 24)); e = int(rng.integers(5, 20)); sh = int(rng.integers(-3, 4))
             j0 = int(rng.integers(e + 8, L - r)); j1 = j0 - 1 - e - max(0, sh)
-            rd[j0:j0 + r] = win[30 + j0:30 + j0 + r]
-            rd[j1:j1 + e] = win[30 + sh + j1:30 + sh + j1 + e]
+            rd[j0:j0 + r] = win[margin + j0:30 + j0 + r]
+            rd[j1:j1 + e] = win[margin + sh + j1:30 + sh + j1 + e]
         elif k == 3:        # a true alignment with a few mismatches and possibly an indel
-            rd = win[30:30 + L].copy()
+            rd = win[margin:margin + L].copy()
             for _ in range(int(rng.integers(0, 12))):
                 rd[rng.integers(0, L)] = rng.integers(0, 4)
             if rng.random() < 0.5:
                 p = int(rng.integers(20, L - 20)); g = int(rng.integers(1, 6))
                 rd = np.concatenate([rd[:p], rd[p + g:], rng.integers(0, 4, g).astype(np.uint8)]) if rng.random() < 0.5 else np.concatenate([rd[:p], rng.integers(0, 4, g).astype(np.uint8), rd[p:L - g]])
         elif k == 4:        # stretches on both sides of the run, and a partial alignment of ~ cutoff matches with mismatches inside
-            r = int(rng.integers(12, 20)); j0 = int(rng.integers(30, L - r - 30))
-            rd[j0:j0 + r] = win[30 + j0:30 + j0 + r]
+            r = int(rng.integers(12, 20)); j0 = int(rng.integers(15, L - r - 15))
+            rd[j0:j0 + r] = win[margin + j0:30 + j0 + r]
             a = int(rng.integers(4, 14)); b = int(rng.integers(4, 14))
-            rd[j0 - 1 - a:j0 - 1] = win[30 + j0 - 1 - a:30 + j0 - 1]
-            rd[j0 + r + 1:j0 + r + 1 + b] = win[30 + j0 + r + 1:30 + j0 + r + 1 + b]
+            rd[j0 - 1 - a:j0 - 1] = win[margin + j0 - 1 - a:30 + j0 - 1]
+            rd[j0 + r + 1:j0 + r + 1 + b] = win[margin + j0 + r + 1:30 + j0 + r + 1 + b]
         elif k == 5:        # low complexity: read and window share a short tandem repeat (many diagonals match)
             unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.uint8)
             rep = np.tile(unit, 300)
-            a = int(rng.integers(0, 40)); b = min(int(rng.integers(20, 90)), L - a)
-            win = win.copy(); win[30 + a:30 + a + b] = rep[:b]
+            a = int(rng.integers(0, min(40, L - 25))); b = min(int(rng.integers(20, 90)), L - a)
+            win = win.copy(); win[margin + a:30 + a + b] = rep[:b]
             text[ws:ws + m] = win
             rd[a:a + b] = rep[:b]
         # k == 6: a random read (no run: not eligible)
@@ -65,7 +65,8 @@ def _make_instances(rng, text, n, kinds, lo=101, hi=160):
 
 
 @pytest.mark.parametrize("kinds,seed,lo,hi", [((0,), 1, 101, 160), ((7, 1, 2, 4), 2, 101, 160), ((0, 1, 2, 3, 4, 5, 6, 7), 3, 101, 160),
-                                              ((0,), 4, 161, 320), ((0, 1, 2, 3, 4, 5, 6, 7), 5, 140, 320), ((7, 1, 2, 4), 6, 290, 320)])
+                                              ((0,), 4, 161, 320), ((0, 1, 2, 3, 4, 5, 6, 7), 5, 140, 320), ((7, 1, 2, 4), 6, 290, 320),
+                                              ((0,), 7, 60, 100), ((0, 1, 2, 3, 4, 5, 6, 7), 8, 45, 100), ((7, 1, 2, 4), 9, 90, 100)])
 def test_certificate_never_rejects_an_alignment(kinds, seed, lo, hi):
     from megapath_amd import hipapi as H
     from megapath_amd.index_builder import build_index_arrays
@@ -73,19 +74,24 @@ def test_certificate_never_rejects_an_alignment(kinds, seed, lo, hi):
     rng = np.random.default_rng(seed)
     text = rng.integers(0, 4, 1 << 20).astype(np.uint8)
     n = (60000 if hi <= 160 else 30000) * int(os.environ.get("MP_THERMO_TEST_SCALE", "1"))      # (one-off campaigns: MP_THERMO_TEST_SCALE=10)
-    reads, tasks, kind = _make_instances(rng, text, n, kinds, lo, hi)  # (kind 5 plants repeats into the text: build the index afterwards)
+    short = hi <= 100                                                  # round 4: reads of up to 100 bases, windows of read + 2 x 25 (the kernel's margin-25 variant)
+    reads, tasks, kind = _make_instances(rng, text, n, kinds, lo, hi, 25 if short else 30)  # (kind 5 plants repeats into the text: build the index afterwards)
     arrs = build_index_arrays([("t", text)], sa_interval=16)
     ix = H.Index.from_arrays(0, **arrs)
     ctx = H.Context(ix)
     seqs = [bytes(b"ACGT"[c] for c in r) for r in reads]
     packed, lens, W = H.pack_reads(seqs, 161 if hi <= 160 else 321)
     ctx.set_reads(packed, lens)
-    cert, st = ctx.test_dp_thermo(tasks)
+    cert, st = ctx.test_dp_thermo(tasks, 0 if short else -1)
     score = ctx.sgdp_scores(tasks, 130, 130)
     cutoff = np.maximum(30, (0.2 * lens[tasks["read_id"]]).astype(np.int64))
     bad = np.nonzero((cert != 0) & (score >= cutoff))[0]
     assert len(bad) == 0, (bad[:10], score[bad[:10]], kind[bad[:10]])
     assert sum(st) == n and st[0] == int((cert != 0).sum())
+    if short:
+        # the other variants must refuse these shapes (windows of read + 50): nothing may be certified by the wrong geometry
+        c1, st1 = ctx.test_dp_thermo(tasks, 1)
+        assert not c1.any() and st1[3] == n
     # the exact scores themselves against the oracle's callDP on a sample (dp_fill_kernel is pinned by the golden vectors; this guards the harness)
     for t in rng.integers(0, n, 40):
         rd = reads[t] if tasks["strand"][t] == 1 else _comp_rev(reads[t])
@@ -95,14 +101,96 @@ def test_certificate_never_rejects_an_alignment(kinds, seed, lo, hi):
         assert (got if got >= cutoff[t] else 0) == (want[0] if want[0] >= cutoff[t] else 0), t
     # usefulness: pure chance seeds are nearly all certified
     if kinds == (0,):
-        assert st[0] > (0.9 if hi <= 160 else 0.8) * n, st
+        assert st[0] > (0.9 if hi <= 160 else 0.8) * n, st       # (short reads: smaller tables, the same share and more)
     if 3 in kinds:
         assert not cert[(kind == 3) & (score >= cutoff)].any()
     ctx.close()
     ix.close()
 
 
-@pytest.mark.parametrize("read_len,len_range", [(151, None), (250, None), (300, (75, 300))])
+def _make_rescue_instances(rng, text, n, kinds, lo, hi):
+    """mate-rescue windows (HalfEndAlgnBatch::pack, DV-DPfunctions.cpp:1151-1231): up to 751 rows, no seed; the mate may be there, partly there, or not"""
+    from megapath_amd import hipapi as H
+    N = len(text)
+    reads, tasks, kind = [], np.zeros(n, dtype=H.DP_TASK_DTYPE), np.zeros(n, dtype=np.int32)
+    for t in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        k = int(kinds[rng.integers(0, len(kinds))])
+        m = int(rng.integers(max(L + 1, 300), 752)) if k != 6 else int(rng.integers(1, L + 20))      # 6: a window cut short by the end of the text (shorter than the read, even)
+        ws = int(rng.integers(0, N - m - 64))
+        win = text[ws:ws + m]
+        rd = rng.integers(0, 4, L).astype(np.uint8)
+        if k == 1:          # the mate is there: a true alignment somewhere in the window, a few mismatches, possibly an indel, possibly junk ends (soft clips)
+            o = int(rng.integers(0, m - L + 1)) if m >= L else 0
+            src = win[o:o + L].copy()
+            if len(src) == L:
+                rd = src
+                for _ in range(int(rng.integers(0, 14))):
+                    rd[rng.integers(0, L)] = rng.integers(0, 4)
+                if rng.random() < 0.5:
+                    p = int(rng.integers(10, L - 10)); g = int(rng.integers(1, 6))
+                    rd = np.concatenate([rd[:p], rd[p + g:], rng.integers(0, 4, g).astype(np.uint8)]) if rng.random() < 0.5 else np.concatenate([rd[:p], rng.integers(0, 4, g).astype(np.uint8), rd[p:L - g]])
+                if rng.random() < 0.3:
+                    j = int(rng.integers(5, 40)); rd[:j] = rng.integers(0, 4, j)
+        elif k == 2:        # near the cutoff: one exact stretch of 20 .. 34 bases, a second one of 3 .. 14 right after a mismatch or a short gap
+            r = int(rng.integers(20, 35)); e = int(rng.integers(3, 15)); sh = int(rng.integers(-3, 4))
+            o = int(rng.integers(5, m - L - 5)) if m > L + 12 else 5
+            j0 = int(rng.integers(0, L - r - e - 8)); j1 = j0 + r + 1 + max(0, -sh)
+            if o + j1 + sh + e < m and o + j0 + r < m:
+                rd[j0:j0 + r] = win[o + j0:o + j0 + r]
+                rd[j1:j1 + e] = win[o + sh + j1:o + sh + j1 + e]
+        elif k == 3:        # a stretch at the very first or the very last rows of the window (the sweep's edges)
+            r = int(rng.integers(22, 45))
+            if rng.random() < 0.5:
+                j0 = int(rng.integers(0, L - r + 1)); rd[j0:j0 + r] = win[:r]
+            else:
+                j0 = int(rng.integers(0, L - r + 1)); rd[j0:j0 + r] = win[m - r:]
+        elif k == 5:        # low complexity: read and window share a short tandem repeat
+            unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.uint8)
+            rep = np.tile(unit, 400)
+            a = int(rng.integers(0, max(1, m - 100))); b = min(int(rng.integers(20, 120)), L, m - a)
+            win = win.copy(); win[a:a + b] = rep[:b]
+            text[ws:ws + m] = win
+            ra = int(rng.integers(0, L - b + 1)); rd[ra:ra + b] = rep[:b]
+        # k == 0, 6: a random read: nothing there
+        strand = 1 + int(rng.integers(0, 2))
+        reads.append(rd if strand == 1 else _comp_rev(rd))
+        tasks[t] = (t, strand, ws, m, 0)
+        kind[t] = k
+    return reads, tasks, kind
+
+
+@pytest.mark.parametrize("kinds,seed,lo,hi", [((0,), 11, 101, 160), ((0, 1, 2, 3, 5, 6), 12, 75, 160), ((1, 2, 3), 13, 140, 160), ((0,), 14, 161, 320), ((0, 1, 2, 3, 5, 6), 15, 100, 320),
+                                              ((1, 2, 3), 16, 250, 320)])
+def test_rescue_window_certificate_never_rejects_an_alignment(kinds, seed, lo, hi):
+    """round 4: the run-less variants for the windows of the mate rescue (up to 751 rows): certified => the exact DP stays below the cutoff"""
+    from megapath_amd import hipapi as H
+    from megapath_amd.index_builder import build_index_arrays
+    rng = np.random.default_rng(seed)
+    text = rng.integers(0, 4, 1 << 20).astype(np.uint8)
+    n = (24000 if hi <= 160 else 12000) * int(os.environ.get("MP_THERMO_TEST_SCALE", "1"))
+    reads, tasks, kind = _make_rescue_instances(rng, text, n, kinds, lo, hi)
+    arrs = build_index_arrays([("t", text)], sa_interval=16)
+    ix = H.Index.from_arrays(0, **arrs)
+    ctx = H.Context(ix)
+    seqs = [bytes(b"ACGT"[c] for c in r) for r in reads]
+    packed, lens, W = H.pack_reads(seqs, 161 if hi <= 160 else 321)
+    ctx.set_reads(packed, lens)
+    cert, st = ctx.test_dp_thermo(tasks, 3 if hi <= 160 else 4)
+    score = ctx.sgdp_scores(tasks, 130, 130)
+    cutoff = np.maximum(30, (0.2 * lens[tasks["read_id"]]).astype(np.int64))
+    bad = np.nonzero((cert != 0) & (score >= cutoff))[0]
+    assert len(bad) == 0, (bad[:10], score[bad[:10]], kind[bad[:10]])
+    assert sum(st) == n and st[0] == int((cert != 0).sum())
+    if kinds == (0,):
+        assert st[0] > 0.9 * n, st                      # windows without the mate are what the variant is for
+    if 1 in kinds:
+        assert (score[kind == 1] >= cutoff[kind == 1]).mean() > 0.8 and not cert[(kind == 1) & (score >= cutoff)].any()
+    ctx.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("read_len,len_range", [(151, None), (250, None), (300, (75, 300)), (100, (40, 100))])
 def test_rescue_round_equal_with_and_without_certificate(read_len, len_range):
     """the product path: the same single-end and mate-rescue hits with the certificate on and off (17-base seeds, many random and broken mates)"""
     import ctypes as C
@@ -115,7 +203,7 @@ def test_rescue_round_equal_with_and_without_certificate(read_len, len_range):
     seqs = [x for pr in zip(r1, r2) for x in pr]
     packed, lens, W = H.pack_reads(seqs, read_len + 1)
     outs = []
-    for on in (True, False):
+    for on in (1, 0, 2):                              # every variant | off | round 3's coverage (single-end windows of 101 .. 320-base reads)
         ctx = H.Context(ix)
         ctx.set_dp_thermo(on)
         ctx.set_reads(packed, lens)
@@ -128,6 +216,7 @@ def test_rescue_round_equal_with_and_without_certificate(read_len, len_range):
         outs.append((a, b, ns, nr, ctx.dp_thermo_stats()))
         ctx.close()
     assert outs[0][2] > 500 and outs[0][3] > 50
-    assert outs[0][:4] == outs[1][:4]
+    assert outs[0][:4] == outs[1][:4] == outs[2][:4]
     assert outs[0][4][0] > 0 and outs[1][4] == (0, 0, 0, 0)
+    assert outs[0][4][0] > outs[2][4][0]              # the mate-rescue windows (and reads of up to 100 bases) are certified too now
     ix.close()

@@ -699,7 +699,7 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
         t_gen = time.time() - t0
         threads = min(os.cpu_count() or 16, int(os.environ.get("MP_BENCH_E2E_THREADS", "16")))
 
-        def run(a, b, n_pairs, extra_env=None):
+        def run(a, b, n_pairs, extra_env=None, threads=threads):
             env = dict(os.environ, MP_TIMING="1", MP_DEVICE=str(device))
             env.update(extra_env or {})
             env.pop("LOCAL_RANK", None)
@@ -771,6 +771,17 @@ def e2e_cli_leg(args, text, prefix, ini_path, read_L, device, tmpdir, n_batches=
         for pr in procs:
             pr.wait()
         res["gz"] = run(g1 + ".gz", g2 + ".gz", gz_pairs)                                       # several threads per stream (host/par_gzip.h)
+        # the same at more host threads (-T sets the reader's, the formatters' and the inflaters' share): where does the host side saturate?
+        # (a GPU box's share of its host's cores may be smaller than what os.cpu_count() reports: the CPUs this process may run on are listed)
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except Exception:  # noqa: BLE001
+            usable = os.cpu_count() or 1
+        res["host_cpus"] = {"os_cpu_count": os.cpu_count(), "sched_affinity": usable, "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None)}
+        for T in (32, 64):
+            if (os.cpu_count() or 1) >= T and T > threads:
+                res["gz_T%d" % T] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_INFLATE_THREADS": str(min(16, T * 3 // 8))}, threads=T)
+                res["plain_T%d" % T] = run(f1, f2, n_batches * P, threads=T)
         if os.environ.get("MP_BENCH_E2E_FULL") == "1":                                            # the round-3 comparisons, not part of the default run
             res["gz_one_thread_per_file"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_PARGZ_MIN": str(1 << 60)})     # the reader's own decoder, one thread per stream
             res["gz_zlib"] = run(g1 + ".gz", g2 + ".gz", gz_pairs, {"MP_INFLATE": "zlib"})        # the same files through zlib's gzread, as the reference reads them

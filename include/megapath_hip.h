@@ -220,6 +220,8 @@ int mp_deep_dp_round(mp_ctx *ctx, const mp_align_params *params, uint64_t *out_n
  * results are identical either way.  on = 0 sends every instance through the full-table kernels.  The counters report
  * how many instances went through the band kernel and how many of those were re-run, since the context was created. */
 int mp_ctx_set_dp_band(mp_ctx *ctx, int on);
+/* test hook: caller-given instances through the band scheme of the deep-DP round (results must equal mp_sgdp_batch's); MP_ERANGE where it does not apply */
+int mp_test_dp_band(mp_ctx *ctx, const mp_dp_task *tasks, uint32_t n, int clip_left, int clip_right, mp_dp_result *out_results);
 int mp_ctx_dp_band_stats(mp_ctx *ctx, uint64_t *out_n_band, uint64_t *out_n_full);
 /* Measurement aid.  While on, every DP launch of the rounds also adds up the cells it computes (one small extra kernel per
  * launch, so leave it off in timed runs): `cells_full_table` = (window + 1) x read length of every instance submitted --

@@ -89,6 +89,7 @@ struct mp_ctx {
     DevBuf<uint8_t> th_cert;                     // dp_thermo_kernel: instances certified unable to reach their cutoff
     DevBuf<unsigned long long> th_stats;
     unsigned long long th_total[4] = {0, 0, 0, 0};
+    int th_rescue_skip = 0;                      // calls the mate-rescue variant of the certificate still sits out (run_dp_filtered)
     DevBuf<uint32_t> sel_flag, sel_idx;          // score-only pre-pass of the rescue DP batches
     DevBuf<mp_dp_task> sel_tasks;
     DevBuf<mp_dp_result> sel_res;
@@ -901,10 +902,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->ix->device);
     const size_t seed_lds = (size_t)256 * (mp_scan_stride(W) | 1u) * sizeof(uint32_t);
     int per_cu = 0;
-    // an index without any optional table (an NT chunk's lean layout, or every table switched off): the build of the kernel without their states
-    const bool lean = !dix.kmer17 && !dix.kmer15x3 && !dix.lkt16 && !dix.lkt16u && !dix.sa_dense;
-    static const bool lean_env = !getenv("MP_SEED_LEAN") || atoi(getenv("MP_SEED_LEAN")) != 0;     // 0: measurement switch -- the general build on a lean index
-    auto kern = lean && lean_env ? seed_kernel<true> : seed_kernel<false>;
+    auto kern = seed_kernel;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, seed_lds) != hipSuccess || per_cu < 1) per_cu = 4;
     const unsigned blocks = std::min<unsigned>(grid_for(n_items, 256), (unsigned)n_cu * (unsigned)per_cu);
     HIPCHK(hipEventRecord(c->ev[0], s));
@@ -950,8 +948,8 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
                            c->over_slot.p, c->big_slabs.p, c->seeds.p, c->hit_row.p, c->ctr.p, slab_limit);
         MP_TRACE(s, "expand_hits_kernel");
         if (n_hits)
-            hipLaunchKernelGGL(locate_kernel, dim3(grid_for(n_hits, 256)), dim3(256), 0, s, dix, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
-                               c->ctr.p);
+            hipLaunchKernelGGL(locate_kernel, dim3(grid_for(((uint64_t)n_hits + 1) / 2, 256)), dim3(256), 0, s, dix, c->seeds.p, c->hit_row.p, n_hits, c->d_lens, P, c->hits.p,
+                               c->ctr.p);      // (one lane per two hits)
         MP_TRACE(s, "locate_kernel");
     }
     HIPCHK(hipEventRecord(c->ev[3], s));
@@ -1355,8 +1353,18 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
         if (c->max_len > 100 && max_win <= MP_TH_MAXM_WIDE) cls[n_cls++] = ThClass{100u, MP_TH_MAXL, 1};
         if (c->max_len > MP_TH_MAXL && c->max_len <= MP_TH_MAXL_WIDE && max_win <= MP_TH_MAXM_WIDE) cls[n_cls++] = ThClass{MP_TH_MAXL, MP_TH_MAXL_WIDE, 2};
     } else if (thermo_more && max_win <= MP_TH_MAXM_RESCUE && c->max_len <= MP_TH_MAXL_WIDE) {
-        cls[n_cls++] = ThClass{(uint32_t)MP_MIN_ALIGNABLE_LEN - 1, MP_TH_MAXL, 3};
-        if (c->max_len > MP_TH_MAXL) cls[n_cls++] = ThClass{MP_TH_MAXL, MP_TH_MAXL_WIDE, 4};
+        // Where the mate IS there (most pairs of a clean library) the certificate finds a plane-T bit and the filter runs all the same: the variant
+        // pays only for read sets with many mates that are not (broken pairs, chimeras, contamination).  Whether it does is a property of the read
+        // set, so the context watches the share of instances the last trial certified: below a third it sits out the next 15 calls, then tries again.
+        // (Results do not depend on it: a certificate only ever replaces a filter call that would have said "no".)
+        const char *sw = getenv("MP_DP_THERMO_RESCUE");
+        const bool always = sw && atoi(sw) == 2;                                           // test switch: no sitting out, no minimum size
+        const bool sit_out = !always && c->th_rescue_skip > 0;
+        if (sit_out) c->th_rescue_skip--;
+        else if (n >= 4096 || always) {
+            cls[n_cls++] = ThClass{(uint32_t)MP_MIN_ALIGNABLE_LEN - 1, MP_TH_MAXL, 3};
+            if (c->max_len > MP_TH_MAXL) cls[n_cls++] = ThClass{MP_TH_MAXL, MP_TH_MAXL_WIDE, 4};
+        }
     }
     // every instance in ONE class and no list needed: the single-end windows of a batch of 101 .. 160-base reads (the NT stage's shape)
     const bool one_launch = !rescue_windows && n_cls == 1 && cls[0].kind == 1 && c->min_len > 100 && c->max_len <= MP_TH_MAXL && max_win <= MP_TH_MAXM;
@@ -1392,8 +1400,21 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
                 HIPCHK(hipStreamSynchronize(s));
                 if (n_k == 0) continue;
                 hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, n, c->score_list.p, (const uint32_t *)nullptr);
-                launch_class(cls[k].kind, n_k, (const uint32_t *)c->score_list.p);
-                HIPCHK(hipStreamSynchronize(s));                                 // the list buffer is reused by the next class
+                const uint32_t *lst = c->score_list.p;
+                static const bool sort_lists = !getenv("MP_DP_THERMO_SORT") || atoi(getenv("MP_DP_THERMO_SORT")) != 0;     // 0: measurement switch
+                if (sort_lists && cls[k].kind <= 2 && n_k >= 4096) {
+                    // windows around a seed are read + 2 x margin long: in a class of mixed read lengths the list goes out sorted by window length, so
+                    // that a wavefront's instances need about the same number of rows (the flag / scan buffers are free again: keys in, keys out)
+                    if (c->und_list[0].reserve(n_k + 2)) return MP_ENOMEM;
+                    hipLaunchKernelGGL(thermo_window_key_kernel, dim3(grid_for(n_k, 256)), dim3(256), 0, s, d_tasks, (const uint32_t *)c->score_list.p, n_k, c->sel_flag.p);
+                    size_t tb = 0;
+                    if (hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t *)c->sel_flag.p, c->sel_idx.p, (const uint32_t *)c->score_list.p, c->und_list[0].p, (int)n_k, 0, 10, s) != hipSuccess) return MP_ENODEV;
+                    if (c->cub_tmp.reserve(tb + 256)) return MP_ENOMEM;
+                    if (hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, (const uint32_t *)c->sel_flag.p, c->sel_idx.p, (const uint32_t *)c->score_list.p, c->und_list[0].p, (int)n_k, 0, 10, s) != hipSuccess) return MP_ENODEV;
+                    lst = c->und_list[0].p;
+                }
+                launch_class(cls[k].kind, n_k, lst);
+                HIPCHK(hipStreamSynchronize(s));                                 // the list buffers are reused by the next class
             }
         }
         MP_TRACE(s, "dp_thermo_kernel");
@@ -1407,6 +1428,7 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
         HIPCHK(hipMemcpyAsync(ths, c->th_stats.p, sizeof ths, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         for (int k = 0; k < 4; k++) c->th_total[k] += ths[k];
+        if (rescue_windows && 3 * ths[0] < (unsigned long long)n) c->th_rescue_skip = 15;      // (see above)
         if (n_und) {
             hipLaunchKernelGGL(dp_band_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c->sel_flag.p, c->sel_idx.p, n, c->score_list.p, (const uint32_t *)nullptr);
             census_add(c, CENSUS_FULL_SCORE, d_tasks, c->score_list.p, n_und, 0);
@@ -1782,6 +1804,30 @@ extern "C" int mp_sgdp_batch(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int
     if (out_ops) HIPCHK(hipMemcpy(out_ops, c->ops.p, (size_t)n * ops_stride, hipMemcpyDeviceToHost));
     if (out_ms_fill) *out_ms_fill = f;
     if (out_ms_trace) *out_ms_trace = t;
+    return MP_OK;
+}
+
+// Test hook: the same instances through the BAND scheme of the deep-DP round (block-match pre-filter with its no-table short cuts, band passes, second
+// tier, full table for what is left: run_dp_band) -- scores, start offsets and tie counts must equal mp_sgdp_batch's.  MP_ERANGE where the scheme does
+// not apply (reads longer than 320 bases, windows wider than read + 60, clips below the guard band).
+extern "C" int mp_test_dp_band(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int clip_left, int clip_right, mp_dp_result *out_results)
+{
+    if (!c || !tasks || !out_results || !c->d_reads) return MP_EINVAL;
+    if (n == 0) return MP_OK;
+    HIPCHK(hipSetDevice(c->ix->device));
+    uint32_t max_win = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        if (tasks[t].read_id >= c->n_reads || (tasks[t].strand != 1 && tasks[t].strand != 2)) return MP_EINVAL;
+        if (tasks[t].win_len > MP_DP_MAX_WIN || tasks[t].win_start + tasks[t].win_len > c->ix->n) return MP_ERANGE;
+        max_win = std::max(max_win, tasks[t].win_len);
+    }
+    if (!band_applicable(c, max_win, clip_left, clip_right)) return MP_ERANGE;
+    if (c->tasks_tmp.reserve(n) || c->res_tmp.reserve(n)) return MP_ENOMEM;
+    HIPCHK(hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, c->stream));
+    float f = 0, t = 0;
+    int rc = run_dp_band(c, c->tasks_tmp.p, n, max_win, clip_left, clip_right, c->res_tmp.p, &f, &t, true);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out_results, c->res_tmp.p, (size_t)n * sizeof(mp_dp_result), hipMemcpyDeviceToHost));
     return MP_OK;
 }
 

@@ -90,7 +90,20 @@ __device__ __forceinline__ uint32_t mp_lf(const mp_dev_index &ix, uint32_t idx)
     mp_blk_view v;
     mp_blk_match(q0, q1, q2, q3, c, v);
     // symbols of this block counted: [0, so] -- so + 1 may be 192: the rank up to so, plus the symbol itself
-    return ix.cum[c] + mp_blk_rank(v, so) + 1u;
+    // (the cumulative count by selects: ix.cum[c] with a per-lane c would be a second, dependent load from the argument block in every step)
+    const uint32_t cumc = c == 0 ? ix.cum[0] : c == 1 ? ix.cum[1] : c == 2 ? ix.cum[2] : ix.cum[3];
+    return cumc + mp_blk_rank(v, so) + 1u;
+}
+
+// The same step with the block already in registers (locate_kernel keeps the loads of two walks in flight before it consumes either)
+__device__ __forceinline__ uint32_t mp_lf_blk(const mp_dev_index &ix, uint32_t s, const uint4 &q0, const uint4 &q1, const uint4 &q2, const uint4 &q3)
+{
+    const uint32_t b = s / MP_OCC_SYMS, so = s - b * MP_OCC_SYMS;
+    const uint32_t c = mp_blk_symbol(q1, q2, q3, so);
+    mp_blk_view v;
+    mp_blk_match(q0, q1, q2, q3, c, v);
+    const uint32_t cumc = c == 0 ? ix.cum[0] : c == 1 ? ix.cum[1] : c == 2 ? ix.cum[2] : ix.cum[3];
+    return cumc + mp_blk_rank(v, so) + 1u;
 }
 
 __global__ void occ_query_kernel(mp_dev_index ix, const uint64_t *idx, const uint32_t *sym, uint64_t n, uint64_t *out)
@@ -536,10 +549,9 @@ struct mp_lane_state {
 };
 
 // (94 VGPRs: five waves per SIMD.  Held to 80 registers for a sixth wave, and with two items per lane, the kernel was slower: DESIGN.md section 4)
-// LEAN: the index has none of the optional tables (the layout of an NT chunk: rank blocks, 13-mer table, sampled suffix array) -- the states that
-// read them (pre-filter entries, 16-mer tables, text comparison) are compiled out: the same walk with fewer registers, more wavefronts per SIMD.
-template <bool LEAN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
+// (Measured in round 4 and not kept: a build with the states of the optional tables compiled out for lean chunks -- 67 VGPRs, seven waves per SIMD -- runs the
+// NT stage's seeding at the very same rate, 12.3 ms per 256 Ki pairs and chunk; holding this build to 96 VGPRs for a fifth wave made the human-filter step 5 % slower.)
+__global__ void __launch_bounds__(256)
 seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ lens, uint32_t n_items, uint32_t W, mp_dev_mmp P,
             mp_seed_rec *__restrict__ slabs, uint32_t *__restrict__ seeds_per_rs, uint32_t *__restrict__ hits_per_rs,
             uint32_t *__restrict__ overflow_rs, uint32_t *__restrict__ over_slot, uint32_t overflow_cap, unsigned int *queue, mp_counters *ctr,
@@ -550,9 +562,9 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
     const uint32_t S = mp_scan_stride(W);
     uint32_t *const sl = s_scan + threadIdx.x * (S | 1u);
     const uint32_t n = ix.n;
-    const bool pf = !LEAN && ix.kmer17 && P.seed_min_length >= (int)ix.kmer_k;
+    const bool pf = ix.kmer17 && P.seed_min_length >= (int)ix.kmer_k;
     const uint64_t kmask = (1ull << (2 * ix.kmer_k)) - 1;             // (kmer15x3 and the 16-mer tables exist only with 17-mers)
-    const bool text_ok = !LEAN && ix.sa_dense && ix.sa_dense_shift == 0;
+    const bool text_ok = ix.sa_dense && ix.sa_dense_shift == 0;
     const uint32_t cum0 = ix.cum[0], cum1 = ix.cum[1], cum2 = ix.cum[2], cum3 = ix.cum[3];
     mp_lane_events ev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mp_lane_state s;
@@ -614,10 +626,10 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 if (kind == MK_BEGIN && s.aux == 0) alen = lens[s.rs >> 1];
             } else if (kind != MK_NONE) {
                 const uint32_t *p = reinterpret_cast<const uint32_t *>(s.ptr);
-                const bool one = LEAN ? s.aux != 0 : (kind == MK_SA || (kind == MK_PRE && !ix.kmer15x3) || (kind == MK_LKT13 && s.aux));      // (LEAN: the only word loads are the 13-mer table's)
+                const bool one = kind == MK_SA || (kind == MK_PRE && !ix.kmer15x3) || (kind == MK_LKT13 && s.aux);
                 a0 = p[0];
                 a1 = p[one ? 0 : 1];
-                if (!LEAN && kind == MK_PRE && ix.kmer15x3) { const uint2 e2 = *reinterpret_cast<const uint2 *>(ix.kmer15x3 + s.aux); b0 = e2.x; b1 = e2.y; }
+                if (kind == MK_PRE && ix.kmer15x3) { const uint2 e2 = *reinterpret_cast<const uint2 *>(ix.kmer15x3 + s.aux); b0 = e2.x; b1 = e2.y; }
             }
         }
         // the one wait of the trip: everything issued above (and the stores of the trip before) has landed
@@ -643,11 +655,11 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 }
                 s.aux++;
                 if (s.aux * 16u < S) { next = MK_BEGIN; s.ptr = reinterpret_cast<const uint4 *>(s.ptr) + 4; }
-            } else if (kind == MK_LKT13 || (!LEAN && (kind == MK_LKT16 || kind == MK_LKT16U))) {
+            } else if (kind == MK_LKT13 || kind == MK_LKT16 || kind == MK_LKT16U) {
                 // LKT (re)start: the table stands for the first 13 (16) bases of the seed
                 uint32_t nextl, nextr;
                 int k;
-                if (LEAN || kind == MK_LKT13) { nextl = s.aux ? 1u : a0 + 1; nextr = a1; k = MP_LKT_K - 1; ev.lkt++; }
+                if (kind == MK_LKT13) { nextl = s.aux ? 1u : a0 + 1; nextr = a1; k = MP_LKT_K - 1; ev.lkt++; }
                 else {
                     if (kind == MK_LKT16U) { nextl = q0.x; nextr = q0.y; } else { nextl = a0 + 1; nextr = a1; }
                     k = 15; ev.lkt16++; ev.skipped += 3;                  // the three extension steps the table stands for
@@ -656,7 +668,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 if (nextl <= nextr) {
                     s.l = nextl; s.r = nextr; ++s.seed_len; ++s.i;
                     if (s.i >= s.len) fin = true;
-                    else if (!LEAN && kind == MK_LKT16U && nextl == nextr && q0.z != 0xFFFFFFFFu) {
+                    else if (kind == MK_LKT16U && nextl == nextr && q0.z != 0xFFFFFFFFu) {
                         // a 16-mer that occurs once: the entry says where, and what stands in front of it -- compared right away
                         s.upos = q0.z; s.uvalid = true; trev = q0.w; text_now = true;
                     }
@@ -687,11 +699,11 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                         if (s.i >= s.len) fin = true;
                     } else mid_close = true;
                 }
-            } else if (!LEAN && kind == MK_SA) {
+            } else if (kind == MK_SA) {
                 // the text position of a match whose range became a single row: from here on it is extended by comparing with the text
                 s.upos = a0; s.uvalid = true;
                 if (a0 == 0) { mid_close = true; ev.skipped++; }           // the text starts here: what the failing rank query reports
-            } else if (!LEAN && kind == MK_TEXT) {
+            } else if (kind == MK_TEXT) {
                 const uint32_t pend = s.upos - 1;                          // text base that must equal scan base s.i
                 uint32_t t16;                                               // text bases pend-15 .. pend, LSB-first
                 if (pend >= 15) t16 = (uint32_t)((((uint64_t)a1 << 32) | a0) >> (2 * ((pend - 15) & 15)));
@@ -700,7 +712,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 trev = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);    // text base pend in bits 1:0, pend - 1 in 3:2, ...
                 text_now = true; ev.text++;
             }
-            if (!LEAN && text_now) {
+            if (text_now) {
                 // The next base of the backward search is the text base in front of the match, 16 of them per word instead of one
                 // rank block each.  The range cannot shrink any more (the re-seed bookkeeping stands still) and the seed is
                 // reported by its text position (MP_SEED_LOCATED).
@@ -736,7 +748,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                     const uint64_t win = off < 16 ? (((uint64_t)w1 << 32) | w0) : (((uint64_t)w2 << 32) | w1);
                     return win >> (2 * (off & 15));
                 };
-                if (!LEAN && kind == MK_PRE) {
+                if (kind == MK_PRE) {
                     // what just arrived, as one bit per position: is the 17-mer that starts there anywhere in the text?  s.nf = present
                     // bits (low half) and known bits (high half) of the positions pg .. pg + 15; the two entries answer three positions each,
                     // from the offsets the lane chose when it asked (kept in s.nf meanwhile)
@@ -807,7 +819,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                     }
                     if (start_here) {
                         const uint32_t key16 = (uint32_t)bases_at(s.i);
-                        if (!LEAN && pf && ix.lkt16 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
+                        if (pf && ix.lkt16 && (key16 & (MP_LKT_ENTRIES - 1)) != 0) {
                             // the 17-mer is reachable, so its first 16 bases are: their SA range straight from the 16-mer table instead of
                             // the 13-mer table and three extension steps (all below seed_min_length, none observable).  Keys whose 13
                             // rightmost bases are 'A' keep the 13-mer path (kernels_index.hip, lkt16_hist_kernel).
@@ -904,30 +916,84 @@ expand_hits_kernel(const mp_seed_rec *__restrict__ slabs, const uint32_t *__rest
     }
 }
 
+// One lane walks TWO hits at once (t and t + half): an LF step is one dependent 64-byte gather and a wavefront that waits for ONE of them per
+// lane spends 78 % of its time parked (profiles/r04_nt_pmc_sq_counters.json: 1.27 TB/s, 37 % of the gather rate the seeding kernel reaches in the
+// same chunks).  Both blocks are requested before either is used; the walks are independent, so the order of the results is unchanged.
 __global__ void __launch_bounds__(256)
 locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint32_t *__restrict__ hit_row, uint32_t n_tasks,
               const uint32_t *__restrict__ lens, mp_dev_mmp P, mp_seed_hit *__restrict__ hits, mp_counters *ctr)
 {
+    const uint32_t half = (n_tasks + 1) / 2;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t my_lf = 0;
-    if (t < n_tasks) {
-        const mp_sa_seed s = seeds[t];
-        const uint32_t read = s.read_strand >> 1, strand = s.read_strand & 1;
-        const uint32_t len = lens[read];
-        uint32_t steps = 0;
-        const bool located = s.sa_diff == MP_SEED_LOCATED;          // the seeding kernel already knows the text position
-        const uint64_t sav = located ? (uint64_t)hit_row[t] : mp_sa_value(ix, hit_row[t], &steps);
-        my_lf = steps;
-        const uint32_t off = s.query_offset, seedlen = s.seed_len;
-        // unsigned 64-bit arithmetic: the projection may wrap exactly as in the reference (DV-DPfunctions.cpp:2489)
-        const uint64_t target = strand == 0 ? sav - off : sav - ((uint64_t)len - seedlen - off);
-        mp_seed_hit h;
-        h.offset = target;
-        h.length = (uint16_t)seedlen;
-        h.qo = (uint16_t)off;
-        h.strand = (uint16_t)strand;
-        h.mult = (seedlen >= (uint32_t)P.good_seed_len || seedlen >= len / 2 || located) ? (uint16_t)1 : (uint16_t)(s.sa_diff + 1);
-        hits[t] = h;
+    if (t < half) {
+        const uint32_t tt[2] = {t, t + half};
+        const bool have[2] = {true, t + half < n_tasks};
+        mp_sa_seed sd[2];
+        uint32_t idx[2] = {0, 0}, steps[2] = {0, 0};
+        bool located[2] = {true, true};
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (have[k]) { sd[k] = seeds[tt[k]]; idx[k] = hit_row[tt[k]]; located[k] = sd[k].sa_diff == MP_SEED_LOCATED; }    // located: the seeding kernel already knows the text position
+        uint64_t sav[2] = {0, 0};
+        const bool pow2 = !ix.sa_dense && ix.sa_shift != 0xFFFFFFFFu;
+        if (pow2) {
+            // sampled rows every 2^k: the two walks side by side
+            const uint32_t mask = ix.sa_interval - 1;
+            bool walk[2] = {have[0] && !located[0] && (idx[0] & mask) != 0, have[1] && !located[1] && (idx[1] & mask) != 0};
+            while (walk[0] || walk[1]) {
+                uint4 q[2][4];
+                uint32_t sym_at[2] = {0, 0};
+                bool load[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    load[k] = walk[k] && idx[k] != ix.inv_sa0;              // (the '$' row: LF = 0 without a look-up)
+                    if (load[k]) {
+                        uint32_t kk = idx[k] + 1;
+                        kk -= (kk > ix.inv_sa0);
+                        sym_at[k] = kk - 1;
+                        const uint4 *p = reinterpret_cast<const uint4 *>(ix.occ + sym_at[k] / MP_OCC_SYMS);
+                        q[k][0] = p[0]; q[k][1] = p[1]; q[k][2] = p[2]; q[k][3] = p[3];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                    if (walk[k]) {
+                        idx[k] = load[k] ? mp_lf_blk(ix, sym_at[k], q[k][0], q[k][1], q[k][2], q[k][3]) : 0u;
+                        steps[k]++;
+                        walk[k] = (idx[k] & mask) != 0;
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if (have[k]) {
+                    const uint32_t qq = idx[k] >> ix.sa_shift;
+                    // SA[0] is kept as -1 so that walking through the '$' row yields text position `steps - 1` (BWT.c:242,994-996)
+                    sav[k] = located[k] ? (uint64_t)idx[k] : (qq == 0 ? ~0ull : (uint64_t)ix.sa[qq]) + steps[k];
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if (have[k]) sav[k] = located[k] ? (uint64_t)idx[k] : mp_sa_value(ix, idx[k], &steps[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (!have[k]) continue;
+            const mp_sa_seed s = sd[k];
+            const uint32_t read = s.read_strand >> 1, strand = s.read_strand & 1;
+            const uint32_t len = lens[read];
+            my_lf += steps[k];
+            const uint32_t off = s.query_offset, seedlen = s.seed_len;
+            // unsigned 64-bit arithmetic: the projection may wrap exactly as in the reference (DV-DPfunctions.cpp:2489)
+            const uint64_t target = strand == 0 ? sav[k] - off : sav[k] - ((uint64_t)len - seedlen - off);
+            mp_seed_hit h;
+            h.offset = target;
+            h.length = (uint16_t)seedlen;
+            h.qo = (uint16_t)off;
+            h.strand = (uint16_t)strand;
+            h.mult = (seedlen >= (uint32_t)P.good_seed_len || seedlen >= len / 2 || located[k]) ? (uint16_t)1 : (uint16_t)(s.sa_diff + 1);
+            hits[tt[k]] = h;
+        }
     }
     // one counter update per block: a single address takes only ~100 M atomics per second chip-wide, and a launch of
     // 57 M hits has 890 k wavefronts

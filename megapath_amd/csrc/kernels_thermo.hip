@@ -314,6 +314,14 @@ dp_thermo_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__
     dp_thermo_body<T, LPS, MARGIN, RUNLESS, MAXM_P>(text, reads, lens, Wr, tasks, n_tasks, cert, list, stats);
 }
 
+// key[s] = window length of the instance in slot s of a class list: a wavefront sweeps as many rows as the LONGEST window among its instances, so the
+// lists of classes with mixed read lengths are handed over sorted by window length (run_dp_filtered)
+__global__ void thermo_window_key_kernel(const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ list, uint32_t n, uint32_t *__restrict__ key)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) key[s] = tasks[list[s]].win_len;
+}
+
 // flag[t] = 1 for the instances the certificate left undecided; the certified ones get the filter's answer "score 0"
 __global__ void thermo_flag_kernel(const uint8_t *__restrict__ cert, uint32_t n, uint32_t *__restrict__ flag, mp_fill_result *__restrict__ fill)
 {

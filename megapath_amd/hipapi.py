@@ -106,7 +106,7 @@ class IndexInfo(C.Structure):
 
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_clone", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_target_chr", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy", "mp_ctx_set_index",
-           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_thermo", "mp_ctx_dp_thermo_stats", "mp_test_dp_thermo", "mp_test_dp_thermo_kind", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
+           "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_test_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_thermo", "mp_ctx_dp_thermo_stats", "mp_test_dp_thermo", "mp_test_dp_thermo_kind", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
            "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_ctx_set_hit_copies", "mp_reduce_begin", "mp_reduce_chunk", "mp_reduce_finish", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_strerror",
            "mp_test_sort_longer_seed", "mp_coverage_create", "mp_coverage_destroy", "mp_coverage_add", "mp_coverage_finish", "mp_coverage_seq_stats",
            "mp_coverage_spike_intervals", "mp_coverage_spike_bases", "mp_build_index_arrays"]
@@ -175,6 +175,7 @@ def load_library():
     lib.mp_index_prefilter3.argtypes = [vp, vp, C.c_uint64, vp]
     lib.mp_ctx_set_prefilter.argtypes = [vp, C.c_int]
     lib.mp_ctx_set_dp_band.argtypes = [vp, C.c_int]
+    lib.mp_test_dp_band.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, vp]
     lib.mp_ctx_dp_band_stats.argtypes = [vp, u64p, u64p]
     lib.mp_ctx_set_dp_census.argtypes = [vp, C.c_int]
     lib.mp_ctx_set_dp_thermo.argtypes = [vp, C.c_int]
@@ -478,6 +479,20 @@ class Context:
         f, t = C.c_float(), C.c_float()
         _chk(load_library().mp_sgdp_batch(self._h, tasks_np.ctypes.data, n, clip_left, clip_right, res.ctypes.data, None, 0, C.byref(f), C.byref(t)), "mp_sgdp_batch")
         return res["score"][:n].copy()
+
+    def sgdp_results(self, tasks_np: np.ndarray, clip_left: int, clip_right: int, band: bool = False) -> np.ndarray:
+        """(score, hit_loc, max_score_count) of a numpy array of DP_TASK_DTYPE records: band=False the full-table kernels (mp_sgdp_batch), band=True
+        the band scheme of the deep-DP round with its pre-filter short cuts (test hook mp_test_dp_band)"""
+        assert tasks_np.dtype == DP_TASK_DTYPE and tasks_np.flags.c_contiguous
+        n = len(tasks_np)
+        res = np.zeros(max(n, 1), dtype=np.dtype([("score", "<i4"), ("hit_loc", "<u4"), ("max_score_count", "<u4"), ("n_ops", "<u4")]))
+        lib = load_library()
+        if band:
+            _chk(lib.mp_test_dp_band(self._h, tasks_np.ctypes.data, n, clip_left, clip_right, res.ctypes.data), "mp_test_dp_band")
+        else:
+            f, t = C.c_float(), C.c_float()
+            _chk(lib.mp_sgdp_batch(self._h, tasks_np.ctypes.data, n, clip_left, clip_right, res.ctypes.data, None, 0, C.byref(f), C.byref(t)), "mp_sgdp_batch")
+        return res[:n]
 
     def set_dp_census(self, on: bool):
         _chk(load_library().mp_ctx_set_dp_census(self._h, int(bool(on))), "mp_ctx_set_dp_census")

@@ -44,7 +44,9 @@ for rnd in range(args.rounds):
                # which optional index tables the run may build (every combination takes another path through the seeding kernels)
                env={k: str(int(v)) for k, v in (("MP_KMER_FILTER", rng.choice([0, 1, 1, 1, 16])), ("MP_KMER15", rng.random() < 0.7), ("MP_LKT16", rng.random() < 0.7),
                                                 ("MP_SA_DENSE", rng.random() < 0.7), ("MP_LKT16U", rng.random() < 0.7), ("MP_SA_DENSE_SPACING", rng.choice([1, 1, 2, 4])),
-                                                ("MP_DP_DIAG", rng.random() < 0.8), ("MP_DP_ONE_MISMATCH", rng.choice([0, 1, 2, 2, 2])), ("MP_DP_RESCUE_BAND", rng.random() < 0.8), ("MP_MERGE_ROWS", rng.random() < 0.8))},
+                                                ("MP_DP_DIAG", rng.random() < 0.8), ("MP_DP_ONE_MISMATCH", rng.choice([0, 1, 2, 2, 2])), ("MP_DP_RESCUE_BAND", rng.random() < 0.8), ("MP_MERGE_ROWS", rng.random() < 0.8),
+                                                # round 4: the certificate's variants for short reads / mate-rescue windows; -b with resident chunks through the device reduction or every chunk's lists
+                                                ("MP_DP_THERMO_MORE", rng.random() < 0.75), ("MP_BAM_HOST_MERGE", rng.random() < 0.3))},
                kw=dict(sub=float(rng.choice([0.0, 0.005, 0.01, 0.03, 0.06])), ins=float(rng.choice([0.0, 0.001, 0.004])), dele=float(rng.choice([0.0, 0.001, 0.004])),
                        random_frac=float(rng.choice([0.0, 0.05, 0.3])), broken_mate_frac=float(rng.choice([0.0, 0.1, 0.3])),
                        noisy_mate_frac=float(rng.choice([0.0, 0.2])), noisy_sub=0.15, n_frac=float(rng.choice([0.0, 0.002])),
@@ -54,7 +56,9 @@ for rnd in range(args.rounds):
                        frag_mean=read_len + 200, frag_sd=40, frag_min=read_len + 20, frag_max=min(740, read_len + 420)))
     print("round %d: %r" % (rnd, cfg), flush=True)
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
-        n_chunks = cfg["chunks"] if not cfg["bam"] else 0
+        n_chunks = cfg["chunks"]
+        if cfg["env"].get("MP_BAM_HOST_MERGE") == "0":
+            del cfg["env"]["MP_BAM_HOST_MERGE"]           # (the switch is "set or not set")
         genome = synth.random_genome(cfg["n_bases"], cfg["gseed"], n_seqs=max(cfg["n_seqs"], n_chunks), repeat_frac=cfg["rep"])
         prefix = os.path.join(tmp, "g.index")
         if n_chunks:
@@ -91,7 +95,10 @@ for rnd in range(args.rounds):
                 p = O.default_params(L=L, mode=cfg["mode"], nc=(c == 0))
                 set_ini(p, cfg["ini"])
                 st = O.AlignStats()
-                assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), want.encode(), None, C.byref(st)) == 0
+                if cfg["bam"]:      # every run of the chain writes the same -o prefix (runMegaPath.sh:199): the last chunk's BAM records remain
+                    assert lib.mpo_align_fastq_bam(ix, C.byref(p), in1.encode(), in2.encode(), want.encode(), None, os.path.join(tmp, "obam").encode(), 1, b"rg1", C.byref(st)) == 0
+                else:
+                    assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), want.encode(), None, C.byref(st)) == 0
                 lib.mpo_index_close(ix)
                 if c + 1 < n_chunks:
                     lines = open(want, "rb").read().split(b"\n")

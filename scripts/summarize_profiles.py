@@ -9,7 +9,7 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(out_dir, "summary")
 os.makedirs(dst, exist_ok=True)
-OURS = ("census", "dp_thermo_kernel", "thermo_flag", "single_hit", "rescue_hit", "seed_kernel", "seed_overflow_kernel", "expand_hits_kernel", "locate_kernel", "merge_kernel", "pair_kernel", "dp_fill_kernel", "dp_score_kernel", "dp_band_kernel", "dp_band_select", "dp_prefilter_kernel", "dp_class_flag", "dp_band_classify", "dp_band_list", "dp_select_kernel", "dp_compact_kernel", "dp_scatter_kernel", "dp_trace_kernel",
+OURS = ("reduce_", "floor_", "cand_first", "dp_len_class", "dp_nonempty", "dp_gather_tasks", "dp_scatter_list", "census", "dp_thermo_kernel", "thermo_flag", "single_hit", "rescue_hit", "seed_kernel", "seed_overflow_kernel", "expand_hits_kernel", "locate_kernel", "merge_kernel", "pair_kernel", "dp_fill_kernel", "dp_score_kernel", "dp_band_kernel", "dp_band_select", "dp_prefilter_kernel", "dp_class_flag", "dp_band_classify", "dp_band_list", "dp_select_kernel", "dp_compact_kernel", "dp_scatter_kernel", "dp_trace_kernel",
         "dp_ops_fix_kernel", "build_left_tasks", "build_right_tasks", "collect_pair_hits", "gather64_kernel", "prep_scan_kernel", "mark_done", "failed_flag",
         "list_failed", "single_cand", "single_task", "mate_rescue_task", "occ_count_kernel", "occ_build_kernel", "text_build_kernel", "lkt_hist_kernel")
 
@@ -31,8 +31,8 @@ if line:
 
 # ---- VALU counters of the DP kernels (pass 4)
 import collections
-for sub, suffix, cmd in (("valu", "", "python3 bench.py --pmc-child --steps 1 --warmup 0"),
-                         ("valu_nt2", "_nt2_ini", "python3 bench.py --pmc-child --steps 1 --warmup 0 --ini soap4-nt2.ini --L 151 (17-base seeds: the single-end rescue at work)")):
+for sub, suffix, cmd in (("valu", "", "python3 bench.py --pmc-child nt (one single-context step of the headline batch through 3 chunks)"),
+                         ("valu_human", "_human_filter", "python3 bench.py --pmc-child human (one step of the human-filter leg: ONE 2.95 Gbp index, every optional table, soap4.ini)")):
   cc = newest(os.path.join(out_dir, sub, "**", "*counter_collection.csv"))
   kt = newest(os.path.join(out_dir, sub, "**", "*kernel_trace.csv"))
   if cc and kt:

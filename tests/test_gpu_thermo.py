@@ -23,19 +23,21 @@ def _make_instances(rng, text, n, kinds, lo=101, hi=160, margin=30):
         win = text[ws:ws + m]
         k = int(kinds[rng.integers(0, len(kinds))])
         rd = rng.integers(0, 4, L).astype(np.uint8)
+        if L < 70 and k in (1, 2, 4):
+            k = 7           # (the planted shapes below need room: short reads get the plain run of 12 .. 26 instead)
         if k in (0, 7):     # a chance seed: a run of 17 .. 19 (7: 12 .. 26) on the seed's diagonal, nothing else
             r = int(rng.integers(17, 20)) if k == 0 else int(rng.integers(12, 27)); j0 = int(rng.integers(0, L - r + 1))
-            rd[j0:j0 + r] = win[margin + j0:30 + j0 + r]
+            rd[j0:j0 + r] = win[margin + j0:margin + j0 + r]
         elif k == 1:        # near the cutoff: the run, then a second exact stretch right after a mismatch or a short gap (same or shifted diagonal)
             r = int(rng.integers(14, 24)); e = int(rng.integers(5, 20)); sh = int(rng.integers(-3, 4))
             j0 = int(rng.integers(0, L - r - e - 8)); j1 = j0 + r + 1 + max(0, -sh)
-            rd[j0:j0 + r] = win[margin + j0:30 + j0 + r]
-            rd[j1:j1 + e] = win[margin + sh + j1:30 + sh + j1 + e]
+            rd[j0:j0 + r] = win[margin + j0:margin + j0 + r]
+            rd[j1:j1 + e] = win[margin + sh + j1:margin + sh + j1 + e]
         elif k == 2:        # as 1 but the second stretch BEFORE the run
             r = int(rng.integers(14, 24)); e = int(rng.integers(5, 20)); sh = int(rng.integers(-3, 4))
             j0 = int(rng.integers(e + 8, L - r)); j1 = j0 - 1 - e - max(0, sh)
-            rd[j0:j0 + r] = win[margin + j0:30 + j0 + r]
-            rd[j1:j1 + e] = win[margin + sh + j1:30 + sh + j1 + e]
+            rd[j0:j0 + r] = win[margin + j0:margin + j0 + r]
+            rd[j1:j1 + e] = win[margin + sh + j1:margin + sh + j1 + e]
         elif k == 3:        # a true alignment with a few mismatches and possibly an indel
             rd = win[margin:margin + L].copy()
             for _ in range(int(rng.integers(0, 12))):
@@ -45,15 +47,15 @@ def _make_instances(rng, text, n, kinds, lo=101, hi=160, margin=30):
                 rd = np.concatenate([rd[:p], rd[p + g:], rng.integers(0, 4, g).astype(np.uint8)]) if rng.random() < 0.5 else np.concatenate([rd[:p], rng.integers(0, 4, g).astype(np.uint8), rd[p:L - g]])
         elif k == 4:        # stretches on both sides of the run, and a partial alignment of ~ cutoff matches with mismatches inside
             r = int(rng.integers(12, 20)); j0 = int(rng.integers(15, L - r - 15))
-            rd[j0:j0 + r] = win[margin + j0:30 + j0 + r]
+            rd[j0:j0 + r] = win[margin + j0:margin + j0 + r]
             a = int(rng.integers(4, 14)); b = int(rng.integers(4, 14))
-            rd[j0 - 1 - a:j0 - 1] = win[margin + j0 - 1 - a:30 + j0 - 1]
-            rd[j0 + r + 1:j0 + r + 1 + b] = win[margin + j0 + r + 1:30 + j0 + r + 1 + b]
+            rd[j0 - 1 - a:j0 - 1] = win[margin + j0 - 1 - a:margin + j0 - 1]
+            rd[j0 + r + 1:j0 + r + 1 + b] = win[margin + j0 + r + 1:margin + j0 + r + 1 + b]
         elif k == 5:        # low complexity: read and window share a short tandem repeat (many diagonals match)
             unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.uint8)
             rep = np.tile(unit, 300)
             a = int(rng.integers(0, min(40, L - 25))); b = min(int(rng.integers(20, 90)), L - a)
-            win = win.copy(); win[margin + a:30 + a + b] = rep[:b]
+            win = win.copy(); win[margin + a:margin + a + b] = rep[:b]
             text[ws:ws + m] = win
             rd[a:a + b] = rep[:b]
         # k == 6: a random read (no run: not eligible)
@@ -191,8 +193,9 @@ def test_rescue_window_certificate_never_rejects_an_alignment(kinds, seed, lo, h
 
 
 @pytest.mark.parametrize("read_len,len_range", [(151, None), (250, None), (300, (75, 300)), (100, (40, 100))])
-def test_rescue_round_equal_with_and_without_certificate(read_len, len_range):
+def test_rescue_round_equal_with_and_without_certificate(read_len, len_range, monkeypatch):
     """the product path: the same single-end and mate-rescue hits with the certificate on and off (17-base seeds, many random and broken mates)"""
+    monkeypatch.setenv("MP_DP_THERMO_RESCUE", "2")        # the mate-rescue variant whatever the batch size and its last trial's yield (run_dp_filtered)
     import ctypes as C
     from megapath_amd import hipapi as H, index_builder, synth
     genome = synth.random_genome(3000000, 77, n_seqs=2, repeat_frac=0.05)

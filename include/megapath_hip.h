@@ -148,6 +148,8 @@ typedef struct {
                                     * hit that was not already reported by its text position, is read by locate -- or, when the whole suffix
                                     * array is resident, by the merge kernel, which then makes its keys straight from the seed records
                                     * (ms_locate = 0: no expand / locate launch) */
+    uint64_t n_lf_steps;           /* LF steps of the locate kernel (one rank block each; they are part of n_occ and n_occ_loaded): what is left of
+                                    * n_occ_loaded are the seeding kernel's own blocks */
 } mp_seed_stats;
 
 int mp_seed_batch(mp_ctx *ctx, const mp_mmp_params *params, mp_seed_stats *out_stats);

@@ -975,6 +975,7 @@ extern "C" int mp_seed_batch(mp_ctx *c, const mp_mmp_params *params, mp_seed_sta
     st.n_seeds = h.n_seeds; st.n_prefilter = h.n_kmer; st.n_occ_loaded = h.n_occ_loaded;
     st.n_lkt16 = h.n_lkt16; st.n_prefilter_loads = h.n_kmer_loads; st.n_text_words = h.n_text_words; st.n_steps_skipped = h.n_steps_skipped;
     st.n_sa_seed_kernel = h.n_sa;
+    st.n_lf_steps = h.n_lf;
     float ms_over = 0;
     (void)hipEventElapsedTime(&st.ms_seed, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&ms_over, c->ev[8], c->ev[9]);     // items redone with the full-size slab belong to K1
@@ -1361,7 +1362,9 @@ int run_dp_filtered(mp_ctx *c, const mp_dp_task *d_tasks, uint32_t n, uint32_t m
         const bool always = sw && atoi(sw) == 2;                                           // test switch: no sitting out, no minimum size
         const bool sit_out = !always && c->th_rescue_skip > 0;
         if (sit_out) c->th_rescue_skip--;
-        else if (n >= 4096 || always) {
+        else if (n >= 65536 || always) {
+            // (a launch of this variant takes ~0.45 ms however few instances it gets -- 782 dependent steps per wavefront --, the filter 21 ns per instance: below
+            // some ten thousand instances the filter alone is faster even where every instance would be certified)
             cls[n_cls++] = ThClass{(uint32_t)MP_MIN_ALIGNABLE_LEN - 1, MP_TH_MAXL, 3};
             if (c->max_len > MP_TH_MAXL) cls[n_cls++] = ThClass{MP_TH_MAXL, MP_TH_MAXL_WIDE, 4};
         }

@@ -1006,7 +1006,7 @@ locate_kernel(mp_dev_index ix, const mp_sa_seed *__restrict__ seeds, const uint3
         for (int w = 0; w < 256 / MP_WAVE; w++) lf += s_lf[w];
         // an LF step is one rank query = one rank block (mp_lf).  Suffix-array reads are not counted here (one atomic per
         // block on one address would cost more than the kernel): n_sa = hits - located seeds, known after seed_kernel
-        if (lf) { atomicAdd(&ctr->n_occ, (unsigned long long)lf); atomicAdd(&ctr->n_occ_loaded, (unsigned long long)lf); }
+        if (lf) { atomicAdd(&ctr->n_occ, (unsigned long long)lf); atomicAdd(&ctr->n_occ_loaded, (unsigned long long)lf); atomicAdd(&ctr->n_lf, (unsigned long long)lf); }
     }
     if (t == 0) atomicAdd(&ctr->n_hits, (unsigned long long)n_tasks);
 }

@@ -117,7 +117,7 @@ struct mp_dev_mmp {
 
 struct mp_counters {           // device-side event counters
     unsigned long long n_occ, n_lkt, n_sa, n_seeds, n_hits, n_seedpos, n_cand, overflow, n_kmer, n_occ_loaded;
-    unsigned long long n_lkt16, n_kmer_loads, n_text_words, n_steps_skipped, n_located, n_wave_trips, n_lane_trips;
+    unsigned long long n_lkt16, n_kmer_loads, n_text_words, n_steps_skipped, n_located, n_wave_trips, n_lane_trips, n_lf;
 };
 
 struct mp_hit_task { uint32_t seed_slot; uint32_t k; };                         // one SA row to locate

@@ -44,7 +44,7 @@ class SeedStats(C.Structure):
     _fields_ = [("n_occ", C.c_uint64), ("n_lkt", C.c_uint64), ("n_sa", C.c_uint64), ("n_seeds", C.c_uint64),
                 ("n_hits", C.c_uint64), ("n_seedpos", C.c_uint64), ("ms_seed", C.c_float), ("ms_locate", C.c_float),
                 ("ms_merge", C.c_float), ("reserved", C.c_float), ("n_prefilter", C.c_uint64), ("n_occ_loaded", C.c_uint64),
-                ("n_lkt16", C.c_uint64), ("n_prefilter_loads", C.c_uint64), ("n_text_words", C.c_uint64), ("n_steps_skipped", C.c_uint64), ("n_sa_seed_kernel", C.c_uint64)]
+                ("n_lkt16", C.c_uint64), ("n_prefilter_loads", C.c_uint64), ("n_text_words", C.c_uint64), ("n_steps_skipped", C.c_uint64), ("n_sa_seed_kernel", C.c_uint64), ("n_lf_steps", C.c_uint64)]
 
 
 class DpCensus(C.Structure):

@@ -24,12 +24,16 @@ arrs = index_builder.build_index_arrays([("chr%d" % (i + 1), tc[b[i]:b[i + 1]]) 
 del tc
 torch.cuda.empty_cache()
 gix = H.Index.from_arrays(0, **arrs)
-lw = bench.Workload(text, 1 << 18, seed=2000, **sims[leg])
-par = H.AlignParams(lw.max_len, 750, 130, 130, H.MmpParams.nt2())
+if leg == "human_filter":
+    lw = bench.Workload(text, 1 << 20, seed=1000, read_len=150, L=150)
+    par = H.AlignParams(lw.max_len, 750, 130, 130, H.MmpParams.human())
+else:
+    lw = bench.Workload(text, 1 << 18, seed=2000, **sims[leg])
+    par = H.AlignParams(lw.max_len, 750, 130, 130, H.MmpParams.nt2())
 ctx = H.Context(gix)
 ctx.set_dp_thermo(level)
 bench.step(ctx, lw, par)
-el, la = bench.run_steps(ctx, lw, par, 2)
-print(leg, "thermo level", level, "pairs/s", round(2 * lw.n_pairs / el), {k[3:]: round(la[k] / 2, 2) for k in la if k.startswith("ms_")}, "thermo stats", ctx.dp_thermo_stats())
+el, la = bench.run_steps(ctx, lw, par, 4)
+print(leg, "thermo level", level, "pairs/s", round(4 * lw.n_pairs / el), {k[3:]: round(la[k] / 4, 2) for k in la if k.startswith("ms_")}, "thermo stats", ctx.dp_thermo_stats())
 ctx.close()
 gix.close()

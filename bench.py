@@ -461,38 +461,72 @@ NT_KEYS = ("seed", "locate", "merge", "pair", "fill", "trace", "rescue_tasks", "
 NT_EVENTS = ("n_occ_loaded", "n_lkt", "n_sa", "n_seedpos", "n_seeds", "n_hits", "n_lf_steps")
 
 
-def nt_step(ctx, wl, chunks, params, acc=None, bam=True, mode=1):
+TOP_FLOOR = 0 if os.environ.get("MP_TOP_FLOOR") == "0" else 95          # the NT stage runs with -top 95 (runMegaPath.sh:199); MP_TOP_FLOOR=0: one pass, every rescue round in full
+
+
+def nt_step(ctx, wl, chunks, params, acc=None, bam=True, mode=1, top_floor=TOP_FLOOR):
     """One batch through every resident chunk, as bin/soap4-mi355x runs the NT stage's command line (`-b ... -F -top 95`, runMegaPath.sh:199):
     upload of the packed reads; per chunk the deep-DP round, the rescue round and the reduction of the chunk's hits to per-mate
     (reference, score) keys on the device; the LAST chunk's three hit lists also travel to the host (the BAM side files that remain after
-    the chain are the last chunk's); after the last chunk one sort of the batch's keys and their way to pinned host memory."""
+    the chain are the last chunk's); after the last chunk one sort of the batch's keys and their way to pinned host memory.  With more than one chunk the
+    executable makes two passes (the -top rule across chunks: the rescue rounds start once the best score of every read over the deep-DP rounds of ALL chunks is
+    known, and leave out the pairs whose rescue work cannot reach top% of it) -- same output, see kernels_floor.hip."""
     n_chunks = len(chunks)
     ctx.set_reads(wl.packed_np, wl.lens_np)
     ctx.reduce_begin(n_chunks)
     cls = np.zeros(wl.n_pairs + 1, dtype=np.uint8)
-    for ci, ix in enumerate(chunks):
+
+    def note(ci, st, nh, rst, red):
+        if acc is None:
+            return
+        grp = acc["source_chunk" if ci == 0 else "other_chunks"]
+        if st is not None:
+            for k, v in zip(NT_KEYS[:6], (st.seed.ms_seed, st.seed.ms_locate, st.seed.ms_merge, st.ms_pair, st.ms_dp_fill, st.ms_dp_trace)):
+                grp[k] = grp.get(k, 0.0) + float(v)
+            for k in NT_EVENTS:
+                grp[k] = grp.get(k, 0) + int(getattr(st.seed, k))
+            grp["pair_hits"] = grp.get("pair_hits", 0) + int(nh)
+            grp["chunks"] = grp.get("chunks", 0) + 1
+        if rst is not None:
+            for k, v in zip(NT_KEYS[6:], (rst.ms_tasks, rst.ms_dp_fill, rst.ms_dp_trace)):
+                grp[k] = grp.get(k, 0.0) + float(v)
+            for k, v in (("single_dp_tasks", rst.n_single_tasks), ("single_hits", rst.n_single_hits), ("rescue_hits", rst.n_rescue_hits), ("failed_pairs", rst.n_failed_pairs),
+                         ("floor_pairs", rst.n_floor_pairs), ("floor_tasks", rst.n_floor_tasks)):
+                grp[k] = grp.get(k, 0) + int(v)
+        grp["entries"] = grp.get("entries", 0) + int(red[3])
+
+    def whole(ci):
         last = ci + 1 == n_chunks
-        ctx.set_index(ix)
+        ctx.set_index(chunks[ci])
         ctx.set_hit_copies(bam and last)
         _, nh, st = ctx.deep_dp_round(params, fetch=False)
         _, _, rst = ctx.rescue_round(params, False, fetch=False)
         red = ctx.reduce_chunk(mode, ci, cls if last else None)
         if bam and last:
             ctx.pair_hits_view(); ctx.single_hits_view(); ctx.rescue_hits_view()
-        if acc is None:
-            continue
-        grp = acc["source_chunk" if ci == 0 else "other_chunks"]
-        vals = (st.seed.ms_seed, st.seed.ms_locate, st.seed.ms_merge, st.ms_pair, st.ms_dp_fill, st.ms_dp_trace, rst.ms_tasks, rst.ms_dp_fill, rst.ms_dp_trace)
-        for k, v in zip(NT_KEYS, vals):
-            grp[k] = grp.get(k, 0.0) + float(v)
-        for k in NT_EVENTS:
-            grp[k] = grp.get(k, 0) + int(getattr(st.seed, k))
-        grp["pair_hits"] = grp.get("pair_hits", 0) + int(nh)
-        grp["single_dp_tasks"] = grp.get("single_dp_tasks", 0) + int(rst.n_single_tasks)
-        grp["single_hits"] = grp.get("single_hits", 0) + int(rst.n_single_hits)
-        grp["rescue_hits"] = grp.get("rescue_hits", 0) + int(rst.n_rescue_hits)
-        grp["entries"] = grp.get("entries", 0) + int(red[3])
-        grp["chunks"] = grp.get("chunks", 0) + 1
+        note(ci, st, nh, rst, red)
+    if not top_floor or n_chunks < 2:
+        for ci in range(n_chunks):
+            whole(ci)
+    else:
+        # two passes (the -top rule across chunks, kernels_floor.hip): the deep-DP round of every chunk first, the last chunk as ever, then the rescue rounds
+        ctx.set_hit_copies(False)
+        for ci in range(n_chunks - 1):
+            ctx.set_index(chunks[ci])
+            _, nh, st = ctx.deep_dp_round(params, fetch=False)
+            red = ctx.reduce_chunk(mode, ci, None, parts=1)
+            ctx.chunk_stash(ci)
+            note(ci, st, nh, None, red)
+        whole(n_chunks - 1)
+        ctx.set_hit_copies(False)
+        for ci in range(n_chunks - 1):
+            ctx.set_index(chunks[ci])
+            ctx.chunk_unstash(ci)
+            ctx.set_score_floor(top_floor)
+            _, _, rst = ctx.rescue_round(params, False, fetch=False)
+            ctx.set_score_floor(0)
+            red = ctx.reduce_chunk(mode, ci, None, parts=2)
+            note(ci, None, 0, rst, red)
     return ctx.reduce_finish()
 
 
@@ -1027,7 +1061,7 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MP_BENCH_GENOME_MBP", "2950")), help="bases per index chunk (< 4295 Mbp: 32-bit positions per chunk)")
     ap.add_argument("--nt-replica-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_GB", "242")),
                     help="HBM bytes (GB) of index the replica makes resident (as many lean chunks of --genome-mbp as that takes and as fit)")
-    ap.add_argument("--nt-headroom-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_HEADROOM_GB", "24")), help="GiB of HBM kept free of index for the batch buffers")
+    ap.add_argument("--nt-headroom-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_HEADROOM_GB", "56")), help="GiB of HBM kept free of index for the batch buffers")
     ap.add_argument("--nt-pairs", type=int, default=int(os.environ.get("MP_BENCH_NT_PAIRS", str(1 << 18))), help="pairs per step and GPU of the headline workload")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "3")),
                     help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")
@@ -1213,6 +1247,12 @@ def main():
             "kernel_ms_source_chunk": {k: src.get(k, 0.0) / max(1, src.get("chunks", 1)) for k in NT_KEYS},
             "per_pair_per_other_chunk": {k: o.get(k, 0) / (n_o * lp) for k in NT_EVENTS + ("single_dp_tasks", "single_hits", "rescue_hits", "pair_hits", "entries")},
             "per_pair_source_chunk": {k: src.get(k, 0) / (max(1, src.get("chunks", 1)) * lp) for k in NT_EVENTS + ("single_dp_tasks", "single_hits", "rescue_hits", "pair_hits", "entries")},
+            "top_rule_across_chunks": {"top_percent": TOP_FLOOR, "failed_pairs_per_other_chunk": o.get("failed_pairs", 0) / n_o, "rescue_rounds_left_out_per_other_chunk": o.get("floor_pairs", 0) / n_o,
+                                       "share_of_failed_pairs_left_out": (o.get("floor_pairs", 0) / o["failed_pairs"]) if o.get("failed_pairs") else None,
+                                       "instances_left_out_per_pair_per_other_chunk": o.get("floor_tasks", 0) / (n_o * lp),
+                                       "note": "kernels_floor.hip: the rescue rounds run after the deep-DP rounds of all chunks; a pair whose rescue work in a chunk cannot produce an "
+                                               "entry of top% of its best known score loses it there (decided per pair from a sound bound on every single-end instance); 0 = off "
+                                               "(MP_TOP_FLOOR=0: one pass)"},
             "rescue_certificate_per_pair_per_chunk": dict(zip(("certified_no_alignment", "score_of_10_elsewhere", "bound_reaches_cutoff", "not_eligible"),
                                                               [(b - a) / (S * lp * n_chunks) for a, b in zip(th_a, th_b)])),
             "hit_count_allreduce": {"references": int(len(ref_counts)), "entries_counted": int(ref_counts.sum()), "ranks": world, "backend": (backend if world > 1 else None),

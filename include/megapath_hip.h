@@ -285,6 +285,7 @@ typedef struct {              /* one successful mate rescue: the aligned mate's 
 typedef struct {
     uint64_t n_failed_pairs, n_single_tasks, n_single_hits, n_rescue_tasks, n_rescue_hits;
     float ms_tasks, ms_dp_fill, ms_dp_trace, ms_total;
+    uint64_t n_floor_pairs, n_floor_tasks;    /* mp_ctx_set_score_floor: failed pairs whose rescue work in this chunk was left out, and their single-end instances */
 } mp_rescue_stats;
 
 int mp_rescue_round(mp_ctx *ctx, const mp_align_params *params, int skip_default_dp, mp_rescue_stats *out_stats);
@@ -333,6 +334,20 @@ int mp_reduce_begin(mp_ctx *ctx, uint32_t n_chunks);
 /* out_pair_class (may be NULL): per pair of the batch how THIS chunk aligned it -- 0 deep-DP round, 1 mate rescue, 2 neither: the order
  * the reference writes a batch in (alignment.cpp:105-330); the caller's array of n_reads / 2 bytes is filled when the call returns. */
 int mp_reduce_chunk(mp_ctx *ctx, int megapath_mode, uint32_t chunk_index, mp_reduce_stats *out_stats, uint8_t *out_pair_class);
+/* The -top rule across resident chunks (kernels_floor.hip; getMappingFromHeader BGS-IO.cpp:1348-1371 keeps what reaches top% of a read's best score over ALL
+ * chunks): with every chunk resident a batch goes through them in two passes --
+ *   pass 1, chunks 0 .. n-2:  mp_ctx_set_index, mp_deep_dp_round, mp_reduce_chunk_part(.., 1, ..) [the pair hits; raises the best score known per read], mp_chunk_stash(c)
+ *   the last chunk as ever:   mp_ctx_set_index, mp_deep_dp_round, mp_rescue_round, mp_reduce_chunk (its classes are the sections of the output; its lists feed -b)
+ *   pass 2, chunks 0 .. n-2:  mp_ctx_set_index, mp_chunk_unstash(c), mp_ctx_set_score_floor(top), mp_rescue_round, mp_reduce_chunk_part(.., 2, ..)
+ * -- and mp_rescue_round leaves out the rescue work of pairs for which NOTHING it could produce in that chunk can reach top% of the best score already known
+ * (decided per pair from a sound upper bound on every single-end instance; the results that remain are the reference's own, the entries left out are ones the
+ * printer's final filter drops anyway).  mp_reduce_finish's list is the same with the floor on and off. */
+int mp_reduce_chunk_part(mp_ctx *ctx, int megapath_mode, uint32_t chunk_index, int parts /* 1 pair hits, 2 rescue round's hits + counts + classes, 3 both */,
+                         mp_reduce_stats *out_stats, uint8_t *out_pair_class);
+int mp_ctx_set_score_floor(mp_ctx *ctx, int top_percent);      /* 0 = off (default): every rescue round does all its work */
+int mp_test_floor_bound(mp_ctx *ctx, const mp_dp_task *tasks, uint32_t n, uint16_t *out_ub);   /* test hook: the rule's upper bound per instance (>= its exact DP score) */
+int mp_chunk_stash(mp_ctx *ctx, uint32_t slot);               /* after mp_deep_dp_round: keep what the chunk's rescue round needs (seed positions, aligned pairs) */
+int mp_chunk_unstash(mp_ctx *ctx, uint32_t slot);             /* after mp_ctx_set_index of the same chunk: put it back; mp_rescue_round may follow */
 int mp_reduce_finish(mp_ctx *ctx, const uint64_t **out_keys, uint64_t *out_n);
 
 typedef struct mp_coverage mp_coverage;
@@ -360,6 +375,7 @@ int mp_build_index_arrays(int device, const uint8_t *codes, uint64_t n, uint32_t
 
 /* Library / device probe: fails loudly (MP_ENODEV) when no gfx950 device is usable. */
 int mp_device_check(int device, char *out_name, size_t name_cap);
+int mp_device_memory(int device, uint64_t *out_free, uint64_t *out_total);   /* bytes of the GPU's memory free / in all, right now */
 const char *mp_strerror(int code);
 
 #ifdef __cplusplus

@@ -16,6 +16,7 @@
 #include "kernels_thermo.hip"
 #include "kernels_cov.hip"
 #include "kernels_reduce.hip"
+#include "kernels_floor.hip"
 #include "kernels_build.hip"
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -141,6 +142,16 @@ struct mp_ctx {
     size_t h_red_cap = 0;
     uint32_t red_chunks = 0;
     bool copy_hits = true;                     // mp_ctx_set_hit_copies: the rounds send their hit lists to pinned host memory
+    // the -top rule across resident chunks (kernels_floor.hip): best score known per read (raised by every mp_reduce_chunk call), the top percentage
+    // (0 = the rescue rounds do all their work), what mp_chunk_stash keeps of a chunk between its deep-DP round and its rescue round
+    DevBuf<uint32_t> best_known;
+    int floor_top = 0;
+    DevBuf<uint16_t> floor_ub;
+    DevBuf<unsigned long long> floor_counts;
+    struct Stash { size_t off = 0, bytes = 0; uint64_t n_hits = 0; uint32_t n_reads = 0; const mp_index *ix = nullptr; mp_seed_stats seed{}; bool used = false; };
+    std::vector<Stash> stash;
+    uint8_t *stash_arena = nullptr;
+    size_t stash_cap = 0, stash_used = 0;
 };
 
 // ------------------------------------------------------------------------------------------------ misc
@@ -811,6 +822,8 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     if (c->red_out) (void)hipFree(c->red_out);
     if (c->h_red) (void)hipHostFree(c->h_red);
     c->resc_done.release(); c->red_flag.release(); c->red_slot.release(); c->red_counts.release(); c->red_cls.release();
+    c->best_known.release(); c->floor_ub.release(); c->floor_counts.release();
+    if (c->stash_arena) (void)hipFree(c->stash_arena);
     c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
     c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release(); c->rtasks_c.release(); c->rres_c.release(); c->rlist.release();
     delete c;
@@ -837,9 +850,15 @@ extern "C" int mp_ctx_set_index(mp_ctx *c, mp_index *ix)
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint32_t n_reads = c->n_reads;
     int rc = forget_batch(c);                                   // seeds and hit lists belong to the index they were computed on
-    c->n_reads = n_reads;                                       // the reads stay
+    c->n_reads = n_reads;                                       // the reads stay (and what mp_chunk_stash keeps of other chunks)
     c->ix = ix;
     return rc;
+}
+
+static void forget_stash(mp_ctx *c)
+{
+    for (auto &st : c->stash) st.used = false;
+    c->stash_used = 0;
 }
 
 extern "C" int mp_set_reads(mp_ctx *c, const uint32_t *packed, uint32_t W, const uint32_t *lengths, uint32_t n_reads)
@@ -854,6 +873,7 @@ extern "C" int mp_set_reads(mp_ctx *c, const uint32_t *packed, uint32_t W, const
     HIPCHK(hipStreamSynchronize(c->stream));
     c->d_reads = c->reads.p; c->d_lens = c->lens.p;
     c->n_reads = n_reads; c->W = W; c->max_len = mx; c->min_len = n_reads ? mn : 0;
+    forget_stash(c);
     return forget_batch(c);
 }
 
@@ -862,6 +882,7 @@ extern "C" int mp_set_reads_device(mp_ctx *c, const uint32_t *d_packed, uint32_t
     if (!c || !d_packed || !d_lengths || W == 0 || (n_reads & 1) || max_length > W * 16) return MP_EINVAL;
     c->d_reads = d_packed; c->d_lens = d_lengths;
     c->n_reads = n_reads; c->W = W; c->max_len = max_length; c->min_len = 0;
+    forget_stash(c);
     return forget_batch(c);
 }
 
@@ -2047,6 +2068,34 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
         hipLaunchKernelGGL(single_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->scand.p, c->rs_base.p, c->n_scand.p,
                            c->s_off.p, c->d_lens, c->ix->n, c->stasks.p);
         MP_TRACE(s, "single_task_kernel");
+        // ---- the -top rule across chunks (mp_ctx_set_score_floor, kernels_floor.hip): pairs whose rescue work here cannot put anything into a header lose
+        // their instances -- a cheap bound per instance, a decision per pair, then the task list once more without them
+        static const bool floor_env = !getenv("MP_TOP_FLOOR") || atoi(getenv("MP_TOP_FLOOR")) != 0;
+        if (floor_env && c->floor_top > 0 && c->red_chunks > 0 && c->best_known.p && nst >= 64 && c->max_len <= MP_FLOOR_MAXL) {
+            if (c->floor_ub.reserve(nst + 2) || c->floor_counts.reserve(2)) return MP_ENOMEM;
+            HIPCHK(hipMemsetAsync(c->floor_counts.p, 0, 2 * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(floor_bound_kernel, dim3(grid_for(nst, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->stasks.p, nst,
+                               (const uint32_t *)c->best_known.p, c->floor_top, c->floor_ub.p);
+            hipLaunchKernelGGL(floor_decide_kernel, dim3(grid_for(nf / 2 + 1, 256)), dim3(256), 0, s, (const uint32_t *)c->failed_reads.p, nf, (const uint32_t *)c->s_off.p,
+                               (const uint16_t *)c->floor_ub.p, c->d_lens, (const uint32_t *)c->best_known.p, c->floor_top, c->n_scand.p, c->floor_counts.p);
+            MP_TRACE(s, "floor kernels");
+            HIPCHK(hipGetLastError());
+            unsigned long long fc[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(fc, c->floor_counts.p, sizeof fc, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            st.n_floor_pairs = fc[0]; st.n_floor_tasks = fc[1];
+            if (fc[0]) {
+                rc = exclusive_scan_u32(c, c->n_scand.p, c->s_off.p, nf + 1);
+                if (rc) return rc;
+                HIPCHK(hipMemcpyAsync(&nst, c->s_off.p + nf, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                c->n_stasks = nst;
+                st.n_single_tasks = nst;
+                hipLaunchKernelGGL(single_task_kernel, dim3(grid_for(nf, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->scand.p, c->rs_base.p, c->n_scand.p,
+                                   c->s_off.p, c->d_lens, c->ix->n, c->stasks.p);
+                MP_TRACE(s, "single_task_kernel (after the floor)");
+            }
+        }
         HIPCHK(hipEventRecord(t1, s));
         census_add(c, CENSUS_FULL_EQUIV, c->stasks.p, nullptr, nst, 0);
         const uint32_t max_win = c->max_len + 60;
@@ -2220,6 +2269,122 @@ extern "C" int mp_test_sort_longer_seed(int device, const uint32_t *seed_len, co
 }
 
 
+// free / total bytes of a GPU's memory right now (the executable sizes its batches by it when the -top rule needs room for its stash)
+extern "C" int mp_device_memory(int device, uint64_t *out_free, uint64_t *out_total)
+{
+    if (!out_free || !out_total) return MP_EINVAL;
+    int rc = mp_device_check(device, nullptr, 0);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    *out_free = f; *out_total = t;
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the -top rule across resident chunks
+// 0: the rescue rounds do all their work.  1 .. 100 (the executable's -top value): mp_rescue_round leaves out the rescue work of pairs that cannot put an
+// entry of top% of their best KNOWN score into a header (kernels_floor.hip) -- to be switched off for the last chunk of a database (its classes are the
+// sections of the output) and whenever the hit lists themselves are wanted.  Needs a reduction in progress (mp_reduce_begin): that is where the best scores live.
+extern "C" int mp_ctx_set_score_floor(mp_ctx *c, int top_percent)
+{
+    if (!c || top_percent < 0 || top_percent > 100) return MP_EINVAL;
+    c->floor_top = top_percent;
+    return MP_OK;
+}
+
+// test hook: the bound of kernels_floor.hip for caller-given instances of the reads now set (every instance, whatever is known about its read);
+// out_ub[t] >= the exact DP score of instance t is what the rule's soundness rests on.  0xFFFF: shape not covered.
+extern "C" int mp_test_floor_bound(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, uint16_t *out_ub)
+{
+    if (!c || !tasks || !out_ub || !c->d_reads) return MP_EINVAL;
+    if (n == 0) return MP_OK;
+    for (uint32_t t = 0; t < n; t++) {
+        if (tasks[t].read_id >= c->n_reads || (tasks[t].strand != 1 && tasks[t].strand != 2)) return MP_EINVAL;
+        if (tasks[t].win_len > MP_DP_MAX_WIN || tasks[t].win_start + tasks[t].win_len > c->ix->n) return MP_ERANGE;
+    }
+    HIPCHK(hipSetDevice(c->ix->device));
+    hipStream_t s = c->stream;
+    DevBuf<uint32_t> known;
+    if (c->tasks_tmp.reserve(n) || c->floor_ub.reserve(n + 2) || known.reserve((size_t)c->n_reads + 1)) { known.release(); return MP_ENOMEM; }
+    hipError_t e = hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(known.p, 0x01, ((size_t)c->n_reads + 1) * 4, s);                 // 0x01010101: "a very good score is known for every read"
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(floor_bound_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->tasks_tmp.p, n,
+                           (const uint32_t *)known.p, 100, c->floor_ub.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_ub, c->floor_ub.p, (size_t)n * 2, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    known.release();
+    return e == hipSuccess ? MP_OK : MP_ENODEV;
+}
+
+// Between the two passes over the resident chunks: after mp_deep_dp_round (and mp_reduce_chunk_part(.., 1)) of the bound chunk, keeps what its rescue round
+// needs -- the seed positions of every read and which pairs the round aligned -- in the context's stash (one arena, exact sizes); mp_chunk_unstash(slot),
+// after the context has been bound to that chunk again, puts it back, and mp_rescue_round carries on as if nothing had happened in between.
+// A new batch (mp_set_reads) empties the stash.
+extern "C" int mp_chunk_stash(mp_ctx *c, uint32_t slot)
+{
+    if (!c || !c->seeded || !c->deep_done || slot >= MP_RED_MAX_CHUNKS) return MP_EINVAL;
+    HIPCHK(hipSetDevice(c->ix->device));
+    hipStream_t s = c->stream;
+    if (c->stash.size() <= slot) c->stash.resize(slot + 1);
+    const size_t n_items = 2 * (size_t)c->n_reads, n_pairs = c->n_reads / 2;
+    const size_t b_seed = (size_t)c->n_hits_total * sizeof(mp_seedpos), b_rs = (n_items + 1) * 4, b_np = (size_t)c->n_reads * 4, b_pd = (n_pairs + 1) * 4;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t need = up(b_seed) + up(b_rs) + 2 * up(b_np) + up(b_pd);
+    if (c->stash_used + need > c->stash_cap) {
+        // grow: what this chunk needed times the chunks still to come (the reduction knows how many chunks the batch goes through), a tenth of slack
+        const size_t n_more = c->red_chunks > slot ? c->red_chunks - slot : 1;
+        size_t want = c->stash_used + need * n_more + need / 10 * n_more + (1u << 20);
+        uint8_t *q = nullptr;
+        if (hipMalloc((void **)&q, want) != hipSuccess) return MP_ENOMEM;
+        if (c->stash_used) { if (hipMemcpyAsync(q, c->stash_arena, c->stash_used, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(q); return MP_ENODEV; } }
+        if (c->stash_arena) (void)hipFree(c->stash_arena);
+        c->stash_arena = q; c->stash_cap = want;
+    }
+    mp_ctx::Stash &st = c->stash[slot];
+    st.off = c->stash_used; st.bytes = need; st.n_hits = c->n_hits_total; st.n_reads = c->n_reads; st.ix = c->ix; st.seed = c->last_seed; st.used = true;
+    uint8_t *p = c->stash_arena + st.off;
+    if (b_seed) HIPCHK(hipMemcpyAsync(p, c->seedpos.p, b_seed, hipMemcpyDeviceToDevice, s));
+    p += up(b_seed);
+    HIPCHK(hipMemcpyAsync(p, c->rs_base.p, b_rs, hipMemcpyDeviceToDevice, s)); p += up(b_rs);
+    HIPCHK(hipMemcpyAsync(p, c->n_pos.p, b_np, hipMemcpyDeviceToDevice, s)); p += up(b_np);
+    HIPCHK(hipMemcpyAsync(p, c->n_neg.p, b_np, hipMemcpyDeviceToDevice, s)); p += up(b_np);
+    HIPCHK(hipMemcpyAsync(p, c->pair_done.p, b_pd, hipMemcpyDeviceToDevice, s));
+    c->stash_used += need;
+    HIPCHK(hipStreamSynchronize(s));
+    return MP_OK;
+}
+
+extern "C" int mp_chunk_unstash(mp_ctx *c, uint32_t slot)
+{
+    if (!c || slot >= c->stash.size() || !c->stash[slot].used) return MP_EINVAL;
+    const mp_ctx::Stash &st = c->stash[slot];
+    if (st.ix != c->ix || st.n_reads != c->n_reads) return MP_EINVAL;              // bind the chunk first (mp_ctx_set_index); same batch
+    HIPCHK(hipSetDevice(c->ix->device));
+    hipStream_t s = c->stream;
+    const size_t n_items = 2 * (size_t)c->n_reads, n_pairs = c->n_reads / 2;
+    const size_t b_seed = (size_t)st.n_hits * sizeof(mp_seedpos), b_rs = (n_items + 1) * 4, b_np = (size_t)c->n_reads * 4, b_pd = (n_pairs + 1) * 4;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    if (c->seedpos.reserve((size_t)st.n_hits + 64) || c->rs_base.reserve(n_items + 2) || c->n_pos.reserve(c->n_reads + 1) || c->n_neg.reserve(c->n_reads + 1) ||
+        c->pair_done.reserve(n_pairs + 1)) return MP_ENOMEM;
+    const uint8_t *p = c->stash_arena + st.off;
+    if (b_seed) HIPCHK(hipMemcpyAsync(c->seedpos.p, p, b_seed, hipMemcpyDeviceToDevice, s));
+    p += up(b_seed);
+    HIPCHK(hipMemcpyAsync(c->rs_base.p, p, b_rs, hipMemcpyDeviceToDevice, s)); p += up(b_rs);
+    HIPCHK(hipMemcpyAsync(c->n_pos.p, p, b_np, hipMemcpyDeviceToDevice, s)); p += up(b_np);
+    HIPCHK(hipMemcpyAsync(c->n_neg.p, p, b_np, hipMemcpyDeviceToDevice, s)); p += up(b_np);
+    HIPCHK(hipMemcpyAsync(c->pair_done.p, p, b_pd, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->n_hits_total = st.n_hits; c->last_seed = st.seed;
+    c->seeded = true; c->deep_done = true; c->rescued = false;
+    c->n_pair_hits_host = 0;                                                       // (that round's pair hits were reduced when they were made: mp_reduce_chunk_part(.., 1))
+    c->n_single_hits_host = 0; c->n_rescue_hits_host = 0;
+    return MP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ per-reference reduction over chunks
 static std::mutex g_tr_mu;
 static int ensure_translate(mp_index *ix)
@@ -2266,6 +2431,9 @@ extern "C" int mp_reduce_begin(mp_ctx *c, uint32_t n_chunks)
     if (!c || n_chunks == 0 || n_chunks > MP_RED_MAX_CHUNKS) return MP_EINVAL;
     if (c->n_reads > (1u << 22)) return MP_ERANGE;                      // 22 bits of read id in a key
     c->red_n = 0; c->red_chunks = n_chunks;
+    HIPCHK(hipSetDevice(c->ix->device));
+    if (c->best_known.reserve((size_t)c->n_reads + 1)) return MP_ENOMEM;
+    HIPCHK(hipMemsetAsync(c->best_known.p, 0, ((size_t)c->n_reads + 1) * 4, c->stream));
     return MP_OK;
 }
 
@@ -2273,7 +2441,14 @@ extern "C" int mp_reduce_begin(mp_ctx *c, uint32_t n_chunks)
 // entries to the batch's accumulator.  chunk_index counts from 0 in database order.
 extern "C" int mp_reduce_chunk(mp_ctx *c, int megapath_mode, uint32_t chunk_index, mp_reduce_stats *out_stats, uint8_t *out_pair_class)
 {
-    if (!c || !c->deep_done || c->red_chunks == 0 || chunk_index >= c->red_chunks) return MP_EINVAL;
+    return mp_reduce_chunk_part(c, megapath_mode, chunk_index, 3, out_stats, out_pair_class);
+}
+
+// The same in two parts, for the two passes of the -top rule (mp_chunk_stash): parts & 1 = the pair hits of the deep-DP round just done, parts & 2 = the
+// rescue round's hits, the counts and the classes.  Every call raises the best score known per read by what it adds.
+extern "C" int mp_reduce_chunk_part(mp_ctx *c, int megapath_mode, uint32_t chunk_index, int parts, mp_reduce_stats *out_stats, uint8_t *out_pair_class)
+{
+    if (!c || !c->deep_done || c->red_chunks == 0 || chunk_index >= c->red_chunks || (parts & 3) == 0 || !c->best_known.p) return MP_EINVAL;
     mp_index *ix = c->ix;
     if (ix->seq_names.size() > MP_RED_MAX_SEQ) return MP_ERANGE;        // 22 bits of sequence id in a key
     HIPCHK(hipSetDevice(ix->device));
@@ -2282,7 +2457,7 @@ extern "C" int mp_reduce_chunk(mp_ctx *c, int megapath_mode, uint32_t chunk_inde
     hipStream_t s = c->stream;
     // the hit lists of the round are on their way to the host on the copy stream: they stay valid on the device meanwhile
     const uint32_t n_pairs = c->n_reads / 2;
-    const size_t n_ph = c->n_pair_hits_host, n_rh = c->rescued ? c->n_rescue_hits_host : 0, n_sh = c->rescued ? c->n_single_hits_host : 0;
+    const size_t n_ph = (parts & 1) ? c->n_pair_hits_host : 0, n_rh = (parts & 2) && c->rescued ? c->n_rescue_hits_host : 0, n_sh = (parts & 2) && c->rescued ? c->n_single_hits_host : 0;
     const size_t add = 2 * n_ph + 2 * n_rh + n_sh;
     rc = grow_keys(c->red_keys, c->red_cap, c->red_n + add, c->red_n, s);
     if (rc) return rc;
@@ -2296,10 +2471,13 @@ extern "C" int mp_reduce_chunk(mp_ctx *c, int megapath_mode, uint32_t chunk_inde
     if (n_rh) hipLaunchKernelGGL(reduce_pairs_kernel<true>, dim3(grid_for(n_rh, 256)), dim3(256), 0, s, (const void *)c->d_rescue_hits.p, (uint32_t)n_rh, c->d_lens, tr, megapath_mode, inv, k + 2 * n_ph, c->resc_done.p);
     if (n_sh) hipLaunchKernelGGL(reduce_singles_kernel, dim3(grid_for(n_sh, 256)), dim3(256), 0, s, (const mp_single_hit *)c->d_single_hits.p, (uint32_t)n_sh, c->d_lens, tr, megapath_mode, inv,
                                  (const uint32_t *)c->pair_done.p, (const uint32_t *)c->resc_done.p, k + 2 * n_ph + 2 * n_rh);
+    if (add) hipLaunchKernelGGL(floor_best_kernel, dim3(grid_for(add, 256)), dim3(256), 0, s, (const unsigned long long *)k, (uint64_t)add, c->best_known.p, c->n_reads);
     if (out_pair_class && c->red_cls.reserve(n_pairs + 4)) return MP_ENOMEM;
-    hipLaunchKernelGGL(reduce_count_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, s, (const uint32_t *)c->pair_done.p, (const uint32_t *)c->resc_done.p, n_pairs, c->red_counts.p,
-                       out_pair_class ? c->red_cls.p : (uint8_t *)nullptr);
-    if (out_pair_class && n_pairs) HIPCHK(hipMemcpyAsync(out_pair_class, c->red_cls.p, n_pairs, hipMemcpyDeviceToHost, s));
+    if (parts & 2) {
+        hipLaunchKernelGGL(reduce_count_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, s, (const uint32_t *)c->pair_done.p, (const uint32_t *)c->resc_done.p, n_pairs, c->red_counts.p,
+                           out_pair_class ? c->red_cls.p : (uint8_t *)nullptr);
+        if (out_pair_class && n_pairs) HIPCHK(hipMemcpyAsync(out_pair_class, c->red_cls.p, n_pairs, hipMemcpyDeviceToHost, s));
+    }
     MP_TRACE(s, "reduce kernels");
     HIPCHK(hipGetLastError());
     c->red_n += add;

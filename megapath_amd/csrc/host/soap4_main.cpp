@@ -147,6 +147,7 @@ struct Batch {
     std::vector<uint8_t> red_class;         // per pair: how the LAST chunk aligned it (0 deep-DP round, 1 mate rescue, 2 neither): the sections of the output
     mp_reduce_stats red_last{};             // how the last chunk's pairs were aligned (the closing line counts that chunk, as the last run of a chain would)
     uint64_t red_dp_instances = 0;
+    uint64_t red_floor_pairs = 0;           // (pair, chunk) combinations whose rescue work the -top rule left out
     uint64_t seq = 0;                       // position of the batch in the input: the printer writes batches in this order
 };
 
@@ -1298,7 +1299,7 @@ struct Writer {
 void die(int rc, const char *what) { if (rc) fatal("[soap4-mi355x] %s failed: %s (%d)\n", what, mp_strerror(rc), rc); }
 
 struct Stats {
-    uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0;
+    uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0, floor_pairs = 0;
     double t_read = 0, t_upload = 0, t_deep = 0, t_sort = 0, t_cigar = 0, t_emit_deep = 0, t_rescue = 0, t_emit_rest = 0;   // seconds (MP_TIMING=1 prints them)
 };
 
@@ -1779,6 +1780,60 @@ void gpu_stage_reduced(mp_ctx *ctx, const Params &p, Batch &bt, uint32_t chunk, 
     st.t_sort += now_s() - t0;
 }
 
+// The two passes of the -top rule across resident chunks (mp_chunk_stash, kernels_floor.hip): pass 1 = the deep-DP round of a chunk and its pair hits into
+// the reduction (which raises the best score known per read); pass 2 = the chunk's rescue round, without the pairs that cannot put anything into a header.
+// false: the stash is out of memory -- the chunk's deep-DP round is done and reduced, its rescue round has to follow at once (finish_unstashed)
+bool gpu_stage_pass1(mp_ctx *ctx, const Params &p, Batch &bt, uint32_t chunk, Stats &st)
+{
+    double t0 = now_s();
+    const mp_align_params ap = align_params_of(p, false);
+    uint64_t nh = 0;
+    mp_round_stats rs;
+    die(mp_deep_dp_round(ctx, &ap, &nh, &rs), "mp_deep_dp_round");
+    st.t_deep += now_s() - t0; t0 = now_s();
+    mp_reduce_stats red{};
+    die(mp_reduce_chunk_part(ctx, p.mode, chunk, 1, &red, nullptr), "mp_reduce_chunk_part");
+    bt.red_dp_instances += 2 * rs.n_candidates;
+    const int rc = mp_chunk_stash(ctx, chunk);
+    if (rc != 0 && rc != MP_ENOMEM) die(rc, "mp_chunk_stash");
+    st.t_sort += now_s() - t0;
+    return rc == 0;
+}
+
+void finish_unstashed(mp_ctx *ctx, const Params &p, Batch &bt, uint32_t chunk, Stats &st)
+{
+    double t0 = now_s();
+    const mp_align_params ap = align_params_of(p, false);
+    mp_rescue_stats rst{};
+    die(mp_rescue_round(ctx, &ap, p.skip_default_dp ? 1 : 0, &rst), "mp_rescue_round");
+    st.t_rescue += now_s() - t0; t0 = now_s();
+    mp_reduce_stats red{};
+    die(mp_reduce_chunk_part(ctx, p.mode, chunk, 2, &red, nullptr), "mp_reduce_chunk_part");
+    bt.red_dp_instances += rst.n_single_tasks + rst.n_rescue_tasks;
+    st.t_sort += now_s() - t0;
+}
+
+void gpu_stage_pass2(mp_ctx *ctx, const Params &p, Batch &bt, uint32_t chunk, int top_percent, Stats &st)
+{
+    double t0 = now_s();
+    const mp_align_params ap = align_params_of(p, false);
+    die(mp_chunk_unstash(ctx, chunk), "mp_chunk_unstash");
+    die(mp_ctx_set_score_floor(ctx, top_percent), "mp_ctx_set_score_floor");
+    mp_rescue_stats rst{};
+    die(mp_rescue_round(ctx, &ap, p.skip_default_dp ? 1 : 0, &rst), "mp_rescue_round");
+    die(mp_ctx_set_score_floor(ctx, 0), "mp_ctx_set_score_floor");
+    st.t_rescue += now_s() - t0; t0 = now_s();
+    mp_reduce_stats red{};
+    die(mp_reduce_chunk_part(ctx, p.mode, chunk, 2, &red, nullptr), "mp_reduce_chunk_part");
+    bt.red_dp_instances += rst.n_single_tasks + rst.n_rescue_tasks;
+    bt.red_floor_pairs += rst.n_floor_pairs;
+    if (getenv("MP_TIMING"))
+        fprintf(stderr, "[Main] batch %llu chunk %u, rescue pass: %llu failed pairs, %llu left out by the -top rule (%llu instances), %llu instances run, %llu + %llu hits\n",
+                (unsigned long long)bt.seq, chunk, (unsigned long long)rst.n_failed_pairs, (unsigned long long)rst.n_floor_pairs, (unsigned long long)rst.n_floor_tasks,
+                (unsigned long long)rst.n_single_tasks, (unsigned long long)rst.n_single_hits, (unsigned long long)rst.n_rescue_hits);
+    st.t_sort += now_s() - t0;
+}
+
 void finish_reduced(mp_ctx *ctx, Batch &bt, Stats &st)
 {
     const double t0 = now_s();
@@ -1798,7 +1853,7 @@ void output_reduced(mp_index *const *chunks, uint32_t n_chunks, const Params &p,
 {
     const double t0 = now_s();
     const uint32_t n_pairs = bt.n_reads / 2;
-    st.pairs += n_pairs; st.dp += bt.red_dp_instances;
+    st.pairs += n_pairs; st.dp += bt.red_dp_instances; st.floor_pairs += bt.red_floor_pairs;
     st.deep += bt.red_last.n_deep_pairs; st.rescued += bt.red_last.n_rescued_pairs; st.unpaired += bt.red_last.n_unpaired_pairs;
     // the batch in the reference's order (alignment.cpp:105-330): the pairs of the deep-DP round, the rescued pairs, the rest -- as the last chunk saw them
     std::vector<uint32_t> order[3];
@@ -2060,6 +2115,26 @@ int main(int argc, char **argv)
     if (reduce_on_device)
         for (mp_index *ix : devices[0].chunks) { mp_index_info info; mp_index_get_info(ix, &info); if (info.num_seq >= (1u << 22)) reduce_on_device = false; }
     if (p.max_read_length > 512 || p.batch_pairs > (1u << 21)) reduce_on_device = false;       // scores must stay below 1024, read ids below 2^22
+    // The -top rule across resident chunks (kernels_floor.hip): on whenever the reduction is and there is more than one chunk; MP_TOP_FLOOR=0 switches it off
+    // (one pass over the chunks, every rescue round does all its work: the test of the rule)
+    const int top_percent = (int)(p.top * 100.0 + 0.5);
+    const bool top_floor = reduce_on_device && n_chunks >= 2 && top_percent >= 1 && top_percent <= 100 && !(getenv("MP_TOP_FLOOR") && atoi(getenv("MP_TOP_FLOOR")) == 0);
+    std::atomic<bool> stash_warned{false};
+    if (top_floor && !getenv("MP_BATCH_PAIRS")) {
+        // the rule keeps the seed positions of every chunk but the last between its two passes: ~1.2 KB per pair and chunk with 17-base seeds (67 located
+        // hits of 16 bytes per pair and 2.95 Gbp chunk), for every worker's batch.  Batches are sized so that this fits into half of what the indexes left free.
+        uint64_t mfree = 0, mtotal = 0;
+        if (mp_device_memory(devices[0].id, &mfree, &mtotal) == 0) {
+            const double per_pair = 1200.0 * (double)(n_chunks - 1);
+            const size_t fit = (size_t)(0.5 * (double)mfree / (per_pair * (double)workers_per_gpu));
+            const size_t want = std::max<size_t>(16384, fit / 4096 * 4096);
+            if (want < p.batch_pairs) {
+                p.batch_pairs = want;
+                fprintf(stderr, "[Main] %zu index chunks resident, %.1f GB of HBM free: batches of %zu pairs (the -top rule keeps every chunk's seed positions between its two passes)\n",
+                        n_chunks, mfree / 1e9, p.batch_pairs);
+            }
+        }
+    }
     const bool carry_rewrite = getenv("MP_CARRY_REWRITE") != nullptr;     // test switch: merge every comment again in every chunk, also where the chunk adds nothing     // test switch: merge every comment again in every chunk, also where the chunk adds nothing
     std::thread printer([&]() {
         Formatters fm(getenv("MP_PRINTER_THREADS") ? std::max(1, atoi(getenv("MP_PRINTER_THREADS"))) : std::max(1, threads / 2));
@@ -2099,13 +2174,33 @@ int main(int argc, char **argv)
                 if (!plumbing_only && reduce_on_device) {
                     upload_reads(ctx, *b, st);
                     die(mp_reduce_begin(ctx, (uint32_t)n_chunks), "mp_reduce_begin");
-                    b->red_dp_instances = 0;
-                    for (size_t c = 0; c < n_chunks; c++) {
+                    b->red_dp_instances = 0; b->red_floor_pairs = 0;
+                    auto whole_chunk = [&](size_t c) {
                         if (n_chunks > 1 || c > 0) die(mp_ctx_set_index(ctx, dev.chunks[c]), "mp_ctx_set_index");
                         const bool last = c + 1 == n_chunks;
                         if (bam) die(mp_ctx_set_hit_copies(ctx, last ? 1 : 0), "mp_ctx_set_hit_copies");
                         if (bam && last) gpu_stage(ctx, p, *b, b->ch[c], true, threads, st, (int)c);
                         else gpu_stage_reduced(ctx, p, *b, (uint32_t)c, last, st);
+                    };
+                    if (!top_floor) for (size_t c = 0; c < n_chunks; c++) whole_chunk(c);
+                    else {
+                        // two passes (the -top rule across chunks): the deep-DP round of every chunk first -- it fixes the best score each read is known
+                        // to reach --, the last chunk as ever (its classes are the sections of the output, its lists feed -b), then the rescue rounds.
+                        // Should the stash run out of memory at chunk c (a batch with far more seeds than the sizing assumed), that chunk and the ones
+                        // after it are done in one go as without the rule; the chunks already stashed still get their second pass.
+                        if (bam) die(mp_ctx_set_hit_copies(ctx, 0), "mp_ctx_set_hit_copies");
+                        size_t n_stashed = 0;
+                        for (size_t c = 0; c + 1 < n_chunks; c++) {
+                            die(mp_ctx_set_index(ctx, dev.chunks[c]), "mp_ctx_set_index");
+                            if (n_stashed == c && gpu_stage_pass1(ctx, p, *b, (uint32_t)c, st)) n_stashed = c + 1;
+                            else {
+                                if (n_stashed == c) { finish_unstashed(ctx, p, *b, (uint32_t)c, st); if (!stash_warned.exchange(true)) fprintf(stderr, "[soap4-mi355x] the -top rule's stash does not fit at chunk %zu of %zu (batch of %u pairs): the remaining chunks are aligned in one pass; a smaller MP_BATCH_PAIRS gives it room\n", c, n_chunks, b->n_reads / 2); }
+                                else gpu_stage_reduced(ctx, p, *b, (uint32_t)c, false, st);
+                            }
+                        }
+                        whole_chunk(n_chunks - 1);
+                        if (bam) die(mp_ctx_set_hit_copies(ctx, 0), "mp_ctx_set_hit_copies");
+                        for (size_t c = 0; c < n_stashed; c++) { die(mp_ctx_set_index(ctx, dev.chunks[c]), "mp_ctx_set_index"); gpu_stage_pass2(ctx, p, *b, (uint32_t)c, top_percent, st); }
                     }
                     finish_reduced(ctx, *b, st);
                 } else if (!plumbing_only) {
@@ -2173,8 +2268,10 @@ int main(int argc, char **argv)
     for (const Stats &w : st_worker) { st.t_upload += w.t_upload; st.t_deep += w.t_deep; st.t_rescue += w.t_rescue; st.t_sort += w.t_sort; st.t_cigar += w.t_cigar; }
     fprintf(stderr, "[Main] %llu pairs: %llu aligned by deep DP, %llu by mate rescue, %llu unpaired; %llu DP instances\n", (unsigned long long)st.pairs,
             (unsigned long long)st.deep, (unsigned long long)st.rescued, (unsigned long long)st.unpaired, (unsigned long long)st.dp);
-    fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped; %zu GPU(s) x %d worker(s), %zu index chunk(s)%s)\n", t_loop,
-            st.pairs / std::max(t_loop, 1e-9), devices.size(), workers_per_gpu, n_chunks, reduce_on_device ? ", per-reference scores reduced on the device" : "");
+    fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped; %zu GPU(s) x %d worker(s), %zu index chunk(s)%s%s)\n", t_loop,
+            st.pairs / std::max(t_loop, 1e-9), devices.size(), workers_per_gpu, n_chunks, reduce_on_device ? ", per-reference scores reduced on the device" : "",
+            top_floor ? ", rescue rounds after the deep-DP rounds of all chunks (-top rule)" : "");
+    if (top_floor) fprintf(stderr, "[Main] -top rule: %llu (pair, chunk) rescue rounds left out\n", (unsigned long long)st.floor_pairs);
     if (getenv("MP_TIMING"))
         fprintf(stderr, "[Main] seconds: reading and packing %.2f (own threads), upload %.2f, deep-DP round %.2f, sort %.2f, BAM CIGARs %.2f, output of deep pairs %.2f, rescue round %.2f, output of the rest %.2f\n",
                 st.t_read, st.t_upload, st.t_deep, st.t_sort, st.t_cigar, st.t_emit_deep, st.t_rescue, st.t_emit_rest);

@@ -1,0 +1,175 @@
+// megapath_amd/csrc/kernels_floor.hip -- product code: the `-top` rule across resident index chunks (included by api.hip).
+//
+// The annotated FASTQ keeps, per read, the entries that reach top% of the read's best score over ALL chunks (getMappingFromHeader BGS-IO.cpp:1348-1371,
+// pairDeepDPOutputFastqAPI :2034-2089, unproperlypairDPOutputFastqAPI :1422-1441; DESIGN.md section 4, "Reduction over chunks": one filter with the final
+// best score prints exactly what the chain prints).  With every chunk resident the best score a read is KNOWN to reach (the deep-DP round of every chunk,
+// reduced on the device: mp_reduce_chunk_part) is there before the rescue rounds of the chunks start, and a rescue round whose results cannot reach top% of it
+// can be left out -- for most pairs that align well somewhere, that is the rescue work of every other chunk: ~60 single-end DP instances per pair and chunk
+// around chance 17-mers (DV-DPForSingleReads.cpp:121-215), all failing a cutoff of 30, let alone of 100.
+//
+// What may be left out is decided per PAIR, not per instance: the mate rescue starts from the LAST four single-end hits of a read in (score descending)
+// order (DV-DPfunctions.cpp:1048-1079) and a rescued pair hides its single-end entries (the writers' precedence), so low-scoring hits
+// decide what is rescued from and what is printed.  A pair keeps ALL its rescue work in this chunk unless NO entry it could produce can matter:
+//   U_x        an upper bound on the score of every single-end instance of mate x in this chunk (below), 0 without instances
+//   T_x        = top% of the best score known for mate x (entries below it are never printed); an entry of score s is certainly irrelevant iff 100 s < top B_x - 100
+//   single-end entry of x                  irrelevant iff U_x below T_x
+//   rescue anchored at x (needs a hit of x) impossible iff U_x < cutoff(x); else its entries are: both mates on one sequence -> U_x + L_y in both headers,
+//                                           irrelevant iff below min(T_x, T_y); on different sequences -> each its own score: x's irrelevant as above, the
+//                                           rescued mate's at most L_y: irrelevant iff L_y below T_y
+// (the rescued mate scores at most its length).  Pairs of the LAST chunk always keep their work: that chunk's classes are the sections of the output.
+//
+// The bound U: blocks of five read bases (MP_FLOOR_K).  Score <= L - loss, and every block whose 5-mer occurs NOWHERE in the window costs the alignment at
+// least 3 -- its five columns cannot all be matched in a row without an event (they would spell the 5-mer in the window), so they hold a mismatch (1 + 2), an
+// inserted column (a run of g of them costs 2 + 2 g >= 3 per block it touches), a deletion between two of them (>= 3), or they are clipped (a whole block 5;
+// the two blocks the clips end in at least 1 each).  With E such blocks: U = L - 3 max(0, E - 2) - min(E, 2), for each of the five block phases; the smallest is
+// taken.  The window's 5-mers go into a 1024-bit set per instance in LDS (one column of words per lane: no bank conflicts, no atomics across lanes): ~2 500
+// instructions per instance against the certificate kernel's 44 000.  A random 150 x 210 instance around a 17-20-base seed gets U = 84 +- 4 (true maximum ~20);
+// the largest over a pair's ~60 instances is ~93 (blocks of six: the same; of seven: 99), so pairs whose best known score leaves min(T) - L_mate above that --
+// mates within ~4.5 % of the reference -- lose their rescue work in every other chunk.  tests/test_gpu_top_floor.py: U >= the exact DP score on the certificate
+// tests' adversarial instances; the executable's output with the rule == without it == the chained oracle's.
+#pragma once
+
+#define MP_FLOOR_K 5              // block length: 5 and 6 bound equally well (prototype: the largest U over a pair's 60 instances 93.2 / 92.7), 5 needs a quarter of the LDS
+#define MP_FLOOR_WORDS ((1 << (2 * MP_FLOOR_K)) / 32)     // 32 words of 32 bits per instance
+#define MP_FLOOR_MAXL 320
+#define MP_FLOOR_MAXM 384
+#define MP_FLOOR_SKIP 0xFFFFu                              // no bound computed (the pair cannot be dropped anyway, or the shape is not covered)
+
+// 100 x score below which an entry of a read whose best known score is `best` is certainly not printed (one score point of slack for the double comparison
+// `score >= best * top` of the writers); <= 0: everything may matter
+__device__ __forceinline__ long long mp_floor_thr100(uint32_t best, int top_pct) { return (long long)top_pct * (long long)best - 100; }
+
+// One lane per single-end DP instance (task): ub[t] = the bound U, or MP_FLOOR_SKIP.
+__global__ void __launch_bounds__(64)
+floor_bound_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
+                   const mp_dp_task *__restrict__ tasks, uint32_t n_tasks, const uint32_t *__restrict__ best_known, int top_pct, uint16_t *__restrict__ ub)
+{
+    __shared__ uint32_t s_set[MP_FLOOR_WORDS][64];       // [word][lane]
+    const int lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * 64u + (uint32_t)lane;
+    bool work = t < n_tasks;
+    mp_dp_task task{};
+    int L = 0, m = 0;
+    if (work) {
+        task = tasks[t];
+        L = (int)lens[task.read_id]; m = (int)task.win_len;
+        // a mate whose pair could not be dropped whatever the bound says (nothing known about it or about its mate's side of the conditions) needs none
+        const uint32_t bx = best_known[task.read_id];
+        if (mp_floor_thr100(bx, top_pct) <= 0 || L > MP_FLOOR_MAXL || L < MP_FLOOR_K || m > MP_FLOOR_MAXM || m < 1) { ub[t] = MP_FLOOR_SKIP; work = false; }
+    }
+    if (!__any(work)) return;
+    for (int w = 0; w < MP_FLOOR_WORDS; w++) s_set[w][lane] = 0u;
+    uint32_t a[MP_FLOOR_MAXL / 16 + 1], win[MP_FLOOR_MAXM / 16 + 2];
+#pragma unroll
+    for (int k = 0; k <= MP_FLOOR_MAXL / 16; k++) a[k] = 0;
+#pragma unroll
+    for (int k = 0; k < MP_FLOOR_MAXM / 16 + 2; k++) win[k] = 0;
+    if (work) {
+        const uint32_t *rd = reads + (uint64_t)task.read_id * Wr;
+        const int nw = (L + 15) / 16;
+#pragma unroll
+        for (int k = 0; k < MP_FLOOR_MAXL / 16; k++) a[k] = mp_oriented_word(rd, nw, L, task.strand, k);
+        const uint64_t q0 = task.win_start >> 4;
+        const uint32_t sh = 2u * (uint32_t)(task.win_start & 15);
+        const int tw = (m + 15) / 16;
+#pragma unroll
+        for (int k = 0; k < MP_FLOOR_MAXM / 16 + 1; k++)
+            if (k < tw) {
+                uint64_t two = (uint64_t)text[q0 + k];
+                if (sh) two |= (uint64_t)text[q0 + k + 1] << 32;                  // (never a word past the window's last)
+                win[k] = (uint32_t)(two >> sh);
+            }
+        // the window's 6-mers into the set
+#pragma unroll
+        for (int k = 0; k < MP_FLOOR_MAXM / 16 + 1; k++) {
+            if (16 * k + MP_FLOOR_K > m) break;
+            const uint64_t two = ((uint64_t)win[k + 1] << 32) | win[k];
+            const int last = min(16, m - MP_FLOOR_K + 1 - 16 * k);
+            for (int u = 0; u < last; u++) {
+                const uint32_t key = (uint32_t)(two >> (2 * u)) & ((1u << (2 * MP_FLOOR_K)) - 1u);
+                atomicOr(&s_set[key >> 5][lane], 1u << (key & 31u));             // (this lane's own column: a plain ds_or)
+            }
+        }
+        // the read's 6-mers, every start: start j belongs to block phase j % 6; E of the six phases in six bytes of one word pair
+        unsigned long long E = 0;
+        int ph = 0;
+#pragma unroll
+        for (int k = 0; k < MP_FLOOR_MAXL / 16; k++) {
+            if (16 * k + MP_FLOOR_K > L) break;
+            const uint64_t two = ((uint64_t)a[k + 1] << 32) | a[k];
+            const int last = min(16, L - MP_FLOOR_K + 1 - 16 * k);
+            for (int u = 0; u < last; u++) {
+                const uint32_t key = (uint32_t)(two >> (2 * u)) & ((1u << (2 * MP_FLOOR_K)) - 1u);
+                const uint32_t present = (s_set[key >> 5][lane] >> (key & 31u)) & 1u;
+                E += (unsigned long long)(present ^ 1u) << (8 * ph);
+                ph = ph == MP_FLOOR_K - 1 ? 0 : ph + 1;
+            }
+        }
+        int U = L;
+#pragma unroll
+        for (int p = 0; p < MP_FLOOR_K; p++) {
+            const int e = (int)((E >> (8 * p)) & 255u);
+            const int u = L - 3 * max(0, e - 2) - min(e, 2);
+            U = min(U, u);
+        }
+        ub[t] = (uint16_t)max(U, 0);
+    }
+}
+
+// One lane per failed pair (its mates are the failed reads of slots 2k, 2k + 1; their tasks are task_off[slot] .. task_off[slot + 1]): n_cand of both
+// mates becomes 0 when nothing the pair's rescue work in this chunk could produce can matter (header of this file); counts[0] += dropped pairs,
+// counts[1] += their instances.
+__global__ void floor_decide_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed, const uint32_t *__restrict__ task_off, const uint16_t *__restrict__ ub,
+                                    const uint32_t *__restrict__ lens, const uint32_t *__restrict__ best_known, int top_pct, uint32_t *__restrict__ n_cand,
+                                    unsigned long long *__restrict__ counts)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    bool drop = false;
+    uint32_t n_inst = 0;
+    if (2 * k + 1 < n_failed) {
+        const uint32_t ra = failed_reads[2 * k], rb = failed_reads[2 * k + 1];
+        if ((ra ^ rb) == 1u) {                                                    // (always: both mates of a failed pair are listed, in read order)
+            uint32_t U[2] = {0, 0};
+            bool known = true;
+            for (int x = 0; x < 2; x++)
+                for (uint32_t t = task_off[2 * k + x]; t < task_off[2 * k + x + 1]; t++) {
+                    const uint32_t u = ub[t];
+                    if (u == MP_FLOOR_SKIP) known = false;
+                    U[x] = max(U[x], u);
+                }
+            n_inst = task_off[2 * k + 2] - task_off[2 * k];
+            if (known && n_inst) {
+                const long long L[2] = {(long long)lens[ra], (long long)lens[rb]};
+                const long long T[2] = {mp_floor_thr100(best_known[ra], top_pct), mp_floor_thr100(best_known[rb], top_pct)};
+                const long long Tmin = T[0] < T[1] ? T[0] : T[1];
+                drop = true;
+                for (int x = 0; x < 2; x++) {
+                    const int y = 1 - x;
+                    const bool has = task_off[2 * k + x + 1] > task_off[2 * k + x];
+                    if (!has) continue;                                           // no instance of x: no single-end hit of x, nothing anchored at x
+                    if (100 * (long long)U[x] >= T[x]) drop = false;              // a single-end entry of x could be printed
+                    if ((long long)U[x] >= (long long)mp_dp_cutoff((int)L[x])) {  // x may have a single-end hit: a rescue of y anchored at it
+                        if (100 * ((long long)U[x] + L[y]) >= Tmin) drop = false; //   both on one sequence: the sum in both headers
+                        if (100 * L[y] >= T[y]) drop = false;                     //   on different sequences: the rescued mate's own score in its header
+                    }
+                }
+            }
+        }
+        if (drop) { n_cand[2 * k] = 0; n_cand[2 * k + 1] = 0; }
+    }
+    const unsigned long long b = __ballot(drop);
+    unsigned long long inst = drop ? (unsigned long long)n_inst : 0ull;
+    for (int o = MP_WAVE / 2; o > 0; o >>= 1) inst += __shfl_down(inst, o);
+    if ((threadIdx.x & (MP_WAVE - 1)) == 0 && b) { atomicAdd(&counts[0], (unsigned long long)__popcll(b)); atomicAdd(&counts[1], inst); }
+}
+
+// best_known[read] = max(best_known[read], score of the key) for the keys a reduction call has just written (null keys excluded)
+__global__ void floor_best_kernel(const unsigned long long *__restrict__ keys, uint64_t n, uint32_t *__restrict__ best_known, uint32_t n_reads)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    if (k == 0xFFFFFFFFFFFFFFFFull) return;
+    const uint32_t read = (uint32_t)(k >> 42), score = 1023u - (uint32_t)(k & 1023u);
+    if (read < n_reads) atomicMax(&best_known[read], score);
+}

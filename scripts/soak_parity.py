@@ -46,7 +46,9 @@ for rnd in range(args.rounds):
                                                 ("MP_SA_DENSE", rng.random() < 0.7), ("MP_LKT16U", rng.random() < 0.7), ("MP_SA_DENSE_SPACING", rng.choice([1, 1, 2, 4])),
                                                 ("MP_DP_DIAG", rng.random() < 0.8), ("MP_DP_ONE_MISMATCH", rng.choice([0, 1, 2, 2, 2])), ("MP_DP_RESCUE_BAND", rng.random() < 0.8), ("MP_MERGE_ROWS", rng.random() < 0.8),
                                                 # round 4: the certificate's variants for short reads / mate-rescue windows; -b with resident chunks through the device reduction or every chunk's lists
-                                                ("MP_DP_THERMO_MORE", rng.random() < 0.75), ("MP_BAM_HOST_MERGE", rng.random() < 0.3))},
+                                                ("MP_DP_THERMO_MORE", rng.random() < 0.75), ("MP_BAM_HOST_MERGE", rng.random() < 0.3),
+                                                # the -top rule across resident chunks (two passes, pairs that cannot reach top% of their best known score lose their rescue work) on / off
+                                                ("MP_TOP_FLOOR", rng.random() < 0.7))},
                kw=dict(sub=float(rng.choice([0.0, 0.005, 0.01, 0.03, 0.06])), ins=float(rng.choice([0.0, 0.001, 0.004])), dele=float(rng.choice([0.0, 0.001, 0.004])),
                        random_frac=float(rng.choice([0.0, 0.05, 0.3])), broken_mate_frac=float(rng.choice([0.0, 0.1, 0.3])),
                        noisy_mate_frac=float(rng.choice([0.0, 0.2])), noisy_sub=0.15, n_frac=float(rng.choice([0.0, 0.002])),

@@ -1,0 +1,154 @@
+"""The -top rule across resident chunks (kernels_floor.hip, mp_chunk_stash / mp_ctx_set_score_floor): with several chunks resident the executable runs
+the deep-DP round of every chunk first and leaves out, in the rescue rounds that follow, the pairs whose rescue work in a chunk cannot put an entry of top%
+of their best known score into a header.  What is printed must not change: the chained oracle (the reference's chain, restated) is the judge, and the
+one-pass run (MP_TOP_FLOOR=0) its witness.  The databases here are built so that the rule has real work to leave out: diverged copies (12-25 %) of the
+reads' genome in the other chunks give the reads seeds, single-end hits and mate rescues there -- all far below 95 % of what they score at home."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import ROOT, fastq_records
+from megapath_amd import index_builder, synth
+
+pytestmark = pytest.mark.gpu
+
+B = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _mutate(rng, seq, div, indel=0.0):
+    s = seq.copy()
+    k = rng.random(len(s)) < div
+    s[k] = B[(np.searchsorted(B, s[k]) + rng.integers(1, 4, size=int(k.sum()))) & 3]
+    if indel > 0:
+        keep = rng.random(len(s)) >= indel
+        s = s[keep]
+    return s
+
+
+def _run(prefixes, f1, f2, out, ini, L, extra_env, flags):
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", ",".join(prefixes), f1, f2, "-o", out + ".o", "-C", os.path.join(ROOT, "tests", ini), "-L", str(L), "-T", "3", "-u", "750",
+           "-top", "95", "-nc"] + flags
+    env = dict(os.environ, MP_BATCH_PAIRS="1500", **extra_env)
+    with open(out, "wb") as fo:
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    return r.stderr.decode()
+
+
+@pytest.mark.parametrize("mode,seed,read_len", [("-F", 1, 150), ("-P", 2, 150), ("-F", 3, 100), ("-F", 4, 250)])
+def test_top_rule_across_chunks_changes_nothing(tmp_path, mode, seed, read_len):
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    home = [("home%d" % i, B[rng.integers(0, 4, size=150000)]) for i in range(2)]
+    # chunk 0 = home; chunks 1, 2: unrelated sequence + diverged copies of stretches of home (seeds and weak hits for home's reads); chunk 3 (the last):
+    # unrelated + a NEAR copy (entries that do reach 95 %) + a far one
+    def copy_of(k, a, n, div, indel=0.0):
+        return _mutate(rng, home[k][1][a:a + n], div, indel)
+    chunks = [
+        home,
+        [("c1_rand", B[rng.integers(0, 4, size=120000)]), ("c1_far12", copy_of(0, 10000, 60000, 0.12)), ("c1_far20", copy_of(1, 30000, 60000, 0.20, 0.004))],
+        [("c2_rand", B[rng.integers(0, 4, size=100000)]), ("c2_far15", copy_of(0, 60000, 70000, 0.15, 0.003)), ("c2_far25", copy_of(1, 80000, 50000, 0.25))],
+        [("c3_rand", B[rng.integers(0, 4, size=100000)]), ("c3_near1", copy_of(0, 20000, 40000, 0.01)), ("c3_far18", copy_of(1, 5000, 60000, 0.18))],
+    ]
+    prefixes = []
+    for c, part in enumerate(chunks):
+        pc = str(tmp_path / ("c%d.index" % c))
+        index_builder.write_index_files(pc, index_builder.build_index_arrays(part, sa_interval=16))
+        prefixes.append(pc)
+    names, r1, r2 = synth.simulate_pairs(home, 4000, read_len, 7100 + seed, sub=0.012, ins=0.001, dele=0.001, random_frac=0.1, broken_mate_frac=0.15, noisy_mate_frac=0.1, noisy_sub=0.15,
+                                         frag_mean=read_len + 200, frag_sd=40, frag_min=read_len + 20, frag_max=min(740, read_len + 420))
+    f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    synth.write_fastq_pair(f1, f2, names, r1, r2)
+    L = read_len + 1
+    ini = "soap4-nt2.ini"
+    on = str(tmp_path / "on.fq")
+    off = str(tmp_path / "off.fq")
+    err_on = _run(prefixes, f1, f2, on, ini, L, {}, [mode])
+    err_off = _run(prefixes, f1, f2, off, ini, L, {"MP_TOP_FLOOR": "0"}, [mode])
+    assert "-top rule" in err_on and "-top rule" not in err_off
+    left_out = int(err_on.split("-top rule: ")[1].split()[0])
+    # the chain of the reference, restated: chunk after chunk, each run reading the last one's stdout
+    lib = O.oracle()
+    in1, in2 = f1, f2
+    want = str(tmp_path / "want.fq")
+    for c, pc in enumerate(prefixes):
+        ix = lib.mpo_index_open(pc.encode())
+        p = O.default_params(L=L, mode=1 if mode == "-F" else 2, nc=(c == 0))
+        st = O.AlignStats()
+        assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), want.encode(), None, C.byref(st)) == 0
+        lib.mpo_index_close(ix)
+        if c + 1 < len(prefixes):
+            lines = open(want, "rb").read().split(b"\n")
+            in1, in2 = str(tmp_path / ("chain_%d_1.fq" % c)), str(tmp_path / ("chain_%d_2.fq" % c))
+            with open(in1, "wb") as fa, open(in2, "wb") as fb:
+                for i in range(0, len(lines) - 7, 8):
+                    fa.write(b"\n".join(lines[i:i + 4]) + b"\n")
+                    fb.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
+    w = fastq_records(want)
+    assert fastq_records(off) == w                   # the one-pass run: the chain
+    assert fastq_records(on) == w                    # the two passes with the rule: the same records
+    # the rule did leave work out -- and the database did offer entries from several chunks (near copy in the last chunk) that had to survive it
+    assert left_out > 300, (left_out, err_on[-600:])
+    assert sum(1 for r in w if r[2].count(",c3_near1") and r[2].count(",home")) > 100
+
+
+def test_top_rule_with_bam_and_host_merge_paths(tmp_path):
+    """-b with the rule (the NT stage's real command line): stdout and the last chunk's BAM records equal to the one-pass run's"""
+    import bamtext
+    rng = np.random.Generator(np.random.PCG64(7777))
+    home = [("home", B[rng.integers(0, 4, size=200000)])]
+    chunks = [home, [("x_far", _mutate(rng, home[0][1][20000:120000], 0.14))], [("y_rand", B[rng.integers(0, 4, size=80000)]), ("y_near", _mutate(rng, home[0][1][50000:90000], 0.02))]]
+    prefixes = []
+    for c, part in enumerate(chunks):
+        pc = str(tmp_path / ("c%d.index" % c))
+        index_builder.write_index_files(pc, index_builder.build_index_arrays(part, sa_interval=16))
+        prefixes.append(pc)
+    names, r1, r2 = synth.simulate_pairs(home, 3000, 150, 7801, sub=0.01, random_frac=0.05, broken_mate_frac=0.2, frag_mean=350, frag_sd=40, frag_min=170, frag_max=570)
+    f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    synth.write_fastq_pair(f1, f2, names, r1, r2)
+    outs = {}
+    for tag, env in (("on", {}), ("off", {"MP_TOP_FLOOR": "0"})):
+        out = str(tmp_path / (tag + ".fq"))
+        _run(prefixes, f1, f2, out, "soap4-nt2.ini", 151, env, ["-F", "-b", "-D", "rg", "-A", "s"])
+        outs[tag] = (fastq_records(out), [sorted(bamtext.read_bam(out + ".o." + k)[2]) for k in ("dpout.1", "gout.1", "unpair")])
+    assert outs["on"][0] == outs["off"][0]
+    assert outs["on"][1] == outs["off"][1] and len(outs["on"][1][0]) > 100
+
+
+@pytest.mark.parametrize("lo,hi,margin,seed", [(101, 160, 30, 21), (45, 100, 25, 22), (161, 320, 30, 23)])
+def test_floor_bound_is_an_upper_bound_of_the_exact_dp(lo, hi, margin, seed):
+    """what the rule rests on: U (blocks of six read bases that occur nowhere in the window cost >= 3 each, six block phases) is never below the exact DP score --
+    on the certificate tests' adversarial instances (chance seeds, second stretches, true alignments with mismatches and indels, tandem repeats, both strands)
+    and on mate-rescue windows; and it is small where nothing is there"""
+    from megapath_amd import hipapi as H
+    import test_gpu_thermo as T
+    rng = np.random.default_rng(seed)
+    text = rng.integers(0, 4, 1 << 20).astype(np.uint8)
+    n = 30000
+    reads, tasks, kind = T._make_instances(rng, text, n, (0, 1, 2, 3, 4, 5, 6, 7), lo, hi, margin)
+    if hi <= 160:
+        r2, t2, k2 = T._make_rescue_instances(rng, text, 6000, (0, 1, 2, 3, 5, 6), max(lo, 75), hi)
+        t2["read_id"] += n
+        reads += r2; tasks = np.concatenate([tasks, t2]); kind = np.concatenate([kind, 100 + k2])
+    arrs = index_builder.build_index_arrays([("t", text)], sa_interval=16)
+    ix = H.Index.from_arrays(0, **arrs)
+    ctx = H.Context(ix)
+    seqs = [bytes(b"ACGT"[c] for c in r) for r in reads]
+    packed, lens, W = H.pack_reads(seqs, 161 if hi <= 160 else 321)
+    ctx.set_reads(packed, lens)
+    ub = ctx.test_floor_bound(np.ascontiguousarray(tasks)).astype(np.int64)
+    res = ctx.sgdp_results(np.ascontiguousarray(tasks), 130, 130)
+    # (sgdp returns 0 below the cutoff: the bound must hold for every score that is reported, and those are the ones that could ever be printed)
+    covered = ub != 0xFFFF
+    bad = np.nonzero(covered & (res["score"] > ub))[0]
+    assert len(bad) == 0, (bad[:10], res["score"][bad[:10]], ub[bad[:10]], kind[bad[:10]])
+    assert covered[tasks["win_len"] <= 384].all()
+    rl = lens[tasks["read_id"]].astype(np.int64)
+    assert (res["score"][kind == 3] > 0.4 * rl[kind == 3]).mean() > 0.8        # the true alignments are there ...
+    chance = ub[(kind == 0) & covered]
+    assert np.median(chance / rl[(kind == 0) & covered]) < 0.72 and len(chance) > 1000      # ... and a chance seed's window is bounded far below them
+    ctx.close()
+    ix.close()

@@ -2054,7 +2054,7 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
         if (c->failed_reads.reserve(nf + 1) || c->n_scand.reserve(nf + 2) || c->s_off.reserve(nf + 2) || c->scand.reserve(c->n_hits_total + 64)) return MP_ENOMEM;
         hipLaunchKernelGGL(list_failed_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, s, c->failed_flag.p, c->failed_off.p, n_reads, c->failed_reads.p);
         MP_TRACE(s, "list_failed_kernel");
-        hipLaunchKernelGGL(single_cand_kernel, dim3(grid_for(nf + 1, 128)), dim3(128), 0, s, c->failed_reads.p, nf, c->seedpos.p, c->rs_base.p, c->n_pos.p,
+        hipLaunchKernelGGL(single_cand_kernel, dim3(grid_for(nf + 1, 64)), dim3(64), 0, s, c->failed_reads.p, nf, c->seedpos.p, c->rs_base.p, c->n_pos.p,
                            c->n_neg.p, c->scand.p, c->n_scand.p);
         MP_TRACE(s, "single_cand_kernel");
         rc = exclusive_scan_u32(c, c->n_scand.p, c->s_off.p, nf + 1);

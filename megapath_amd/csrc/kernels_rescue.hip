@@ -35,14 +35,21 @@ struct mp_single_cand { uint64_t pos; uint32_t strand; uint32_t seed_len; };
 // 2*floor(log2 n) levels are used up; then one insertion pass, guarded for the first 16 elements only.
 // Records move as one 16-byte register quad (x, y = pos; z = strand; w = seed_len): no struct temporaries, no scratch memory.
 typedef uint4 mp_cand_q;
-__device__ __forceinline__ mp_cand_q mp_lsl_ld(const mp_single_cand *a, int i) { return *reinterpret_cast<const mp_cand_q *>(a + i); }
-__device__ __forceinline__ void mp_lsl_st(mp_single_cand *a, int i, mp_cand_q v) { *reinterpret_cast<mp_cand_q *>(a + i) = v; }
-__device__ __forceinline__ uint32_t mp_lsl_len(const mp_single_cand *a, int i) { return a[i].seed_len; }
-__device__ __forceinline__ void mp_lsl_swap(mp_single_cand *a, int i, int j) { const mp_cand_q t = mp_lsl_ld(a, i); mp_lsl_st(a, i, mp_lsl_ld(a, j)); mp_lsl_st(a, j, t); }
+// The array being sorted: records `stride` quads apart -- 1 for a read's slice of the candidate array in global memory, the block's lane count for a
+// column of the LDS staging area of single_cand_kernel (element e of lane l at [e][l]: 16-byte accesses without bank conflicts).  Same algorithm, same
+// comparisons, same result either way; only the latency of every dependent access differs (a read's ~30 candidates are moved some hundred times).
+struct mp_cand_arr {
+    mp_cand_q *p; int stride;
+    __device__ __forceinline__ mp_cand_arr at(int first) const { return mp_cand_arr{p + (size_t)first * stride, stride}; }
+};
+__device__ __forceinline__ mp_cand_q mp_lsl_ld(const mp_cand_arr &a, int i) { return a.p[(size_t)i * a.stride]; }
+__device__ __forceinline__ void mp_lsl_st(const mp_cand_arr &a, int i, mp_cand_q v) { a.p[(size_t)i * a.stride] = v; }
+__device__ __forceinline__ uint32_t mp_lsl_len(const mp_cand_arr &a, int i) { return a.p[(size_t)i * a.stride].w; }
+__device__ __forceinline__ void mp_lsl_swap(const mp_cand_arr &a, int i, int j) { const mp_cand_q t = mp_lsl_ld(a, i); mp_lsl_st(a, i, mp_lsl_ld(a, j)); mp_lsl_st(a, j, t); }
 static_assert(sizeof(mp_single_cand) == 16, "candidates move as 16-byte quads");
 
 // __adjust_heap + __push_heap of libstdc++ (bits/stl_heap.h) with "longer seed first" as the order
-__device__ __forceinline__ void mp_lsl_sift(mp_single_cand *a, int hole, int len, mp_cand_q v)
+__device__ __forceinline__ void mp_lsl_sift(const mp_cand_arr &a, int hole, int len, mp_cand_q v)
 {
     const int top = hole;
     int child = hole;
@@ -61,7 +68,7 @@ __device__ __forceinline__ void mp_lsl_sift(mp_single_cand *a, int hole, int len
 // arrays would be scratch memory, which no kernel of this library uses.  An entry packs first | last << 12 | depth << 24
 // (a read has < 4096 candidates: at most MP_SEED_BIG seeds per strand); at most one entry per partition level is pending.
 #define MP_LSL_STACK 26
-__device__ __forceinline__ void mp_sort_longer_seed(mp_single_cand *a, int n, uint32_t *stk, int stride)
+__device__ __forceinline__ void mp_sort_longer_seed(const mp_cand_arr &a, int n, uint32_t *stk, int stride)
 {
     if (n <= 1) return;
     if (n > 16 && n < 4096) {
@@ -76,7 +83,7 @@ __device__ __forceinline__ void mp_sort_longer_seed(mp_single_cand *a, int n, ui
             // the left ones first and stacking the right ones gives the same array
             while (last - first > 16) {
                 if (depth == 0) {
-                    mp_single_cand *h = a + first;
+                    const mp_cand_arr h = a.at(first);
                     const int len = last - first;
                     for (int parent = (len - 2) / 2;; parent--) { mp_lsl_sift(h, parent, len, mp_lsl_ld(h, parent)); if (parent == 0) break; }
                     for (int e2 = len; e2 > 1;) { --e2; const mp_cand_q v = mp_lsl_ld(h, e2); mp_lsl_st(h, e2, mp_lsl_ld(h, 0)); mp_lsl_sift(h, 0, e2, v); }
@@ -121,18 +128,20 @@ __global__ void sort_longer_seed_test_kernel(mp_single_cand *__restrict__ cand, 
 {
     __shared__ uint32_t s_stk[MP_LSL_STACK][64];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_arrays) mp_sort_longer_seed(cand + off[t], (int)(off[t + 1] - off[t]), &s_stk[0][threadIdx.x], 64);
+    if (t < n_arrays) mp_sort_longer_seed(mp_cand_arr{reinterpret_cast<mp_cand_q *>(cand + off[t]), 1}, (int)(off[t + 1] - off[t]), &s_stk[0][threadIdx.x], 64);
 }
 
 // One lane per failed read.  The read's kept seeds (the seed pool) sit at seedpos[rs_base[2r] ..) sorted by
 // (strand, pos), which is the order RadixTraitsCandidateInfo produces (DV-DPForSingleReads.cpp:108-118).
 // Candidates are written to cand[rs_base[2r] ..) (same capacity) and counted in n_cand[slot].
-__global__ void __launch_bounds__(128)
+#define MP_SCAND_LDS 40        // candidates of a read staged in LDS (a read of the NT stage has ~30 seeds; more: the read's slice of the global array as before)
+__global__ void __launch_bounds__(64)
 single_cand_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed, const mp_seedpos *__restrict__ seedpos,
                    const uint32_t *__restrict__ rs_base, const uint32_t *__restrict__ n_pos, const uint32_t *__restrict__ n_neg,
                    mp_single_cand *__restrict__ cand, uint32_t *__restrict__ n_cand)
 {
-    __shared__ uint32_t s_stk[MP_LSL_STACK][128];
+    __shared__ uint32_t s_stk[MP_LSL_STACK][64];
+    __shared__ mp_cand_q s_c[MP_SCAND_LDS][64];              // [element][lane]: 40 KB
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot > n_failed) return;
     if (slot == n_failed) { n_cand[slot] = 0; return; }
@@ -140,6 +149,8 @@ single_cand_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed,
     const mp_seedpos *sp = seedpos + rs_base[2 * r];
     const int n = (int)(n_pos[r] + n_neg[r]);
     mp_single_cand *out = cand + rs_base[2 * r];
+    const bool in_lds = n <= MP_SCAND_LDS;
+    const mp_cand_arr arr = in_lds ? mp_cand_arr{&s_c[0][threadIdx.x], 64} : mp_cand_arr{reinterpret_cast<mp_cand_q *>(out), 1};
     int nm = 0;
     // singleMerge: drop seeds < 17, merge followers within DPS_DIVIDE_GAP (5) on the same strand keeping the longer one
     for (int p = 0; p < n; p++) {
@@ -153,13 +164,14 @@ single_cand_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed,
             } else break;
             ++p;
         }
-        out[nm++] = cur;
+        mp_lsl_st(arr, nm++, mp_cand_q{(uint32_t)cur.pos, (uint32_t)(cur.pos >> 32), cur.strand, cur.seed_len});
     }
     // longest first, in the very order std::sort(.., LongerSeedLength()) leaves equal lengths in (DV-DPfunctions.cpp:334):
     // the cut at 200 below makes that order output-visible.  Then drop < 0.6 x best, cap at 200.
-    mp_sort_longer_seed(out, nm, &s_stk[0][threadIdx.x], 128);
-    while (nm > 0 && (double)out[nm - 1].seed_len < (double)out[0].seed_len * 0.6) nm--;
+    mp_sort_longer_seed(arr, nm, &s_stk[0][threadIdx.x], 64);
+    while (nm > 0 && (double)mp_lsl_len(arr, nm - 1) < (double)mp_lsl_len(arr, 0) * 0.6) nm--;
     if (nm > MP_SINGLE_MAX) nm = MP_SINGLE_MAX;
+    if (in_lds) for (int i = 0; i < nm; i++) *reinterpret_cast<mp_cand_q *>(out + i) = mp_lsl_ld(arr, i);
     n_cand[slot] = (uint32_t)nm;
 }
 

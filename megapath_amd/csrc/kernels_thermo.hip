@@ -46,12 +46,30 @@
 #define MP_TH_T_RESCUE_WIDE 12
 #define MP_TH_MINRUN 12            // a run shorter than this is no seed: no certificate
 
-// lane l receives lane l-1's value AND-ed with the mask of "has a left neighbour", in ONE instruction (lane 0, which has no source, reads 0)
-__device__ __forceinline__ uint32_t th_from_left_and(uint32_t v, uint32_t mask)
+// Lane l receives lane l-1's planes 1 .. N AND-ed with the mask of "has a left neighbour", one v_and_b32_dpp each (lane 0, which has no source, reads 0).
+// A DPP operand read within two wait states of the VALU instruction that wrote the register returns the register's OLD content (gfx9 data hazard; five
+// wait states after a VALU write of EXEC), and the compiler's hazard recognizer does not look into asm statements.  Until round 4 these were N separate
+// one-instruction asm statements, safe only by the luck of the schedule: a build whose loop put a producer next to one of them certified differently
+// from run to run (found by comparing two builds instance by instance).  Hence ONE statement per group: every input is complete when it begins, nothing
+// can be scheduled into it, and it opens with the wait states itself.  (The compiler's own DPP builtin handles the hazard too, but turns the AND into a
+// select, does not fold the move, and the kernel then spills.)
+// In place (destination = source register of the own lane: the sources of all lanes are read before any is written), so the group needs no register more.
+#define TH_L(k) "v_and_b32_dpp %[x" #k "], %[x" #k "], %[m] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define TH_X(k) [x##k] "+v"(x[k])
+#define TH_LINES_7 TH_L(1) TH_L(2) TH_L(3) TH_L(4) TH_L(5) TH_L(6) TH_L(7)
+#define TH_REGS_7 TH_X(1), TH_X(2), TH_X(3), TH_X(4), TH_X(5), TH_X(6), TH_X(7)
+#define TH_COMMA ,
+#define TH_GROUP(lines, regs) asm("s_nop 4\n\t" lines : regs : [m] "v"(m))
+template <int N>
+__device__ __forceinline__ void th_from_left_and(uint32_t (&x)[N + 1], uint32_t m)
 {
-    uint32_t r;
-    asm("v_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(mask));
-    return r;
+    static_assert(N >= 7 && N <= 12, "planes per group");
+    if constexpr (N == 7) TH_GROUP(TH_LINES_7, TH_REGS_7);
+    else if constexpr (N == 8) TH_GROUP(TH_LINES_7 TH_L(8), TH_REGS_7 TH_COMMA TH_X(8));
+    else if constexpr (N == 9) TH_GROUP(TH_LINES_7 TH_L(8) TH_L(9), TH_REGS_7 TH_COMMA TH_X(8) TH_COMMA TH_X(9));
+    else if constexpr (N == 10) TH_GROUP(TH_LINES_7 TH_L(8) TH_L(9) TH_L(10), TH_REGS_7 TH_COMMA TH_X(8) TH_COMMA TH_X(9) TH_COMMA TH_X(10));
+    else if constexpr (N == 11) TH_GROUP(TH_LINES_7 TH_L(8) TH_L(9) TH_L(10) TH_L(11), TH_REGS_7 TH_COMMA TH_X(8) TH_COMMA TH_X(9) TH_COMMA TH_X(10) TH_COMMA TH_X(11));
+    else TH_GROUP(TH_LINES_7 TH_L(8) TH_L(9) TH_L(10) TH_L(11) TH_L(12), TH_REGS_7 TH_COMMA TH_X(8) TH_COMMA TH_X(9) TH_COMMA TH_X(10) TH_COMMA TH_X(11) TH_COMMA TH_X(12));
 }
 
 // cert[t] = 1: instance t cannot reach its cutoff (no alignment); 0: undecided, the filter has to look at it.
@@ -65,7 +83,7 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
                unsigned long long *__restrict__ stats /* [0] certified [1] overflow [2] bound too high [3] not eligible */)
 {
     constexpr int TE = T - 3, NC = MP_TH_COLS;
-    static_assert(T >= 8 && T <= 14, "planes");
+    static_assert(T >= 10 && T <= 12, "planes (th_from_left_and: groups of T and T - 3)");
     static_assert(LPS == 32 || LPS == 64, "lanes per set");
     constexpr int SETS = 64 / LPS, MAXL = NC * LPS, MAXM = MAXM_P;
     static_assert(MAXM % 16 == 0, "whole words of window");
@@ -131,6 +149,10 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
             if (!RUNLESS && rlen < MP_TH_MINRUN) ok = false;
         }
     }
+    // (the lanes that own read columns: see `steps` below)
+    int lmax = ok ? L : 0;
+    for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o));
+    const int n_lanes = __builtin_amdgcn_readfirstlane(min(LPS, (lmax + NC - 1) / NC));
     // ---------------------------------------------------------------- transposition: one ballot per word, both halves at once
 #pragma unroll
     for (int k = 0; k < MAXL / 16; k++) {
@@ -199,7 +221,11 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
 #pragma unroll
     for (int t = 0; t <= T; t++) { accR[t] = 0; accL[t] = 0; }
     const uint32_t nb = l ? 0xFFFFFFFFu : 0u;       // the first lane of a half has no left neighbour: its column -1 is the table's edge (H = 0)
-    const int steps = mmax + LPS - 1;
+    // The sweep ends when the last lane that OWNS read columns has done the last row: the lanes right of the longest read of the wavefront's instances hold no
+    // cell of any table (data only flows to the right and down, and what a gap carries into such a column is below the cell it left, which the accumulators
+    // have seen), so they need not finish.  150-base reads: 30 lanes, 210 + 29 = 239 steps = 40 turns of six instead of 41.
+    // (the loop below is a do-while on purpose: as a for loop with this bound the narrow variants spill registers into scratch memory inside the sweep)
+    const int steps = mmax + max(n_lanes, 1) - 1;
     // Rows above the table (a lane starts l steps late) need no test: every input there is 0 and stays 0.  Rows below it are computed as rows
     // that match nothing: what appears there is never above the cell it came from, so the accumulators may see it.
     // The seed's diagonal meets lane l in its column K at step s = (NC + 1) l + MARGIN + K: with the steps taken NC + 1 at a time, K is a
@@ -210,9 +236,11 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         // what the left neighbour published at the end of the previous step: its last column in MY row (G) and, kept from the step before, one row up (H)
         uint32_t gotH[T + 1], gotG[TE + 1];
 #pragma unroll
-        for (int t = 1; t <= T; t++) gotH[t] = th_from_left_and(outH[t], nb);
+        for (int t = 1; t <= T; t++) gotH[t] = outH[t];
 #pragma unroll
-        for (int t = 1; t <= TE; t++) gotG[t] = th_from_left_and(outG[t], nb);
+        for (int t = 1; t <= TE; t++) gotG[t] = outG[t];
+        th_from_left_and<T>(gotH, nb);
+        th_from_left_and<TE>(gotG, nb);
         const int ri = s - l + OFF;                                             // my window row (i = s - l), as stored
         const uint32_t wv = s_wv[h][ri], w0 = s_w0[h][ri], w1 = s_w1[h][ri], rowgt = RUNLESS ? 0u : s_rg[h][ri];
         const uint32_t onl = !RUNLESS && (NC + 1) * l + MARGIN + K == s ? 0xFFFFFFFFu : 0u;   // this lane's column K is on the seed's diagonal
@@ -272,10 +300,12 @@ dp_thermo_body(const uint32_t *__restrict__ text, const uint32_t *__restrict__ r
         for (int t = 1; t <= TE; t++) outG[t] = G[t];
     };
     static_assert(NC == 5, "six steps per turn");
-    for (int s = 0; s < steps; s += NC + 1) {         // (the last turn may run up to five rows further down: rows that match nothing)
+    int s = 0;
+    do {                                              // (the last turn may run up to five rows further down: rows that match nothing)
         step(std::integral_constant<int, 0>{}, s); step(std::integral_constant<int, 1>{}, s + 1); step(std::integral_constant<int, 2>{}, s + 2);
         step(std::integral_constant<int, 3>{}, s + 3); step(std::integral_constant<int, 4>{}, s + 4); step(std::integral_constant<int, 5>{}, s + 5);
-    }
+        s += NC + 1;
+    } while (s < steps);
     // ---------------------------------------------------------------- per instance: OR over the lanes of its half, then read its bit
     auto half_or = [&](uint32_t v) -> uint32_t {
         for (int o = 1; o < LPS; o <<= 1) v |= (uint32_t)__shfl_xor((int)v, o);

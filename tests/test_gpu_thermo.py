@@ -162,6 +162,45 @@ def _make_rescue_instances(rng, text, n, kinds, lo, hi):
     return reads, tasks, kind
 
 
+@pytest.mark.parametrize("name,lo,hi,margin,variant", [("narrow", 101, 160, 30, 1), ("short", 45, 100, 25, 0), ("wide", 161, 320, 30, 2), ("rescue", 75, 160, 0, 3), ("rescue_wide", 100, 320, 0, 4)])
+def test_certificate_is_a_function_of_the_instance_alone(name, lo, hi, margin, variant):
+    """The 32 instances of a word share nothing but the number of steps their wavefront sweeps, and more steps add nothing: the same instance must get
+    the same answer whatever it is grouped with, and run after run.  (Round 4: the lane-to-lane transfers were one-instruction asm statements whose DPP
+    operand could be read within the two wait states after the instruction that wrote it -- a build with another schedule answered a few instances in
+    a thousand differently from run to run, in both directions.  Mixed read lengths and a second order of the same instances show that.)"""
+    from megapath_amd import hipapi as H
+    from megapath_amd.index_builder import build_index_arrays
+    rng = np.random.default_rng(99)
+    text = rng.integers(0, 4, 1 << 21).astype(np.uint8)
+    n = 40000
+    if variant >= 3:
+        reads, tasks, kind = _make_rescue_instances(rng, text, n, (0, 0, 0, 1, 2, 3, 5, 6), lo, hi)
+    else:
+        reads, tasks, kind = _make_instances(rng, text, n, (0, 0, 0, 1, 2, 3, 4, 5, 6, 7), lo, hi, margin)
+    arrs = build_index_arrays([("t", text)], sa_interval=16)
+    ix = H.Index.from_arrays(0, **arrs)
+    ctx = H.Context(ix)
+    seqs = [bytes(b"ACGT"[c] for c in r) for r in reads]
+    packed, lens, W = H.pack_reads(seqs, 161 if hi <= 160 else 321)
+    ctx.set_reads(packed, lens)
+    tasks = np.ascontiguousarray(tasks)
+    first, st = ctx.test_dp_thermo(tasks, variant)
+    first = first.copy()
+    assert 0.2 * n < st[0] < 0.9 * n, st
+    for rep in range(2):
+        again, _ = ctx.test_dp_thermo(tasks, variant)
+        assert (again == first).all(), (name, rep, int((again != first).sum()))
+    # another grouping: sorted by window length (what run_dp_filtered hands over), and a random order
+    for order in (np.argsort(tasks["win_len"], kind="stable"), rng.permutation(n)):
+        got, _ = ctx.test_dp_thermo(np.ascontiguousarray(tasks[order]), variant)
+        back = np.empty(n, dtype=np.uint8)
+        back[order] = got
+        bad = np.nonzero(back != first)[0]
+        assert len(bad) == 0, (name, len(bad), [(int(t), int(first[t]), int(back[t]), int(kind[t]), int(lens[tasks["read_id"][t]]), int(tasks["win_len"][t])) for t in bad[:8]])
+    ctx.close()
+    ix.close()
+
+
 @pytest.mark.parametrize("kinds,seed,lo,hi", [((0,), 11, 101, 160), ((0, 1, 2, 3, 5, 6), 12, 75, 160), ((1, 2, 3), 13, 140, 160), ((0,), 14, 161, 320), ((0, 1, 2, 3, 5, 6), 15, 100, 320),
                                               ((1, 2, 3), 16, 250, 320)])
 def test_rescue_window_certificate_never_rejects_an_alignment(kinds, seed, lo, hi):

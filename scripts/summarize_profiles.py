@@ -24,6 +24,30 @@ if stats:
     keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in OURS)]
     with open(os.path.join(dst, "%s_kernel_stats_bench.csv" % tag), "w", newline="") as f:
         csv.writer(f).writerows(keep)
+    # every kernel of the run (library kernels of hipcub and torch included), the 80 largest by total time: what the filtered table leaves out
+    with open(os.path.join(dst, "%s_kernel_stats_bench_all_top80.csv" % tag), "w", newline="") as f:
+        csv.writer(f).writerows(rows[:81])
+# the same trace restricted to the steps: every kernel (copy and fill kernels of the runtime included) that starts after the first seed_kernel does,
+# i.e. without the building of the replica -- calls, total and share of the window
+trace = newest(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"))
+if trace:
+    import collections as _c
+    recs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace[0]))]
+    seeds = [a for a, b, k in recs if k.startswith("seed_kernel")]
+    if seeds:
+        t0 = min(seeds)
+        t1 = max(b for a, b, k in recs)
+        agg = _c.defaultdict(lambda: [0, 0])
+        for a, b, k in recs:
+            if a >= t0:
+                name = k.split("(")[0][:110]
+                agg[name][0] += 1; agg[name][1] += b - a
+        busy = sum(v[1] for v in agg.values())
+        with open(os.path.join(dst, "%s_kernel_stats_steps_only.csv" % tag), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "ShareOfKernelTime", "window_ns=%d" % (t1 - t0), "kernel_time_ns=%d" % busy])
+            for name, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+                w.writerow([name, n, tot, tot // n, "%.4f" % (tot / busy)])
 line = [l for l in open(os.path.join(out_dir, "bench_under_rocprof.json")) if l.startswith("{")]
 if line:
     open(os.path.join(dst, "%s_bench_under_rocprof.json" % tag), "w").write(line[-1])

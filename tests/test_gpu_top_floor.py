@@ -29,9 +29,9 @@ def _mutate(rng, seq, div, indel=0.0):
     return s
 
 
-def _run(prefixes, f1, f2, out, ini, L, extra_env, flags):
+def _run(prefixes, f1, f2, out, ini, L, extra_env, flags, top=95, nc=True):
     cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", ",".join(prefixes), f1, f2, "-o", out + ".o", "-C", os.path.join(ROOT, "tests", ini), "-L", str(L), "-T", "3", "-u", "750",
-           "-top", "95", "-nc"] + flags
+           "-top", str(top)] + (["-nc"] if nc else []) + flags
     env = dict(os.environ, MP_BATCH_PAIRS="1500", **extra_env)
     with open(out, "wb") as fo:
         r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
@@ -39,11 +39,18 @@ def _run(prefixes, f1, f2, out, ini, L, extra_env, flags):
     return r.stderr.decode()
 
 
-@pytest.mark.parametrize("mode,seed,read_len", [("-F", 1, 150), ("-P", 2, 150), ("-F", 3, 100), ("-F", 4, 250)])
-def test_top_rule_across_chunks_changes_nothing(tmp_path, mode, seed, read_len):
+def _split_pairs(fq, out1, out2):
+    lines = open(fq, "rb").read().split(b"\n")
+    with open(out1, "wb") as fa, open(out2, "wb") as fb:
+        for i in range(0, len(lines) - 7, 8):
+            fa.write(b"\n".join(lines[i:i + 4]) + b"\n")
+            fb.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
+
+
+def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comments=False, min_left_out=300):
     rng = np.random.Generator(np.random.PCG64(7000 + seed))
     home = [("home%d" % i, B[rng.integers(0, 4, size=150000)]) for i in range(2)]
-    # chunk 0 = home; chunks 1, 2: unrelated sequence + diverged copies of stretches of home (seeds and weak hits for home's reads); chunk 3 (the last):
+    # chunk 0 = home; chunks 1, 2: unrelated sequence + diverged copies of stretches of home (seeds and weak hits for home's reads); the last chunk:
     # unrelated + a NEAR copy (entries that do reach 95 %) + a far one
     def copy_of(k, a, n, div, indel=0.0):
         return _mutate(rng, home[k][1][a:a + n], div, indel)
@@ -53,6 +60,9 @@ def test_top_rule_across_chunks_changes_nothing(tmp_path, mode, seed, read_len):
         [("c2_rand", B[rng.integers(0, 4, size=100000)]), ("c2_far15", copy_of(0, 60000, 70000, 0.15, 0.003)), ("c2_far25", copy_of(1, 80000, 50000, 0.25))],
         [("c3_rand", B[rng.integers(0, 4, size=100000)]), ("c3_near1", copy_of(0, 20000, 40000, 0.01)), ("c3_far18", copy_of(1, 5000, 60000, 0.18))],
     ]
+    pre = [("pre_rand", B[rng.integers(0, 4, size=60000)]), ("pre_near3", copy_of(0, 0, 90000, 0.03)), ("pre_far10", copy_of(1, 0, 90000, 0.10))]
+    if n_chunks == 2:
+        chunks = [chunks[1], chunks[0]] if with_comments else [chunks[0], chunks[3]]
     prefixes = []
     for c, part in enumerate(chunks):
         pc = str(tmp_path / ("c%d.index" % c))
@@ -64,35 +74,73 @@ def test_top_rule_across_chunks_changes_nothing(tmp_path, mode, seed, read_len):
     synth.write_fastq_pair(f1, f2, names, r1, r2)
     L = read_len + 1
     ini = "soap4-nt2.ini"
+    lib = O.oracle()
+    m = 1 if mode == "-F" else 2
+    if with_comments:
+        # the reads arrive with header comments of an earlier stage (no -nc anywhere): entries of a database that is NOT among the chunks, some of them
+        # better than anything the chunks hold, some worse
+        pp = str(tmp_path / "pre.index")
+        index_builder.write_index_files(pp, index_builder.build_index_arrays(pre, sa_interval=16))
+        ix = lib.mpo_index_open(pp.encode())
+        p0 = O.default_params(L=L, mode=m, nc=True, top=top)
+        st = O.AlignStats()
+        annotated = str(tmp_path / "pre.fq")
+        assert lib.mpo_align_fastq(ix, C.byref(p0), f1.encode(), f2.encode(), annotated.encode(), None, C.byref(st)) == 0
+        lib.mpo_index_close(ix)
+        f1, f2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+        _split_pairs(annotated, f1, f2)
+        assert sum(1 for l in open(f1, "rb") if l.startswith(b"@") and b"SCORE:" in l) > 1000
     on = str(tmp_path / "on.fq")
     off = str(tmp_path / "off.fq")
-    err_on = _run(prefixes, f1, f2, on, ini, L, {}, [mode])
-    err_off = _run(prefixes, f1, f2, off, ini, L, {"MP_TOP_FLOOR": "0"}, [mode])
+    err_on = _run(prefixes, f1, f2, on, ini, L, {}, [mode], top=top, nc=not with_comments)
+    err_off = _run(prefixes, f1, f2, off, ini, L, {"MP_TOP_FLOOR": "0"}, [mode], top=top, nc=not with_comments)
     assert "-top rule" in err_on and "-top rule" not in err_off
     left_out = int(err_on.split("-top rule: ")[1].split()[0])
     # the chain of the reference, restated: chunk after chunk, each run reading the last one's stdout
-    lib = O.oracle()
     in1, in2 = f1, f2
     want = str(tmp_path / "want.fq")
     for c, pc in enumerate(prefixes):
         ix = lib.mpo_index_open(pc.encode())
-        p = O.default_params(L=L, mode=1 if mode == "-F" else 2, nc=(c == 0))
+        p = O.default_params(L=L, mode=m, nc=(c == 0 and not with_comments), top=top)
         st = O.AlignStats()
         assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), want.encode(), None, C.byref(st)) == 0
         lib.mpo_index_close(ix)
         if c + 1 < len(prefixes):
-            lines = open(want, "rb").read().split(b"\n")
             in1, in2 = str(tmp_path / ("chain_%d_1.fq" % c)), str(tmp_path / ("chain_%d_2.fq" % c))
-            with open(in1, "wb") as fa, open(in2, "wb") as fb:
-                for i in range(0, len(lines) - 7, 8):
-                    fa.write(b"\n".join(lines[i:i + 4]) + b"\n")
-                    fb.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
+            _split_pairs(want, in1, in2)
     w = fastq_records(want)
     assert fastq_records(off) == w                   # the one-pass run: the chain
     assert fastq_records(on) == w                    # the two passes with the rule: the same records
-    # the rule did leave work out -- and the database did offer entries from several chunks (near copy in the last chunk) that had to survive it
-    assert left_out > 300, (left_out, err_on[-600:])
+    # the rule did leave work out
+    assert left_out >= min_left_out, (left_out, err_on[-600:])
+    return w
+
+
+@pytest.mark.parametrize("mode,seed,read_len", [("-F", 1, 150), ("-P", 2, 150), ("-F", 3, 100), ("-F", 4, 250)])
+def test_top_rule_across_chunks_changes_nothing(tmp_path, mode, seed, read_len):
+    w = _check_rule(tmp_path, mode, seed, read_len)
+    # the database did offer entries from several chunks (near copy in the last chunk) that had to survive the rule
     assert sum(1 for r in w if r[2].count(",c3_near1") and r[2].count(",home")) > 100
+
+
+@pytest.mark.parametrize("top,min_left_out", [(100, 300), (60, 0), (1, 0)])
+def test_top_rule_at_other_percentages(tmp_path, top, min_left_out):
+    """-top 100: only ties of the best survive, the rule has the most to leave out; -top 60: entries of the 12 % copies stay in the headers, and a rescued pair
+    could reach 60 % of any best score (bound + mate length): the rule leaves everything in; -top 1: everything may matter, the same"""
+    _check_rule(tmp_path, "-F", 30 + top, 150, top=top, min_left_out=min_left_out)
+
+
+def test_top_rule_with_two_chunks(tmp_path):
+    """the smallest case: pass 1 is the first chunk's deep-DP round alone, the last chunk keeps all its work"""
+    _check_rule(tmp_path, "-F", 41, 150, n_chunks=2, min_left_out=0)
+
+
+@pytest.mark.parametrize("mode,n_chunks", [("-F", 4), ("-P", 4), ("-F", 2)])
+def test_top_rule_with_comments_of_an_earlier_stage(tmp_path, mode, n_chunks):
+    """no -nc: the headers the reads come with take part in the filter (their best score may be above everything the chunks hold, which the device
+    does not know: its floor is then lower than the chain's threshold, never higher); with two chunks the reads' home is the LAST one"""
+    w = _check_rule(tmp_path, mode, 50 + n_chunks + (mode == "-P"), 150, n_chunks=n_chunks, with_comments=True, min_left_out=0)
+    assert sum(1 for r in w if r[2].count(",pre_near3") and r[2].count(",home")) > 100
 
 
 def test_top_rule_with_bam_and_host_merge_paths(tmp_path):

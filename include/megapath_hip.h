@@ -286,6 +286,7 @@ typedef struct {
     uint64_t n_failed_pairs, n_single_tasks, n_single_hits, n_rescue_tasks, n_rescue_hits;
     float ms_tasks, ms_dp_fill, ms_dp_trace, ms_total;
     uint64_t n_floor_pairs, n_floor_tasks;    /* mp_ctx_set_score_floor: failed pairs whose rescue work in this chunk was left out, and their single-end instances */
+    uint64_t n_floor_mate_tried, n_floor_mate_pairs;   /* of those: pairs kept by the first half of the rule for the rescued mate's length alone, and how many of them the bound on the mate's windows released */
 } mp_rescue_stats;
 
 int mp_rescue_round(mp_ctx *ctx, const mp_align_params *params, int skip_default_dp, mp_rescue_stats *out_stats);
@@ -346,6 +347,7 @@ int mp_reduce_chunk_part(mp_ctx *ctx, int megapath_mode, uint32_t chunk_index, i
                          mp_reduce_stats *out_stats, uint8_t *out_pair_class);
 int mp_ctx_set_score_floor(mp_ctx *ctx, int top_percent);      /* 0 = off (default): every rescue round does all its work */
 int mp_test_floor_bound(mp_ctx *ctx, const mp_dp_task *tasks, uint32_t n, uint16_t *out_ub);   /* test hook: the rule's upper bound per instance (>= its exact DP score) */
+int mp_test_floor_mate_bound(mp_ctx *ctx, const mp_dp_task *tasks, uint32_t n, int insert_high, uint16_t *out_ub);   /* test hook: the bound on the mate rescued from a hit inside instance t's window (tasks grouped by read, ascending; reads 2k and 2k + 1 are mates) */
 int mp_chunk_stash(mp_ctx *ctx, uint32_t slot);               /* after mp_deep_dp_round: keep what the chunk's rescue round needs (seed positions, aligned pairs) */
 int mp_chunk_unstash(mp_ctx *ctx, uint32_t slot);             /* after mp_ctx_set_index of the same chunk: put it back; mp_rescue_round may follow */
 int mp_reduce_finish(mp_ctx *ctx, const uint64_t **out_keys, uint64_t *out_n);

@@ -148,6 +148,7 @@ struct mp_ctx {
     int floor_top = 0;
     DevBuf<uint16_t> floor_ub;
     DevBuf<unsigned long long> floor_counts;
+    DevBuf<uint8_t> floor_hope;                 // [failed pair] kept by floor_decide_kernel for the mate's length alone
     struct Stash { size_t off = 0, bytes = 0; uint64_t n_hits = 0; uint32_t n_reads = 0; const mp_index *ix = nullptr; mp_seed_stats seed{}; bool used = false; };
     std::vector<Stash> stash;
     uint8_t *stash_arena = nullptr;
@@ -822,7 +823,7 @@ extern "C" int mp_ctx_destroy(mp_ctx *c)
     if (c->red_out) (void)hipFree(c->red_out);
     if (c->h_red) (void)hipHostFree(c->h_red);
     c->resc_done.release(); c->red_flag.release(); c->red_slot.release(); c->red_counts.release(); c->red_cls.release();
-    c->best_known.release(); c->floor_ub.release(); c->floor_counts.release();
+    c->best_known.release(); c->floor_ub.release(); c->floor_counts.release(); c->floor_hope.release();
     if (c->stash_arena) (void)hipFree(c->stash_arena);
     c->pair_done.release(); c->failed_flag.release(); c->failed_off.release(); c->failed_reads.release(); c->n_scand.release(); c->s_off.release();
     c->rsrc.release(); c->scand.release(); c->stasks.release(); c->rtasks.release(); c->sres.release(); c->rres.release(); c->rtasks_c.release(); c->rres_c.release(); c->rlist.release();
@@ -2072,18 +2073,26 @@ extern "C" int mp_rescue_round(mp_ctx *c, const mp_align_params *ap, int skip_de
         // their instances -- a cheap bound per instance, a decision per pair, then the task list once more without them
         static const bool floor_env = !getenv("MP_TOP_FLOOR") || atoi(getenv("MP_TOP_FLOOR")) != 0;
         if (floor_env && c->floor_top > 0 && c->red_chunks > 0 && c->best_known.p && nst >= 64 && c->max_len <= MP_FLOOR_MAXL) {
-            if (c->floor_ub.reserve(nst + 2) || c->floor_counts.reserve(2)) return MP_ENOMEM;
-            HIPCHK(hipMemsetAsync(c->floor_counts.p, 0, 2 * sizeof(unsigned long long), s));
+            // MP_TOP_FLOOR_MATE=0: without the bound on the rescued mate (floor_mate_kernel): the rule as first built, a test / measurement switch
+            static const bool mate_env = !getenv("MP_TOP_FLOOR_MATE") || atoi(getenv("MP_TOP_FLOOR_MATE")) != 0;
+            const bool mate_rule = mate_env && !skip_default_dp && ap->insert_high > 0 && ap->insert_high <= 4096;
+            if (c->floor_ub.reserve(nst + 2) || c->floor_counts.reserve(4) || (mate_rule && c->floor_hope.reserve(nf / 2 + 2))) return MP_ENOMEM;
+            HIPCHK(hipMemsetAsync(c->floor_counts.p, 0, 4 * sizeof(unsigned long long), s));
             hipLaunchKernelGGL(floor_bound_kernel, dim3(grid_for(nst, 64)), dim3(64), 0, s, c->ix->d.text, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->stasks.p, nst,
                                (const uint32_t *)c->best_known.p, c->floor_top, c->floor_ub.p);
             hipLaunchKernelGGL(floor_decide_kernel, dim3(grid_for(nf / 2 + 1, 256)), dim3(256), 0, s, (const uint32_t *)c->failed_reads.p, nf, (const uint32_t *)c->s_off.p,
-                               (const uint16_t *)c->floor_ub.p, c->d_lens, (const uint32_t *)c->best_known.p, c->floor_top, c->n_scand.p, c->floor_counts.p);
+                               (const uint16_t *)c->floor_ub.p, c->d_lens, (const uint32_t *)c->best_known.p, c->floor_top, c->n_scand.p, c->floor_counts.p,
+                               mate_rule ? c->floor_hope.p : (uint8_t *)nullptr);
+            if (mate_rule && nf >= 2)
+                hipLaunchKernelGGL(floor_mate_kernel, dim3(nf / 2), dim3(64), 0, s, c->ix->d.text, (uint64_t)c->ix->n, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->stasks.p,
+                                   (const uint32_t *)c->failed_reads.p, nf, (const uint32_t *)c->s_off.p, (const uint16_t *)c->floor_ub.p, (const uint32_t *)c->best_known.p,
+                                   c->floor_top, (const uint8_t *)c->floor_hope.p, ap->insert_high, c->n_scand.p, c->floor_counts.p, (uint16_t *)nullptr);
             MP_TRACE(s, "floor kernels");
             HIPCHK(hipGetLastError());
-            unsigned long long fc[2] = {0, 0};
+            unsigned long long fc[4] = {0, 0, 0, 0};
             HIPCHK(hipMemcpyAsync(fc, c->floor_counts.p, sizeof fc, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            st.n_floor_pairs = fc[0]; st.n_floor_tasks = fc[1];
+            st.n_floor_pairs = fc[0]; st.n_floor_tasks = fc[1]; st.n_floor_mate_tried = fc[2]; st.n_floor_mate_pairs = fc[3];
             if (fc[0]) {
                 rc = exclusive_scan_u32(c, c->n_scand.p, c->s_off.p, nf + 1);
                 if (rc) return rc;
@@ -2318,6 +2327,45 @@ extern "C" int mp_test_floor_bound(mp_ctx *c, const mp_dp_task *tasks, uint32_t 
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     known.release();
     return e == hipSuccess ? MP_OK : MP_ENODEV;
+}
+
+// test hook: floor_mate_kernel's bound on the rescued mate for caller-given single-end instances -- tasks grouped by read, reads in ascending order, the
+// instances of read 2k (anchor; its mate is read 2k + 1) and of read 2k + 1 (mate: read 2k).  out_ub[t] >= the exact DP score of the mate in ANY window
+// mate_rescue_task_kernel can make from a hit inside instance t's window is what the rule's second half rests on.
+extern "C" int mp_test_floor_mate_bound(mp_ctx *c, const mp_dp_task *tasks, uint32_t n, int insert_high, uint16_t *out_ub)
+{
+    if (!c || !tasks || !out_ub || !c->d_reads || insert_high <= 0 || insert_high > 4096 || (c->n_reads & 1)) return MP_EINVAL;
+    if (n == 0) return MP_OK;
+    if (c->max_len > MP_FLOOR_MAXL) return MP_ERANGE;
+    std::vector<uint32_t> off((size_t)c->n_reads + 2, 0), fr(c->n_reads);
+    for (uint32_t t = 0; t < n; t++) {
+        if (tasks[t].read_id >= c->n_reads || (tasks[t].strand != 1 && tasks[t].strand != 2) || (t && tasks[t].read_id < tasks[t - 1].read_id)) return MP_EINVAL;
+        if (tasks[t].win_len > MP_DP_MAX_WIN || tasks[t].win_start + tasks[t].win_len > c->ix->n) return MP_ERANGE;
+        off[tasks[t].read_id + 1]++;
+    }
+    for (uint32_t r = 0; r < c->n_reads; r++) { off[r + 1] += off[r]; fr[r] = r; }
+    HIPCHK(hipSetDevice(c->ix->device));
+    hipStream_t s = c->stream;
+    DevBuf<uint32_t> known, d_off, d_fr;
+    DevBuf<uint16_t> d_ub, d_out;
+    auto done = [&](int rc) { known.release(); d_off.release(); d_fr.release(); d_ub.release(); d_out.release(); return rc; };
+    if (c->tasks_tmp.reserve(n) || known.reserve((size_t)c->n_reads + 1) || d_off.reserve(off.size()) || d_fr.reserve(fr.size() + 1) || d_ub.reserve(n + 2) || d_out.reserve(n + 2))
+        return done(MP_ENOMEM);
+    hipError_t e = hipMemcpyAsync(c->tasks_tmp.p, tasks, (size_t)n * sizeof(mp_dp_task), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_fr.p, fr.data(), fr.size() * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(known.p, 0x01, ((size_t)c->n_reads + 1) * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ub.p, 0, (size_t)n * 2, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out.p, 0xFF, (size_t)n * 2, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(floor_mate_kernel, dim3(c->n_reads / 2), dim3(64), 0, s, c->ix->d.text, (uint64_t)c->ix->n, c->d_reads, c->d_lens, c->W, (const mp_dp_task *)c->tasks_tmp.p,
+                           (const uint32_t *)d_fr.p, c->n_reads, (const uint32_t *)d_off.p, (const uint16_t *)d_ub.p, (const uint32_t *)known.p, 100, (const uint8_t *)nullptr,
+                           insert_high, (uint32_t *)nullptr, (unsigned long long *)nullptr, d_out.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_ub, d_out.p, (size_t)n * 2, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    return done(e == hipSuccess ? MP_OK : MP_ENODEV);
 }
 
 // Between the two passes over the resident chunks: after mp_deep_dp_round (and mp_reduce_chunk_part(.., 1)) of the bound chunk, keeps what its rescue round

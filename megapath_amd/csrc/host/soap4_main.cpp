@@ -148,6 +148,7 @@ struct Batch {
     mp_reduce_stats red_last{};             // how the last chunk's pairs were aligned (the closing line counts that chunk, as the last run of a chain would)
     uint64_t red_dp_instances = 0;
     uint64_t red_floor_pairs = 0;           // (pair, chunk) combinations whose rescue work the -top rule left out
+    uint64_t red_floor_mate_pairs = 0;      // ... of them by the bound on the rescued mate's windows
     uint64_t seq = 0;                       // position of the batch in the input: the printer writes batches in this order
 };
 
@@ -1299,7 +1300,7 @@ struct Writer {
 void die(int rc, const char *what) { if (rc) fatal("[soap4-mi355x] %s failed: %s (%d)\n", what, mp_strerror(rc), rc); }
 
 struct Stats {
-    uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0, floor_pairs = 0;
+    uint64_t pairs = 0, deep = 0, rescued = 0, unpaired = 0, dp = 0, floor_pairs = 0, floor_mate_pairs = 0;
     double t_read = 0, t_upload = 0, t_deep = 0, t_sort = 0, t_cigar = 0, t_emit_deep = 0, t_rescue = 0, t_emit_rest = 0;   // seconds (MP_TIMING=1 prints them)
 };
 
@@ -1827,6 +1828,7 @@ void gpu_stage_pass2(mp_ctx *ctx, const Params &p, Batch &bt, uint32_t chunk, in
     die(mp_reduce_chunk_part(ctx, p.mode, chunk, 2, &red, nullptr), "mp_reduce_chunk_part");
     bt.red_dp_instances += rst.n_single_tasks + rst.n_rescue_tasks;
     bt.red_floor_pairs += rst.n_floor_pairs;
+    bt.red_floor_mate_pairs += rst.n_floor_mate_pairs;
     if (getenv("MP_TIMING"))
         fprintf(stderr, "[Main] batch %llu chunk %u, rescue pass: %llu failed pairs, %llu left out by the -top rule (%llu instances), %llu instances run, %llu + %llu hits\n",
                 (unsigned long long)bt.seq, chunk, (unsigned long long)rst.n_failed_pairs, (unsigned long long)rst.n_floor_pairs, (unsigned long long)rst.n_floor_tasks,
@@ -1853,7 +1855,7 @@ void output_reduced(mp_index *const *chunks, uint32_t n_chunks, const Params &p,
 {
     const double t0 = now_s();
     const uint32_t n_pairs = bt.n_reads / 2;
-    st.pairs += n_pairs; st.dp += bt.red_dp_instances; st.floor_pairs += bt.red_floor_pairs;
+    st.pairs += n_pairs; st.dp += bt.red_dp_instances; st.floor_pairs += bt.red_floor_pairs; st.floor_mate_pairs += bt.red_floor_mate_pairs;
     st.deep += bt.red_last.n_deep_pairs; st.rescued += bt.red_last.n_rescued_pairs; st.unpaired += bt.red_last.n_unpaired_pairs;
     // the batch in the reference's order (alignment.cpp:105-330): the pairs of the deep-DP round, the rescued pairs, the rest -- as the last chunk saw them
     std::vector<uint32_t> order[3];
@@ -2174,7 +2176,7 @@ int main(int argc, char **argv)
                 if (!plumbing_only && reduce_on_device) {
                     upload_reads(ctx, *b, st);
                     die(mp_reduce_begin(ctx, (uint32_t)n_chunks), "mp_reduce_begin");
-                    b->red_dp_instances = 0; b->red_floor_pairs = 0;
+                    b->red_dp_instances = 0; b->red_floor_pairs = 0; b->red_floor_mate_pairs = 0;
                     auto whole_chunk = [&](size_t c) {
                         if (n_chunks > 1 || c > 0) die(mp_ctx_set_index(ctx, dev.chunks[c]), "mp_ctx_set_index");
                         const bool last = c + 1 == n_chunks;
@@ -2271,7 +2273,8 @@ int main(int argc, char **argv)
     fprintf(stderr, "[Main] alignment loop %.2f s (%.0f pairs/s, reading and packing overlapped; %zu GPU(s) x %d worker(s), %zu index chunk(s)%s%s)\n", t_loop,
             st.pairs / std::max(t_loop, 1e-9), devices.size(), workers_per_gpu, n_chunks, reduce_on_device ? ", per-reference scores reduced on the device" : "",
             top_floor ? ", rescue rounds after the deep-DP rounds of all chunks (-top rule)" : "");
-    if (top_floor) fprintf(stderr, "[Main] -top rule: %llu (pair, chunk) rescue rounds left out\n", (unsigned long long)st.floor_pairs);
+    if (top_floor) fprintf(stderr, "[Main] -top rule: %llu (pair, chunk) rescue rounds left out, %llu of them by the bound on the rescued mate\n", (unsigned long long)st.floor_pairs,
+                           (unsigned long long)st.floor_mate_pairs);
     if (getenv("MP_TIMING"))
         fprintf(stderr, "[Main] seconds: reading and packing %.2f (own threads), upload %.2f, deep-DP round %.2f, sort %.2f, BAM CIGARs %.2f, output of deep pairs %.2f, rescue round %.2f, output of the rest %.2f\n",
                 st.t_read, st.t_upload, st.t_deep, st.t_sort, st.t_cigar, st.t_emit_deep, st.t_rescue, st.t_emit_rest);

@@ -121,10 +121,10 @@ floor_bound_kernel(const uint32_t *__restrict__ text, const uint32_t *__restrict
 // counts[1] += their instances.
 __global__ void floor_decide_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed, const uint32_t *__restrict__ task_off, const uint16_t *__restrict__ ub,
                                     const uint32_t *__restrict__ lens, const uint32_t *__restrict__ best_known, int top_pct, uint32_t *__restrict__ n_cand,
-                                    unsigned long long *__restrict__ counts)
+                                    unsigned long long *__restrict__ counts, uint8_t *__restrict__ hopeful /* may be null; [pair] */)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    bool drop = false;
+    bool drop = false, hope = false;
     uint32_t n_inst = 0;
     if (2 * k + 1 < n_failed) {
         const uint32_t ra = failed_reads[2 * k], rb = failed_reads[2 * k + 1];
@@ -143,24 +143,147 @@ __global__ void floor_decide_kernel(const uint32_t *__restrict__ failed_reads, u
                 const long long T[2] = {mp_floor_thr100(best_known[ra], top_pct), mp_floor_thr100(best_known[rb], top_pct)};
                 const long long Tmin = T[0] < T[1] ? T[0] : T[1];
                 drop = true;
+                bool single_ok = true;
                 for (int x = 0; x < 2; x++) {
                     const int y = 1 - x;
                     const bool has = task_off[2 * k + x + 1] > task_off[2 * k + x];
                     if (!has) continue;                                           // no instance of x: no single-end hit of x, nothing anchored at x
-                    if (100 * (long long)U[x] >= T[x]) drop = false;              // a single-end entry of x could be printed
+                    if (100 * (long long)U[x] >= T[x]) { drop = false; single_ok = false; }      // a single-end entry of x could be printed
                     if ((long long)U[x] >= (long long)mp_dp_cutoff((int)L[x])) {  // x may have a single-end hit: a rescue of y anchored at it
                         if (100 * ((long long)U[x] + L[y]) >= Tmin) drop = false; //   both on one sequence: the sum in both headers
                         if (100 * L[y] >= T[y]) drop = false;                     //   on different sequences: the rescued mate's own score in its header
                     }
                 }
+                // kept only because a rescued mate was credited with its whole length: floor_mate_kernel looks at what its windows can really give it
+                hope = !drop && single_ok;
             }
         }
         if (drop) { n_cand[2 * k] = 0; n_cand[2 * k + 1] = 0; }
+        if (hopeful) hopeful[k] = hope ? 1 : 0;
     }
     const unsigned long long b = __ballot(drop);
     unsigned long long inst = drop ? (unsigned long long)n_inst : 0ull;
     for (int o = MP_WAVE / 2; o > 0; o >>= 1) inst += __shfl_down(inst, o);
     if ((threadIdx.x & (MP_WAVE - 1)) == 0 && b) { atomicAdd(&counts[0], (unsigned long long)__popcll(b)); atomicAdd(&counts[1], inst); }
+}
+
+// ---- the rescued mate's side of the rule.  floor_decide_kernel credits a mate rescued from a hit of x with its whole length L_y, which keeps every pair whose
+// mates are more than ~4.8 % away from their best alignment (150-base reads, -top 95: U_x + L_y against 95 % of the pair's score).  What a rescue anchored at
+// instance i of x can give the mate is bounded by the text it searches: [hit, hit + insert_high) to the right of a forward hit, the mirror image to the left of
+// a reverse one (mate_rescue_task_kernel, HalfEndAlgnBatch::pack DV-DPfunctions.cpp:1151-1231) -- whatever the hit's offset in x's window, a part of the
+// ~960 bases S_i = x's window extended by insert_high on that side.  The same block argument as above with blocks of SIX (a 1 024-base text holds a given
+// 6-mer with probability 0.21, a 5-mer with 0.61): U_y(i) = L_y - 3 max(0, E - 2) - min(E, 2), E = blocks of the oriented mate whose 6-mer occurs nowhere in S_i,
+// the smallest over the six block phases.  The pair loses its rescue work when, for every instance i of either mate that could be a hit (U_x(i) >= cutoff),
+// 100 (U_x(i) + U_y(i)) is below min(T_x, T_y) and 100 U_y(i) below T_y.
+// One wavefront per pair that floor_decide_kernel marked (`hopeful`), one lane per instance.  A 4 096-bit set per instance would be 32 KB of LDS per
+// wavefront (the reason the bound of x uses blocks of five); here the 6-mers of the four oriented mates (2 mates x 2 strands: 4 x 512 bytes, shared by the
+// wavefront) are the filter: a lane streams its ~960 text bases, and only the 6-mers that occur in the mate at all (3.6 % of them) enter the lane's own set --
+// 1 024 bits addressed by the key's low ten bits.  Two 6-mers that differ in the last base alone share a bit: a block may count as present that is not,
+// which only raises the bound.
+#define MP_FLOOR_KM 6
+#define MP_FLOOR_KM_WORDS ((1 << (2 * MP_FLOOR_KM)) / 32)      // 128
+#define MP_FLOOR_PM_WORDS 32                                    // the lane's own hashed set
+__global__ void __launch_bounds__(64)
+floor_mate_kernel(const uint32_t *__restrict__ text, uint64_t text_len, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
+                  const mp_dp_task *__restrict__ tasks, const uint32_t *__restrict__ failed_reads, uint32_t n_failed, const uint32_t *__restrict__ task_off,
+                  const uint16_t *__restrict__ ub, const uint32_t *__restrict__ best_known, int top_pct, const uint8_t *__restrict__ hopeful /* null: every pair */,
+                  int insert_high, uint32_t *__restrict__ n_cand /* null: no decision (test hook) */, unsigned long long *__restrict__ counts /* [2] pairs looked at, [3] dropped here */,
+                  uint16_t *__restrict__ ub_mate /* may be null: U_y per instance */)
+{
+    __shared__ uint32_t s_y[4][MP_FLOOR_KM_WORDS];            // [2 * mate + (strand - 1)]
+    __shared__ uint32_t s_rd[4][MP_FLOOR_MAXL / 16 + 2];      // the oriented mates, 16 bases per word
+    __shared__ uint32_t s_p[MP_FLOOR_PM_WORDS][64];           // [word][lane]
+    const uint32_t k = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (2 * k + 1 >= n_failed || (hopeful && !hopeful[k])) return;
+    const uint32_t r0 = failed_reads[2 * k];
+    if ((r0 ^ failed_reads[2 * k + 1]) != 1u) return;
+    const int Lm[2] = {(int)lens[r0], (int)lens[r0 ^ 1u]};
+    if (Lm[0] > MP_FLOOR_MAXL || Lm[1] > MP_FLOOR_MAXL) return;                  // (uniform: the pair keeps its work)
+    for (int w = lane; w < 4 * MP_FLOOR_KM_WORDS; w += 64) (&s_y[0][0])[w] = 0u;
+    for (int w = lane; w < 4 * (MP_FLOOR_MAXL / 16 + 2); w += 64) {
+        const int q = w / (MP_FLOOR_MAXL / 16 + 2), kk = w % (MP_FLOOR_MAXL / 16 + 2);
+        const int L = Lm[q >> 1];
+        s_rd[q][kk] = mp_oriented_word(reads + (uint64_t)(r0 ^ (uint32_t)(q >> 1)) * Wr, (L + 15) / 16, L, 1u + (uint32_t)(q & 1), kk);
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; q++) {
+        const int L = Lm[q >> 1];
+        for (int j = lane; j + MP_FLOOR_KM <= L; j += 64) {
+            const uint64_t two = ((uint64_t)s_rd[q][(j >> 4) + 1] << 32) | s_rd[q][j >> 4];
+            const uint32_t key = (uint32_t)(two >> (2 * (j & 15))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);
+            atomicOr(&s_y[q][key >> 5], 1u << (key & 31u));
+        }
+    }
+    __syncthreads();
+    const uint32_t t0 = task_off[2 * k], t1 = task_off[2 * k + 1], t2 = task_off[2 * k + 2];
+    const long long T[2] = {mp_floor_thr100(best_known[r0], top_pct), mp_floor_thr100(best_known[r0 ^ 1u], top_pct)};
+    const long long Tmin = T[0] < T[1] ? T[0] : T[1];
+    bool all_ok = true;
+    for (uint32_t base = t0; base < t2; base += 64) {                             // (uniform trip count)
+        const uint32_t t = base + (uint32_t)lane;
+        const bool have = t < t2;
+        bool ok = true;
+        if (have) {
+            const int x = t >= t1 ? 1 : 0, y = 1 - x;
+            const mp_dp_task task = tasks[t];
+            const int alen = Lm[x], ulen = Lm[y];
+            const uint32_t ux = ub[t];
+            int Uy = ulen;
+            if (ulen < MP_MIN_ALIGNABLE_LEN) Uy = 0;                              // no rescue instance is made for such a mate
+            else if (ulen >= MP_FLOOR_KM) {
+                // S_i: every text base a rescue anchored at a hit inside this window can look at
+                uint64_t ws, we;
+                if (task.strand == 1) { ws = task.win_start; we = task.win_start + task.win_len + (uint64_t)insert_high; }
+                else { const uint64_t lo = task.win_start + (uint64_t)alen; ws = lo > (uint64_t)insert_high ? lo - (uint64_t)insert_high : 0; we = task.win_start + task.win_len + (uint64_t)alen; }
+                if (we > text_len) we = text_len;
+                const int q = 2 * y + (task.strand == 1 ? 1 : 0);                 // the mate is searched on the other strand
+                for (int w = 0; w < MP_FLOOR_PM_WORDS; w++) s_p[w][lane] = 0u;
+                // whole text words: up to 15 bases more on either side (and 'A's before the first word) only add 6-mers to the set.  Sixteen positions per
+                // trip, no branch: a 6-mer that is none of the mate's ORs a zero into the lane's set.
+                const uint32_t *sy = s_y[q];
+                uint32_t prev = 0u;
+                for (uint64_t wi = ws >> 4, w_end = (we + 15) >> 4; wi < w_end; wi++) {
+                    const uint32_t cur = text[wi];
+                    const uint64_t both = ((uint64_t)cur << 32) | prev;
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const uint32_t key = (uint32_t)(both >> (2 * (u + 16 - (MP_FLOOR_KM - 1)))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);     // the 6-mer that ends at base u of this word
+                        const uint32_t hit = (sy[key >> 5] >> (key & 31u)) & 1u;
+                        atomicOr(&s_p[(key >> 5) & (MP_FLOOR_PM_WORDS - 1)][lane], hit << (key & 31u));
+                    }
+                    prev = cur;
+                }
+                unsigned long long E = 0;
+                int ph = 0;
+                for (int j = 0; j + MP_FLOOR_KM <= ulen; j++) {
+                    const uint64_t two = ((uint64_t)s_rd[q][(j >> 4) + 1] << 32) | s_rd[q][j >> 4];
+                    const uint32_t kj = (uint32_t)(two >> (2 * (j & 15))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);
+                    const uint32_t present = (s_p[(kj >> 5) & (MP_FLOOR_PM_WORDS - 1)][lane] >> (kj & 31u)) & 1u;
+                    E += (unsigned long long)(present ^ 1u) << (8 * ph);
+                    ph = ph == MP_FLOOR_KM - 1 ? 0 : ph + 1;
+                }
+                for (int pp = 0; pp < MP_FLOOR_KM; pp++) {
+                    const int e = (int)((E >> (8 * pp)) & 255u);
+                    Uy = min(Uy, ulen - 3 * max(0, e - 2) - min(e, 2));
+                }
+                Uy = max(Uy, 0);
+            }
+            if (ub_mate) ub_mate[t] = (uint16_t)Uy;
+            if (ux == MP_FLOOR_SKIP) ok = false;
+            else if ((long long)ux >= (long long)mp_dp_cutoff(alen) && ulen >= MP_MIN_ALIGNABLE_LEN)
+                ok = 100 * ((long long)ux + (long long)Uy) < Tmin && 100 * (long long)Uy < T[y];
+        }
+        if (__ballot(have && !ok)) all_ok = false;
+    }
+    if (lane == 0) {
+        const bool drop = all_ok && n_cand && t2 > t0;
+        if (drop) { n_cand[2 * k] = 0; n_cand[2 * k + 1] = 0; }
+        if (counts) {
+            atomicAdd(&counts[2], 1ull);
+            if (drop) { atomicAdd(&counts[0], 1ull); atomicAdd(&counts[1], (unsigned long long)(t2 - t0)); atomicAdd(&counts[3], 1ull); }
+        }
+    }
 }
 
 // best_known[read] = max(best_known[read], score of the key) for the keys a reduction call has just written (null keys excluded)

@@ -96,7 +96,7 @@ class RescueHit(C.Structure):
 class RescueStats(C.Structure):
     _fields_ = [("n_failed_pairs", C.c_uint64), ("n_single_tasks", C.c_uint64), ("n_single_hits", C.c_uint64), ("n_rescue_tasks", C.c_uint64),
                 ("n_rescue_hits", C.c_uint64), ("ms_tasks", C.c_float), ("ms_dp_fill", C.c_float), ("ms_dp_trace", C.c_float), ("ms_total", C.c_float),
-                ("n_floor_pairs", C.c_uint64), ("n_floor_tasks", C.c_uint64)]
+                ("n_floor_pairs", C.c_uint64), ("n_floor_tasks", C.c_uint64), ("n_floor_mate_tried", C.c_uint64), ("n_floor_mate_pairs", C.c_uint64)]
 
 
 class IndexInfo(C.Structure):
@@ -108,7 +108,7 @@ class IndexInfo(C.Structure):
 EXPORTS = ["mp_index_open", "mp_index_from_arrays", "mp_index_clone", "mp_index_close", "mp_index_get_info", "mp_index_seq_name",
            "mp_index_chr_and_pos", "mp_index_chr_and_pos_batch", "mp_index_chr_pos_segment", "mp_index_target_chr", "mp_index_seq_info", "mp_index_fetch_text", "mp_index_occ", "mp_index_sa", "mp_index_lkt", "mp_index_copy_lkt", "mp_index_prefilter", "mp_index_prefilter3", "mp_index_check_lkt16", "mp_ctx_create", "mp_ctx_destroy", "mp_ctx_set_index",
            "mp_set_reads", "mp_set_reads_device", "mp_seed_batch", "mp_ctx_set_prefilter", "mp_ctx_set_dp_band", "mp_test_dp_band", "mp_ctx_dp_band_stats", "mp_ctx_set_dp_thermo", "mp_ctx_dp_thermo_stats", "mp_test_dp_thermo", "mp_test_dp_thermo_kind", "mp_ctx_set_dp_census", "mp_ctx_get_dp_census", "mp_get_seeds", "mp_sgdp_batch", "mp_deep_dp_round",
-           "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_ctx_set_hit_copies", "mp_reduce_begin", "mp_reduce_chunk", "mp_reduce_chunk_part", "mp_ctx_set_score_floor", "mp_chunk_stash", "mp_test_floor_bound", "mp_chunk_unstash", "mp_reduce_finish", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_device_memory", "mp_strerror",
+           "mp_get_pair_hits", "mp_get_pair_hits_view", "mp_ctx_set_hit_copies", "mp_reduce_begin", "mp_reduce_chunk", "mp_reduce_chunk_part", "mp_ctx_set_score_floor", "mp_chunk_stash", "mp_test_floor_bound", "mp_test_floor_mate_bound", "mp_chunk_unstash", "mp_reduce_finish", "mp_rescue_round", "mp_get_single_hits", "mp_get_rescue_hits", "mp_get_single_hits_view", "mp_get_rescue_hits_view", "mp_bench_gather64", "mp_device_check", "mp_device_memory", "mp_strerror",
            "mp_test_sort_longer_seed", "mp_coverage_create", "mp_coverage_destroy", "mp_coverage_add", "mp_coverage_finish", "mp_coverage_seq_stats",
            "mp_coverage_spike_intervals", "mp_coverage_spike_bases", "mp_build_index_arrays"]
 
@@ -207,6 +207,7 @@ def load_library():
     lib.mp_ctx_set_score_floor.argtypes = [vp, C.c_int]
     lib.mp_chunk_stash.argtypes = [vp, C.c_uint32]
     lib.mp_test_floor_bound.argtypes = [vp, vp, C.c_uint32, vp]
+    lib.mp_test_floor_mate_bound.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
     lib.mp_chunk_unstash.argtypes = [vp, C.c_uint32]
     lib.mp_reduce_finish.argtypes = [vp, C.POINTER(vp), u64p]
     lib.mp_bench_gather64.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]
@@ -581,6 +582,13 @@ class Context:
         assert tasks_np.dtype == DP_TASK_DTYPE and tasks_np.flags.c_contiguous
         out = np.zeros(max(len(tasks_np), 1), dtype=np.uint16)
         _chk(load_library().mp_test_floor_bound(self._h, tasks_np.ctypes.data, len(tasks_np), out.ctypes.data), "mp_test_floor_bound")
+        return out[:len(tasks_np)]
+
+    def test_floor_mate_bound(self, tasks_np: np.ndarray, insert_high: int) -> np.ndarray:
+        """test hook: the bound on the score of the mate (read_id ^ 1) rescued from a hit inside each instance's window (tasks grouped by read, ascending)"""
+        assert tasks_np.dtype == DP_TASK_DTYPE and tasks_np.flags.c_contiguous
+        out = np.zeros(max(len(tasks_np), 1), dtype=np.uint16)
+        _chk(load_library().mp_test_floor_mate_bound(self._h, tasks_np.ctypes.data, len(tasks_np), int(insert_high), out.ctypes.data), "mp_test_floor_mate_bound")
         return out[:len(tasks_np)]
 
     def chunk_stash(self, slot: int):

@@ -47,7 +47,7 @@ def _split_pairs(fq, out1, out2):
             fb.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
 
 
-def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comments=False, min_left_out=300):
+def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comments=False, min_left_out=300, sub=0.012, min_by_mate=0):
     rng = np.random.Generator(np.random.PCG64(7000 + seed))
     home = [("home%d" % i, B[rng.integers(0, 4, size=150000)]) for i in range(2)]
     # chunk 0 = home; chunks 1, 2: unrelated sequence + diverged copies of stretches of home (seeds and weak hits for home's reads); the last chunk:
@@ -68,7 +68,7 @@ def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comment
         pc = str(tmp_path / ("c%d.index" % c))
         index_builder.write_index_files(pc, index_builder.build_index_arrays(part, sa_interval=16))
         prefixes.append(pc)
-    names, r1, r2 = synth.simulate_pairs(home, 4000, read_len, 7100 + seed, sub=0.012, ins=0.001, dele=0.001, random_frac=0.1, broken_mate_frac=0.15, noisy_mate_frac=0.1, noisy_sub=0.15,
+    names, r1, r2 = synth.simulate_pairs(home, 4000, read_len, 7100 + seed, sub=sub, ins=0.001, dele=0.001, random_frac=0.1, broken_mate_frac=0.15, noisy_mate_frac=0.1, noisy_sub=0.15,
                                          frag_mean=read_len + 200, frag_sd=40, frag_min=read_len + 20, frag_max=min(740, read_len + 420))
     f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
     synth.write_fastq_pair(f1, f2, names, r1, r2)
@@ -113,6 +113,12 @@ def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comment
     assert fastq_records(on) == w                    # the two passes with the rule: the same records
     # the rule did leave work out
     assert left_out >= min_left_out, (left_out, err_on[-600:])
+    by_mate = int(err_on.split("rescue rounds left out, ")[1].split()[0])
+    assert by_mate >= min_by_mate, (by_mate, left_out)
+    # ... and the first half of the rule alone (no bound on the rescued mate): the same records again
+    mid = str(tmp_path / "mid.fq")
+    err_mid = _run(prefixes, f1, f2, mid, ini, L, {"MP_TOP_FLOOR_MATE": "0"}, [mode], top=top, nc=not with_comments)
+    assert fastq_records(mid) == w and int(err_mid.split("rescue rounds left out, ")[1].split()[0]) == 0
     return w
 
 
@@ -121,6 +127,13 @@ def test_top_rule_across_chunks_changes_nothing(tmp_path, mode, seed, read_len):
     w = _check_rule(tmp_path, mode, seed, read_len)
     # the database did offer entries from several chunks (near copy in the last chunk) that had to survive the rule
     assert sum(1 for r in w if r[2].count(",c3_near1") and r[2].count(",home")) > 100
+
+
+@pytest.mark.parametrize("mode,read_len,sub", [("-F", 150, 0.06), ("-P", 150, 0.05), ("-F", 100, 0.06), ("-F", 250, 0.07)])
+def test_top_rule_for_mates_far_from_their_best_alignment(tmp_path, mode, read_len, sub):
+    """reads 5-7 % away from their home: a pair's best score leaves less than a mate's length of room, the first half of the rule (which credits a rescued
+    mate with its whole length) keeps them all -- the bound on the windows the rescue can search (floor_mate_kernel) is what releases them"""
+    _check_rule(tmp_path, mode, 60 + read_len + int(100 * sub), read_len, sub=sub, min_left_out=300, min_by_mate=200)
 
 
 @pytest.mark.parametrize("top,min_left_out", [(100, 300), (60, 0), (1, 0)])
@@ -198,5 +211,110 @@ def test_floor_bound_is_an_upper_bound_of_the_exact_dp(lo, hi, margin, seed):
     assert (res["score"][kind == 3] > 0.4 * rl[kind == 3]).mean() > 0.8        # the true alignments are there ...
     chance = ub[(kind == 0) & covered]
     assert np.median(chance / rl[(kind == 0) & covered]) < 0.72 and len(chance) > 1000      # ... and a chance seed's window is bounded far below them
+    ctx.close()
+    ix.close()
+
+
+def _rescue_window(ws, hit, strand, alen, ulen, ilo, ihi, text_len):
+    """mate_rescue_task_kernel's window (HalfEndAlgnBatch::pack, DV-DPfunctions.cpp:1151-1231): (mate's strand, start, length) or None"""
+    algn = ws + hit
+    if strand == 1:
+        r_end = algn + ihi
+        r_start = max(algn + ilo - ulen, algn)
+        if r_start < text_len and r_end <= text_len:
+            return 2, r_start, r_end - r_start
+    else:
+        l_start = algn + alen - ihi
+        l_end = algn + alen - ilo + ulen
+        if l_end >= algn + alen:
+            l_end = algn + alen - 1
+        if 0 <= l_start < text_len and l_end <= text_len and l_end > l_start:
+            return 1, l_start, l_end - l_start
+    return None
+
+
+@pytest.mark.parametrize("lo,hi,ihi,seed", [(140, 160, 750, 31), (75, 160, 750, 32), (161, 320, 750, 33), (100, 150, 400, 34)])
+def test_floor_mate_bound_covers_every_window_a_rescue_can_search(lo, hi, ihi, seed):
+    """the second half of the rule: U_y(t) (blocks of six mate bases that occur nowhere in the ~960 text bases a rescue anchored inside instance t's window can
+    look at) is never below the exact DP score of the mate in any window mate_rescue_task_kernel would make -- hit offsets across the whole window, both
+    strands, mates planted with mismatches / indels / soft-clipped ends / only partly inside the window, tandem repeats shared by mate and text -- and it is
+    small where the mate is not there"""
+    from megapath_amd import hipapi as H
+    import test_gpu_thermo as T
+    rng = np.random.default_rng(seed)
+    N = 1 << 20
+    text = rng.integers(0, 4, N).astype(np.uint8)
+    n_pairs = 2500
+    reads, anchors = [], []                     # anchors: (read id, strand, window start, window length, kind)
+    for k in range(n_pairs):
+        L = [int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))]
+        rd = [rng.integers(0, 4, L[0]).astype(np.uint8), rng.integers(0, 4, L[1]).astype(np.uint8)]       # as stored (strand 1 orientation)
+        kind = int(rng.integers(0, 6))
+        for x in (0, 1):
+            y = 1 - x
+            for _ in range(int(rng.integers(1, 4))):
+                strand = 1 + int(rng.integers(0, 2))
+                m = L[x] + int(rng.integers(20, 61))
+                ws = int(rng.integers(ihi + 400, N - ihi - 800))
+                anchors.append((2 * k + x, strand, ws, m, kind))
+                if kind == 0 or rng.random() < 0.4:
+                    continue                                            # nothing planted for this anchor
+                # plant the mate somewhere in the text a rescue from this window can reach; the rescue looks for it on the other strand:
+                # oriented mate = text segment (mutated); stored mate = that, or its reverse complement when the rescue's strand is 2
+                h = int(rng.integers(0, m))
+                w = _rescue_window(ws, h, strand, L[x], L[y], max(L), ihi, N)
+                if w is None:
+                    continue
+                ystrand, a, wl = w
+                if kind == 5:                                           # a tandem repeat in the text, and in the mate
+                    unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.uint8)
+                    b = int(rng.integers(30, 200))
+                    o = int(rng.integers(0, max(1, wl - b)))
+                    text[a + o:a + o + b] = np.resize(unit, b)
+                    seg = np.resize(unit, L[y]).copy()
+                    seg[rng.integers(0, L[y], 8)] = rng.integers(0, 4, 8)
+                else:
+                    o = int(rng.integers(-L[y] // 2, wl - L[y] // 2)) if kind == 4 else int(rng.integers(0, max(1, wl - L[y])))   # 4: partly outside the window
+                    seg = text[a + o:a + o + L[y]].copy()
+                    if len(seg) < L[y]:
+                        continue
+                    for _ in range(int(rng.integers(0, 16))):
+                        seg[rng.integers(0, L[y])] = rng.integers(0, 4)
+                    if kind == 2:
+                        p = int(rng.integers(10, L[y] - 10)); g = int(rng.integers(1, 6))
+                        seg = np.concatenate([seg[:p], seg[p + g:], rng.integers(0, 4, g).astype(np.uint8)]) if rng.random() < 0.5 else np.concatenate([seg[:p], rng.integers(0, 4, g).astype(np.uint8), seg[p:L[y] - g]])
+                    if kind == 3:
+                        j = int(rng.integers(5, 50)); seg[:j] = rng.integers(0, 4, j)
+                rd[y] = seg if ystrand == 1 else T._comp_rev(seg)
+        reads += rd
+    anchors.sort(key=lambda a: a[0])
+    tasks = np.zeros(len(anchors), dtype=H.DP_TASK_DTYPE)
+    for t, (r, strand, ws, m, kind) in enumerate(anchors):
+        tasks[t] = (r, strand, ws, m, 0)
+    arrs = index_builder.build_index_arrays([("t", text)], sa_interval=16)
+    ix = H.Index.from_arrays(0, **arrs)
+    ctx = H.Context(ix)
+    seqs = [bytes(b"ACGT"[c] for c in r) for r in reads]
+    packed, lens, W = H.pack_reads(seqs, 161 if hi <= 160 else 321)
+    ctx.set_reads(packed, lens)
+    uy = ctx.test_floor_mate_bound(np.ascontiguousarray(tasks), ihi).astype(np.int64)
+    assert (uy != 0xFFFF).all()
+    # every window a rescue could make from these anchors: hit offsets 0, the last row, and four in between
+    ilo = int(lens.max())
+    rt, src = [], []
+    for t, (r, strand, ws, m, kind) in enumerate(anchors):
+        for h in sorted({0, m - 1, *[int(v) for v in rng.integers(0, m, 4)]}):
+            w = _rescue_window(ws, h, strand, int(lens[r]), int(lens[r ^ 1]), ilo, ihi, N)
+            if w is not None:
+                rt.append((r ^ 1, w[0], w[1], w[2], 0)); src.append(t)
+    rtasks = np.array(rt, dtype=H.DP_TASK_DTYPE)
+    src = np.array(src)
+    res = ctx.sgdp_results(np.ascontiguousarray(rtasks), 130, 130)
+    bad = np.nonzero(res["score"] > uy[src])[0]
+    assert len(bad) == 0, (len(bad), [(int(res["score"][b]), int(uy[src[b]]), anchors[src[b]]) for b in bad[:8]])
+    kinds = np.array([a[4] for a in anchors])
+    ml = lens[tasks["read_id"] ^ 1].astype(np.int64)
+    assert (res["score"] > 0.5 * ml[src]).mean() > 0.15                                     # planted mates are found ...
+    assert np.median(uy[kinds == 0] / ml[kinds == 0]) < (0.8 if ihi > 500 else 0.7)        # ... and where none is, the bound says so
     ctx.close()
     ix.close()

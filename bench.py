@@ -491,7 +491,7 @@ def nt_step(ctx, wl, chunks, params, acc=None, bam=True, mode=1, top_floor=TOP_F
             for k, v in zip(NT_KEYS[6:], (rst.ms_tasks, rst.ms_dp_fill, rst.ms_dp_trace)):
                 grp[k] = grp.get(k, 0.0) + float(v)
             for k, v in (("single_dp_tasks", rst.n_single_tasks), ("single_hits", rst.n_single_hits), ("rescue_hits", rst.n_rescue_hits), ("failed_pairs", rst.n_failed_pairs),
-                         ("floor_pairs", rst.n_floor_pairs), ("floor_tasks", rst.n_floor_tasks)):
+                         ("floor_pairs", rst.n_floor_pairs), ("floor_tasks", rst.n_floor_tasks), ("floor_mate_tried", rst.n_floor_mate_tried), ("floor_mate_pairs", rst.n_floor_mate_pairs)):
                 grp[k] = grp.get(k, 0) + int(v)
         grp["entries"] = grp.get("entries", 0) + int(red[3])
 
@@ -1250,9 +1250,12 @@ def main():
             "top_rule_across_chunks": {"top_percent": TOP_FLOOR, "failed_pairs_per_other_chunk": o.get("failed_pairs", 0) / n_o, "rescue_rounds_left_out_per_other_chunk": o.get("floor_pairs", 0) / n_o,
                                        "share_of_failed_pairs_left_out": (o.get("floor_pairs", 0) / o["failed_pairs"]) if o.get("failed_pairs") else None,
                                        "instances_left_out_per_pair_per_other_chunk": o.get("floor_tasks", 0) / (n_o * lp),
+                                       "share_left_out_by_the_bound_on_the_rescued_mate": (o.get("floor_mate_pairs", 0) / o["failed_pairs"]) if o.get("failed_pairs") else None,
+                                       "share_looked_at_by_that_bound": (o.get("floor_mate_tried", 0) / o["failed_pairs"]) if o.get("failed_pairs") else None,
                                        "note": "kernels_floor.hip: the rescue rounds run after the deep-DP rounds of all chunks; a pair whose rescue work in a chunk cannot produce an "
-                                               "entry of top% of its best known score loses it there (decided per pair from a sound bound on every single-end instance); 0 = off "
-                                               "(MP_TOP_FLOOR=0: one pass)"},
+                                               "entry of top% of its best known score loses it there (decided per pair from sound bounds: blocks of five read bases absent from "
+                                               "every single-end window; for the pairs that leaves, blocks of six mate bases absent from the text a rescue could search -- "
+                                               "MP_TOP_FLOOR_MATE=0: without the second); 0 = off (MP_TOP_FLOOR=0: one pass)"},
             "rescue_certificate_per_pair_per_chunk": dict(zip(("certified_no_alignment", "score_of_10_elsewhere", "bound_reaches_cutoff", "not_eligible"),
                                                               [(b - a) / (S * lp * n_chunks) for a, b in zip(th_a, th_b)])),
             "hit_count_allreduce": {"references": int(len(ref_counts)), "entries_counted": int(ref_counts.sum()), "ranks": world, "backend": (backend if world > 1 else None),

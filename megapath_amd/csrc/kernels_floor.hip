@@ -239,20 +239,32 @@ floor_mate_kernel(const uint32_t *__restrict__ text, uint64_t text_len, const ui
                 if (we > text_len) we = text_len;
                 const int q = 2 * y + (task.strand == 1 ? 1 : 0);                 // the mate is searched on the other strand
                 for (int w = 0; w < MP_FLOOR_PM_WORDS; w++) s_p[w][lane] = 0u;
-                // whole text words: up to 15 bases more on either side (and 'A's before the first word) only add 6-mers to the set.  Sixteen positions per
-                // trip, no branch: a 6-mer that is none of the mate's ORs a zero into the lane's set.
+                // whole text words: up to 63 bases more on either side (and 'A's before the first word) only add 6-mers to the set.  Sixteen positions per
+                // trip, their sixteen filter look-ups independent of each other; the few that hit (0.6 per trip and lane) enter the lane's set afterwards.
+                // (text words in aligned groups of four, one 16-byte load each: the packed text is allocated with four words to spare, api.hip mp_index_*)
                 const uint32_t *sy = s_y[q];
                 uint32_t prev = 0u;
-                for (uint64_t wi = ws >> 4, w_end = (we + 15) >> 4; wi < w_end; wi++) {
-                    const uint32_t cur = text[wi];
-                    const uint64_t both = ((uint64_t)cur << 32) | prev;
+                for (uint64_t wi = (ws >> 4) & ~(uint64_t)3, w_end = (we + 15) >> 4; wi < w_end; wi += 4) {
+                    const uint4 four = *reinterpret_cast<const uint4 *>(text + wi);
+                    const uint32_t wd[4] = {four.x, four.y, four.z, four.w};
 #pragma unroll
-                    for (int u = 0; u < 16; u++) {
-                        const uint32_t key = (uint32_t)(both >> (2 * (u + 16 - (MP_FLOOR_KM - 1)))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);     // the 6-mer that ends at base u of this word
-                        const uint32_t hit = (sy[key >> 5] >> (key & 31u)) & 1u;
-                        atomicOr(&s_p[(key >> 5) & (MP_FLOOR_PM_WORDS - 1)][lane], hit << (key & 31u));
+                    for (int g = 0; g < 4; g++) {
+                        const uint32_t cur = wd[g];
+                        const uint64_t both = ((uint64_t)cur << 32) | prev;
+                        uint32_t hits = 0u;
+#pragma unroll
+                        for (int u = 0; u < 16; u++) {
+                            const uint32_t key = (uint32_t)(both >> (2 * (u + 16 - (MP_FLOOR_KM - 1)))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);     // the 6-mer that ends at base u of this word
+                            hits |= ((sy[key >> 5] >> (key & 31u)) & 1u) << u;
+                        }
+                        while (hits) {
+                            const int u = __ffs((int)hits) - 1;
+                            hits &= hits - 1u;
+                            const uint32_t key = (uint32_t)(both >> (2 * (u + 16 - (MP_FLOOR_KM - 1)))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);
+                            atomicOr(&s_p[(key >> 5) & (MP_FLOOR_PM_WORDS - 1)][lane], 1u << (key & 31u));
+                        }
+                        prev = cur;
                     }
-                    prev = cur;
                 }
                 unsigned long long E = 0;
                 int ph = 0;

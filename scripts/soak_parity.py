@@ -48,7 +48,10 @@ for rnd in range(args.rounds):
                                                 # round 4: the certificate's variants for short reads / mate-rescue windows; -b with resident chunks through the device reduction or every chunk's lists
                                                 ("MP_DP_THERMO_MORE", rng.random() < 0.75), ("MP_BAM_HOST_MERGE", rng.random() < 0.3),
                                                 # the -top rule across resident chunks (two passes, pairs that cannot reach top% of their best known score lose their rescue work) on / off
-                                                ("MP_TOP_FLOOR", rng.random() < 0.7))},
+                                                ("MP_TOP_FLOOR", rng.random() < 0.7), ("MP_TOP_FLOOR_MATE", rng.random() < 0.75))},
+               # chunked databases: besides the copied repeats, every chunk may get a DIVERGED copy of a stretch of another chunk's sequence -- entries near and
+               # below top% of a read's best score in other chunks, which is what the -top rule across chunks decides about
+               div_copy=float(rng.choice([0.0, 0.02, 0.05, 0.1, 0.2])), div_seed=int(rng.integers(1, 1 << 30)),
                kw=dict(sub=float(rng.choice([0.0, 0.005, 0.01, 0.03, 0.06])), ins=float(rng.choice([0.0, 0.001, 0.004])), dele=float(rng.choice([0.0, 0.001, 0.004])),
                        random_frac=float(rng.choice([0.0, 0.05, 0.3])), broken_mate_frac=float(rng.choice([0.0, 0.1, 0.3])),
                        noisy_mate_frac=float(rng.choice([0.0, 0.2])), noisy_sub=0.15, n_frac=float(rng.choice([0.0, 0.002])),
@@ -66,6 +69,18 @@ for rnd in range(args.rounds):
         if n_chunks:
             # sequences dealt round-robin to the chunks (copied repeats then cross chunk borders: one read, hits in several chunks)
             parts = [[genome[i] for i in range(len(genome)) if i % n_chunks == c] for c in range(n_chunks)]
+            if cfg["div_copy"] > 0:
+                drng = np.random.default_rng(cfg["div_seed"])
+                letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+                for c in range(n_chunks):
+                    src = parts[(c + 1) % n_chunks][0][1]
+                    n = int(min(len(src), drng.integers(20000, 120000)))
+                    a = int(drng.integers(0, len(src) - n + 1))
+                    seg = np.array(src[a:a + n], dtype=np.uint8, copy=True)
+                    k = (drng.random(n) < cfg["div_copy"]) & np.isin(seg, letters)
+                    seg[k] = letters[(np.searchsorted(letters, seg[k]) + drng.integers(1, 4, size=int(k.sum()))) & 3]
+                    seg = seg[drng.random(n) >= 0.002]                                  # a few deletions
+                    parts[c] = parts[c] + [("divcopy%d" % c, seg)]
             prefixes = []
             for c, part in enumerate(parts):
                 pc = os.path.join(tmp, "c%d.index" % c)

@@ -923,7 +923,7 @@ def human_filter_leg(args, H, index_builder, simulate, text, arrs, dev, device, 
     elapsed_single, acc = run_steps(ctx, wl, params, K)
     band1, th1 = ctx.dp_band_stats(), ctx.dp_thermo_stats()
     elapsed = elapsed_single
-    n_ctx = max(1, args.contexts)
+    n_ctx = max(1, args.leg_contexts)
     if n_ctx > 1:
         cuts = [P * i // n_ctx for i in range(n_ctx + 1)]
         slices = [WorkloadSlice(wl, cuts[i], cuts[i + 1]) for i in range(n_ctx)]
@@ -1063,8 +1063,9 @@ def main():
                     help="HBM bytes (GB) of index the replica makes resident (as many lean chunks of --genome-mbp as that takes and as fit)")
     ap.add_argument("--nt-headroom-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_HEADROOM_GB", "56")), help="GiB of HBM kept free of index for the batch buffers")
     ap.add_argument("--nt-pairs", type=int, default=int(os.environ.get("MP_BENCH_NT_PAIRS", str(1 << 18))), help="pairs per step and GPU of the headline workload")
-    ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "3")),
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "4")),
                     help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")
+    ap.add_argument("--leg-contexts", type=int, default=int(os.environ.get("MP_BENCH_LEG_CONTEXTS", "3")), help="contexts of the human-filter leg (one index: three, as the executable's workers per GPU)")
     ap.add_argument("--single-steps", type=int, default=int(os.environ.get("MP_BENCH_SINGLE_STEPS", "1")), help="untimed one-context steps the per-kernel HIP-event times and the roofline come from")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--pairs-per-step", type=int, default=int(os.environ.get("MP_BENCH_PAIRS", str(1 << 20))), help="pairs per step of the human-filter leg")
@@ -1167,6 +1168,7 @@ def main():
     if rank == 0:
         log("[bench] %d warm-up step(s) of %d pairs through %d chunks: %.1f s" % (Wm, lp, n_chunks, time.time() - t_w))
     elapsed = nt_run_contexts(ctxs, slices, rep.chunks, params, K, barrier)          # THE timed region: K steps between barriers + device syncs
+    hbm_free_timed = int(torch.cuda.mem_get_info()[0])                               # (the contexts' buffers only ever grow: what is free now was free throughout)
     for c in ctxs[1:]:
         c.close()
     # the run the per-kernel HIP-event times, the event counts and the roofline come from: ONE context doing the whole batch on one stream (kernels of
@@ -1222,7 +1224,7 @@ def main():
                        "command_line": "soap4 pair <chunk i> in_1.fq in_2.fq -b -o <prefix>.nt.bam -L %d -T <n> -u 750 -F -C soap4-nt2.ini -top 95 [-nc for i = 0], i = 0 .. %d "
                                        "(runMegaPath.sh:191-208), as ONE process: bin/soap4-mi355x pair <chunk 0>,...,<chunk %d> ..." % (args.read_len + 1, n_chunks - 1, n_chunks - 1),
                        "index_replicated_per_gpu": True, "chunks": n_chunks, "bases_resident": n_chunks * n_bases, "index_bytes_in_hbm": rep.index_bytes,
-                       "bytes_per_base": rep.index_bytes / (n_chunks * n_bases), "hbm_total_bytes": rep.hbm_total, "pairs_per_step_per_gpu": lp, "contexts_per_gpu": n_ctx,
+                       "bytes_per_base": rep.index_bytes / (n_chunks * n_bases), "hbm_total_bytes": rep.hbm_total, "pairs_per_step_per_gpu": lp, "contexts_per_gpu": n_ctx, "hbm_free_bytes_during_timed_steps": hbm_free_timed,
                        "ini": "soap4-nt2.ini", "L": args.read_len + 1, "u": 750, "top": 95, "replica_load_s": rep.load_s},
             "chunk_pair_alignments_per_s": world * K * lp * n_chunks / elapsed,
             "single_context": {"ms_per_step": el_single * 1e3, "pairs_per_s": lp / el_single, "steps": S,

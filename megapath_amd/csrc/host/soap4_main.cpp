@@ -2021,10 +2021,11 @@ int main(int argc, char **argv)
     const bool plumbing_only = getenv("MP_PLUMBING_TEST") != nullptr;
     if (plumbing_only) fprintf(stderr, "[soap4-mi355x] MP_PLUMBING_TEST: NO ALIGNMENT IS DONE -- host plumbing test only, every pair is reported unaligned\n");
     int workers_per_gpu = 3;                   // three contexts per GPU: the memory-bound seeding of one batch overlaps with the VALU-bound DP of the others (bench.py: +4 % over two)
-    if (const char *e = getenv("MP_WORKERS_PER_GPU")) workers_per_gpu = std::max(1, atoi(e));
     fill_char_map();
 
     const size_t n_chunks = prefixes.size();
+    if (n_chunks >= 2) workers_per_gpu = 4;    // several resident chunks (the NT stage): a batch stays on the device for seconds, four side by side measured +3 % over three (bench.py --contexts)
+    if (const char *e = getenv("MP_WORKERS_PER_GPU")) workers_per_gpu = std::max(1, atoi(e));
     std::vector<Device> devices(gpu_ids.size());
     if (!plumbing_only) {
         // every GPU loads its own replica of every chunk, the GPUs side by side

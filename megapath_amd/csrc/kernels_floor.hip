@@ -179,9 +179,11 @@ __global__ void floor_decide_kernel(const uint32_t *__restrict__ failed_reads, u
 // wavefront (the reason the bound of x uses blocks of five); here the 6-mers of the four oriented mates (2 mates x 2 strands: 4 x 512 bytes, shared by the
 // wavefront) are the filter: a lane streams its ~960 text bases, and only the 6-mers that occur in the mate at all (3.6 % of them) enter the lane's own set --
 // 1 024 bits addressed by the key's low ten bits.  Two 6-mers that differ in the last base alone share a bit: a block may count as present that is not,
-// which only raises the bound.
+// which only raises the bound.  The filter is laid out by the FIVE bases two neighbouring 6-mers share (one byte per 5-mer: low nibble = the bases that may
+// stand before it, high nibble = the bases that may follow it), so one look-up answers two text positions.
 #define MP_FLOOR_KM 6
 #define MP_FLOOR_KM_WORDS ((1 << (2 * MP_FLOOR_KM)) / 32)      // 128
+#define MP_FLOOR_CORE_WORDS ((1 << (2 * (MP_FLOOR_KM - 1))) / 4)    // 1 024 bytes
 #define MP_FLOOR_PM_WORDS 32                                    // the lane's own hashed set
 __global__ void __launch_bounds__(64)
 floor_mate_kernel(const uint32_t *__restrict__ text, uint64_t text_len, const uint32_t *__restrict__ reads, const uint32_t *__restrict__ lens, uint32_t Wr,
@@ -190,7 +192,7 @@ floor_mate_kernel(const uint32_t *__restrict__ text, uint64_t text_len, const ui
                   int insert_high, uint32_t *__restrict__ n_cand /* null: no decision (test hook) */, unsigned long long *__restrict__ counts /* [2] pairs looked at, [3] dropped here */,
                   uint16_t *__restrict__ ub_mate /* may be null: U_y per instance */)
 {
-    __shared__ uint32_t s_y[4][MP_FLOOR_KM_WORDS];            // [2 * mate + (strand - 1)]
+    __shared__ uint32_t s_y[4][MP_FLOOR_CORE_WORDS];          // [2 * mate + (strand - 1)][5-mer] bytes
     __shared__ uint32_t s_rd[4][MP_FLOOR_MAXL / 16 + 2];      // the oriented mates, 16 bases per word
     __shared__ uint32_t s_p[MP_FLOOR_PM_WORDS][64];           // [word][lane]
     const uint32_t k = blockIdx.x;
@@ -200,7 +202,7 @@ floor_mate_kernel(const uint32_t *__restrict__ text, uint64_t text_len, const ui
     if ((r0 ^ failed_reads[2 * k + 1]) != 1u) return;
     const int Lm[2] = {(int)lens[r0], (int)lens[r0 ^ 1u]};
     if (Lm[0] > MP_FLOOR_MAXL || Lm[1] > MP_FLOOR_MAXL) return;                  // (uniform: the pair keeps its work)
-    for (int w = lane; w < 4 * MP_FLOOR_KM_WORDS; w += 64) (&s_y[0][0])[w] = 0u;
+    for (int w = lane; w < 4 * MP_FLOOR_CORE_WORDS; w += 64) (&s_y[0][0])[w] = 0u;
     for (int w = lane; w < 4 * (MP_FLOOR_MAXL / 16 + 2); w += 64) {
         const int q = w / (MP_FLOOR_MAXL / 16 + 2), kk = w % (MP_FLOOR_MAXL / 16 + 2);
         const int L = Lm[q >> 1];
@@ -212,7 +214,9 @@ floor_mate_kernel(const uint32_t *__restrict__ text, uint64_t text_len, const ui
         for (int j = lane; j + MP_FLOOR_KM <= L; j += 64) {
             const uint64_t two = ((uint64_t)s_rd[q][(j >> 4) + 1] << 32) | s_rd[q][j >> 4];
             const uint32_t key = (uint32_t)(two >> (2 * (j & 15))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);
-            atomicOr(&s_y[q][key >> 5], 1u << (key & 31u));
+            const uint32_t tail = key >> 2, head = key & ((1u << (2 * (MP_FLOOR_KM - 1))) - 1u);       // the 5-mers after the first base / before the last
+            atomicOr(&s_y[q][tail >> 2], (1u << (key & 3u)) << (8u * (tail & 3u)));
+            atomicOr(&s_y[q][head >> 2], (16u << (key >> (2 * (MP_FLOOR_KM - 1)))) << (8u * (head & 3u)));
         }
     }
     __syncthreads();
@@ -241,42 +245,65 @@ floor_mate_kernel(const uint32_t *__restrict__ text, uint64_t text_len, const ui
                 for (int w = 0; w < MP_FLOOR_PM_WORDS; w++) s_p[w][lane] = 0u;
                 // whole text words: up to 63 bases more on either side (and 'A's before the first word) only add 6-mers to the set.  Sixteen positions per
                 // trip, their sixteen filter look-ups independent of each other; the few that hit (0.6 per trip and lane) enter the lane's set afterwards.
-                // (text words in aligned groups of four, one 16-byte load each: the packed text is allocated with four words to spare, api.hip mp_index_*)
-                const uint32_t *sy = s_y[q];
+                // (text words in aligned groups of four, one 16-byte load each, eight groups in flight at a time; the packed text is allocated with four
+                // words to spare, api.hip mp_index_*)
+                const uint8_t *sy = reinterpret_cast<const uint8_t *>(s_y[q]);
                 uint32_t prev = 0u;
-                for (uint64_t wi = (ws >> 4) & ~(uint64_t)3, w_end = (we + 15) >> 4; wi < w_end; wi += 4) {
-                    const uint4 four = *reinterpret_cast<const uint4 *>(text + wi);
-                    const uint32_t wd[4] = {four.x, four.y, four.z, four.w};
+                const uint64_t w_end = (we + 15) >> 4;
+                for (uint64_t wi = (ws >> 4) & ~(uint64_t)3; wi < w_end; wi += 32) {
+                    uint4 buf[8];
 #pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const uint32_t cur = wd[g];
-                        const uint64_t both = ((uint64_t)cur << 32) | prev;
-                        uint32_t hits = 0u;
+                    for (int b = 0; b < 8; b++) buf[b] = wi + 4 * b < w_end ? *reinterpret_cast<const uint4 *>(text + wi + 4 * b) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
-                        for (int u = 0; u < 16; u++) {
-                            const uint32_t key = (uint32_t)(both >> (2 * (u + 16 - (MP_FLOOR_KM - 1)))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);     // the 6-mer that ends at base u of this word
-                            hits |= ((sy[key >> 5] >> (key & 31u)) & 1u) << u;
+                    for (int b = 0; b < 8; b++) {
+                        if (wi + 4 * b >= w_end) break;
+                        const uint32_t wd[4] = {buf[b].x, buf[b].y, buf[b].z, buf[b].w};
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const uint32_t cur = wd[g];
+                            const uint64_t both = ((uint64_t)cur << 32) | prev;
+                            uint32_t hits = 0u;
+#pragma unroll
+                            for (int u = 0; u < 16; u += 2) {
+                                // the 6-mers that end at bases u and u + 1 of this word: seven bases, the middle five are the look-up
+                                const uint32_t seven = (uint32_t)(both >> (2 * (u + 16 - (MP_FLOOR_KM - 1)))) & ((1u << (2 * MP_FLOOR_KM + 2)) - 1u);
+                                const uint32_t byte = sy[(seven >> 2) & ((1u << (2 * (MP_FLOOR_KM - 1))) - 1u)];
+                                hits |= ((byte >> (seven & 3u)) & 1u) << u;
+                                hits |= ((byte >> (4u + (seven >> (2 * MP_FLOOR_KM)))) & 1u) << (u + 1);
+                            }
+                            while (hits) {
+                                const int u = __ffs((int)hits) - 1;
+                                hits &= hits - 1u;
+                                const uint32_t key = (uint32_t)(both >> (2 * (u + 16 - (MP_FLOOR_KM - 1)))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);
+                                atomicOr(&s_p[(key >> 5) & (MP_FLOOR_PM_WORDS - 1)][lane], 1u << (key & 31u));
+                            }
+                            prev = cur;
                         }
-                        while (hits) {
-                            const int u = __ffs((int)hits) - 1;
-                            hits &= hits - 1u;
-                            const uint32_t key = (uint32_t)(both >> (2 * (u + 16 - (MP_FLOOR_KM - 1)))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);
-                            atomicOr(&s_p[(key >> 5) & (MP_FLOOR_PM_WORDS - 1)][lane], 1u << (key & 31u));
-                        }
-                        prev = cur;
                     }
                 }
-                unsigned long long E = 0;
-                int ph = 0;
-                for (int j = 0; j + MP_FLOOR_KM <= ulen; j++) {
-                    const uint64_t two = ((uint64_t)s_rd[q][(j >> 4) + 1] << 32) | s_rd[q][j >> 4];
-                    const uint32_t kj = (uint32_t)(two >> (2 * (j & 15))) & ((1u << (2 * MP_FLOOR_KM)) - 1u);
-                    const uint32_t present = (s_p[(kj >> 5) & (MP_FLOOR_PM_WORDS - 1)][lane] >> (kj & 31u)) & 1u;
-                    E += (unsigned long long)(present ^ 1u) << (8 * ph);
-                    ph = ph == MP_FLOOR_KM - 1 ? 0 : ph + 1;
+                // the mate's own 6-mers, sixteen starts per trip (their look-ups independent of each other): start j belongs to block phase j % 6
+                uint32_t Ec[MP_FLOOR_KM] = {0u, 0u, 0u, 0u, 0u, 0u};
+                int ph0 = 0;                                                  // phase of this trip's first start
+                for (int kw = 0; 16 * kw + MP_FLOOR_KM <= ulen; kw++) {
+                    const uint64_t two = ((uint64_t)s_rd[q][kw + 1] << 32) | s_rd[q][kw];
+                    const int last = min(16, ulen - MP_FLOOR_KM + 1 - 16 * kw);
+                    uint32_t absent = 0u;
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const uint32_t kj = (uint32_t)(two >> (2 * u)) & ((1u << (2 * MP_FLOOR_KM)) - 1u);
+                        absent |= (((s_p[(kj >> 5) & (MP_FLOOR_PM_WORDS - 1)][lane] >> (kj & 31u)) & 1u) ^ 1u) << u;
+                    }
+                    absent &= (1u << last) - 1u;
+#pragma unroll
+                    for (int pp = 0; pp < MP_FLOOR_KM; pp++) {
+                        const int c = pp >= ph0 ? pp - ph0 : pp + MP_FLOOR_KM - ph0;     // the starts u of this trip with (ph0 + u) % 6 == pp: u = c, c + 6, c + 12
+                        Ec[pp] += (uint32_t)__popc(absent & ((0x1041u << c) & 0xFFFFu));
+                    }
+                    ph0 = (ph0 + 16) % MP_FLOOR_KM;
                 }
+#pragma unroll
                 for (int pp = 0; pp < MP_FLOOR_KM; pp++) {
-                    const int e = (int)((E >> (8 * pp)) & 255u);
+                    const int e = (int)Ec[pp];
                     Uy = min(Uy, ulen - 3 * max(0, e - 2) - min(e, 2));
                 }
                 Uy = max(Uy, 0);

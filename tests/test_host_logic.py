@@ -141,7 +141,7 @@ def test_driver_plumbing_keeps_input_order_across_fake_gpus(tmp_path):
                         "-C", os.path.join(ROOT, "tests", "soap4-nt2.ini"), "-L", "151", "-T", "3", "-u", "750", "-F", "-nc", "-c", "0,1,2"],
                        env=env, capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
-    assert b"NO ALIGNMENT IS DONE" in r.stderr and b"3 GPU(s) x 3 worker(s), 2 index chunk(s)" in r.stderr
+    assert b"NO ALIGNMENT IS DONE" in r.stderr and b"3 GPU(s) x 4 worker(s), 2 index chunk(s)" in r.stderr      # (four workers per GPU with several chunks, three with one)
     names = [l.split(b"\t")[0][1:] for l in r.stdout.split(b"\n") if l.startswith(b"@r")]
     src = [l.split()[0][1:-2] for l in open(os.path.join(d, "reads_a_1.fq"), "rb") if l.startswith(b"@r")]
     assert names[0::2] == src and names[1::2] == src

@@ -14,7 +14,7 @@ cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 2 --warmup 1 --contexts 1 --nt-replica-gb 30 --no-cpu-baseline --no-pmc --no-legs > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "trace done"
 SQ="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
-rocprofv3 --pmc $SQ --kernel-include-regex "dp_fill_kernel|dp_score_kernel|dp_thermo_kernel|seed_kernel|merge_kernel|locate_kernel|expand_hits_kernel|pair_kernel|single_cand_kernel" --kernel-trace --output-format csv -d $OUT/valu -- python3 $ROOT/bench.py --pmc-child nt > $OUT/bench_valu.json 2> $OUT/valu.err
+rocprofv3 --pmc $SQ --kernel-include-regex "dp_fill_kernel|dp_score_kernel|dp_thermo_kernel|seed_kernel|merge_kernel|locate_kernel|expand_hits_kernel|pair_kernel|single_cand_kernel|floor_bound_kernel|floor_mate_kernel" --kernel-trace --output-format csv -d $OUT/valu -- python3 $ROOT/bench.py --pmc-child nt > $OUT/bench_valu.json 2> $OUT/valu.err
 echo "valu nt done"
 rocprofv3 --pmc $SQ --kernel-include-regex "dp_band_kernel|dp_fill_kernel|dp_score_kernel|dp_thermo_kernel|seed_kernel|merge_kernel|pair_kernel|dp_prefilter_kernel" --kernel-trace --output-format csv -d $OUT/valu_human -- python3 $ROOT/bench.py --pmc-child human > $OUT/bench_valu_human.json 2> $OUT/valu_human.err
 echo "valu human done"

@@ -151,16 +151,33 @@ single_cand_kernel(const uint32_t *__restrict__ failed_reads, uint32_t n_failed,
     mp_single_cand *out = cand + rs_base[2 * r];
     const bool in_lds = n <= MP_SCAND_LDS;
     const mp_cand_arr arr = in_lds ? mp_cand_arr{&s_c[0][threadIdx.x], 64} : mp_cand_arr{reinterpret_cast<mp_cand_q *>(out), 1};
+    // the read's seed positions: into the LDS column first, eight 16-byte loads in flight at a time (the merge below reads them one after the other, each
+    // decision depending on the last: straight from global memory that is one memory latency per seed); a candidate is written at or before the seed it
+    // was read from, so the merge works in place
+    static_assert(sizeof(mp_seedpos) == 16, "seed positions move as 16-byte quads");
+    const mp_cand_arr raw = in_lds ? arr : mp_cand_arr{const_cast<mp_cand_q *>(reinterpret_cast<const mp_cand_q *>(sp)), 1};
+    if (in_lds)
+        for (int p0 = 0; p0 < n; p0 += 8) {
+            mp_cand_q q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (p0 + j < n) q[j] = reinterpret_cast<const mp_cand_q *>(sp)[p0 + j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (p0 + j < n) mp_lsl_st(arr, p0 + j, q[j]);
+        }
     int nm = 0;
     // singleMerge: drop seeds < 17, merge followers within DPS_DIVIDE_GAP (5) on the same strand keeping the longer one
+    // (a seed position as a quad: x, y = pos; z = strand_read_id; w = paired_seed_length)
     for (int p = 0; p < n; p++) {
-        const uint32_t slen = sp[p].paired_seed_length & 0x7FFFFFFFu;
+        const mp_cand_q a = mp_lsl_ld(raw, p);
+        const uint32_t slen = a.w & 0x7FFFFFFFu;
         if (slen < 17) continue;
-        mp_single_cand cur; cur.pos = sp[p].pos; cur.strand = (sp[p].strand_read_id >> 31) + 1; cur.seed_len = slen;
+        mp_single_cand cur; cur.pos = ((uint64_t)a.y << 32) | a.x; cur.strand = (a.z >> 31) + 1; cur.seed_len = slen;
         while (p + 1 < n) {
-            const uint32_t nstrand = (sp[p + 1].strand_read_id >> 31) + 1, nlen = sp[p + 1].paired_seed_length & 0x7FFFFFFFu;
-            if (sp[p + 1].pos < cur.pos + 5 && cur.strand == nstrand) {
-                if (nlen > cur.seed_len) { cur.pos = sp[p + 1].pos; cur.seed_len = nlen; }
+            const mp_cand_q b = mp_lsl_ld(raw, p + 1);
+            const uint32_t nstrand = (b.z >> 31) + 1, nlen = b.w & 0x7FFFFFFFu;
+            const uint64_t npos = ((uint64_t)b.y << 32) | b.x;
+            if (npos < cur.pos + 5 && cur.strand == nstrand) {
+                if (nlen > cur.seed_len) { cur.pos = npos; cur.seed_len = nlen; }
             } else break;
             ++p;
         }

@@ -29,8 +29,8 @@ def _mutate(rng, seq, div, indel=0.0):
     return s
 
 
-def _run(prefixes, f1, f2, out, ini, L, extra_env, flags, top=95, nc=True):
-    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", ",".join(prefixes), f1, f2, "-o", out + ".o", "-C", os.path.join(ROOT, "tests", ini), "-L", str(L), "-T", "3", "-u", "750",
+def _run(prefixes, f1, f2, out, ini, L, extra_env, flags, top=95, nc=True, u=750):
+    cmd = [os.path.join(ROOT, "bin", "soap4-mi355x"), "pair", ",".join(prefixes), f1, f2, "-o", out + ".o", "-C", os.path.join(ROOT, "tests", ini), "-L", str(L), "-T", "3", "-u", str(u),
            "-top", str(top)] + (["-nc"] if nc else []) + flags
     env = dict(os.environ, MP_BATCH_PAIRS="1500", **extra_env)
     with open(out, "wb") as fo:
@@ -47,7 +47,7 @@ def _split_pairs(fq, out1, out2):
             fb.write(b"\n".join(lines[i + 4:i + 8]) + b"\n")
 
 
-def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comments=False, min_left_out=300, sub=0.012, min_by_mate=0):
+def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comments=False, min_left_out=300, sub=0.012, min_by_mate=0, u=750):
     rng = np.random.Generator(np.random.PCG64(7000 + seed))
     home = [("home%d" % i, B[rng.integers(0, 4, size=150000)]) for i in range(2)]
     # chunk 0 = home; chunks 1, 2: unrelated sequence + diverged copies of stretches of home (seeds and weak hits for home's reads); the last chunk:
@@ -69,7 +69,7 @@ def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comment
         index_builder.write_index_files(pc, index_builder.build_index_arrays(part, sa_interval=16))
         prefixes.append(pc)
     names, r1, r2 = synth.simulate_pairs(home, 4000, read_len, 7100 + seed, sub=sub, ins=0.001, dele=0.001, random_frac=0.1, broken_mate_frac=0.15, noisy_mate_frac=0.1, noisy_sub=0.15,
-                                         frag_mean=read_len + 200, frag_sd=40, frag_min=read_len + 20, frag_max=min(740, read_len + 420))
+                                         frag_mean=min(read_len + 200, u - 60), frag_sd=40, frag_min=read_len + 20, frag_max=min(u - 10, read_len + 420))
     f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
     synth.write_fastq_pair(f1, f2, names, r1, r2)
     L = read_len + 1
@@ -82,7 +82,7 @@ def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comment
         pp = str(tmp_path / "pre.index")
         index_builder.write_index_files(pp, index_builder.build_index_arrays(pre, sa_interval=16))
         ix = lib.mpo_index_open(pp.encode())
-        p0 = O.default_params(L=L, mode=m, nc=True, top=top)
+        p0 = O.default_params(L=L, mode=m, nc=True, top=top, insert_high=u)
         st = O.AlignStats()
         annotated = str(tmp_path / "pre.fq")
         assert lib.mpo_align_fastq(ix, C.byref(p0), f1.encode(), f2.encode(), annotated.encode(), None, C.byref(st)) == 0
@@ -92,8 +92,8 @@ def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comment
         assert sum(1 for l in open(f1, "rb") if l.startswith(b"@") and b"SCORE:" in l) > 1000
     on = str(tmp_path / "on.fq")
     off = str(tmp_path / "off.fq")
-    err_on = _run(prefixes, f1, f2, on, ini, L, {}, [mode], top=top, nc=not with_comments)
-    err_off = _run(prefixes, f1, f2, off, ini, L, {"MP_TOP_FLOOR": "0"}, [mode], top=top, nc=not with_comments)
+    err_on = _run(prefixes, f1, f2, on, ini, L, {}, [mode], top=top, nc=not with_comments, u=u)
+    err_off = _run(prefixes, f1, f2, off, ini, L, {"MP_TOP_FLOOR": "0"}, [mode], top=top, nc=not with_comments, u=u)
     assert "-top rule" in err_on and "-top rule" not in err_off
     left_out = int(err_on.split("-top rule: ")[1].split()[0])
     # the chain of the reference, restated: chunk after chunk, each run reading the last one's stdout
@@ -101,7 +101,7 @@ def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comment
     want = str(tmp_path / "want.fq")
     for c, pc in enumerate(prefixes):
         ix = lib.mpo_index_open(pc.encode())
-        p = O.default_params(L=L, mode=m, nc=(c == 0 and not with_comments), top=top)
+        p = O.default_params(L=L, mode=m, nc=(c == 0 and not with_comments), top=top, insert_high=u)
         st = O.AlignStats()
         assert lib.mpo_align_fastq(ix, C.byref(p), in1.encode(), in2.encode(), want.encode(), None, C.byref(st)) == 0
         lib.mpo_index_close(ix)
@@ -117,7 +117,7 @@ def _check_rule(tmp_path, mode, seed, read_len, top=95, n_chunks=4, with_comment
     assert by_mate >= min_by_mate, (by_mate, left_out)
     # ... and the first half of the rule alone (no bound on the rescued mate): the same records again
     mid = str(tmp_path / "mid.fq")
-    err_mid = _run(prefixes, f1, f2, mid, ini, L, {"MP_TOP_FLOOR_MATE": "0"}, [mode], top=top, nc=not with_comments)
+    err_mid = _run(prefixes, f1, f2, mid, ini, L, {"MP_TOP_FLOOR_MATE": "0"}, [mode], top=top, nc=not with_comments, u=u)
     assert fastq_records(mid) == w and int(err_mid.split("rescue rounds left out, ")[1].split()[0]) == 0
     return w
 
@@ -134,6 +134,12 @@ def test_top_rule_for_mates_far_from_their_best_alignment(tmp_path, mode, read_l
     """reads 5-7 % away from their home: a pair's best score leaves less than a mate's length of room, the first half of the rule (which credits a rescued
     mate with its whole length) keeps them all -- the bound on the windows the rescue can search (floor_mate_kernel) is what releases them"""
     _check_rule(tmp_path, mode, 60 + read_len + int(100 * sub), read_len, sub=sub, min_left_out=300, min_by_mate=200)
+
+
+@pytest.mark.parametrize("u,read_len,sub", [(420, 150, 0.06), (1000, 150, 0.05), (300, 100, 0.012)])
+def test_top_rule_with_other_insert_limits(tmp_path, u, read_len, sub):
+    """-u decides how far from a hit a mate is searched, i.e. the text the second bound looks at (short, and the longest the rescue DP takes with 150-base reads: windows of 1 001 rows)"""
+    _check_rule(tmp_path, "-F", 90 + u % 97, read_len, sub=sub, u=u, min_left_out=200)
 
 
 @pytest.mark.parametrize("top,min_left_out", [(100, 300), (60, 0), (1, 0)])

@@ -400,12 +400,14 @@ class NtReplica:
     alignment in one chunk and only chance matches in the others."""
 
     KNOBS = {"MP_KMER_FILTER": "0", "MP_KMER15": "0", "MP_LKT16": "0", "MP_SA_DENSE": "0"}      # the lean layout: none of the optional tables
+    LKT14 = os.environ.get("MP_BENCH_NT_LKT14", "1")      # ... and the 13-mer table as 8-byte entries with a seed's first extension step in them (+256 MiB per chunk)
 
     def __init__(self, args, H, index_builder, simulate, dev, device, n_bases, max_chunks=None, keep_arrays=False):
         self.chunks = []
         self.arrs_b = None
         saved = {k: os.environ.get(k) for k in self.KNOBS}
-        os.environ.update(dict(self.KNOBS, MP_KMER_FILTER=os.environ.get("MP_BENCH_NT_KMER", "0")))
+        saved["MP_LKT14"] = os.environ.get("MP_LKT14")
+        os.environ.update(dict(self.KNOBS, MP_KMER_FILTER=os.environ.get("MP_BENCH_NT_KMER", "0"), MP_LKT14=self.LKT14))
         try:
             t0 = time.time()
             self.text_a = simulate.genome(n_bases, seed=3, device=dev)
@@ -428,7 +430,8 @@ class NtReplica:
             del arrs_b
             per_chunk = int(self.chunks[0].info.device_bytes)
             free_b, total_b = torch.cuda.mem_get_info()
-            want = int(args.nt_replica_gb * 1e9 // per_chunk) + 1
+            lean = per_chunk - ((1 << 28) + 8 if self.LKT14 != "0" else 0)                     # --nt-replica-gb counts the database in the lean layout proper
+            want = int(args.nt_replica_gb * 1e9 // lean) + 1
             fit = 2 + max(0, int((free_b - (int(args.nt_headroom_gb) << 30)) // per_chunk))     # the rest stays free for the batch buffers and traceback slabs
             self.n_chunks = max(2, min(want, fit, max_chunks or (1 << 30)))
             t1 = time.time()
@@ -1061,7 +1064,8 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MP_BENCH_GENOME_MBP", "2950")), help="bases per index chunk (< 4295 Mbp: 32-bit positions per chunk)")
     ap.add_argument("--nt-replica-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_GB", "242")),
                     help="HBM bytes (GB) of index the replica makes resident (as many lean chunks of --genome-mbp as that takes and as fit)")
-    ap.add_argument("--nt-headroom-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_HEADROOM_GB", "56")), help="GiB of HBM kept free of index for the batch buffers")
+    ap.add_argument("--nt-headroom-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_HEADROOM_GB", "36" if NtReplica.LKT14 != "0" else "56")),
+                    help="GiB of HBM kept free of index for the batch buffers (36: 89 chunks with the packed 14-mer tables, 266.6 GB, and 9 GB free during the steps)")
     ap.add_argument("--nt-pairs", type=int, default=int(os.environ.get("MP_BENCH_NT_PAIRS", str(1 << 18))), help="pairs per step and GPU of the headline workload")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "4")),
                     help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")

@@ -149,7 +149,7 @@ struct mp_ctx {
     DevBuf<uint16_t> floor_ub;
     DevBuf<unsigned long long> floor_counts;
     DevBuf<uint8_t> floor_hope;                 // [failed pair] kept by floor_decide_kernel for the mate's length alone
-    struct Stash { size_t off = 0, bytes = 0; uint64_t n_hits = 0; uint32_t n_reads = 0; const mp_index *ix = nullptr; mp_seed_stats seed{}; bool used = false; };
+    struct Stash { size_t off = 0, bytes = 0; uint64_t n_hits = 0; uint32_t n_reads = 0; const mp_index *ix = nullptr; mp_seed_stats seed{}; bool used = false, packed = false; };
     std::vector<Stash> stash;
     uint8_t *stash_arena = nullptr;
     size_t stash_cap = 0, stash_used = 0;
@@ -447,6 +447,24 @@ static int upload_index(int device, mp_host_index &h, mp_index **out)
             ix->device_bytes += bytes; ix->bytes_lkt16u = bytes;
         }
     }
+    if (const char *e = getenv("MP_LKT14")) {
+        // the 13-mer table as 8-byte entries with a seed's first extension step in them (mp_dev_index::lkt14, lkt14_build_kernel): 512 MiB IN PLACE of
+        // the table's 256 -- a seed start of the lean layout then costs one rank block less (3.8 -> 2.6 per start against a 2.95 Gbp chunk).  Explicit only
+        // (the NT stage's many resident chunks: bench.py); the seeds are the same either way.
+        if (atoi(e) != 0) {
+            const size_t bytes = ((size_t)MP_LKT_ENTRIES + 1) * sizeof(uint2);
+            unsigned long long *d_n = nullptr, h_n = 0;
+            if (hipMalloc(&ix->d_lkt14, bytes) != hipSuccess || hipMalloc((void **)&d_n, 8) != hipSuccess || hipMemset(d_n, 0, 8) != hipSuccess) { if (d_n) (void)hipFree(d_n); mp_index_close(ix); return MP_ENOMEM; }
+            hipLaunchKernelGGL(lkt14_build_kernel, dim3(grid_for((uint64_t)MP_LKT_ENTRIES + 1, 256)), dim3(256), 0, 0, ix->d, (uint2 *)ix->d_lkt14, d_n);
+            const bool ok = hipMemcpy(&h_n, d_n, 8, hipMemcpyDeviceToHost) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            (void)hipFree(d_n);
+            if (!ok) { mp_index_close(ix); return MP_ENODEV; }
+            if (getenv("MP_DEBUG")) fprintf(stderr, "[megapath_hip] lkt14: %llu of %u entries keep the 13-mer path\n", h_n, MP_LKT_ENTRIES);
+            (void)hipFree(ix->d_lkt); ix->d_lkt = nullptr; ix->d.lkt = nullptr;
+            ix->d.lkt14 = (const uint2 *)ix->d_lkt14;
+            ix->device_bytes += bytes; ix->device_bytes -= ix->bytes_lkt; ix->bytes_lkt14 = bytes; ix->bytes_lkt = 0;
+        }
+    }
     *out = ix;
     return MP_OK;
 }
@@ -488,13 +506,13 @@ extern "C" int mp_index_clone(const mp_index *src, mp_index **out)
     HIPCHK(hipSetDevice(src->device));
     mp_index *ix = new (std::nothrow) mp_index(*src);                 // annotation, sizes and the kernel view (pointers fixed below)
     if (!ix) return MP_ENOMEM;
-    ix->d_occ = ix->d_lkt = ix->d_sa = ix->d_text = ix->d_kmer = ix->d_sa_dense = ix->d_lkt16 = ix->d_kmer15 = ix->d_lkt16u = nullptr;
+    ix->d_occ = ix->d_lkt = ix->d_sa = ix->d_text = ix->d_kmer = ix->d_sa_dense = ix->d_lkt16 = ix->d_kmer15 = ix->d_lkt16u = ix->d_lkt14 = nullptr;
     ix->host_text = std::make_shared<mp_index::HostText>();
     ix->d_tr_grid = ix->d_tr_start = ix->d_tr_chr = nullptr;          // uploaded again on first use
     struct Arr { void *const *from; void **to; size_t bytes; };
     const Arr arrs[] = {{&src->d_occ, &ix->d_occ, src->bytes_occ}, {&src->d_lkt, &ix->d_lkt, src->bytes_lkt}, {&src->d_sa, &ix->d_sa, src->bytes_sa},
                         {&src->d_text, &ix->d_text, src->bytes_text}, {&src->d_kmer, &ix->d_kmer, src->bytes_kmer}, {&src->d_sa_dense, &ix->d_sa_dense, src->bytes_sa_dense},
-                        {&src->d_lkt16, &ix->d_lkt16, src->bytes_lkt16}, {&src->d_kmer15, &ix->d_kmer15, src->bytes_kmer15}, {&src->d_lkt16u, &ix->d_lkt16u, src->bytes_lkt16u}};
+                        {&src->d_lkt16, &ix->d_lkt16, src->bytes_lkt16}, {&src->d_kmer15, &ix->d_kmer15, src->bytes_kmer15}, {&src->d_lkt16u, &ix->d_lkt16u, src->bytes_lkt16u}, {&src->d_lkt14, &ix->d_lkt14, src->bytes_lkt14}};
     for (const Arr &a : arrs) {
         if (!*a.from || a.bytes == 0) continue;
         if (hipMalloc(a.to, a.bytes) != hipSuccess) { mp_index_close(ix); return MP_ENOMEM; }
@@ -503,7 +521,7 @@ extern "C" int mp_index_clone(const mp_index *src, mp_index **out)
     if (hipDeviceSynchronize() != hipSuccess) { mp_index_close(ix); return MP_ENODEV; }
     ix->d.occ = (const mp_occ_block *)ix->d_occ; ix->d.lkt = (const uint32_t *)ix->d_lkt; ix->d.sa = (const uint32_t *)ix->d_sa; ix->d.text = (const uint32_t *)ix->d_text;
     ix->d.kmer17 = (const uint32_t *)ix->d_kmer; ix->d.sa_dense = (const uint32_t *)ix->d_sa_dense; ix->d.lkt16 = (const uint32_t *)ix->d_lkt16;
-    ix->d.kmer15x3 = (const unsigned long long *)ix->d_kmer15; ix->d.lkt16u = (const uint4 *)ix->d_lkt16u;
+    ix->d.kmer15x3 = (const unsigned long long *)ix->d_kmer15; ix->d.lkt16u = (const uint4 *)ix->d_lkt16u; ix->d.lkt14 = (const uint2 *)ix->d_lkt14;
     *out = ix;
     return MP_OK;
 }
@@ -514,6 +532,7 @@ extern "C" int mp_index_close(mp_index *ix)
     (void)hipSetDevice(ix->device);
     if (ix->d_occ) (void)hipFree(ix->d_occ);
     if (ix->d_lkt) (void)hipFree(ix->d_lkt);
+    if (ix->d_lkt14) (void)hipFree(ix->d_lkt14);
     if (ix->d_sa) (void)hipFree(ix->d_sa);
     if (ix->d_text) (void)hipFree(ix->d_text);
     if (ix->d_kmer) (void)hipFree(ix->d_kmer);
@@ -698,9 +717,14 @@ extern "C" int mp_index_lkt(const mp_index *ix, const uint32_t *key, uint64_t n,
 
 extern "C" int mp_index_copy_lkt(const mp_index *ix, uint32_t *out)
 {
-    if (!ix || !out || !ix->d_lkt) return MP_EINVAL;
+    if (!ix || !out || (!ix->d_lkt && !ix->d_lkt14)) return MP_EINVAL;
     HIPCHK(hipSetDevice(ix->device));
-    HIPCHK(hipMemcpy(out, ix->d_lkt, (size_t)MP_LKT_ENTRIES * 4, hipMemcpyDeviceToHost));
+    if (ix->d_lkt) { HIPCHK(hipMemcpy(out, ix->d_lkt, (size_t)MP_LKT_ENTRIES * 4, hipMemcpyDeviceToHost)); return MP_OK; }
+    // the table lives in the 8-byte entries (mp_dev_index::lkt14): lkt[k] = entry[k + 1].x
+    std::vector<uint2> e;
+    try { e.resize((size_t)MP_LKT_ENTRIES + 1); } catch (...) { return MP_ENOMEM; }
+    HIPCHK(hipMemcpy(e.data(), ix->d_lkt14, e.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < MP_LKT_ENTRIES; k++) out[k] = e[k + 1].x;
     return MP_OK;
 }
 
@@ -2379,8 +2403,12 @@ extern "C" int mp_chunk_stash(mp_ctx *c, uint32_t slot)
     hipStream_t s = c->stream;
     if (c->stash.size() <= slot) c->stash.resize(slot + 1);
     const size_t n_items = 2 * (size_t)c->n_reads, n_pairs = c->n_reads / 2;
-    const size_t b_seed = (size_t)c->n_hits_total * sizeof(mp_seedpos), b_rs = (n_items + 1) * 4, b_np = (size_t)c->n_reads * 4, b_pd = (n_pairs + 1) * 4;
+    // seed positions as 8-byte words (kernels_floor.hip, stash_pack_kernel) when the batch's pair numbers fit 21 bits; MP_STASH_PLAIN=1: as they stand (test switch)
+    static const bool plain_env = getenv("MP_STASH_PLAIN") && atoi(getenv("MP_STASH_PLAIN")) != 0;
+    const bool packed = !plain_env && c->n_reads <= (1u << 22);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_rs = (n_items + 1) * 4, b_np = (size_t)c->n_reads * 4, b_pd = (n_pairs + 1) * 4;
+    const size_t b_seed = (size_t)c->n_hits_total * (packed ? sizeof(unsigned long long) : sizeof(mp_seedpos));
     const size_t need = up(b_seed) + up(b_rs) + 2 * up(b_np) + up(b_pd);
     if (c->stash_used + need > c->stash_cap) {
         // grow: what this chunk needed times the chunks still to come (the reduction knows how many chunks the batch goes through), a tenth of slack
@@ -2392,10 +2420,13 @@ extern "C" int mp_chunk_stash(mp_ctx *c, uint32_t slot)
         if (c->stash_arena) (void)hipFree(c->stash_arena);
         c->stash_arena = q; c->stash_cap = want;
     }
+    uint8_t *p = c->stash_arena + c->stash_used;
+    if (b_seed && packed) {
+        hipLaunchKernelGGL(stash_pack_kernel, dim3(grid_for(c->n_hits_total, 256)), dim3(256), 0, s, (const mp_seedpos *)c->seedpos.p, (uint64_t)c->n_hits_total, (unsigned long long *)p);
+        MP_TRACE(s, "stash_pack_kernel");
+    } else if (b_seed) HIPCHK(hipMemcpyAsync(p, c->seedpos.p, b_seed, hipMemcpyDeviceToDevice, s));
     mp_ctx::Stash &st = c->stash[slot];
-    st.off = c->stash_used; st.bytes = need; st.n_hits = c->n_hits_total; st.n_reads = c->n_reads; st.ix = c->ix; st.seed = c->last_seed; st.used = true;
-    uint8_t *p = c->stash_arena + st.off;
-    if (b_seed) HIPCHK(hipMemcpyAsync(p, c->seedpos.p, b_seed, hipMemcpyDeviceToDevice, s));
+    st.off = c->stash_used; st.bytes = need; st.n_hits = c->n_hits_total; st.n_reads = c->n_reads; st.ix = c->ix; st.seed = c->last_seed; st.used = true; st.packed = packed;
     p += up(b_seed);
     HIPCHK(hipMemcpyAsync(p, c->rs_base.p, b_rs, hipMemcpyDeviceToDevice, s)); p += up(b_rs);
     HIPCHK(hipMemcpyAsync(p, c->n_pos.p, b_np, hipMemcpyDeviceToDevice, s)); p += up(b_np);
@@ -2414,12 +2445,15 @@ extern "C" int mp_chunk_unstash(mp_ctx *c, uint32_t slot)
     HIPCHK(hipSetDevice(c->ix->device));
     hipStream_t s = c->stream;
     const size_t n_items = 2 * (size_t)c->n_reads, n_pairs = c->n_reads / 2;
-    const size_t b_seed = (size_t)st.n_hits * sizeof(mp_seedpos), b_rs = (n_items + 1) * 4, b_np = (size_t)c->n_reads * 4, b_pd = (n_pairs + 1) * 4;
+    const size_t b_seed = (size_t)st.n_hits * (st.packed ? sizeof(unsigned long long) : sizeof(mp_seedpos)), b_rs = (n_items + 1) * 4, b_np = (size_t)c->n_reads * 4, b_pd = (n_pairs + 1) * 4;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     if (c->seedpos.reserve((size_t)st.n_hits + 64) || c->rs_base.reserve(n_items + 2) || c->n_pos.reserve(c->n_reads + 1) || c->n_neg.reserve(c->n_reads + 1) ||
         c->pair_done.reserve(n_pairs + 1)) return MP_ENOMEM;
     const uint8_t *p = c->stash_arena + st.off;
-    if (b_seed) HIPCHK(hipMemcpyAsync(c->seedpos.p, p, b_seed, hipMemcpyDeviceToDevice, s));
+    if (b_seed && st.packed) {
+        hipLaunchKernelGGL(stash_unpack_kernel, dim3(grid_for(st.n_hits, 256)), dim3(256), 0, s, (const unsigned long long *)p, (uint64_t)st.n_hits, (uint64_t)c->ix->d.n, (mp_seedpos *)c->seedpos.p);
+        MP_TRACE(s, "stash_unpack_kernel");
+    } else if (b_seed) HIPCHK(hipMemcpyAsync(c->seedpos.p, p, b_seed, hipMemcpyDeviceToDevice, s));
     p += up(b_seed);
     HIPCHK(hipMemcpyAsync(c->rs_base.p, p, b_rs, hipMemcpyDeviceToDevice, s)); p += up(b_rs);
     HIPCHK(hipMemcpyAsync(c->n_pos.p, p, b_np, hipMemcpyDeviceToDevice, s)); p += up(b_np);

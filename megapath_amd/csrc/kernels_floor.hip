@@ -335,3 +335,32 @@ __global__ void floor_best_kernel(const unsigned long long *__restrict__ keys, u
     const uint32_t read = (uint32_t)(k >> 42), score = 1023u - (uint32_t)(k & 1023u);
     if (read < n_reads) atomicMax(&best_known[read], score);
 }
+
+// ---- what mp_chunk_stash keeps of a chunk's seed positions, 8 bytes each instead of 16 (the stash of a 256 Ki-pair batch over 88 chunks: 13 GB instead of 25):
+// position (low word: a chunk holds < 2^32 bases, and a projection that wrapped below zero comes back by the sign extension key_pos makes of it, kernels_seed.hip)
+// | covered length (10 bits; a read has at most MP_SEED_BIG = 384 bases) | pair number (21 bits: batches of up to 2 Mi pairs, mp_chunk_stash checks) | strand.
+// (The array has a slot per located hit and only the kept seeds of a read are filled in; what the other slots hold is never read, before or after.)
+__device__ __forceinline__ mp_seedpos mp_stash_unpack(unsigned long long w, uint64_t text_len)
+{
+    mp_seedpos sp;
+    const uint64_t o = w & 0xFFFFFFFFull;
+    sp.pos = o >= text_len ? (o | 0xFFFFFFFF00000000ull) : o;
+    sp.paired_seed_length = (uint32_t)(w >> 32) & 1023u;
+    sp.strand_read_id = ((uint32_t)((w >> 42) & 0x1FFFFFu) << 1) | ((uint32_t)(w >> 63) << 31);
+    return sp;
+}
+
+__global__ void stash_pack_kernel(const mp_seedpos *__restrict__ in, uint64_t n, unsigned long long *__restrict__ out)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mp_seedpos sp = in[i];
+    out[i] = (sp.pos & 0xFFFFFFFFull) | ((unsigned long long)(sp.paired_seed_length & 1023u) << 32) |
+             ((unsigned long long)((sp.strand_read_id >> 1) & 0x1FFFFFu) << 42) | ((unsigned long long)(sp.strand_read_id >> 31) << 63);
+}
+
+__global__ void stash_unpack_kernel(const unsigned long long *__restrict__ in, uint64_t n, uint64_t text_len, mp_seedpos *__restrict__ out)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mp_stash_unpack(in[i], text_len);
+}

@@ -16,6 +16,13 @@
 
 #define MP_WAVE 64
 
+// The SA range of a 13-mer (LT.h:49-55): [lkt[k - 1] + 1, lkt[k]], from the plain table or from the 8-byte entries that stand for it (mp_dev_index::lkt14)
+__device__ __forceinline__ void mp_lkt13_range(const mp_dev_index &ix, uint32_t k, uint32_t &l, uint32_t &r)
+{
+    if (ix.lkt) { l = k ? ix.lkt[k - 1] + 1 : 1; r = ix.lkt[k]; }
+    else { l = ix.lkt14[k].x + 1; r = ix.lkt14[k + 1].x; }
+}
+
 // ------------------------------------------------------------------------------------------------ FM-index primitives
 // A rank block in registers: running counts, and per 32 symbols one dense mask of the positions that hold symbol c.
 struct mp_blk_view {
@@ -160,8 +167,9 @@ __global__ void lkt_query_kernel(mp_dev_index ix, const uint32_t *key, uint64_t 
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t < n) {
         uint32_t k = key[t];
-        out_l[t] = k ? (uint64_t)ix.lkt[k - 1] + 1 : 1;
-        out_r[t] = ix.lkt[k];
+        uint32_t l, r;
+        mp_lkt13_range(ix, k, l, r);
+        out_l[t] = l; out_r[t] = r;
     }
 }
 
@@ -253,6 +261,35 @@ __device__ __forceinline__ void mp_occ_pair(const mp_dev_index &ix, uint32_t k1,
     o2 = mp_blk_rank(v, off2);
 }
 
+// The 13-mer table as 8-byte entries that carry the first extension step (mp_dev_index::lkt14; ix.lkt still resident here, ix.lkt14 null).  Entry Q = the 13-mer
+// c.P' (first base c, then twelve): the four 13-mers P'.d lie side by side in the table, so the step "put c in front" maps their ranges onto four ranges
+// side by side again -- the 14-mers Q.d -- and what the entry has to hold is where the first begins and how long each is.  Where that first range does not
+// begin right behind lkt[Q - 1] (a suffix shorter than 14 bases at the end of the text), or a count does not fit a byte, the entry says 255 four times.
+__global__ void lkt14_build_kernel(mp_dev_index ix, uint2 *__restrict__ out, unsigned long long *__restrict__ n_plain /* entries without the short cut */)
+{
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t > MP_LKT_ENTRIES) return;
+    const uint32_t Q = (uint32_t)t;
+    if (Q == MP_LKT_ENTRIES) { out[Q] = make_uint2(ix.lkt[MP_LKT_ENTRIES - 1], 0xFFFFFFFFu); return; }
+    const uint32_t x = Q ? ix.lkt[Q - 1] : 0u;
+    const uint32_t c = Q >> (2 * (MP_LKT_K - 1)), rest = Q & ((1u << (2 * (MP_LKT_K - 1))) - 1u);
+    uint32_t packed = 0, expect = x + 1;
+    bool plain = false;
+#pragma unroll
+    for (uint32_t d = 0; d < 4; d++) {
+        uint32_t l, r, o1, o2;
+        mp_lkt13_range(ix, rest * 4u + d, l, r);
+        mp_occ_pair(ix, l, r + 1, c, o1, o2);                      // (an empty range [l, l - 1] yields an empty one)
+        const uint32_t nl = ix.cum[c] + o1 + 1, nr = ix.cum[c] + o2;
+        const uint32_t cnt = nr + 1 - nl;
+        if (nl != expect || nr + 1 < nl || cnt >= 255u) plain = true;
+        packed |= (cnt & 255u) << (8 * d);
+        expect = nr + 1;
+    }
+    if (plain) { packed = 0xFFFFFFFFu; atomicAdd(n_plain, 1ull); }
+    out[Q] = make_uint2(x, packed);
+}
+
 // Test aid: for the 16-mer starting at every text position s <= n - 4 (and for `n_random` arbitrary keys) compares the
 // 16-mer table's range with what the index's own procedure yields: 13-mer table, then three backward-search steps.
 __global__ void lkt16_check_kernel(mp_dev_index ix, uint64_t n_text, uint64_t n_random, unsigned long long *__restrict__ out /* [checked, mismatches] */)
@@ -273,7 +310,8 @@ __global__ void lkt16_check_kernel(mp_dev_index ix, uint64_t n_text, uint64_t n_
     }
     if ((key16 & (MP_LKT_ENTRIES - 1)) == 0) return;           // keys the seeding kernel leaves to the 13-mer path
     const uint32_t key13 = key16 & (MP_LKT_ENTRIES - 1);
-    uint32_t l = key13 ? ix.lkt[key13 - 1] + 1 : 1, r = ix.lkt[key13];
+    uint32_t l, r;
+    mp_lkt13_range(ix, key13, l, r);
     for (int step = 0; step < 3 && l <= r; step++) {
         const uint32_t c = (key16 >> (26 + 2 * step)) & 3u;
         uint32_t o1, o2;
@@ -427,8 +465,8 @@ __device__ __forceinline__ bool mp_mmp_trip(const mp_dev_index &ix, const mp_dev
             if (s.i >= s.len) finished = true;
         } else {
             const uint32_t key = (uint32_t)(two >> sh) & (MP_LKT_ENTRIES - 1);
-            const uint32_t nextl = key ? ix.lkt[key - 1] + 1 : 1;
-            const uint32_t nextr = ix.lkt[key];
+            uint32_t nextl, nextr;
+            mp_lkt13_range(ix, key, nextl, nextr);
             ev.lkt++;
             s.i += MP_LKT_K - 1;
             s.seed_len = MP_LKT_K - 1;
@@ -529,7 +567,7 @@ __device__ __forceinline__ void mp_mmp_begin(mp_mmp_state &s, const uint32_t *sc
 // next load in its state: a trip issues the loads of all lanes together (three instruction groups: a 64-byte block, one
 // 16-byte entry, one or two words), waits once, then every lane consumes what it got and derives its next address.  The read's
 // scan-order bases live in LDS (one row per lane), so cutting keys and comparing with the text costs no global load.
-enum { MK_NONE = 0, MK_PRE, MK_LKT13, MK_LKT16, MK_SA, MK_TEXT,      // one or two words
+enum { MK_NONE = 0, MK_PRE, MK_LKT13, MK_LKT16, MK_SA, MK_TEXT, MK_LKT14,      // one or two words
        MK_LKT16U,                                                     // one 16-byte entry
        MK_OCC, MK_OCC2, MK_BEGIN };                                   // a 64-byte block
 
@@ -565,6 +603,8 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
     const bool pf = ix.kmer17 && P.seed_min_length >= (int)ix.kmer_k;
     const uint64_t kmask = (1ull << (2 * ix.kmer_k)) - 1;             // (kmer15x3 and the 16-mer tables exist only with 17-mers)
     const bool text_ok = ix.sa_dense && ix.sa_dense_shift == 0;
+    const bool packed = ix.lkt14 != nullptr;                          // the 13-mer table as 8-byte entries with the first extension step in them
+    const bool lkt14_ok = packed && P.seed_min_length > MP_LKT_K;     // (a 13-base seed must not be reportable: nothing shorter than 14 bases leaves that look-up)
     const uint32_t cum0 = ix.cum[0], cum1 = ix.cum[1], cum2 = ix.cum[2], cum3 = ix.cum[3];
     mp_lane_events ev = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mp_lane_state s;
@@ -628,7 +668,7 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 const uint32_t *p = reinterpret_cast<const uint32_t *>(s.ptr);
                 const bool one = kind == MK_SA || (kind == MK_PRE && !ix.kmer15x3) || (kind == MK_LKT13 && s.aux);
                 a0 = p[0];
-                a1 = p[one ? 0 : 1];
+                a1 = p[one ? 0 : (packed && kind == MK_LKT13) ? 2 : 1];      // (packed: lkt[k - 1] and lkt[k] are the first words of two neighbouring entries)
                 if (kind == MK_PRE && ix.kmer15x3) { const uint2 e2 = *reinterpret_cast<const uint2 *>(ix.kmer15x3 + s.aux); b0 = e2.x; b1 = e2.y; }
             }
         }
@@ -655,11 +695,23 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                 }
                 s.aux++;
                 if (s.aux * 16u < S) { next = MK_BEGIN; s.ptr = reinterpret_cast<const uint4 *>(s.ptr) + 4; }
-            } else if (kind == MK_LKT13 || kind == MK_LKT16 || kind == MK_LKT16U) {
-                // LKT (re)start: the table stands for the first 13 (16) bases of the seed
+            } else if (kind == MK_LKT14 && ((a1 >> (8 * s.aux)) & 255u) == 255u) {
+                // no short cut for this entry (mp_dev_index::lkt14): the 13-mer path, one trip more
+                const uint32_t key = (uint32_t)(((((uint64_t)sl[((uint32_t)s.i >> 4) + 1] << 32) | sl[(uint32_t)s.i >> 4]) >> (2 * ((uint32_t)s.i & 15)))) & (MP_LKT_ENTRIES - 1);
+                next = MK_LKT13; s.aux = 0; s.ptr = ix.lkt14 + key; ev.lkt++;
+            } else if (kind == MK_LKT13 || kind == MK_LKT16 || kind == MK_LKT16U || kind == MK_LKT14) {
+                // LKT (re)start: the table stands for the first 13 (14, 16) bases of the seed
                 uint32_t nextl, nextr;
                 int k;
                 if (kind == MK_LKT13) { nextl = s.aux ? 1u : a0 + 1; nextr = a1; k = MP_LKT_K - 1; ev.lkt++; }
+                else if (kind == MK_LKT14) {
+                    // a0 = rows before the 13-mer Q (the 14-mer's first 13 text bases), a1 = the four counts; s.aux = the 14-mer's last text base =
+                    // the seed's first scan base.  An entry with any byte at 255 was sent to the 13-mer path above or holds 255 in all four.
+                    const uint32_t d = s.aux;
+                    const uint32_t below = (d > 0 ? (a1 & 255u) : 0u) + (d > 1 ? ((a1 >> 8) & 255u) : 0u) + (d > 2 ? ((a1 >> 16) & 255u) : 0u);
+                    nextl = a0 + below + 1; nextr = a0 + below + ((a1 >> (8 * d)) & 255u);
+                    k = MP_LKT_K; ev.lkt++; ev.skipped++;                  // the one extension step the entry stands for
+                }
                 else {
                     if (kind == MK_LKT16U) { nextl = q0.x; nextr = q0.y; } else { nextl = a0 + 1; nextr = a1; }
                     k = 15; ev.lkt16++; ev.skipped += 3;                  // the three extension steps the table stands for
@@ -827,7 +879,9 @@ seed_kernel(mp_dev_index ix, const uint32_t *__restrict__ scan, const uint32_t *
                             else { next = MK_LKT16; s.ptr = ix.lkt16 + (key16 - 1); }
                         } else {
                             const uint32_t key = key16 & (MP_LKT_ENTRIES - 1);
-                            next = MK_LKT13; s.aux = key == 0; s.ptr = ix.lkt + (key ? key - 1 : 0);
+                            if (lkt14_ok) { next = MK_LKT14; s.aux = key16 & 3u; s.ptr = ix.lkt14 + ((key16 >> 2) & (MP_LKT_ENTRIES - 1)); }
+                            else if (packed) { next = MK_LKT13; s.aux = 0; s.ptr = ix.lkt14 + key; }
+                            else { next = MK_LKT13; s.aux = key == 0; s.ptr = ix.lkt + (key ? key - 1 : 0); }
                         }
                     }
                 }

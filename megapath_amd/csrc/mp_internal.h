@@ -28,7 +28,13 @@ static_assert(sizeof(mp_occ_block) == 64, "occ block must be one 64-byte sector"
 
 struct mp_dev_index {          // passed by value to kernels
     const mp_occ_block *occ;   // ceil((n+2)/192)+1 blocks
-    const uint32_t *lkt;       // 4^13 inclusive right SA bounds
+    const uint32_t *lkt;       // 4^13 inclusive right SA bounds (nullptr when lkt14 stands for it)
+    const uint2 *lkt14;        // optional, IN PLACE of lkt (MP_LKT14=1; the lean layout of many resident chunks): 4^13 + 1 entries of 8 bytes, one per 13-mer Q =
+                               // the first 13 text bases of four 14-mers: {x = lkt[Q - 1] (0 for Q = 0; entry 4^13: lkt[4^13 - 1]), y = how many suffixes
+                               // continue Q with A, C, G, T, one byte each}: the SA range of the 14-mer Q.d is x + (counts below d) + 1 .. + count of d, i.e.
+                               // the 13-mer look-up AND the first extension step of a seed in one 8-byte load (lkt14_build_kernel makes the counts by that
+                               // very step); a byte of 255 = no short cut for this entry (a count that does not fit, or an entry whose step does not
+                               // begin at x + 1): the 13-mer path, which reads lkt[k] as entry[k + 1].x
     const uint32_t *sa;        // SA[k*interval]; entry 0 unused (handled as -1, BWT.c:242)
     const uint32_t *text;      // 2-bit text, LSB-first, 16 bases per word
     const uint32_t *lkt16;     // optional: 4^16 inclusive right SA bounds of the 16-mers (nullptr = off); used behind the 17-mer filter
@@ -53,10 +59,11 @@ struct mp_translate_row { uint64_t start; uint32_t chr; uint64_t corr; };
 struct mp_index {
     int device = 0;
     mp_dev_index d{};
+    void *d_lkt14 = nullptr;
     void *d_occ = nullptr, *d_lkt = nullptr, *d_sa = nullptr, *d_text = nullptr, *d_kmer = nullptr, *d_sa_dense = nullptr, *d_lkt16 = nullptr, *d_kmer15 = nullptr, *d_lkt16u = nullptr;
     void *d_tr_grid = nullptr, *d_tr_start = nullptr, *d_tr_chr = nullptr;      // the .tra table on the device (kernels_reduce.hip), uploaded on first use
     uint64_t device_bytes = 0;
-    size_t bytes_occ = 0, bytes_lkt = 0, bytes_sa = 0, bytes_text = 0, bytes_kmer = 0, bytes_sa_dense = 0, bytes_lkt16 = 0, bytes_kmer15 = 0, bytes_lkt16u = 0;   // per array (mp_index_clone)
+    size_t bytes_occ = 0, bytes_lkt = 0, bytes_sa = 0, bytes_text = 0, bytes_kmer = 0, bytes_sa_dense = 0, bytes_lkt16 = 0, bytes_kmer15 = 0, bytes_lkt16u = 0, bytes_lkt14 = 0;   // per array (mp_index_clone)
     uint64_t n = 0, inv_sa0 = 0, cum[5] = {0, 0, 0, 0, 0};
     uint32_t sa_interval = 0;
     std::vector<std::string> seq_names;

@@ -221,6 +221,93 @@ def test_seed_stage_with_the_16mer_filter_matches_oracle(oidx, golden_dir, tag, 
     gix.close()
 
 
+@pytest.mark.parametrize("tag,mmp", [("a", H.MmpParams.nt2()), ("b", H.MmpParams.human()), ("c", H.MmpParams.nt2())])
+def test_seed_stage_with_the_packed_14mer_table_matches_oracle(gidx, oidx, golden_dir, tag, mmp, monkeypatch):
+    """MP_LKT14=1: the 13-mer table as 8-byte entries that carry a seed's first extension step (512 MiB in place of 256; the lean layout of many
+    resident chunks).  The same seeds as the oracle's, one rank query pair less per seed start; the 13-mer ranges read back out of the entries
+    equal the plain table's; with the overflow kernel (tag b), which takes the 13-mer path through the entries."""
+    for k in ("MP_KMER_FILTER", "MP_KMER15", "MP_LKT16", "MP_LKT16U", "MP_SA_DENSE"):
+        monkeypatch.setenv(k, "0")
+    monkeypatch.setenv("MP_LKT14", "1")
+    if tag == "b":
+        monkeypatch.setenv("MP_SEED_SLAB_LIMIT", "2")
+    d = os.path.join(golden_dir, "g1")
+    gix = H.Index(os.path.join(d, "ref.fa.index"), 0)
+
+    rng = np.random.default_rng(11)
+    keys = np.concatenate([np.array([0, 1, (1 << 26) - 2, (1 << 26) - 1], dtype=np.uint32), rng.integers(0, 1 << 26, size=200000, dtype=np.uint32)])
+    la, ra = gix.lkt(keys)
+    lb, rb = gidx.lkt(keys)
+    assert np.array_equal(la, lb) and np.array_equal(ra, rb)
+    assert np.array_equal(gix.lkt_table(), gidx.lkt_table())
+    L = int(open(os.path.join(d, "expected_%s.L" % tag)).read())
+    seqs = read_fastq_pairs(os.path.join(d, "reads_%s_1.fq" % tag), os.path.join(d, "reads_%s_2.fq" % tag))
+    packed, lens, W = H.pack_reads(seqs, L)
+    ctx = H.Context(gix)
+    ctx.set_reads(packed, lens)
+    st = ctx.seed_batch(mmp)
+    arr, off = ctx.get_seeds()
+    want, ctr = oracle_seeds(oidx, seqs, L, to_oracle_mmp(mmp))
+    got = [[(arr[i].pos, arr[i].strand_read_id, arr[i].paired_seed_length) for i in range(int(off[r]), int(off[r + 1]))] for r in range(len(seqs))]
+    assert got == want
+    assert (st.n_lkt, st.n_seeds, st.n_hits) == (ctr.n_lkt, ctr.n_seeds, ctr.n_hits)
+    assert st.n_occ < ctr.n_occ and st.n_steps_skipped > 0
+    ctx.close()
+    gix.close()
+
+
+def test_packed_14mer_table_on_a_repeat_rich_genome(tmp_path, monkeypatch):
+    """Entries of the packed table whose counts do not fit a byte (poly-A, two-base and longer tandem repeats: 14-mers with hundreds of
+    occurrences) say "no short cut" and the seed start takes the 13-mer path through the same entries: seeds equal to the oracle's, and both
+    kinds of entry are met."""
+    from megapath_amd import index_builder, synth
+    import oracle_lib as O
+    genome = synth.random_genome(400000, 3301, n_seqs=2, repeat_frac=0.2)
+    rng = np.random.Generator(np.random.PCG64(3302))
+    g2 = []
+    for name, arr in genome:
+        arr = arr.copy()
+        for _ in range(40):                                   # long low-complexity stretches: homopolymers and short-unit tandem repeats
+            u = int(rng.integers(1, 7)); ln = int(rng.integers(400, 3000)); p = int(rng.integers(0, len(arr) - ln - u))
+            unit = arr[p:p + u].copy()
+            arr[p:p + ln] = np.resize(unit, ln)
+        g2.append((name, arr))
+    arrs = index_builder.build_index_arrays(g2, sa_interval=16)
+    prefix = str(tmp_path / "r.index")
+    index_builder.write_index_files(prefix, arrs)
+    for k in ("MP_KMER_FILTER", "MP_KMER15", "MP_LKT16", "MP_LKT16U", "MP_SA_DENSE"):
+        monkeypatch.setenv(k, "0")
+    plain = H.Index(prefix, 0)
+    monkeypatch.setenv("MP_LKT14", "1")
+    gix = H.Index(prefix, 0)
+    keys = np.arange(0, 1 << 26, 97, dtype=np.uint32)
+    la, ra = gix.lkt(keys)
+    lb, rb = plain.lkt(keys)
+    assert np.array_equal(la, lb) and np.array_equal(ra, rb)
+    names, r1, r2 = synth.simulate_pairs(g2, 3000, 150, 3303, sub=0.01, ins=0.001, dele=0.001, random_frac=0.05)
+    seqs = [x for pr in zip(r1, r2) for x in pr]
+    packed, lens, W = H.pack_reads(seqs, 151)
+    mmp = H.MmpParams.nt2()
+    lib = O.oracle()
+    oix = lib.mpo_index_open(prefix.encode())
+    want, ctr = oracle_seeds(oix, seqs, 151, to_oracle_mmp(mmp))
+    lib.mpo_index_close(oix)
+    stats = []
+    for ix in (gix, plain):
+        ctx = H.Context(ix)
+        ctx.set_reads(packed, lens)
+        st = ctx.seed_batch(mmp)
+        arr, off = ctx.get_seeds()
+        got = [[(arr[i].pos, arr[i].strand_read_id, arr[i].paired_seed_length) for i in range(int(off[r]), int(off[r + 1]))] for r in range(len(seqs))]
+        assert got == want
+        assert (st.n_seeds, st.n_hits) == (ctr.n_seeds, ctr.n_hits)
+        stats.append(st)
+        ctx.close()
+    # look-ups: one per seed start with the plain table; with the entries one per start plus one more for each start that met a "no short cut" entry
+    assert stats[0].n_lkt > stats[1].n_lkt == ctr.n_lkt and stats[0].n_steps_skipped > 0 and stats[0].n_occ < stats[1].n_occ
+    gix.close(); plain.close()
+
+
 @pytest.mark.parametrize("dense", [False, True])
 def test_merge_kernel_paths_that_do_not_stage_in_lds(golden_dir, oidx, monkeypatch, dense):
     """merge_kernel handles a block of 64 reads whose hits do not fit in its 32 KB of LDS one lane per read in global memory.  Forced for every

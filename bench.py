@@ -434,6 +434,12 @@ class NtReplica:
             want = int(args.nt_replica_gb * 1e9 // lean) + 1
             fit = 2 + max(0, int((free_b - (int(args.nt_headroom_gb) << 30)) // per_chunk))     # the rest stays free for the batch buffers and traceback slabs
             self.n_chunks = max(2, min(want, fit, max_chunks or (1 << 30)))
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # every rank holds the same database: the smallest replica any rank has room for (the ranks' counters are summed reference by reference afterwards)
+                t = torch.tensor([self.n_chunks], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                self.n_chunks = int(t.item())
             t1 = time.time()
             while len(self.chunks) < self.n_chunks:
                 self.chunks.append(self.chunks[1].clone())
@@ -1064,8 +1070,8 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("MP_BENCH_GENOME_MBP", "2950")), help="bases per index chunk (< 4295 Mbp: 32-bit positions per chunk)")
     ap.add_argument("--nt-replica-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_GB", "242")),
                     help="HBM bytes (GB) of index the replica makes resident (as many lean chunks of --genome-mbp as that takes and as fit)")
-    ap.add_argument("--nt-headroom-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_HEADROOM_GB", "36" if NtReplica.LKT14 != "0" else "56")),
-                    help="GiB of HBM kept free of index for the batch buffers (36: 89 chunks with the packed 14-mer tables, 266.6 GB, and 9 GB free during the steps)")
+    ap.add_argument("--nt-headroom-gb", type=float, default=float(os.environ.get("MP_BENCH_NT_HEADROOM_GB", "32" if NtReplica.LKT14 != "0" else "56")),
+                    help="GiB of HBM kept free of index for the batch buffers (32: room for 90 chunks with the packed 14-mer tables; the 89 of the default replica are 266.6 GB and leave 9 GB free during the steps)")
     ap.add_argument("--nt-pairs", type=int, default=int(os.environ.get("MP_BENCH_NT_PAIRS", str(1 << 18))), help="pairs per step and GPU of the headline workload")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MP_BENCH_CONTEXTS", "4")),
                     help="contexts (HIP stream pairs + host threads) a step's batch is cut across; 1 = one context does the whole batch")

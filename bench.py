@@ -636,7 +636,7 @@ def nt_parity_sample(args, index_builder, rep, td, device, read_len, n_pairs, lk
     common = ["-b", "-o", "S.nt.bam", "-L", str(read_len + 1), "-T", str(T), "-u", "750", "-F", "-C", ini, "-top", "95"]
     # the product first (it reads the original files; the chain below moves them)
     prod_out = os.path.join(td, "prod.out")
-    env = dict(os.environ, MP_DEVICE=str(device), **NtReplica.KNOBS)
+    env = dict(os.environ, MP_DEVICE=str(device), MP_LKT14=NtReplica.LKT14, **NtReplica.KNOBS)
     env.pop("LOCAL_RANK", None)
     with open(prod_out, "wb") as fo, open(os.path.join(td, "prod.err"), "wb") as fe:
         rc = subprocess.call([exe, "pair", prefix_a + "," + prefix_b, "S.nt.tmp_in_1.fq", "S.nt.tmp_in_2.fq"] + common + ["-nc"], stdout=fo, stderr=fe, env=env, cwd=td)

@@ -2124,11 +2124,11 @@ int main(int argc, char **argv)
     const bool top_floor = reduce_on_device && n_chunks >= 2 && top_percent >= 1 && top_percent <= 100 && !(getenv("MP_TOP_FLOOR") && atoi(getenv("MP_TOP_FLOOR")) == 0);
     std::atomic<bool> stash_warned{false};
     if (top_floor && !getenv("MP_BATCH_PAIRS")) {
-        // the rule keeps the seed positions of every chunk but the last between its two passes: ~1.2 KB per pair and chunk with 17-base seeds (67 located
-        // hits of 16 bytes per pair and 2.95 Gbp chunk), for every worker's batch.  Batches are sized so that this fits into half of what the indexes left free.
+        // the rule keeps the seed positions of every chunk but the last between its two passes: ~0.6 KB per pair and chunk with 17-base seeds (67 located
+        // hits per pair and 2.95 Gbp chunk, 8 bytes each: stash_pack_kernel), for every worker's batch.  Batches are sized so that this fits into half of what the indexes left free.
         uint64_t mfree = 0, mtotal = 0;
         if (mp_device_memory(devices[0].id, &mfree, &mtotal) == 0) {
-            const double per_pair = 1200.0 * (double)(n_chunks - 1);
+            const double per_pair = ((getenv("MP_STASH_PLAIN") && atoi(getenv("MP_STASH_PLAIN"))) ? 1200.0 : 620.0) * (double)(n_chunks - 1);
             const size_t fit = (size_t)(0.5 * (double)mfree / (per_pair * (double)workers_per_gpu));
             const size_t want = std::max<size_t>(16384, fit / 4096 * 4096);
             if (want < p.batch_pairs) {

@@ -48,7 +48,9 @@ for rnd in range(args.rounds):
                                                 # round 4: the certificate's variants for short reads / mate-rescue windows; -b with resident chunks through the device reduction or every chunk's lists
                                                 ("MP_DP_THERMO_MORE", rng.random() < 0.75), ("MP_BAM_HOST_MERGE", rng.random() < 0.3),
                                                 # the -top rule across resident chunks (two passes, pairs that cannot reach top% of their best known score lose their rescue work) on / off
-                                                ("MP_TOP_FLOOR", rng.random() < 0.7), ("MP_TOP_FLOOR_MATE", rng.random() < 0.75))},
+                                                ("MP_TOP_FLOOR", rng.random() < 0.7), ("MP_TOP_FLOOR_MATE", rng.random() < 0.75),
+                                                # round 4, late: the 13-mer table as 8-byte entries with a seed's first extension step in them; the stash between the two passes as 16-byte records
+                                                ("MP_LKT14", rng.random() < 0.5), ("MP_STASH_PLAIN", rng.random() < 0.25))},
                # chunked databases: besides the copied repeats, every chunk may get a DIVERGED copy of a stretch of another chunk's sequence -- entries near and
                # below top% of a read's best score in other chunks, which is what the -top rule across chunks decides about
                div_copy=float(rng.choice([0.0, 0.02, 0.05, 0.1, 0.2])), div_seed=int(rng.integers(1, 1 << 30)),

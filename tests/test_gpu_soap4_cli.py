@@ -356,7 +356,7 @@ def test_cli_host_merge_path_equals_reference(golden_dir, tmp_path, tag, L):
         assert outs[0] == outs[1] == fastq_records(want)
 
 
-@pytest.mark.parametrize("rewrite", [False, True, "device"])
+@pytest.mark.parametrize("rewrite", [False, True, "device", "lean", "lean_plain_stash"])
 def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, rewrite):
     """g6: nine index chunks resident in one process (homologous sequences at 0-7 % divergence in several of them) against the last
     stdout of NINE chained runs of the real soap4; with the untouched comments left alone from the second chunk on (the default) and
@@ -369,6 +369,12 @@ def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, re
     env = dict(os.environ, MP_BATCH_PAIRS="64")
     if rewrite == "device":
         pass                                             # the default: per-reference scores reduced on the device over the nine chunks
+    elif str(rewrite).startswith("lean"):
+        # the NT stage's layout: no optional table, the 13-mer table as 8-byte entries with a seed's first extension step in them (MP_LKT14); the seed
+        # positions between the two passes of the -top rule as 8-byte words (default) or as they stand
+        env.update(MP_KMER_FILTER="0", MP_KMER15="0", MP_LKT16="0", MP_SA_DENSE="0", MP_LKT14="1")
+        if rewrite == "lean_plain_stash":
+            env["MP_STASH_PLAIN"] = "1"
     else:
         env["MP_HOST_MERGE"] = "1"                       # hit lists to the host, comments merged chunk after chunk
         if rewrite:
@@ -376,7 +382,7 @@ def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, re
     with open(out, "wb") as fo:
         r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
     assert r.returncode == 0, r.stderr.decode()
-    assert b"9 index chunk(s)" in r.stderr and (b"reduced on the device" in r.stderr) == (rewrite == "device")
+    assert b"9 index chunk(s)" in r.stderr and (b"reduced on the device" in r.stderr) == (rewrite == "device" or str(rewrite).startswith("lean"))
     assert fastq_records(str(out)) == fastq_records(os.path.join(g6, "expected_chain.fq"))
 
 

@@ -2027,6 +2027,27 @@ int main(int argc, char **argv)
     if (n_chunks >= 2) workers_per_gpu = 4;    // several resident chunks (the NT stage): a batch stays on the device for seconds, four side by side measured +3 % over three (bench.py --contexts)
     if (const char *e = getenv("MP_WORKERS_PER_GPU")) workers_per_gpu = std::max(1, atoi(e));
     std::vector<Device> devices(gpu_ids.size());
+    if (!plumbing_only && n_chunks >= 2) {
+        // A database of several chunks gets ONE layout.  Left to itself the library decides index by index from the HBM that is free when the index is opened
+        // (INTEGRATION.md, section 4): the first chunks of the NT database would take every optional table and the rest would not fit.  So: unless the chunks
+        // with all their optional tables (~38 bytes per base) fit into 60 % of the card, every chunk is opened in the lean layout (0.92 B/base + the 13-mer
+        // table), and with the 13-mer tables as 8-byte entries that hold a seed's first extension step (MP_LKT14, +256 MiB per chunk) when that still leaves
+        // 36 GiB for the batches.  Switches the user has set stay as they are.
+        uint64_t bases = 0, mfree = 0, mtotal = 0;
+        for (const std::string &pre : prefixes) { struct stat sb; if (stat((pre + ".pac").c_str(), &sb) == 0) bases += 4ull * (uint64_t)sb.st_size; }
+        if (const char *e = getenv("MP_LAYOUT_HBM_BYTES")) mtotal = strtoull(e, nullptr, 10);           // test aid: decide as if the card had this much
+        else if (mp_device_memory(gpu_ids[0], &mfree, &mtotal) != 0) mtotal = 0;
+        if (bases && mtotal) {
+            const double lean = 0.92 * (double)bases + (double)n_chunks * (double)(1ull << 28), rich = 38.0 * (double)bases;
+            if (rich > 0.6 * (double)mtotal) {
+                const bool lkt14 = lean + (double)n_chunks * (double)(1ull << 28) + (double)(36ull << 30) <= (double)mtotal;
+                for (const char *k : {"MP_KMER_FILTER", "MP_KMER15", "MP_LKT16", "MP_SA_DENSE", "MP_LKT16U"}) setenv(k, "0", 0);
+                if (lkt14) setenv("MP_LKT14", "1", 0);
+                fprintf(stderr, "[Main] %zu index chunks, %.1f Gbp: lean layout for all of them (%.1f GB)%s\n", n_chunks, bases / 1e9,
+                        (lean + (lkt14 ? (double)n_chunks * (double)(1ull << 28) : 0.0)) / 1e9, lkt14 ? ", 13-mer tables with the first extension step in them (MP_LKT14)" : "");
+            }
+        }
+    }
     if (!plumbing_only) {
         // every GPU loads its own replica of every chunk, the GPUs side by side
         std::vector<std::thread> loaders;

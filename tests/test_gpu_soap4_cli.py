@@ -356,7 +356,7 @@ def test_cli_host_merge_path_equals_reference(golden_dir, tmp_path, tag, L):
         assert outs[0] == outs[1] == fastq_records(want)
 
 
-@pytest.mark.parametrize("rewrite", [False, True, "device", "lean", "lean_plain_stash"])
+@pytest.mark.parametrize("rewrite", [False, True, "device", "lean", "lean_plain_stash", "lean_by_itself"])
 def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, rewrite):
     """g6: nine index chunks resident in one process (homologous sequences at 0-7 % divergence in several of them) against the last
     stdout of NINE chained runs of the real soap4; with the untouched comments left alone from the second chunk on (the default) and
@@ -375,6 +375,11 @@ def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, re
         env.update(MP_KMER_FILTER="0", MP_KMER15="0", MP_LKT16="0", MP_SA_DENSE="0", MP_LKT14="1")
         if rewrite == "lean_plain_stash":
             env["MP_STASH_PLAIN"] = "1"
+        if rewrite == "lean_by_itself":
+            # no switch given: the executable decides the layout for the database as a whole (here as if the card were too small for the optional tables)
+            for k in ("MP_KMER_FILTER", "MP_KMER15", "MP_LKT16", "MP_SA_DENSE", "MP_LKT14"):
+                env.pop(k, None)
+            env["MP_LAYOUT_HBM_BYTES"] = "1000000"
     else:
         env["MP_HOST_MERGE"] = "1"                       # hit lists to the host, comments merged chunk after chunk
         if rewrite:
@@ -383,6 +388,7 @@ def test_cli_nine_resident_chunks_equal_reference_chain(golden_dir, tmp_path, re
         r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
     assert r.returncode == 0, r.stderr.decode()
     assert b"9 index chunk(s)" in r.stderr and (b"reduced on the device" in r.stderr) == (rewrite == "device" or str(rewrite).startswith("lean"))
+    assert (b"lean layout for all of them" in r.stderr) == (rewrite == "lean_by_itself")
     assert fastq_records(str(out)) == fastq_records(os.path.join(g6, "expected_chain.fq"))
 
 

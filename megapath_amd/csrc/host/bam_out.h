@@ -432,9 +432,14 @@ private:
         int cur = 0, cur_match = 0, q = 0;
         uint64_t t = pos;
         const size_t L = strlen(sp);
+        // The reference text under the alignment was fetched for the alignment as the DP gave it (its span + 8).  An alignment trimmed on the LEFT at a sequence
+        // boundary is read from pos + trim, where trim counts READ bases -- soft-clipped ones and inserted ones included (PE.cpp:459-620) --, so it may run
+        // past that window: such a base is fetched on its own (rare: an alignment across a boundary whose left part is clipped or holds an insertion).
         auto base = [&](uint64_t p) -> char {
-            if (!ref.codes || p < ref.pos || p - ref.pos >= ref.len) return 'N';
-            return "ACGT"[ref.codes[p - ref.pos] & 3];
+            if (ref.codes && p >= ref.pos && p - ref.pos < ref.len) return "ACGT"[ref.codes[p - ref.pos] & 3];
+            uint8_t code = 0; const uint32_t one = 1;
+            if (mp_index_fetch_text(ix_, &p, &one, 1, &code, 1) != 0) return 'N';
+            return "ACGT"[code & 3];
         };
         const bool md = o_.print_mdnm;
         for (size_t i = 0; i < L; i++) {

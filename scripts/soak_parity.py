@@ -21,6 +21,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--inis", default="both", help="both (drawn per round), soap4.ini or soap4-nt2.ini")
+ap.add_argument("--only", type=int, default=None, help="run only this round of the seed's sequence (the rounds before it are drawn and skipped)")
+ap.add_argument("--env", default="", help="K=V,K=V: switches that override the round's drawn ones (to bisect a differing round)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 lib = O.oracle()
@@ -61,6 +63,11 @@ for rnd in range(args.rounds):
                        junk_end_frac=float(rng.choice([0.0, 0.3])), junk_end_max=int(rng.integers(5, 60)),
                        len_range=(max(20, read_len // 3), read_len) if rng.random() < 0.4 else None,
                        frag_mean=read_len + 200, frag_sd=40, frag_min=read_len + 20, frag_max=min(740, read_len + 420)))
+    if args.only is not None and rnd != args.only:
+        continue
+    for kv in filter(None, args.env.split(",")):
+        k, v = kv.split("=", 1)
+        cfg["env"][k] = v
     print("round %d: %r" % (rnd, cfg), flush=True)
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
         n_chunks = cfg["chunks"]
@@ -148,8 +155,10 @@ for rnd in range(args.rounds):
                 if got_recs != want_recs:
                     bad = [i for i in range(min(len(got_recs), len(want_recs))) if got_recs[i] != want_recs[i]]
                     print("BAM %s DIFFERENT: %d vs %d records" % (kind, len(got_recs), len(want_recs)))
-                    for i in bad[:2]:
-                        print(" got ", got_recs[i][:300]); print(" want", want_recs[i][:300])
+                    print(" %d records differ" % len(bad))
+                    for i in bad[:4]:
+                        gf, wf = got_recs[i].split("\t"), want_recs[i].split("\t")
+                        print(" record", gf[:9], "fields that differ:", [(k, a, b) for k, (a, b) in enumerate(zip(gf, wf)) if a != b][:6], len(gf), len(wf))
                     sys.exit(1)
         a, b = fastq_records(out), fastq_records(want)
         if a != b:

@@ -3,6 +3,7 @@ command line (golden stdout from tests/golden/make_golden.py; order-insensitive,
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -609,6 +610,16 @@ def test_cli_equals_oracle_on_random_workloads(tmp_path, cfg):
     got, want = fastq_records(str(out)), fastq_records(_oracle_stdout(prefix, f1, f2, L, tmp_path))
     assert len(got) == len(want) == 2 * n_pairs
     assert got == want
+
+
+def test_md_text_of_alignments_trimmed_at_a_sequence_start(tmp_path):
+    """Soak seed 4622, round 15 (2 x 250 bp, -P -b -p, two chunks, junk ends): four alignments across a sequence boundary whose LEFT part is dropped
+    (BoundaryCheckDP) and began with soft-clipped bases.  The reference reads the MD text from `pos + trim` with trim counting read bases, the clipped ones
+    included, i.e. up to a read length past the alignment's own span: the writer had only fetched span + 8 bases and printed 'N' beyond them."""
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_parity.py"), "--rounds", "16", "--seed", "4622", "--only", "15"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    assert r.returncode == 0 and b"all 16 rounds equal" in r.stdout, r.stdout.decode()[-2000:]
 
 
 @pytest.mark.parametrize("driver", ["cxx", "py"])
